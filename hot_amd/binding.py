@@ -1,0 +1,380 @@
+"""ctypes binding of the C ABI declared in include/hot_mi355x.h.
+
+`HotLib(path, prefix)` binds one shared library exporting that ABI under the symbol prefix `prefix`
+("hot_" for the HIP product library).  `Context` is the host-side mirror of the reference objects that own
+this path — `MultigridSimulation<T,3>` (Projects/multigrid/MultigridSimulation.h), its
+`ImplicitSolverObjective` (Projects/multigrid/ImplicitSolver.h) and the static `MultigridOperator`
+(Projects/multigrid/MultigridPreconditioner.h): method names follow the reference members they replace
+(particlesToGrid -> p2g, gridToParticles -> g2p, computeResidual -> residual, ...).
+
+Array arguments are numpy arrays (host) or anything exposing `data_ptr()` (torch tensors, host or HIP
+device memory); the library resolves the pointer kind itself.
+"""
+import ctypes as C
+import numpy as np
+
+_DT = {0: np.float32, 1: np.float64}
+
+
+class hot_config(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("device", C.c_int32), ("dx", C.c_double), ("gravity", C.c_double * 3),
+        ("apic_rpic_ratio", C.c_double), ("cfl", C.c_double), ("lsolver", C.c_int32), ("Ainv", C.c_int32),
+        ("smoother", C.c_int32), ("coarseSolver", C.c_int32), ("levelCnt", C.c_int32), ("times", C.c_int32),
+        ("levelscale", C.c_int32), ("omega", C.c_double), ("topomega", C.c_double), ("cneps", C.c_double),
+        ("useCN", C.c_int32), ("project", C.c_int32), ("systemBCProject", C.c_int32), ("linesearch", C.c_int32),
+        ("matrixFree", C.c_int32), ("boundaryType", C.c_int32), ("useAdaptiveHessian", C.c_int32),
+        ("topDownMGS", C.c_int32), ("max_iterations", C.c_int32), ("plasticity", C.c_int32),
+        ("yield_stress", C.c_double), ("snow", C.c_double * 5), ("profile", C.c_int32), ("reserved", C.c_int32 * 7),
+    ]
+
+
+class hot_stats(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32), ("converged", C.c_int32), ("linesearch_trials", C.c_int32),
+        ("linear_iterations", C.c_int32), ("vcycles", C.c_int32), ("dropped_pairs", C.c_int32),
+        ("num_nodes", C.c_int32), ("num_levels", C.c_int32), ("final_scaled_residual", C.c_double),
+        ("energy", C.c_double), ("ms_sort", C.c_double), ("ms_p2g", C.c_double), ("ms_begin", C.c_double),
+        ("ms_hessian", C.c_double), ("ms_mg_build", C.c_double), ("ms_solve", C.c_double), ("ms_g2p", C.c_double),
+        ("ms_total", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every entry point include/hot_mi355x.h declares (tests check each is exported)
+ABI_SYMBOLS = [
+    "default_config", "create", "destroy", "last_error", "sync", "set_particles", "get_particles", "sort",
+    "get_counts", "get_indexing", "p2g", "get_grid", "set_bc", "set_sticky_halfspaces", "begin_step", "get_dv",
+    "set_dv", "update_state", "get_particle_state", "residual", "project", "cn_tolerance", "build_hessian",
+    "matfree_multiply", "build_mg", "get_level", "get_matrix", "get_prolongation", "spmv", "restrict", "prolong",
+    "smooth", "vcycle", "solve", "g2p", "advance", "profile_reset", "profile_count", "profile_get", "version",
+]
+
+
+class HotError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(a.ctypes.data)
+
+
+class HotLib:
+    def __init__(self, path, prefix="hot_"):
+        self.path = str(path)
+        self.prefix = prefix
+        self.lib = C.CDLL(self.path)
+        vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+        P = C.POINTER
+        sig = {
+            "default_config": (None, [P(hot_config)]),
+            "create": (C.c_int, [P(hot_config), P(vp)]),
+            "destroy": (None, [vp]),
+            "last_error": (C.c_char_p, [vp]),
+            "sync": (C.c_int, [vp]),
+            "set_particles": (C.c_int, [vp, i64] + [vp] * 9),
+            "get_particles": (C.c_int, [vp] + [vp] * 7),
+            "sort": (C.c_int, [vp]),
+            "get_counts": (C.c_int, [vp, P(i64), P(i32), P(i32), P(i32)]),
+            "get_indexing": (C.c_int, [vp] + [vp] * 5),
+            "p2g": (C.c_int, [vp]),
+            "get_grid": (C.c_int, [vp, vp, vp, vp]),
+            "set_bc": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp]),
+            "set_sticky_halfspaces": (C.c_int, [vp, i32, vp, vp]),
+            "begin_step": (C.c_int, [vp, dbl]),
+            "get_dv": (C.c_int, [vp, vp]),
+            "set_dv": (C.c_int, [vp, vp]),
+            "update_state": (C.c_int, [vp, vp, P(dbl)]),
+            "get_particle_state": (C.c_int, [vp, vp, vp, vp]),
+            "residual": (C.c_int, [vp, vp]),
+            "project": (C.c_int, [vp, vp]),
+            "cn_tolerance": (C.c_int, [vp, vp]),
+            "build_hessian": (C.c_int, [vp]),
+            "matfree_multiply": (C.c_int, [vp, vp, vp]),
+            "build_mg": (C.c_int, [vp]),
+            "get_level": (C.c_int, [vp, i32, P(i32), P(i32), vp]),
+            "get_matrix": (C.c_int, [vp, i32, vp, vp]),
+            "get_prolongation": (C.c_int, [vp, i32, vp, vp]),
+            "spmv": (C.c_int, [vp, i32, vp, vp]),
+            "restrict": (C.c_int, [vp, i32, vp, vp]),
+            "prolong": (C.c_int, [vp, i32, vp, vp]),
+            "smooth": (C.c_int, [vp, i32, i32, i32, dbl, vp, vp, vp]),
+            "vcycle": (C.c_int, [vp, vp, vp]),
+            "solve": (C.c_int, [vp, P(hot_stats)]),
+            "g2p": (C.c_int, [vp, dbl, P(i32)]),
+            "advance": (C.c_int, [vp, dbl, P(hot_stats)]),
+            "profile_reset": (C.c_int, [vp]),
+            "profile_count": (C.c_int, [vp, P(i32)]),
+            "profile_get": (C.c_int, [vp, i32, C.c_char_p, P(i64), P(dbl)]),
+            "version": (C.c_char_p, []),
+        }
+        self.fn = {}
+        missing = []
+        for name in ABI_SYMBOLS:
+            try:
+                f = getattr(self.lib, prefix + name)
+            except AttributeError:
+                missing.append(prefix + name)
+                continue
+            f.restype, f.argtypes = sig[name]
+            self.fn[name] = f
+        if missing:
+            raise HotError(f"{self.path} does not export: {missing}")
+
+    def default_config(self, **kw):
+        cfg = hot_config()
+        self.fn["default_config"](C.byref(cfg))
+        for k, v in kw.items():
+            if k == "gravity":
+                for d in range(3):
+                    cfg.gravity[d] = float(v[d])
+            elif k == "snow":
+                for d in range(5):
+                    cfg.snow[d] = float(v[d])
+            else:
+                if not hasattr(cfg, k):
+                    raise KeyError(k)
+                setattr(cfg, k, v)
+        return cfg
+
+    def version(self):
+        return self.fn["version"]().decode()
+
+    def context(self, cfg=None, **kw):
+        return Context(self, cfg if cfg is not None else self.default_config(**kw))
+
+
+class Context:
+    """One simulation context (== one MultigridSimulation<T,3> + its objective + MG operator)."""
+
+    def __init__(self, lib, cfg):
+        self.lib = lib
+        self.cfg = cfg
+        self.T = _DT[cfg.dtype]
+        h = C.c_void_p()
+        rc = lib.fn["create"](C.byref(cfg), C.byref(h))
+        if rc != 0 or not h:
+            raise HotError(f"create failed rc={rc}")
+        self.h = h
+        self.Np = 0
+
+    def close(self):
+        if self.h:
+            self.lib.fn["destroy"](self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        rc = self.lib.fn[name](self.h, *args)
+        if rc != 0:
+            msg = self.lib.fn["last_error"](self.h)
+            raise HotError(f"{self.lib.prefix}{name} -> {rc}: {msg.decode() if msg else ''}")
+
+    def _real(self, a):
+        if a is None or hasattr(a, "data_ptr"):
+            return a
+        return np.ascontiguousarray(a, dtype=self.T)
+
+    # ---- particles
+    def set_particles(self, X, V, mass, vol, mu, lam, C_=None, F=None, Jp=None):
+        arrs = [self._real(a) for a in (X, V, mass, C_, F, vol, mu, lam, Jp)]
+        self.Np = int(X.shape[0])
+        self._keep = arrs
+        self._call("set_particles", C.c_int64(self.Np), *[_ptr(a) for a in arrs])
+
+    def get_particles(self):
+        n, T = self.Np, self.T
+        out = dict(X=np.empty((n, 3), T), V=np.empty((n, 3), T), C=np.empty((n, 9), T), F=np.empty((n, 9), T),
+                   mu=np.empty(n, T), lam=np.empty(n, T), Jp=np.empty(n, T))
+        self._call("get_particles", *[_ptr(out[k]) for k in ("X", "V", "C", "F", "mu", "lam", "Jp")])
+        return out
+
+    # ---- sort / indexing
+    def sort(self):
+        self._call("sort")
+
+    def counts(self):
+        np_, ng, nb, nn = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._call("get_counts", C.byref(np_), C.byref(ng), C.byref(nb), C.byref(nn))
+        return dict(Np=np_.value, Ng=ng.value, Nb=nb.value, Nn=nn.value)
+
+    def indexing(self):
+        c = self.counts()
+        out = dict(particle_order=np.empty(c["Np"], np.int32), particle_base_offset=np.empty(c["Np"], np.uint64),
+                   particle_group=np.empty((c["Ng"], 2), np.int32), block_offset=np.empty(c["Ng"], np.uint64),
+                   blocks=np.empty(c["Nb"], np.uint64))
+        self._call("get_indexing", *[_ptr(out[k]) for k in ("particle_order", "particle_base_offset", "particle_group", "block_offset", "blocks")])
+        return out
+
+    # ---- grid
+    def p2g(self):
+        self._call("p2g")
+
+    @property
+    def Nn(self):
+        return self.counts()["Nn"]
+
+    def grid(self):
+        n = self.Nn
+        out = dict(id2coord=np.empty((n, 3), np.int32), mass=np.empty(n, self.T), v=np.empty((n, 3), self.T))
+        self._call("get_grid", _ptr(out["id2coord"]), _ptr(out["mass"]), _ptr(out["v"]))
+        return out
+
+    def set_bc(self, node_id, P, R=None, Rinv=None, slip=None, dv_collide=None):
+        node_id = np.ascontiguousarray(node_id, np.int32)
+        slip = None if slip is None else np.ascontiguousarray(slip, np.uint8)
+        arrs = [self._real(a) for a in (P, R, Rinv)]
+        dvc = self._real(dv_collide)
+        self._call("set_bc", C.c_int32(len(node_id)), _ptr(node_id), _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(slip), _ptr(dvc))
+
+    def set_sticky_halfspaces(self, origin, normal):
+        o = np.ascontiguousarray(origin, np.float64).reshape(-1, 3)
+        n = np.ascontiguousarray(normal, np.float64).reshape(-1, 3)
+        self._call("set_sticky_halfspaces", C.c_int32(len(o)), _ptr(o), _ptr(n))
+
+    def begin_step(self, dt):
+        self._call("begin_step", C.c_double(dt))
+
+    def get_dv(self):
+        out = np.empty((self.Nn, 3), self.T)
+        self._call("get_dv", _ptr(out))
+        return out
+
+    def set_dv(self, dv):
+        self._call("set_dv", _ptr(self._real(dv)))
+
+    # ---- objective
+    def update_state(self, dv=None):
+        e = C.c_double()
+        self._call("update_state", _ptr(self._real(dv)), C.byref(e))
+        return e.value
+
+    def particle_state(self):
+        n = self.Np
+        out = dict(F=np.empty((n, 9), self.T), stress=np.empty((n, 9), self.T), gradV=np.empty((n, 9), self.T))
+        self._call("get_particle_state", _ptr(out["F"]), _ptr(out["stress"]), _ptr(out["gradV"]))
+        return out
+
+    def residual(self):
+        out = np.empty((self.Nn, 3), self.T)
+        self._call("residual", _ptr(out))
+        return out
+
+    def project(self, v):
+        v = np.array(v, dtype=self.T, order="C")
+        self._call("project", _ptr(v))
+        return v
+
+    def cn_tolerance(self):
+        out = np.empty(self.Nn, self.T)
+        self._call("cn_tolerance", _ptr(out))
+        return out
+
+    def build_hessian(self):
+        self._call("build_hessian")
+
+    def matfree_multiply(self, x):
+        y = np.empty((self.Nn, 3), self.T)
+        self._call("matfree_multiply", _ptr(self._real(x)), _ptr(y))
+        return y
+
+    def build_mg(self):
+        self._call("build_mg")
+
+    def level(self, level, coords=True):
+        nr, cs = C.c_int32(), C.c_int32()
+        self._call("get_level", C.c_int32(level), C.byref(nr), C.byref(cs), None)
+        out = dict(nrows=nr.value, colsize=cs.value)
+        if coords:
+            ic = np.empty((nr.value, 3), np.int32)
+            self._call("get_level", C.c_int32(level), C.byref(nr), C.byref(cs), _ptr(ic))
+            out["id2coord"] = ic
+        return out
+
+    def matrix(self, level):
+        info = self.level(level, coords=False)
+        col = np.empty((info["nrows"], info["colsize"]), np.int32)
+        val = np.empty((info["nrows"], info["colsize"], 9), self.T)
+        self._call("get_matrix", C.c_int32(level), _ptr(col), _ptr(val))
+        return col, val
+
+    def prolongation(self, level):
+        n = self.level(level, coords=False)["nrows"]
+        col = np.empty((n, 8), np.int32)
+        w = np.empty((n, 8), self.T)
+        self._call("get_prolongation", C.c_int32(level), _ptr(col), _ptr(w))
+        return col, w
+
+    def spmv(self, level, x):
+        n = self.level(level, coords=False)["nrows"]
+        y = np.empty((n, 3), self.T)
+        self._call("spmv", C.c_int32(level), _ptr(self._real(x)), _ptr(y))
+        return y
+
+    def restrict(self, level, fine):
+        n = self.level(level + 1, coords=False)["nrows"]
+        y = np.empty((n, 3), self.T)
+        self._call("restrict", C.c_int32(level), _ptr(self._real(fine)), _ptr(y))
+        return y
+
+    def prolong(self, level, coarse):
+        n = self.level(level, coords=False)["nrows"]
+        y = np.empty((n, 3), self.T)
+        self._call("prolong", C.c_int32(level), _ptr(self._real(coarse)), _ptr(y))
+        return y
+
+    def smooth(self, level, kind, iterations, u, r, tolerance=0.0, initial_residual=None):
+        u = np.array(u, dtype=self.T, order="C")
+        r = np.array(r, dtype=self.T, order="C")
+        r0 = self._real(initial_residual)
+        self._call("smooth", C.c_int32(level), C.c_int32(kind), C.c_int32(iterations), C.c_double(tolerance), _ptr(u), _ptr(r), _ptr(r0))
+        return u, r
+
+    def vcycle(self, x):
+        y = np.empty((self.Nn, 3), self.T)
+        self._call("vcycle", _ptr(self._real(x)), _ptr(y))
+        return y
+
+    def solve(self):
+        st = hot_stats()
+        self._call("solve", C.byref(st))
+        return st.as_dict()
+
+    def g2p(self, dt):
+        f = C.c_int32()
+        self._call("g2p", C.c_double(dt), C.byref(f))
+        return f.value
+
+    def advance(self, dt):
+        st = hot_stats()
+        self._call("advance", C.c_double(dt), C.byref(st))
+        return st.as_dict()
+
+    def sync(self):
+        self._call("sync")
+
+    # ---- profiling
+    def profile_reset(self):
+        self._call("profile_reset")
+
+    def profile(self):
+        n = C.c_int32()
+        self._call("profile_count", C.byref(n))
+        out = {}
+        for i in range(n.value):
+            name = C.create_string_buffer(128)
+            calls, ms = C.c_int64(), C.c_double()
+            self._call("profile_get", C.c_int32(i), name, C.byref(calls), C.byref(ms))
+            out[name.value.decode()] = dict(calls=calls.value, total_ms=ms.value)
+        return out

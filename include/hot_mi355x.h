@@ -1,0 +1,180 @@
+/*
+ * hot_mi355x.h — C ABI of libhotmi355x.so: the MI355X-native (gfx950 / HIP) implementation of the HOT
+ * per-timestep hot path (APIC P2G/G2P over the SPGrid block grid + Galerkin-multigrid-preconditioned
+ * L-BFGS / projected-Newton inner solve).
+ *
+ * The reference (penn-graphics-research/HOT) has no FFI: its seams are C++ virtuals, std::function members
+ * and function pointers inside one process.  Every entry point below names the reference
+ * member function(s) it replaces (paths relative to the reference tree).  The header-only C++ adapter
+ * include/hot_adapter.hpp re-exposes these as the reference's operator concept
+ * (multiply / precondition / project / smoother function pointer, TVStack = 3 x N column-major).
+ *
+ * Conventions
+ *   - Opaque context, one per host thread; no global state.  All functions return 0 on success and a
+ *     negative hot_status on failure (the reference throws / asserts instead: Lib/Ziran/CS/Util/Debug.h:19,
+ *     SPGrid_Utilities.cpp:75-85); hot_last_error() gives the message.
+ *   - Scalars of arrays are `real` = float (dtype 0) or double (dtype 1) as chosen in hot_config.dtype; the
+ *     executable of the reference hard-codes double (Projects/multigrid/main.cpp:12-13).
+ *   - Array arguments may be HOST or DEVICE pointers (resolved with hipMemcpyDefault); outputs are written
+ *     to wherever the pointer lives.  NULL output pointers are skipped.
+ *   - Vectors over grid DOFs are "TVStack" layout: 3 x Nn column-major == xyz interleaved per node, node ids
+ *     are the reference's g.idx numbering (Lib/MPM/MpmGrid.h:148-161).  3x3 matrices are column-major
+ *     (Eigen default), particle attributes are array-of-structs in the caller's particle index order.
+ */
+#ifndef HOT_MI355X_H
+#define HOT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hot_ctx hot_ctx;
+
+enum hot_status {
+    HOT_OK = 0,
+    HOT_ERR_INVALID = -1, /* bad argument / call order (reference: ZIRAN_ASSERT) */
+    HOT_ERR_DEVICE = -2, /* HIP runtime error */
+    HOT_ERR_CAPACITY = -3, /* exceeds the reference's own int32 limits (MpmSimulationBase.cpp:1071-1072, ImplicitSolver.h:479-480) */
+    HOT_ERR_NUMERIC = -4 /* NaN encountered (reference: FPE trap, main.cpp:36) */
+};
+
+/* Mirrors the knobs of HOTSettings (Projects/multigrid/Configurations.h:18-42) plus the few
+ * MpmSimulationBase members the path reads (dx, gravity, apic_rpic_ratio, cfl: MpmSimulationBase.cpp:28-40). */
+typedef struct hot_config {
+    int32_t dtype; /* 0 = fp32 (GridState 64 B, 4x4x4 blocks), 1 = fp64 (128 B, 2x4x4 blocks) */
+    int32_t device; /* HIP device ordinal */
+    double dx;
+    double gravity[3];
+    double apic_rpic_ratio; /* 1 */
+    double cfl; /* 0.6 */
+    int32_t lsolver; /* 2 = projected Newton + (MG-)PCG, 3 = L-BFGS with MG initial Hessian (HOT) */
+    int32_t Ainv; /* 0 inverse diagonal entries, 1 inverse 3x3 diagonal block */
+    int32_t smoother; /* 0 damped Jacobi, 1 optimal Jacobi, 2 PCG, 5 symmetric coloured GS, 6 Chebyshev */
+    int32_t coarseSolver; /* same option space, applied on the top level */
+    int32_t levelCnt; /* -mg_level */
+    int32_t times; /* -mg_times */
+    int32_t levelscale; /* -mg_scale */
+    double omega; /* -mg_omega (unused by the reference smoothers, kept for parity) */
+    double topomega; /* damped-Jacobi factor, 0.1 */
+    double cneps; /* -cneps */
+    int32_t useCN; /* --usecn: characteristic-norm termination */
+    int32_t project; /* --project: PSD-project dP/dF */
+    int32_t systemBCProject; /* --bcproject */
+    int32_t linesearch; /* --linesearch */
+    int32_t matrixFree; /* --matfree (lsolver 2 only) */
+    int32_t boundaryType; /* -bc: 0 all sticky, 1 has slip */
+    int32_t useAdaptiveHessian; /* --adaptiveH */
+    int32_t topDownMGS;
+    int32_t max_iterations; /* nonlinear iteration cap (reference scenes set 10000) */
+    int32_t plasticity; /* 0 none, 1 VonMisesFixedCorotated, 2 SnowPlasticity */
+    double yield_stress; /* von Mises */
+    double snow[5]; /* psi, theta_c, theta_s, min_Jp, max_Jp */
+    int32_t profile; /* 1: bracket every kernel launch with HIP events on the launch stream */
+    int32_t reserved[7];
+} hot_config;
+
+typedef struct hot_stats {
+    int32_t iterations; /* nonlinear (L-BFGS / Newton) iterations of the last solve */
+    int32_t converged;
+    int32_t linesearch_trials; /* total updateState calls inside lineSearch */
+    int32_t linear_iterations; /* PCG iterations (lsolver 2) or total top-level PCG iterations (lsolver 3) */
+    int32_t vcycles;
+    int32_t dropped_pairs; /* L-BFGS curvature pairs dropped (y^T s <= 0, LBFGS.h:420-425) */
+    int32_t num_nodes;
+    int32_t num_levels;
+    double final_scaled_residual; /* sqrt(sum |r_i|^2/tol_i^2 / Nn) if useCN else |r|_2 */
+    double energy;
+    double ms_sort, ms_p2g, ms_begin, ms_hessian, ms_mg_build, ms_solve, ms_g2p, ms_total; /* host wall clock, device-synchronised */
+} hot_stats;
+
+void hot_default_config(hot_config* cfg); /* HOT's tog.sh command set: -lsolver 3 -Ainv 1 --project --linesearch --bcproject -mg_level 3 -mg_times 1 -coarseSolver 2 -smoother 5 --usecn -cneps 1e-7 */
+int hot_create(const hot_config* cfg, hot_ctx** out);
+void hot_destroy(hot_ctx* ctx);
+const char* hot_last_error(hot_ctx* ctx);
+int hot_sync(hot_ctx* ctx); /* hipStreamSynchronize on the context's stream */
+
+/* ---- particles (the reference's DataManager columns X, V, "m", C, F, "element measure", and the
+ *      CorotatedIsotropic (mu, lambda) per particle; Jp only for SnowPlasticity; Lib/Ziran/Math/Geometry/Particles.h:8-45) */
+int hot_set_particles(hot_ctx*, int64_t Np, const void* X /*3Np*/, const void* V /*3Np*/, const void* mass /*Np*/,
+    const void* C /*9Np, may be NULL = 0*/, const void* F /*9Np, NULL = I*/, const void* vol /*Np*/,
+    const void* mu /*Np*/, const void* lambda /*Np*/, const void* Jp /*Np or NULL = 1*/);
+int hot_get_particles(hot_ctx*, void* X, void* V, void* C, void* F, void* mu, void* lambda, void* Jp);
+
+/* ---- MpmSimulationBase::sortParticlesAndPolluteGrid (Lib/MPM/MpmSimulationBase.cpp:1066-1137) */
+int hot_sort(hot_ctx*);
+int hot_get_counts(hot_ctx*, int64_t* Np, int32_t* Ng /*particle groups*/, int32_t* Nb /*touched blocks*/, int32_t* Nn /*active nodes, valid after hot_p2g*/);
+/* bit-exact with the reference containers of the same names */
+int hot_get_indexing(hot_ctx*, int32_t* particle_order /*Np*/, uint64_t* particle_base_offset /*Np*/,
+    int32_t* particle_group /*2Ng: first,last*/, uint64_t* block_offset /*Ng page ids*/, uint64_t* blocks /*Nb page byte offsets, insertion order*/);
+
+/* ---- particlesToGrid (MpmSimulationBase.cpp:461-533,611-656) + getNumNodes (MpmGrid.h:148-161) + buildMassMatrix (:817-826) */
+int hot_p2g(hot_ctx*);
+int hot_get_grid(hot_ctx*, int32_t* id2coord /*3Nn*/, void* mass /*Nn*/, void* v /*3Nn*/);
+
+/* ---- collision nodes: the output of buildInitialDvAndVnForNewton's collision query
+ *      (MpmSimulationBase.cpp:1139-1184, CollisionObject.h:16-45).  dv_collide = (v_collider - v_node) per
+ *      collision node, NULL = static collider (-v_node).  Call after hot_p2g, before hot_begin_step. */
+int hot_set_bc(hot_ctx*, int32_t Nc, const int32_t* node_id, const void* P /*9Nc*/, const void* R /*9Nc or NULL=I*/,
+    const void* Rinv /*9Nc or NULL=I*/, const uint8_t* slip /*Nc or NULL=0*/, const void* dv_collide /*3Nc or NULL*/);
+/* Built-in device-side collision query for static STICKY analytic half spaces {x : (x-o).n <= 0}
+ * (AnalyticCollisionObject + HalfSpace, re-evaluated every hot_begin_step; replaces hot_set_bc). */
+int hot_set_sticky_halfspaces(hot_ctx*, int32_t n, const double* origin /*3n*/, const double* normal /*3n*/);
+
+/* ---- MultigridSimulation::startBackwardEuler (Projects/multigrid/MultigridSimulation.h:167-186):
+ *      dv0 = g dt (collider dv on collision nodes), vn = v, Fn = F (backupStrain), resetLSFlag */
+int hot_begin_step(hot_ctx*, double dt);
+int hot_get_dv(hot_ctx*, void* dv /*3Nn*/);
+int hot_set_dv(hot_ctx*, const void* dv /*3Nn*/);
+
+/* ---- ImplicitSolverObjective (Projects/multigrid/ImplicitSolver.h) */
+int hot_update_state(hot_ctx*, const void* dv /*3Nn or NULL = current*/, double* energy); /* updateState :237-252 + totalEnergy :254-275 */
+int hot_get_particle_state(hot_ctx*, void* F /*9Np trial F*/, void* stress /*9Np  V_p P Fn^T*/, void* gradV /*9Np*/);
+int hot_residual(hot_ctx*, void* r /*3Nn*/); /* computeResidual :128-155 at the current state */
+int hot_project(hot_ctx*, void* v /*3Nn in/out*/); /* project lambda, MultigridSimulation.h:105-124 */
+int hot_cn_tolerance(hot_ctx*, void* node_tol /*Nn*/); /* evaluatePerNodeCNTolerance :667-696 */
+int hot_build_hessian(hot_ctx*); /* buildMatrix<true> :470-603 (+ buildDiagonal of level 0) */
+int hot_matfree_multiply(hot_ctx*, const void* x, void* y); /* multiply :741-758 with matrix_free */
+
+/* ---- MultigridBuilder::build (Projects/multigrid/MultigridPreconditioner.h:554-703) */
+int hot_build_mg(hot_ctx*);
+int hot_get_level(hot_ctx*, int32_t level, int32_t* nrows, int32_t* colsize, int32_t* id2coord /*3*nrows or NULL*/);
+/* padded-ELL dump of level's system matrix: entryCol[nrows*colsize], entryVal[nrows*colsize*9]
+ * (row-major slots, 3x3 column-major) — SquareMatrix.h:27-34.  Slot order inside a coarse row is
+ * implementation-defined (the reference's is std::unordered_map iteration order, SquareMatrix.h:560-564). */
+int hot_get_matrix(hot_ctx*, int32_t level, int32_t* entryCol, void* entryVal);
+int hot_get_prolongation(hot_ctx*, int32_t level, int32_t* entryCol /*8*nrows(level)*/, void* weight /*8*nrows(level)*/);
+
+/* ---- operators */
+int hot_spmv(hot_ctx*, int32_t level, const void* x, void* y); /* SquareMatrix::multiply :477-487 */
+int hot_restrict(hot_ctx*, int32_t level, const void* fine, void* coarse); /* SparseMPMMatrix::transposeMultiply */
+int hot_prolong(hot_ctx*, int32_t level, const void* coarse, void* fine); /* SparseMPMMatrix::multiply on promats */
+/* smoother plug point (MultigridPreconditioner.h:67-79): kind uses the -smoother numbering */
+int hot_smooth(hot_ctx*, int32_t level, int32_t kind, int32_t iterations, double tolerance, void* u, void* r,
+    const void* initial_residual /* cg_smooth's reference residual, NULL = r */);
+int hot_vcycle(hot_ctx*, const void* in, void* out); /* MultigridOperator::operator() :362-421 */
+
+/* ---- nonlinear solve: LBFGS::solve (Lib/Ziran/Math/Nonlinear/LBFGS.h:300-437) or
+ *      ExtendedNewtonsMethod::solve (ExtendedNewtonsMethod.h:39-66) + computeStep (ImplicitSolver.h:355-432) */
+int hot_solve(hot_ctx*, hot_stats* stats);
+
+/* ---- restoreStrain + constructNewVelocityFromNewtonResult (MpmSimulationBase.cpp:891-901) + gridToParticles
+ *      (:903-1042) + evolveStrain + applyPlasticity (:1044-1064).  flags: bit0 = some particle moved > dx
+ *      (faster_than_grid_cell), bit1 = > cfl*dx/2 */
+int hot_g2p(hot_ctx*, double dt, int32_t* flags);
+
+/* ---- MultigridSimulation::advanceOneTimeStep (MultigridSimulation.h:235-297) with device-side BCs */
+int hot_advance(hot_ctx*, double dt, hot_stats* stats);
+
+/* ---- per-kernel timings gathered with HIP events on the launch stream when cfg.profile = 1 */
+int hot_profile_reset(hot_ctx*);
+int hot_profile_count(hot_ctx*, int32_t* n);
+int hot_profile_get(hot_ctx*, int32_t i, char* name /*>=64 bytes*/, int64_t* calls, double* total_ms);
+
+const char* hot_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOT_MI355X_H */

@@ -1,0 +1,593 @@
+// ORACLE (test infrastructure only — never linked into the product library; only tests/, bench.py's
+// cpu_baseline leg and __graft_entry__.smoke() may load liboracle.so).
+//
+// CPU restatement of the HOT per-timestep hot path, reproducing the reference's data structures and its
+// TBB parallel decomposition with OpenMP (8-colour SPGrid-block passes for every scatter, block loops for
+// gathers, row-parallel ELL SpMV, block-parallel / in-block-sequential symmetric GS; sections that are
+// serial in the reference are serial here).  Every member cites the reference lines it follows.
+//
+// This file: particle storage, sortParticlesAndPolluteGrid, the sparse block grid, kernel iteration,
+// P2G, DOF numbering, mass vector, BCs, G2P.
+#pragma once
+#include "../include/hot_mi355x.h"
+#include "spgrid_index.hpp"
+#include "corotated.hpp"
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include <omp.h>
+
+namespace hot_oracle {
+
+template <class T>
+struct EllMat { // reference Projects/multigrid/SquareMatrix.h:27-34
+    int colsize = 0, nrows = 0;
+    std::vector<int> entryCol;
+    std::vector<M3<T>> entryVal;
+    std::vector<M3<T>> diagonalVal, diagonalEntry, diagonalBlock;
+    std::array<std::vector<std::vector<int>>, 8> coloredBlockDofs;
+    std::vector<std::array<int, 3>> colorOrder;
+    T lMin = (T)1e-8, lMax = (T)1e2;
+};
+
+template <class T>
+struct Sim {
+    static constexpr int LOG2S = sizeof(T) == 4 ? 6 : 7;
+    using Mask = SpMask<LOG2S>;
+    static constexpr int EPB = Mask::elements_per_block;
+    using TV = V3<T>;
+    using TM = M3<T>;
+
+    struct Node { // reference Lib/MPM/MpmGrid.h:15-34 (GridState: v, m, new_v, idx)
+        TV v;
+        T m;
+        TV new_v;
+        int64_t idx;
+    };
+    struct CollisionNode { // reference Lib/Ziran/Math/Geometry/CollisionObject.h:16-45
+        int node_id;
+        TM P, R, Rinv;
+        bool shouldRotate;
+        TV dv;
+        bool has_dv;
+    };
+
+    hot_config cfg;
+    std::string err;
+    T dx = 0, dt = 0;
+    TV gravity;
+
+    // ---- particles
+    int64_t Np = 0;
+    std::vector<TV> X, Vel;
+    std::vector<T> mass, vol, mu, lambda, Jp;
+    std::vector<TM> C, F, Fn;
+    // ---- sort products (reference MpmSimulationBase.h members of the same names)
+    std::vector<uint64_t> particle_sorter, particle_base_offset;
+    std::vector<int> particle_order;
+    std::vector<std::pair<int, int>> particle_group;
+    std::vector<uint64_t> block_offset; // page ids of the particle groups
+    std::vector<uint64_t> blocks; // touched pages (byte offsets) in Set_Page insertion order
+    std::unordered_map<uint64_t, int> page2block;
+    std::vector<std::array<int, 8>> group_nb; // block ids of the 2x2x2 pages each group scatters into
+    // ---- grid
+    std::vector<Node> nodes; // blocks.size()*EPB, block-major, memory order inside a block
+    int num_nodes = 0;
+    std::vector<int> dof_slot;
+    std::vector<std::array<int, 3>> id2coord;
+    std::vector<T> mass_matrix;
+    std::vector<TV> dv, vn;
+    // ---- BC
+    std::vector<CollisionNode> collision_nodes;
+    std::vector<int> bc_of_node;
+    std::vector<double> hs_origin, hs_normal;
+    // ---- particle scratch (reference MpmForceBase members scratch_gradV / scratch_vp / scratch_stress)
+    std::vector<TM> scratch_gradV, scratch_stress;
+    std::vector<TV> scratch_vp;
+    // ---- objective state (ImplicitSolverObjective)
+    double Ek = 0;
+    bool updated = false;
+    std::vector<TV> dv0, rhs, dRhs;
+    std::vector<T> nodeCNTol;
+    T max_cn_tolerance = 0; // computeCharacteristicNorm's max_tol_p (MultigridSimulation.h:128-165)
+    // ---- matrices
+    std::vector<EllMat<T>> sysmats, promats, resmats;
+    std::vector<std::vector<std::array<int, 3>>> level_coords;
+    std::vector<std::vector<TV>> mg_residuals, mg_initialResiduals, mg_sols, mg_dus, mg_dAus, mg_tmps;
+    int mg_level = 0;
+    hot_stats stats;
+
+    // =============================================================== particles
+    void set_particles(int64_t n, const T* x, const T* v, const T* m, const T* c, const T* f, const T* vl, const T* mu_, const T* la, const T* jp)
+    {
+        Np = n;
+        X.resize(n), Vel.resize(n), mass.resize(n), vol.resize(n), mu.resize(n), lambda.resize(n), Jp.resize(n), C.resize(n), F.resize(n);
+        for (int64_t i = 0; i < n; ++i) {
+            for (int d = 0; d < 3; ++d) X[i](d) = x[3 * i + d], Vel[i](d) = v[3 * i + d];
+            mass[i] = m[i], vol[i] = vl[i], mu[i] = mu_[i], lambda[i] = la[i];
+            Jp[i] = jp ? jp[i] : (T)1;
+            if (c)
+                std::memcpy(C[i].a, c + 9 * i, 9 * sizeof(T));
+            else
+                C[i] = TM::zero();
+            if (f)
+                std::memcpy(F[i].a, f + 9 * i, 9 * sizeof(T));
+            else
+                F[i] = TM::identity();
+        }
+    }
+
+    // =============================================================== indexing helpers
+    // B-spline base node: reference Lib/Ziran/Math/Splines/BSplines.h:16-29, MathTools.h:21-25
+    static inline int int_floor(T x)
+    {
+        int i = (int)x;
+        return i - (i > x);
+    }
+    static inline int base_node(T x_index_space) { return int_floor(x_index_space - (T)0.5); }
+
+    // quadratic B-spline weights: reference BSplines.h:55-81 ; BSplineWeights MpmGrid.h:55-78
+    struct Spline {
+        T w[3][3], dw[3][3], one_over_dx;
+        int base[3];
+    };
+    inline void compute_spline(const TV& Xp, Spline& s) const
+    {
+        s.one_over_dx = 1 / dx;
+        for (int d = 0; d < 3; ++d) {
+            T x = s.one_over_dx * Xp(d);
+            int bn = base_node(x);
+            s.base[d] = bn;
+            T d0 = x - bn;
+            T z = ((T)1.5 - d0);
+            T z2 = z * z;
+            s.w[d][0] = (T)0.5 * z2;
+            T d1 = d0 - 1;
+            s.w[d][1] = (T)0.75 - d1 * d1;
+            T d2 = 1 - d1;
+            T zz = (T)1.5 - d2;
+            T zz2 = zz * zz;
+            s.w[d][2] = (T)0.5 * zz2;
+            s.dw[d][0] = -z;
+            s.dw[d][1] = -(T)2 * d1;
+            s.dw[d][2] = zz;
+        }
+    }
+
+    // node slot of kernel node (i,j,k) for a particle with cell offset `base` in group g.  Equivalent to
+    // Packed_Add(base, Linear_Offset(i,j,k)) + virtual-memory lookup in the reference (MpmGrid.h:286-288):
+    // in-page element coordinates carry into at most the +1 page per axis.
+    inline int node_slot(int g, uint64_t base, int i, int j, int k) const
+    {
+        constexpr int xb = Mask::block_xbits, yb = Mask::block_ybits, zb = Mask::block_zbits;
+        int e = (int)((base & 0xfff) >> Mask::data_bits);
+        int ez = e & ((1 << zb) - 1), ey = (e >> zb) & ((1 << yb) - 1), ex = (e >> (zb + yb)) & ((1 << xb) - 1);
+        int nx = ex + i, ny = ey + j, nz = ez + k;
+        int ox = nx >> xb, oy = ny >> yb, oz = nz >> zb;
+        nx &= (1 << xb) - 1, ny &= (1 << yb) - 1, nz &= (1 << zb) - 1;
+        int elem = (nx << (yb + zb)) | (ny << zb) | nz;
+        return group_nb[g][ox * 4 + oy * 2 + oz] * EPB + elem;
+    }
+
+    // reference MpmGrid::iterateKernel (MpmGrid.h:245-296): i outermost; w_ijk, grad w (already / dx)
+    template <class OP>
+    inline void iterate_kernel(const Spline& s, int g, uint64_t base, const OP& op)
+    {
+        T one_over_dx = s.one_over_dx;
+        int coord[3];
+        for (int i = 0; i < 3; ++i) {
+            T wi = s.w[0][i];
+            T dwidxi = one_over_dx * s.dw[0][i];
+            coord[0] = s.base[0] + i;
+            for (int j = 0; j < 3; ++j) {
+                T wj = s.w[1][j];
+                T wij = wi * wj;
+                T dwijdxi = dwidxi * wj;
+                T dwijdxj = wi * one_over_dx * s.dw[1][j];
+                coord[1] = s.base[1] + j;
+                for (int k = 0; k < 3; ++k) {
+                    coord[2] = s.base[2] + k;
+                    T wk = s.w[2][k];
+                    T wijk = wij * wk;
+                    TV dw{ { dwijdxi * wk, dwijdxj * wk, wij * one_over_dx * s.dw[2][k] } };
+                    op(coord, wijk, dw, nodes[node_slot(g, base, i, j, k)]);
+                }
+            }
+        }
+    }
+
+    // coloured block-parallel particle loop: reference MpmSimulationBase.h:251-264 and every
+    // "for color ... tbb::parallel_for over particle_group" site (e.g. MpmSimulationBase.cpp:621-655)
+    template <class OP>
+    void for_each_particle_colored(const OP& op)
+    {
+        for (uint64_t color = 0; color < 8; ++color) {
+#pragma omp parallel for schedule(dynamic, 4)
+            for (int g = 0; g < (int)particle_group.size(); ++g) {
+                if ((block_offset[g] & 7) != color) continue;
+                for (int idx = particle_group[g].first; idx <= particle_group[g].second; ++idx) op(g, particle_order[idx]);
+            }
+        }
+    }
+    template <class OP>
+    void for_each_particle_by_group(const OP& op)
+    {
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int g = 0; g < (int)particle_group.size(); ++g)
+            for (int idx = particle_group[g].first; idx <= particle_group[g].second; ++idx) op(g, particle_order[idx]);
+    }
+    // iterateGrid (MpmGrid.h:205-243): visits nodes with idx >= 0, block-parallel
+    template <class OP>
+    void iterate_grid(const OP& op)
+    {
+#pragma omp parallel for schedule(static)
+        for (int b = 0; b < (int)blocks.size(); ++b) {
+            auto bc = Mask::linear_to_coord(blocks[b]);
+            for (int i = 0; i < (1 << Mask::block_xbits); ++i)
+                for (int j = 0; j < (1 << Mask::block_ybits); ++j)
+                    for (int k = 0; k < (1 << Mask::block_zbits); ++k) {
+                        int e = (i << (Mask::block_ybits + Mask::block_zbits)) | (j << Mask::block_zbits) | k;
+                        Node& g = nodes[(size_t)b * EPB + e];
+                        if (g.idx >= 0) {
+                            int node[3] = { bc[0] + i, bc[1] + j, bc[2] + k };
+                            op(node, g);
+                        }
+                    }
+        }
+    }
+
+    // =============================================================== sortParticlesAndPolluteGrid
+    // reference Lib/MPM/MpmSimulationBase.cpp:1066-1137
+    int sort_particles()
+    {
+        constexpr int index_bits = 32 - Mask::block_bits;
+        if (Np >= (1LL << index_bits)) {
+            err = "particle count exceeds 2^(32-block_bits)";
+            return HOT_ERR_CAPACITY;
+        }
+        particle_base_offset.resize(Np), particle_sorter.resize(Np), particle_order.resize(Np);
+        T one_over_dx = (T)1 / dx;
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < Np; ++i) {
+            int b[3];
+            for (int d = 0; d < 3; ++d) b[d] = base_node(X[i](d) * one_over_dx);
+            uint64_t offset = Mask::linear_offset(b[0], b[1], b[2]);
+            particle_sorter[i] = ((offset >> Mask::data_bits) << index_bits) + (uint64_t)i;
+        }
+        parallel_sort(particle_sorter);
+
+        particle_group.clear();
+        block_offset.clear();
+        int last_index = 0;
+        for (int64_t i = 0; i < Np; ++i)
+            if (i == Np - 1 || (particle_sorter[i] >> 32) != (particle_sorter[i + 1] >> 32)) {
+                particle_group.push_back(std::make_pair(last_index, (int)i));
+                block_offset.push_back(particle_sorter[i] >> 32);
+                last_index = (int)i + 1;
+            }
+        // page map (serial in the reference): Set_Page on the page and its 2x2x2 upper neighbours,
+        // a page is appended to the block list the first time it is set (SPGrid_Page_Map.h:61-70)
+        blocks.clear();
+        page2block.clear();
+        auto set_page = [&](uint64_t offset) {
+            uint64_t page = (offset >> 12) << 12;
+            if (page2block.find(page) == page2block.end()) {
+                page2block[page] = (int)blocks.size();
+                blocks.push_back(page);
+            }
+        };
+        for (int64_t i = 0; i < Np; ++i) {
+            particle_order[i] = (int)(particle_sorter[i] & ((1ll << index_bits) - 1));
+            uint64_t offset = (particle_sorter[i] >> index_bits) << Mask::data_bits;
+            particle_base_offset[particle_order[i]] = offset;
+            if (i == Np - 1 || (particle_sorter[i] >> 32) != (particle_sorter[i + 1] >> 32)) {
+                set_page(offset);
+                int x = 1 << Mask::block_xbits, y = 1 << Mask::block_ybits, z = 1 << Mask::block_zbits;
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b)
+                        for (int c = 0; c < 2; ++c) set_page(Mask::packed_add(offset, Mask::linear_offset(x * a, y * b, z * c)));
+            }
+        }
+        // neighbour table (replaces the reference's virtual-memory addressing)
+        group_nb.resize(particle_group.size());
+        for (size_t g = 0; g < particle_group.size(); ++g) {
+            uint64_t page = block_offset[g] << 12;
+            int x = 1 << Mask::block_xbits, y = 1 << Mask::block_ybits, z = 1 << Mask::block_zbits;
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b)
+                    for (int c = 0; c < 2; ++c) {
+                        uint64_t p = Mask::packed_add(page, Mask::linear_offset(x * a, y * b, z * c));
+                        group_nb[g][a * 4 + b * 2 + c] = page2block[(p >> 12) << 12];
+                    }
+        }
+        // memset of every touched block, idx = -1 (serial in the reference, :1126-1136)
+        nodes.assign(blocks.size() * (size_t)EPB, Node{ TV::zero(), 0, TV::zero(), -1 });
+        num_nodes = 0;
+        collision_nodes.clear();
+        scratch_gradV.assign(Np, TM::zero());
+        scratch_stress.assign(Np, TM::zero());
+        scratch_vp.assign(Np, TV::zero());
+        return 0;
+    }
+
+    static void parallel_sort(std::vector<uint64_t>& a)
+    {
+        // stands in for tbb::parallel_sort (:1087): chunk sort + pairwise merges
+        int nt = omp_get_max_threads();
+        size_t n = a.size();
+        if (n < 1 << 14 || nt == 1) {
+            std::sort(a.begin(), a.end());
+            return;
+        }
+        int chunks = 1;
+        while (chunks < nt) chunks <<= 1;
+        std::vector<size_t> bounds(chunks + 1);
+        for (int c = 0; c <= chunks; ++c) bounds[c] = n * c / chunks;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int c = 0; c < chunks; ++c) std::sort(a.begin() + bounds[c], a.begin() + bounds[c + 1]);
+        for (int width = 1; width < chunks; width <<= 1) {
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int c = 0; c < chunks; c += 2 * width)
+                std::inplace_merge(a.begin() + bounds[c], a.begin() + bounds[c + width], a.begin() + bounds[std::min(c + 2 * width, chunks)]);
+        }
+    }
+
+    // =============================================================== particlesToGrid
+    // reference MpmSimulationBase.cpp:611-656 (particlesToGridHelper<true,false>) + :521-532
+    void particles_to_grid()
+    {
+        for_each_particle_colored([&](int g, int i) {
+            const TV& Xp = X[i];
+            T m = mass[i];
+            TV momentum = Vel[i] * m;
+            TM Cm = C[i] * m;
+            Spline s;
+            compute_spline(Xp, s);
+            iterate_kernel(s, g, particle_base_offset[i], [&](const int* node, T w, const TV& dw, Node& gs) {
+                TV d{ { node[0] * dx - Xp(0), node[1] * dx - Xp(1), node[2] * dx - Xp(2) } };
+                // velocity_delta = [C m | m v ; 0 | m] * [xi - xp ; 1] * w
+                TV dvel = (Cm * d + momentum) * w;
+                gs.m += m * w;
+                gs.v += dvel;
+            });
+        });
+        num_nodes = get_num_nodes();
+        iterate_grid([&](const int*, Node& g) {
+            if (g.m != 0)
+                g.v = g.v * ((T)1 / g.m);
+            else
+                g.v = TV::zero();
+        });
+        // id2coord is filled by ImplicitSolverObjective::buildMatrix in the reference (ImplicitSolver.h:474-477)
+        id2coord.resize(num_nodes);
+        dof_slot.resize(num_nodes);
+#pragma omp parallel for schedule(static)
+        for (int b = 0; b < (int)blocks.size(); ++b) {
+            auto bc = Mask::linear_to_coord(blocks[b]);
+            for (int e = 0; e < EPB; ++e) {
+                Node& g = nodes[(size_t)b * EPB + e];
+                if (g.idx >= 0) {
+                    int ez = e & ((1 << Mask::block_zbits) - 1), ey = (e >> Mask::block_zbits) & ((1 << Mask::block_ybits) - 1), ex = e >> (Mask::block_zbits + Mask::block_ybits);
+                    id2coord[g.idx] = { bc[0] + ex, bc[1] + ey, bc[2] + ez };
+                    dof_slot[g.idx] = b * EPB + e;
+                }
+            }
+        }
+        build_mass_matrix();
+    }
+
+    // reference MpmGrid::getNumNodes (MpmGrid.h:148-161) — serial, insertion-ordered blocks, memory order
+    int get_num_nodes()
+    {
+        int total = 0;
+        for (size_t b = 0; b < blocks.size(); ++b)
+            for (int e = 0; e < EPB; ++e) {
+                Node& g = nodes[b * EPB + e];
+                if (g.m != 0) g.idx = total++;
+            }
+        return total;
+    }
+
+    // reference MpmSimulationBase.cpp:817-826
+    void build_mass_matrix()
+    {
+        mass_matrix.resize(num_nodes);
+        iterate_grid([&](const int*, Node& g) { mass_matrix[g.idx] = g.m; });
+    }
+
+    // =============================================================== BCs
+    int set_bc(int nc, const int32_t* node_id, const T* P, const T* R, const T* Rinv, const uint8_t* slip, const T* dvc)
+    {
+        collision_nodes.resize(nc);
+        for (int c = 0; c < nc; ++c) {
+            CollisionNode& z = collision_nodes[c];
+            if (node_id[c] < 0 || node_id[c] >= num_nodes) {
+                err = "collision node id out of range";
+                return HOT_ERR_INVALID;
+            }
+            z.node_id = node_id[c];
+            std::memcpy(z.P.a, P + 9 * c, 9 * sizeof(T));
+            if (R)
+                std::memcpy(z.R.a, R + 9 * c, 9 * sizeof(T));
+            else
+                z.R = TM::identity();
+            if (Rinv)
+                std::memcpy(z.Rinv.a, Rinv + 9 * c, 9 * sizeof(T));
+            else
+                z.Rinv = TM::identity();
+            z.shouldRotate = slip ? slip[c] != 0 : false;
+            z.has_dv = dvc != nullptr;
+            if (dvc)
+                for (int d = 0; d < 3; ++d) z.dv(d) = dvc[3 * c + d];
+        }
+        return 0;
+    }
+    // device-side convenience of the product, restated: static STICKY half spaces.  Follows
+    // AnalyticCollisionObject::multiObjectCollision for STICKY objects (CollisionObject.cpp:107-148):
+    // normal_basis = I  =>  P = 0, vi = collider velocity = 0.
+    void eval_halfspaces()
+    {
+        if (hs_origin.empty()) return;
+        collision_nodes.clear();
+        for (int n = 0; n < num_nodes; ++n) {
+            bool inside = false;
+            for (size_t h = 0; h < hs_origin.size() / 3; ++h) {
+                double s = 0;
+                for (int d = 0; d < 3; ++d) s += ((double)((T)id2coord[n][d] * dx) - hs_origin[3 * h + d]) * hs_normal[3 * h + d];
+                if (s <= 0) inside = true;
+            }
+            if (inside) {
+                CollisionNode z;
+                z.node_id = n;
+                z.P = TM::zero();
+                z.R = z.Rinv = TM::identity();
+                z.shouldRotate = false;
+                z.has_dv = false;
+                collision_nodes.push_back(z);
+            }
+        }
+    }
+
+    // reference MultigridSimulation::startBackwardEuler (MultigridSimulation.h:167-186) +
+    // buildInitialDvAndVnForNewton (MpmSimulationBase.cpp:1139-1184) + backupStrain (FBasedMpmForceHelper.cpp:24-33)
+    void begin_step(T dt_)
+    {
+        dt = dt_;
+        eval_halfspaces();
+        dv.resize(num_nodes), vn.resize(num_nodes);
+        bc_of_node.assign(num_nodes, -1);
+        for (size_t c = 0; c < collision_nodes.size(); ++c) bc_of_node[collision_nodes[c].node_id] = (int)c;
+        iterate_grid([&](const int*, Node& g) {
+            int id = (int)g.idx;
+            int c = bc_of_node[id];
+            if (c >= 0)
+                dv[id] = collision_nodes[c].has_dv ? collision_nodes[c].dv : g.v * (T)-1;
+            else
+                dv[id] = gravity * dt;
+            vn[id] = g.v;
+        });
+        Fn = F;
+        // resetLSFlag (ImplicitSolver.h:277-282)
+        updated = false;
+        dv0 = dv;
+    }
+
+    // project lambda: reference MultigridSimulation.h:105-124
+    void project(std::vector<TV>& v) const
+    {
+        bool slipmode = cfg.systemBCProject && cfg.boundaryType == 1;
+        for (const auto& z : collision_nodes) {
+            if (slipmode) {
+                if (z.shouldRotate)
+                    v[z.node_id](0) = 0;
+                else
+                    v[z.node_id] = TV::zero();
+            }
+            else
+                v[z.node_id] = z.P * v[z.node_id];
+        }
+    }
+    // reference ImplicitSolver.h:106-125
+    void recover_solution(std::vector<TV>& ddv) const
+    {
+        if (cfg.systemBCProject && cfg.boundaryType == 1)
+            for (const auto& z : collision_nodes)
+                if (z.shouldRotate) ddv[z.node_id] = z.Rinv * ddv[z.node_id];
+    }
+    void transform_residual(std::vector<TV>& r) const
+    {
+        if (cfg.systemBCProject && cfg.boundaryType == 1)
+            for (const auto& z : collision_nodes)
+                if (z.shouldRotate) r[z.node_id] = z.R * r[z.node_id];
+    }
+
+    // =============================================================== gridToParticles
+    // reference MpmSimulationBase.cpp:891-901 (constructNewVelocityFromNewtonResult), :930-1042
+    // (gridToParticlesHelper<true,false,false>), evolveStrain (FBasedMpmForceHelper.cpp:99-114),
+    // applyPlasticity (:1044-1064)
+    int grid_to_particles(double dt_)
+    {
+        F = Fn; // force->restoreStrain(), MultigridSimulation.h:231
+#pragma omp parallel for schedule(static)
+        for (size_t s = 0; s < nodes.size(); ++s) nodes[s].new_v = TV::zero();
+        iterate_grid([&](const int*, Node& g) { g.new_v = g.v + dv[g.idx]; });
+        T D_inverse = (T)4 / (dx * dx); // MpmSimulationBase.cpp:113-118
+        T r = (T)cfg.apic_rpic_ratio;
+        int flags = 0;
+        T dtT = (T)dt_;
+#pragma omp parallel for schedule(dynamic, 4) reduction(| : flags)
+        for (int g = 0; g < (int)particle_group.size(); ++g)
+            for (int idx = particle_group[g].first; idx <= particle_group[g].second; ++idx) {
+                int i = particle_order[idx];
+                TV& Xp = X[i];
+                TV picV = TV::zero();
+                Spline s;
+                compute_spline(Xp, s);
+                TM Bp = TM::zero();
+                TM gradVp = TM::zero();
+                iterate_kernel(s, g, particle_base_offset[i], [&](const int* node, T w, const TV& dw, Node& gs) {
+                    picV += gs.new_v * w;
+                    TV d{ { node[0] * dx - Xp(0), node[1] * dx - Xp(1), node[2] * dx - Xp(2) } };
+                    Bp += outer(gs.new_v * w, d);
+                    gradVp += outer(gs.new_v, dw);
+                });
+                scratch_gradV[i] = gradVp;
+                Vel[i] = picV;
+                TM CC = Bp * D_inverse;
+                C[i] = CC * ((r + 1) * (T)0.5) + CC.transpose() * ((r - 1) * (T)0.5);
+                TV increment = picV * dtT;
+                Xp += increment;
+                T inc = increment.squaredNorm();
+                T dx2 = dx * dx;
+                if (inc > dx2) flags |= 1;
+                if (inc > dx2 * (T)0.25 * (T)(cfg.cfl * cfg.cfl)) flags |= 2;
+            }
+        // evolveStrain
+#pragma omp parallel for schedule(static)
+        for (int64_t p = 0; p < Np; ++p) F[p] = (TM::identity() + scratch_gradV[p] * dtT) * F[p];
+        // applyPlasticity
+        if (cfg.plasticity == 1) {
+#pragma omp parallel for schedule(static)
+            for (int64_t p = 0; p < Np; ++p) von_mises_project(F[p], mu[p], lambda[p], (T)cfg.yield_stress);
+        }
+        else if (cfg.plasticity == 2) {
+#pragma omp parallel for schedule(static)
+            for (int64_t p = 0; p < Np; ++p)
+                snow_project(F[p], mu[p], lambda[p], Jp[p], (T)cfg.snow[0], (T)cfg.snow[1], (T)cfg.snow[2], (T)cfg.snow[3], (T)cfg.snow[4]);
+        }
+        return flags;
+    }
+
+    // members defined in sim_force.hpp / sim_matrix.hpp / sim_solve.hpp
+    void eval_interpolant_and_gradient(const std::vector<TV>& f);
+    void update_position_based_state();
+    double force_total_energy();
+    double total_energy();
+    void update_state(const std::vector<TV>& dv_in);
+    void rasterize_force(T scale, std::vector<TV>& force);
+    void compute_residual(std::vector<TV>& residual);
+    void evaluate_cn_tolerance();
+    void matfree_multiply(const std::vector<TV>& x, std::vector<TV>& b);
+    void build_matrix();
+    static void build_diagonal(EllMat<T>& m, int opt);
+    static void multiply(const EllMat<T>& m, const std::vector<TV>& x, std::vector<TV>& b);
+    static void mark_colors(const std::vector<std::array<int, 3>>& coords, EllMat<T>& m);
+    static void build_product(EllMat<T>& out, const EllMat<T>& l, const EllMat<T>& r);
+    static void build_transpose(EllMat<T>& out, const EllMat<T>& l, int rowcnt);
+    void build_mg();
+    void scaler(const std::vector<TV>& r, std::vector<TV>& mr, const EllMat<T>& A) const;
+    void smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r, std::vector<TV>& du, std::vector<TV>& dAu, int iterations, T tolerance);
+    void vcycle(const std::vector<TV>& in, std::vector<TV>& out);
+    void precondition(const std::vector<TV>& in, std::vector<TV>& out);
+    bool should_exit(const std::vector<TV>& residual);
+    T line_search(std::vector<TV>& ddv, std::vector<TV>& residual, T alpha);
+    bool lbfgs_solve();
+    bool newton_solve();
+    int solve();
+    int advance(double dt_);
+};
+
+} // namespace hot_oracle

@@ -1,0 +1,540 @@
+// ORACLE (test infrastructure only).  Hessian assembly (padded ELL-125 of 3x3 blocks), Galerkin multigrid
+// hierarchy, smoothers and the V-cycle.
+#pragma once
+#include "sim_force.hpp"
+#include <map>
+
+namespace hot_oracle {
+
+static inline int linear_offset125(int dx, int dy, int dz) { return (dx + 2) * 25 + (dy + 2) * 5 + dz + 2; } // ImplicitSolver.h:465-468
+
+// reference ImplicitSolverObjective::buildMatrix<true> (Projects/multigrid/ImplicitSolver.h:470-603) with
+// FBasedMpmForceHelper::runLambdaWithDifferential (Lib/MPM/Force/FBasedMpmForceHelper.h:63-121)
+template <class T>
+void Sim<T>::build_matrix()
+{
+    sysmats.assign(1, EllMat<T>());
+    EllMat<T>& A = sysmats[0];
+    A.colsize = 125;
+    A.nrows = num_nodes;
+    A.entryCol.assign((size_t)num_nodes * 125, -1);
+    A.entryVal.assign((size_t)num_nodes * 125, TM::zero());
+    dRhs.assign(num_nodes, TV::zero());
+    level_coords.assign(1, id2coord);
+    // inertia term
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < num_nodes; ++n) {
+        A.entryCol[(size_t)n * 125 + linear_offset125(0, 0, 0)] = n;
+        A.entryVal[(size_t)n * 125 + linear_offset125(0, 0, 0)] = TM::identity() * mass_matrix[n];
+    }
+    // force term
+    T force_scale = dt * dt;
+    bool proj = cfg.project != 0;
+    for_each_particle_colored([&](int g, int i) {
+        CorotatedScratch<T> s;
+        corotated_update_scratch(F[i], mu[i], lambda[i], proj, s);
+        T ddF[81];
+        corotated_first_piola_derivative(s, ddF);
+        const TM& Fn_local = Fn[i];
+        TM FnT = Fn_local.transpose();
+        Spline sp;
+        compute_spline(X[i], sp);
+        TV cached_w[27];
+        int cached_node[27][3];
+        int cached_idx[27];
+        int cnt = 0;
+        iterate_kernel(sp, g, particle_base_offset[i], [&](const int* node, T, const TV& dw, Node& gs) {
+            if (gs.idx < 0) return;
+            cached_w[cnt] = FnT * dw;
+            cached_node[cnt][0] = node[0], cached_node[cnt][1] = node[1], cached_node[cnt][2] = node[2];
+            cached_idx[cnt++] = (int)gs.idx;
+        });
+        for (int a = 0; a < cnt; ++a) {
+            const TV& wi = cached_w[a];
+            int dofi = cached_idx[a];
+            for (int b = 0; b < cnt; ++b) {
+                const TV& wj = cached_w[b];
+                int dofj = cached_idx[b];
+                if (dofj < dofi) continue;
+                TM dFdX = TM::zero();
+                for (int q = 0; q < 3; ++q)
+                    for (int v = 0; v < 3; ++v) {
+                        T ww = wi(v) * wj(q);
+                        // ddF.block<3,3>(3*v, 3*q)
+                        for (int r = 0; r < 3; ++r)
+                            for (int c = 0; c < 3; ++c) dFdX(r, c) += ddF[(3 * v + r) + 9 * (3 * q + c)] * ww;
+                    }
+                TM delta = dFdX * (force_scale * vol[i]);
+                size_t sij = (size_t)dofi * 125 + linear_offset125(cached_node[a][0] - cached_node[b][0], cached_node[a][1] - cached_node[b][1], cached_node[a][2] - cached_node[b][2]);
+                A.entryCol[sij] = dofj;
+                A.entryVal[sij] += delta;
+                if (dofi != dofj) {
+                    size_t sji = (size_t)dofj * 125 + linear_offset125(cached_node[b][0] - cached_node[a][0], cached_node[b][1] - cached_node[a][1], cached_node[b][2] - cached_node[a][2]);
+                    A.entryCol[sji] = dofi;
+                    A.entryVal[sji] += delta.transpose();
+                }
+            }
+        }
+    });
+    // BC projection of the assembled system (:554-593), or only the padding rule (:594-602)
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < num_nodes; ++i) {
+        size_t st = (size_t)i * 125, ed = st + 125;
+        int ic = cfg.systemBCProject ? bc_of_node[i] : -1;
+        bool iCollide = ic >= 0;
+        bool iSlip = iCollide ? collision_nodes[ic].shouldRotate : false;
+        for (; st < ed; ++st) {
+            int j = A.entryCol[st];
+            if (j == -1) {
+                A.entryCol[st] = i > 0 ? 0 : 1;
+                continue;
+            }
+            if (!cfg.systemBCProject) continue;
+            int jc = bc_of_node[j];
+            bool jCollide = jc >= 0;
+            if (!iCollide && !jCollide) continue;
+            bool jSlip = jCollide ? collision_nodes[jc].shouldRotate : false;
+            TM& val = A.entryVal[st];
+            if ((iCollide && !iSlip) || (jCollide && !jSlip)) {
+                val = (j == i) ? TM::identity() : TM::zero();
+                continue;
+            }
+            if (iSlip) val = collision_nodes[ic].R * val;
+            if (jSlip) val = val * collision_nodes[jc].Rinv;
+            if (iSlip) val(0, 0) = 0, val(0, 1) = 0, val(0, 2) = 0;
+            if (jSlip) val(0, 0) = 0, val(1, 0) = 0, val(2, 0) = 0;
+            if (i == j) val(0, 0) = 1;
+        }
+    }
+}
+
+// reference SquareMatrix::buildDiagonal (Projects/multigrid/SquareMatrix.h:301-324)
+template <class T>
+void Sim<T>::build_diagonal(EllMat<T>& m, int opt)
+{
+    int n = m.nrows;
+    m.diagonalVal.resize(n), m.diagonalBlock.resize(n);
+    if (opt == 0) m.diagonalEntry.resize(n);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        TM d = TM::zero();
+        for (size_t idx = (size_t)i * m.colsize; idx < (size_t)(i + 1) * m.colsize; ++idx)
+            if (m.entryCol[idx] == i) d += m.entryVal[idx];
+        m.diagonalVal[i] = d;
+        if (opt == 0) {
+            TM e = TM::zero();
+            for (int k = 0; k < 3; ++k) e(k, k) = 1 / d(k, k);
+            m.diagonalEntry[i] = e;
+        }
+        m.diagonalBlock[i] = inverse(d);
+    }
+}
+
+// reference SquareMatrix::multiply (SquareMatrix.h:477-487): every padded slot is multiplied
+template <class T>
+void Sim<T>::multiply(const EllMat<T>& m, const std::vector<TV>& x, std::vector<TV>& b)
+{
+    b.resize(m.nrows);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < m.nrows; ++i) {
+        TV sum = TV::zero();
+        for (size_t idx = (size_t)i * m.colsize; idx < (size_t)(i + 1) * m.colsize; ++idx) sum += m.entryVal[idx] * x[m.entryCol[idx]];
+        b[i] = sum;
+    }
+}
+
+// reference markColors lambda (Projects/multigrid/MultigridPreconditioner.h:582-605): always 4^3 blocks,
+// colour = parity bits of the block coordinates, block ids in first-touch order, 1-based index in block
+template <class T>
+void Sim<T>::mark_colors(const std::vector<std::array<int, 3>>& coords, EllMat<T>& m)
+{
+    using ULL = unsigned long long;
+    constexpr ULL hash_seed = 100007;
+    m.colorOrder.resize(coords.size());
+    for (auto& b : m.coloredBlockDofs) b.clear();
+    std::array<int, 8> blockCnts;
+    blockCnts.fill(0);
+    std::array<std::unordered_map<ULL, int>, 8> blockIds;
+    for (int i = 0; i < (int)coords.size(); ++i) {
+        int bi[3];
+        for (int d = 0; d < 3; ++d) bi[d] = coords[i][d] >> 2;
+        int color = ((bi[0] & 1) << 2) | ((bi[1] & 1) << 1) | (bi[2] & 1);
+        ULL key = (ULL)bi[0] * hash_seed * hash_seed + (ULL)bi[1] * hash_seed + (ULL)bi[2];
+        auto it = blockIds[color].find(key);
+        int blockId;
+        if (it == blockIds[color].end()) {
+            blockId = blockCnts[color]++;
+            blockIds[color][key] = blockId;
+            m.coloredBlockDofs[color].emplace_back();
+        }
+        else
+            blockId = it->second;
+        m.coloredBlockDofs[color][blockId].push_back(i);
+        m.colorOrder[i] = { color, blockId, (int)m.coloredBlockDofs[color][blockId].size() };
+    }
+}
+
+// reference SquareMatrix::buildCoarseMatrix (SquareMatrix.h:526-571): out = l * r as padded ELL.  The
+// reference orders the slots of a row by std::unordered_map iteration; here they are ordered by column
+// (the set of (col, value) pairs per row is identical; slot order is not part of the parity contract).
+template <class T>
+void Sim<T>::build_product(EllMat<T>& out, const EllMat<T>& l, const EllMat<T>& r)
+{
+    int n = l.nrows;
+    std::vector<std::vector<std::pair<int, TM>>> rows(n);
+    int colsize = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(max : colsize)
+    for (int i = 0; i < n; ++i) {
+        std::vector<std::pair<int, TM>> tmp;
+        tmp.reserve((size_t)l.colsize * r.colsize);
+        for (size_t j = (size_t)i * l.colsize; j < (size_t)(i + 1) * l.colsize; ++j) {
+            int jj = l.entryCol[j];
+            for (size_t k = (size_t)jj * r.colsize; k < (size_t)(jj + 1) * r.colsize; ++k) tmp.emplace_back(r.entryCol[k], l.entryVal[j] * r.entryVal[k]);
+        }
+        std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<int, TM>& a, const std::pair<int, TM>& b) { return a.first < b.first; });
+        auto& row = rows[i];
+        for (auto& p : tmp) {
+            if (!row.empty() && row.back().first == p.first)
+                row.back().second += p.second;
+            else
+                row.push_back(p);
+        }
+        colsize = std::max(colsize, (int)row.size());
+    }
+    out.colsize = colsize;
+    out.nrows = n;
+    out.entryCol.resize((size_t)n * colsize);
+    out.entryVal.resize((size_t)n * colsize);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        size_t idx = (size_t)i * colsize;
+        for (auto& p : rows[i]) {
+            out.entryCol[idx] = p.first;
+            out.entryVal[idx] = p.second;
+            ++idx;
+        }
+        for (; idx < (size_t)(i + 1) * colsize; ++idx) {
+            out.entryCol[idx] = i > 0 ? 0 : 1;
+            out.entryVal[idx] = TM::zero();
+        }
+    }
+}
+
+// reference SquareMatrix::buildTransposeMatrix (SquareMatrix.h:573-607): pattern transpose, 3x3 values are
+// NOT transposed (they are w*I for the prolongation)
+template <class T>
+void Sim<T>::build_transpose(EllMat<T>& out, const EllMat<T>& l, int rowcnt)
+{
+    std::vector<std::map<int, TM>> data(rowcnt);
+    for (int i = 0; i < l.nrows; ++i)
+        for (size_t j = (size_t)i * l.colsize; j < (size_t)(i + 1) * l.colsize; ++j) {
+            int jj = l.entryCol[j];
+            auto it = data[jj].find(i);
+            if (it == data[jj].end())
+                data[jj][i] = l.entryVal[j];
+            else
+                it->second += l.entryVal[j];
+        }
+    int colsize = 0;
+    for (auto& d : data) colsize = std::max(colsize, (int)d.size());
+    out.colsize = colsize;
+    out.nrows = rowcnt;
+    out.entryCol.resize((size_t)rowcnt * colsize);
+    out.entryVal.resize((size_t)rowcnt * colsize);
+    for (int i = 0; i < rowcnt; ++i) {
+        size_t idx = (size_t)i * colsize;
+        for (auto& p : data[i]) {
+            out.entryCol[idx] = p.first;
+            out.entryVal[idx] = p.second;
+            ++idx;
+        }
+        for (; idx < (size_t)(i + 1) * colsize; ++idx) {
+            out.entryCol[idx] = i > 0 ? 0 : 1;
+            out.entryVal[idx] = TM::zero();
+        }
+    }
+}
+
+// reference MultigridBuilder::build (MultigridPreconditioner.h:554-703), kernel_range == 2 (trilinear P,
+// linear_weight_template :445-466), R = P^T, A_{l+1} = R (A_l P)
+template <class T>
+void Sim<T>::build_mg()
+{
+    using ULL = unsigned long long;
+    constexpr ULL hash_seed = 100007;
+    int levelCnt = cfg.levelCnt;
+    sysmats.resize(1);
+    promats.clear(), resmats.clear();
+    level_coords.resize(1);
+    bool colors = (cfg.coarseSolver == 5 || cfg.smoother == 5);
+    build_diagonal(sysmats[0], cfg.Ainv);
+    if (colors) mark_colors(level_coords[0], sysmats[0]);
+    const T w1d[2][3] = { { 0, 1, 0 }, { 0, (T)0.5, (T)0.5 } };
+    for (int level = 0; level < levelCnt - 1; ++level) {
+        const auto& coords = level_coords[level];
+        std::vector<std::array<int, 3>> new_coords;
+        std::unordered_map<ULL, int> new_coord2id;
+        EllMat<T> P;
+        P.colsize = 8;
+        P.nrows = (int)coords.size();
+        P.entryCol.resize(coords.size() * 8);
+        P.entryVal.resize(coords.size() * 8);
+        for (int i = 0; i < (int)coords.size(); ++i) {
+            int x = coords[i][0], y = coords[i][1], z = coords[i][2];
+            for (int new_x = x / 2; new_x <= x / 2 + 1; ++new_x)
+                for (int new_y = y / 2; new_y <= y / 2 + 1; ++new_y)
+                    for (int new_z = z / 2; new_z <= z / 2 + 1; ++new_z) {
+                        int linear_idx = (new_x - x / 2) * 4 + (new_y - y / 2) * 2 + new_z - z / 2;
+                        T weight = w1d[x & 1][new_x - x / 2 + 1] * w1d[y & 1][new_y - y / 2 + 1] * w1d[z & 1][new_z - z / 2 + 1];
+                        if (weight == 0) {
+                            P.entryCol[(size_t)i * 8 + linear_idx] = P.entryCol[(size_t)i * 8];
+                            P.entryVal[(size_t)i * 8 + linear_idx] = TM::zero();
+                            continue;
+                        }
+                        ULL key = (ULL)new_x * hash_seed * hash_seed + (ULL)new_y * hash_seed + (ULL)new_z;
+                        auto it = new_coord2id.find(key);
+                        int j;
+                        if (it == new_coord2id.end()) {
+                            new_coords.push_back({ new_x, new_y, new_z });
+                            j = (int)new_coords.size() - 1;
+                            new_coord2id[key] = j;
+                        }
+                        else
+                            j = it->second;
+                        P.entryCol[(size_t)i * 8 + linear_idx] = j;
+                        P.entryVal[(size_t)i * 8 + linear_idx] = TM::identity() * weight;
+                    }
+        }
+        EllMat<T> R;
+        build_transpose(R, P, (int)new_coords.size());
+        EllMat<T> AP, RAP;
+        build_product(AP, sysmats[level], P);
+        build_product(RAP, R, AP);
+        build_diagonal(RAP, cfg.Ainv);
+        if (colors) mark_colors(new_coords, RAP);
+        promats.push_back(std::move(P));
+        resmats.push_back(std::move(R));
+        sysmats.push_back(std::move(RAP));
+        level_coords.push_back(std::move(new_coords));
+    }
+    int L = (int)sysmats.size();
+    mg_residuals.resize(L), mg_initialResiduals.resize(L), mg_sols.resize(L), mg_dus.resize(L), mg_dAus.resize(L), mg_tmps.resize(L);
+    for (int l = 0; l < L; ++l) {
+        size_t n = sysmats[l].nrows;
+        mg_residuals[l].assign(n, TV::zero()), mg_initialResiduals[l].assign(n, TV::zero()), mg_sols[l].assign(n, TV::zero());
+        mg_dus[l].assign(n, TV::zero()), mg_dAus[l].assign(n, TV::zero()), mg_tmps[l].assign(n, TV::zero());
+    }
+}
+
+// scale_diagonal_{entry,block}_inverse: MultigridPreconditioner.h:143-154, selected by Ainv (:485-495)
+template <class T>
+void Sim<T>::scaler(const std::vector<TV>& r, std::vector<TV>& mr, const EllMat<T>& A) const
+{
+    mr.resize(r.size());
+    const auto& D = cfg.Ainv == 0 ? A.diagonalEntry : A.diagonalBlock;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < (int)r.size(); ++i) mr[i] = D[i] * r[i];
+}
+
+template <class T>
+static inline T dot_product(const std::vector<V3<T>>& a, const std::vector<V3<T>>& b)
+{
+    // reference dotProduct is a serial Eigen reduction (MultigridPreconditioner.h:155-158)
+    T s = 0;
+    for (size_t i = 0; i < a.size(); ++i) s += a[i].dot(b[i]);
+    return s;
+}
+
+template <class T>
+static inline int color_comp(const std::array<int, 3>& a, const std::array<int, 3>& b)
+{
+    for (int i = 0; i < 3; ++i) {
+        if (a[i] < b[i]) return -1;
+        if (a[i] > b[i]) return 1;
+    }
+    return 0; // the reference falls off the end here (UB, SquareMatrix.h:39-46); equal keys multiply a zero vector
+}
+
+// smoothers: reference MultigridPreconditioner.h:160-173 (jacobi), :174-189 (optimal jacobi), :190-226 (cg),
+// :227-264 (chebyshev), :266-318 (gs)
+template <class T>
+void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r, std::vector<TV>& du, std::vector<TV>& dAu, int iterations, T tolerance)
+{
+    EllMat<T>& A = sysmats[level];
+    int n = A.nrows;
+    // A.project is the objective's projection only on level 0 when the system is NOT BC-projected (:690-693)
+    auto Aproject = [&](std::vector<TV>& v) {
+        if (level == 0 && !cfg.systemBCProject) project(v);
+    };
+    if (kind == 0) {
+        for (; iterations--;) {
+            scaler(r, du, A);
+            for (int i = 0; i < n; ++i) du[i] = du[i] * (T)cfg.topomega;
+            for (int i = 0; i < n; ++i) u[i] += du[i];
+            multiply(A, du, dAu);
+            Aproject(dAu);
+            for (int i = 0; i < n; ++i) r[i] -= dAu[i];
+        }
+    }
+    else if (kind == 1) {
+        for (; iterations--;) {
+            if (std::sqrt(dot_product(r, r)) < tolerance) break;
+            scaler(r, du, A);
+            multiply(A, du, dAu);
+            Aproject(dAu);
+            T omega = dot_product(du, r) / dot_product(du, dAu);
+            for (int i = 0; i < n; ++i) u[i] += du[i] * omega, r[i] -= dAu[i] * omega;
+        }
+    }
+    else if (kind == 2) {
+        std::vector<TV>& z = mg_tmps[level];
+        scaler(mg_initialResiduals[level], z, A);
+        T zTrk0 = dot_product(z, mg_initialResiduals[level]);
+        scaler(r, z, A);
+        du = z;
+        T zTrk = dot_product(z, r);
+        double cgratio = 0.5;
+        tolerance = (T)(zTrk0 * cgratio * cgratio);
+        int cnt = 0;
+        for (; iterations--;) {
+            if (zTrk < tolerance) break;
+            multiply(A, du, dAu);
+            Aproject(dAu);
+            T omega = zTrk / dot_product(dAu, du);
+            for (int i = 0; i < n; ++i) u[i] += du[i] * omega, r[i] -= dAu[i] * omega;
+            scaler(r, z, A);
+            T zTrkPre = zTrk;
+            zTrk = dot_product(z, r);
+            T beta = zTrk / zTrkPre;
+            for (int i = 0; i < n; ++i) du[i] = z[i] + du[i] * beta;
+            ++cnt;
+        }
+        stats.linear_iterations += cnt;
+    }
+    else if (kind == 5) {
+        std::vector<TV>& hdu = mg_tmps[level];
+        iterations = ((iterations + 1) >> 1);
+        for (; iterations--;) {
+            hdu.assign(n, TV::zero());
+            for (int c = 0; c < 8; ++c) {
+#pragma omp parallel for schedule(dynamic, 4)
+                for (int bid = 0; bid < (int)A.coloredBlockDofs[c].size(); ++bid) {
+                    const auto& blockNodes = A.coloredBlockDofs[c][bid];
+                    for (int ii = 0; ii < (int)blockNodes.size(); ++ii) {
+                        int i = blockNodes[ii];
+                        TV sigma = TV::zero();
+                        for (size_t st = (size_t)i * A.colsize; st < (size_t)(i + 1) * A.colsize; ++st) {
+                            int col = A.entryCol[st];
+                            if (color_comp<T>(A.colorOrder[col], A.colorOrder[i]) < 0) sigma += A.entryVal[st] * hdu[col];
+                        }
+                        hdu[i] = A.diagonalBlock[i] * (r[i] - sigma);
+                    }
+                }
+            }
+            for (int i = 0; i < n; ++i) hdu[i] = A.diagonalVal[i] * hdu[i];
+            du.assign(n, TV::zero());
+            for (int c = 7; c >= 0; --c) {
+#pragma omp parallel for schedule(dynamic, 4)
+                for (int bid = 0; bid < (int)A.coloredBlockDofs[c].size(); ++bid) {
+                    const auto& blockNodes = A.coloredBlockDofs[c][bid];
+                    for (int ii = (int)blockNodes.size() - 1; ii >= 0; --ii) {
+                        int i = blockNodes[ii];
+                        TV sigma = TV::zero();
+                        for (size_t st = (size_t)i * A.colsize; st < (size_t)(i + 1) * A.colsize; ++st) {
+                            int col = A.entryCol[st];
+                            if (color_comp<T>(A.colorOrder[col], A.colorOrder[i]) > 0) sigma += A.entryVal[st] * du[col];
+                        }
+                        du[i] = A.diagonalBlock[i] * (hdu[i] - sigma);
+                    }
+                }
+            }
+            for (int i = 0; i < n; ++i) u[i] += du[i];
+            multiply(A, du, dAu);
+            Aproject(dAu);
+            for (int i = 0; i < n; ++i) r[i] -= dAu[i];
+        }
+    }
+    else if (kind == 6) {
+        std::vector<TV>& p = mg_tmps[level];
+        T d = (A.lMax + A.lMin) / 2, c = (A.lMax - A.lMin) / 2;
+        int cnt = 1;
+        iterations--;
+        scaler(r, p, A);
+        T alpha = 1 / d, beta;
+        du = p;
+        multiply(A, du, dAu);
+        Aproject(dAu);
+        for (int i = 0; i < n; ++i) u[i] += du[i] * alpha, r[i] -= dAu[i] * alpha;
+        for (; iterations-- > 0; ++cnt) {
+            scaler(r, p, A);
+            beta = (T)0.5 * c * c * alpha * alpha;
+            if (cnt > 1) beta *= (T)0.5;
+            alpha = 1 / (d - beta / alpha);
+            for (int i = 0; i < n; ++i) du[i] = p[i] + du[i] * beta;
+            multiply(A, du, dAu);
+            Aproject(dAu);
+            for (int i = 0; i < n; ++i) u[i] += du[i] * alpha, r[i] -= dAu[i] * alpha;
+        }
+    }
+}
+
+// reference MultigridOperator::operator() (MultigridPreconditioner.h:362-421) with setup_parameters (:525-551)
+template <class T>
+void Sim<T>::vcycle(const std::vector<TV>& in, std::vector<TV>& out)
+{
+    int levelCnt = (int)sysmats.size();
+    int times = cfg.times, levelscale = cfg.levelscale;
+    int splitLevel;
+    auto downIter = [&](int level) { return times + level * levelscale; };
+    std::function<int(int)> upIter, topIter;
+    if (cfg.topDownMGS) {
+        splitLevel = 1;
+        upIter = [](int) { return 0; };
+        topIter = [](int) { return 10000; };
+    }
+    else {
+        splitLevel = cfg.levelCnt - 1;
+        upIter = downIter;
+        if (cfg.levelCnt == 1)
+            topIter = upIter;
+        else if (!(cfg.coarseSolver == 2 || cfg.coarseSolver == 6))
+            topIter = [&](int level) { return (times + level * levelscale) * 3; };
+        else
+            topIter = [](int) { return 10000; };
+    }
+    auto tolTop = [&](int) { return (T)(cfg.cneps * cfg.cneps); };
+    auto run = [&](bool regular, int level, std::vector<TV>& sol, int its) {
+        smooth(regular ? cfg.smoother : cfg.coarseSolver, level, sol, mg_residuals[level], mg_dus[level], mg_dAus[level], its, regular ? (T)0 : tolTop(level));
+    };
+    stats.vcycles++;
+    mg_residuals[0] = in;
+    if (cfg.systemBCProject)
+        for (int i = 0; i < (int)in.size(); ++i) mg_residuals[0][i] += dRhs[i];
+    out.assign(in.size(), TV::zero());
+    if (levelCnt > 1)
+        multiply(resmats[0], mg_residuals[0], mg_initialResiduals[1]);
+    else
+        mg_initialResiduals[0] = mg_residuals[0];
+    for (int l = 1; l < levelCnt - 1; ++l) multiply(resmats[l], mg_initialResiduals[l], mg_initialResiduals[l + 1]);
+    int level;
+    for (level = 0; level < levelCnt - 1; ++level) {
+        std::vector<TV>& sol = level == 0 ? out : mg_sols[level];
+        mg_level = level;
+        run(level < splitLevel, level, sol, level < splitLevel ? upIter(level) : topIter(level));
+        multiply(resmats[level], mg_residuals[level], mg_residuals[level + 1]);
+        mg_sols[level + 1].assign(sysmats[level + 1].nrows, TV::zero());
+    }
+    mg_level = level;
+    run(false, level, level == 0 ? out : mg_sols[level], topIter(level));
+    for (--level; level >= 0; --level) {
+        std::vector<TV>& sol = level == 0 ? out : mg_sols[level];
+        mg_level = level;
+        multiply(promats[level], mg_sols[level + 1], mg_dus[level]);
+        for (size_t i = 0; i < sol.size(); ++i) sol[i] += mg_dus[level][i];
+        multiply(sysmats[level], mg_dus[level], mg_dAus[level]);
+        for (size_t i = 0; i < sol.size(); ++i) mg_residuals[level][i] -= mg_dAus[level][i];
+        run(level < splitLevel, level, sol, level < splitLevel ? downIter(level) : topIter(level));
+    }
+}
+
+} // namespace hot_oracle

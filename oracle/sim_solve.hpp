@@ -1,0 +1,303 @@
+// ORACLE (test infrastructure only).  Nonlinear solvers: L-BFGS with the V-cycle as initial inverse Hessian
+// (HOT), projected Newton with inexact (MG-)PCG, line search, termination tests, and the time-step driver.
+#pragma once
+#include "sim_matrix.hpp"
+#include <chrono>
+#include <functional>
+
+namespace hot_oracle {
+
+static inline double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// the objective's `precondition` std::function (ImplicitSolver.h:47): the MG operator once the hierarchy
+// exists (SparseMatrixFast.h:56), lumped-mass scaling before (MultigridSimulation.h:170-176)
+template <class T>
+void Sim<T>::precondition(const std::vector<TV>& in, std::vector<TV>& out)
+{
+    if (sysmats.empty() || sysmats[0].diagonalBlock.empty()) {
+        out.resize(in.size());
+        for (int i = 0; i < num_nodes; ++i) out[i] = in[i] * ((T)1 / mass_matrix[i]);
+        return;
+    }
+    vcycle(in, out);
+}
+
+// reference ImplicitSolverObjective::shouldExitByCN (ImplicitSolver.h:174-211) / computeNorm (:158-171)
+template <class T>
+bool Sim<T>::should_exit(const std::vector<TV>& residual)
+{
+    if (!cfg.useCN) {
+        T ns = 0;
+        for (int i = 0; i < num_nodes; ++i) ns += residual[i].squaredNorm();
+        T res = std::sqrt(ns);
+        stats.final_scaled_residual = res;
+        return res < (T)cfg.cneps;
+    }
+    T scaledNorm = 0;
+    for (int i = 0; i < num_nodes; ++i) scaledNorm += residual[i].squaredNorm() / (nodeCNTol[i] * nodeCNTol[i]);
+    if (num_nodes == 0) return true;
+    stats.final_scaled_residual = std::sqrt(scaledNorm / num_nodes);
+    return scaledNorm < num_nodes;
+}
+
+// reference ImplicitSolverObjective::lineSearch (ImplicitSolver.h:312-333)
+template <class T>
+T Sim<T>::line_search(std::vector<TV>& ddv, std::vector<TV>& residual, T alpha)
+{
+    std::vector<TV> dvnew(ddv.size());
+    recover_solution(ddv);
+    double Ek0 = Ek;
+    do {
+        for (size_t i = 0; i < ddv.size(); ++i) dvnew[i] = dv0[i] + ddv[i] * alpha;
+        update_state(dvnew);
+        stats.linesearch_trials++;
+        alpha *= (T)0.5;
+    } while (Ek > Ek0);
+    alpha *= 2;
+    for (size_t i = 0; i < ddv.size(); ++i) ddv[i] = ddv[i] * alpha;
+    transform_residual(ddv);
+    compute_residual(residual);
+    updated = true;
+    dv0 = dvnew;
+    return alpha;
+}
+
+// reference LBFGS::solve (Lib/Ziran/Math/Nonlinear/LBFGS.h:300-437); RingBuffer :23-69 is emulated with
+// vectors (history 8 => at most 8 stored pairs + the working slot)
+template <class T>
+bool Sim<T>::lbfgs_solve()
+{
+    constexpr int historySize = 8;
+    std::vector<TV>& x = dv;
+    std::vector<TV> residual(num_nodes);
+    // updateState / computeResidual honour the `updated` flag (ImplicitSolver.h:132,241)
+    auto updateState = [&]() {
+        if (updated) return;
+        update_state(x);
+    };
+    auto computeResidual = [&]() {
+        if (updated) return;
+        compute_residual(residual);
+    };
+    updateState();
+    computeResidual();
+    struct Pair {
+        std::vector<TV> dx, dg;
+        T dgTdx;
+    };
+    std::vector<Pair> hist; // oldest first; back() is the working slot
+    hist.emplace_back();
+    std::array<T, historySize + 1> ksi;
+    auto push_back = [&]() {
+        hist.emplace_back();
+        if ((int)hist.size() > historySize + 1) hist.erase(hist.begin());
+    };
+    for (int it = 0; it < cfg.max_iterations; ++it) {
+        stats.iterations = it;
+        if (should_exit(residual)) {
+            stats.converged = 1;
+            return true;
+        }
+        bool rebuild = cfg.useAdaptiveHessian ? ((it & 0xf) == 0) : (it == 0);
+        if (rebuild) {
+            // HinvApproxInit (ImplicitSolver.h:335-353)
+            double t0 = now_ms();
+            build_matrix();
+            double t1 = now_ms();
+            build_mg();
+            double t2 = now_ms();
+            stats.ms_hessian += t1 - t0, stats.ms_mg_build += t2 - t1;
+            hist.clear();
+            hist.emplace_back();
+        }
+        hist.back().dg = residual;
+        for (int i = (int)hist.size() - 2; i >= 0; --i) {
+            ksi[i] = dot_product(hist[i].dx, residual) * hist[i].dgTdx;
+            for (int n = 0; n < num_nodes; ++n) residual[n] -= hist[i].dg[n] * ksi[i];
+        }
+        hist.back().dx.resize(num_nodes);
+        precondition(residual, hist.back().dx);
+        project(hist.back().dx);
+        for (int i = 0; i < (int)hist.size() - 1; ++i) {
+            T c = ksi[i] - dot_product(hist[i].dg, hist.back().dx) * hist[i].dgTdx;
+            for (int n = 0; n < num_nodes; ++n) hist.back().dx[n] += hist[i].dx[n] * c;
+        }
+        if (cfg.linesearch) line_search(hist.back().dx, residual, (T)1);
+        recover_solution(hist.back().dx);
+        for (int n = 0; n < num_nodes; ++n) x[n] += hist.back().dx[n];
+        transform_residual(hist.back().dx);
+        updateState();
+        computeResidual();
+        for (int n = 0; n < num_nodes; ++n) hist.back().dg[n] -= residual[n];
+        hist.back().dgTdx = (T)1 / dot_product(hist.back().dg, hist.back().dx);
+        if (hist.back().dgTdx <= 0) {
+            hist.pop_back();
+            stats.dropped_pairs++;
+        }
+        push_back();
+    }
+    stats.iterations = cfg.max_iterations;
+    return false;
+}
+
+// reference ExtendedNewtonsMethod::solve (Lib/Ziran/Math/Nonlinear/ExtendedNewtonsMethod.h:39-66) +
+// ImplicitSolverObjective::computeStep (ImplicitSolver.h:355-432) + InexactConjugateGradient::solve
+// (Lib/Ziran/Math/Linear/InexactConjugateGradient.h:49-103)
+template <class T>
+bool Sim<T>::newton_solve()
+{
+    std::vector<TV>& x = dv;
+    std::vector<TV> residual(num_nodes), step(num_nodes);
+    // cg.tolerance: scene value 1e-4 (MultigridInit3D.h:2500-2501) unless useCN sets maxcntol (MultigridSimulation.h:201-208)
+    T cg_tolerance = cfg.useCN ? max_cn_tolerance : (T)1e-4;
+    for (int it = 0; it < cfg.max_iterations; ++it) {
+        stats.iterations = it;
+        if (!updated) {
+            update_state(x);
+            compute_residual(residual);
+        }
+        if (should_exit(residual)) {
+            stats.converged = 1;
+            return true;
+        }
+        // computeStep
+        step.assign(num_nodes, TV::zero());
+        std::function<void(const std::vector<TV>&, std::vector<TV>&)> prec;
+        if (!cfg.matrixFree) {
+            double t0 = now_ms();
+            build_matrix();
+            double t1 = now_ms();
+            build_mg();
+            double t2 = now_ms();
+            stats.ms_hessian += t1 - t0, stats.ms_mg_build += t2 - t1;
+            if (cfg.levelCnt == 1 && cfg.times == 1)
+                prec = [&](const std::vector<TV>& in, std::vector<TV>& out) { scaler(in, out, sysmats[0]); };
+            else
+                prec = [&](const std::vector<TV>& in, std::vector<TV>& out) { vcycle(in, out); };
+        }
+        else {
+            // buildDiagonal (ImplicitSolver.h:605-665): block diagonal of the matrix-free operator
+            std::vector<TM> diag(num_nodes);
+            for (int n = 0; n < num_nodes; ++n) diag[n] = TM::identity() * mass_matrix[n];
+            bool proj = cfg.project != 0;
+            for_each_particle_colored([&](int g, int i) {
+                CorotatedScratch<T> s;
+                corotated_update_scratch(F[i], mu[i], lambda[i], proj, s);
+                T ddF[81];
+                corotated_first_piola_derivative(s, ddF);
+                TM FnT = Fn[i].transpose();
+                Spline sp;
+                compute_spline(X[i], sp);
+                iterate_kernel(sp, g, particle_base_offset[i], [&](const int*, T, const TV& dw, Node& gs) {
+                    if (gs.idx < 0) return;
+                    TV wi = FnT * dw;
+                    TM dFdX = TM::zero();
+                    for (int q = 0; q < 3; ++q)
+                        for (int v = 0; v < 3; ++v)
+                            for (int r = 0; r < 3; ++r)
+                                for (int c = 0; c < 3; ++c) dFdX(r, c) += ddF[(3 * v + r) + 9 * (3 * q + c)] * wi(v) * wi(q);
+                    diag[gs.idx] += dFdX * (dt * dt * vol[i]);
+                });
+            });
+            std::vector<TM> dinv(num_nodes);
+            for (int n = 0; n < num_nodes; ++n) {
+                if (cfg.Ainv == 0) {
+                    dinv[n] = TM::zero();
+                    for (int k = 0; k < 3; ++k) dinv[n](k, k) = 1 / diag[n](k, k);
+                }
+                else
+                    dinv[n] = inverse(diag[n]);
+            }
+            prec = [dinv](const std::vector<TV>& in, std::vector<TV>& out) {
+                out.resize(in.size());
+                for (size_t n = 0; n < in.size(); ++n) out[n] = dinv[n] * in[n];
+            };
+        }
+        auto Amul = [&](const std::vector<TV>& xx, std::vector<TV>& bb) {
+            if (cfg.matrixFree)
+                matfree_multiply(xx, bb);
+            else
+                multiply(sysmats[0], xx, bb);
+        };
+        std::vector<TV> b = residual;
+        if (cfg.systemBCProject)
+            for (int n = 0; n < num_nodes; ++n) b[n] += dRhs[n];
+        // inexact PCG
+        {
+            std::vector<TV> r(num_nodes), p(num_nodes), q(num_nodes), temp(num_nodes);
+            Amul(step, temp);
+            for (int n = 0; n < num_nodes; ++n) r[n] = b[n] - temp[n];
+            project(r);
+            prec(r, q);
+            p = q;
+            T zTrk = dot_product(r, q);
+            T rpn = std::sqrt(zTrk);
+            T forcing = std::min((T)0.5, std::sqrt(std::max(rpn, cg_tolerance)));
+            T local_tol = forcing * rpn;
+            int cnt = 0;
+            for (; cnt < 10000; ++cnt) {
+                if (rpn < local_tol) break;
+                Amul(p, temp);
+                project(temp);
+                T alpha = zTrk / dot_product(temp, p);
+                for (int n = 0; n < num_nodes; ++n) step[n] += p[n] * alpha, r[n] -= temp[n] * alpha;
+                prec(r, q);
+                T zTrk_last = zTrk;
+                zTrk = dot_product(q, r);
+                T beta = zTrk / zTrk_last;
+                for (int n = 0; n < num_nodes; ++n) p[n] = q[n] + p[n] * beta;
+                rpn = std::sqrt(zTrk);
+            }
+            stats.linear_iterations += cnt;
+        }
+        if (cfg.linesearch) line_search(step, residual, (T)1);
+        recover_solution(step);
+        for (int n = 0; n < num_nodes; ++n) x[n] += step[n];
+        transform_residual(step);
+    }
+    stats.iterations = cfg.max_iterations;
+    return false;
+}
+
+// reference MultigridSimulation::backwardEulerStep (MultigridSimulation.h:188-233), after startBackwardEuler
+template <class T>
+int Sim<T>::solve()
+{
+    std::memset(&stats, 0, sizeof(stats));
+    double t0 = now_ms();
+    if (cfg.useCN) evaluate_cn_tolerance();
+    // a fresh step has no hierarchy yet
+    sysmats.clear();
+    bool ok = cfg.lsolver == 3 ? lbfgs_solve() : newton_solve();
+    (void)ok;
+    stats.num_nodes = num_nodes;
+    stats.num_levels = (int)sysmats.size();
+    stats.energy = Ek;
+    stats.ms_solve = now_ms() - t0;
+    return 0;
+}
+
+// reference MultigridSimulation::advanceOneTimeStep (MultigridSimulation.h:235-297)
+template <class T>
+int Sim<T>::advance(double dt_)
+{
+    double t0 = now_ms();
+    int rc = sort_particles();
+    if (rc) return rc;
+    double t1 = now_ms();
+    particles_to_grid();
+    double t2 = now_ms();
+    begin_step((T)dt_);
+    double t3 = now_ms();
+    solve();
+    double t4 = now_ms();
+    grid_to_particles(dt_);
+    double t5 = now_ms();
+    stats.ms_sort = t1 - t0, stats.ms_p2g = t2 - t1, stats.ms_begin = t3 - t2, stats.ms_g2p = t5 - t4, stats.ms_total = t5 - t0;
+    return 0;
+}
+
+} // namespace hot_oracle
