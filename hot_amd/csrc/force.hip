@@ -1,0 +1,613 @@
+// libhotmi355x — backward-Euler objective pieces on the device.
+//
+//   begin_step      MultigridSimulation::startBackwardEuler (reference Projects/multigrid/MultigridSimulation.h:167-186),
+//                   MpmSimulationBase::buildInitialDvAndVnForNewton (Lib/MPM/MpmSimulationBase.cpp:1139-1184, collision
+//                   query result supplied through hot_set_bc or evaluated here for sticky half spaces),
+//                   FBasedMpmForceHelper::backupStrain (Lib/MPM/Force/FBasedMpmForceHelper.cpp:24-33), resetLSFlag.
+//   k_state         ONE fused particle pass for objective.updateState + totalEnergy + the force rasterisation of
+//                   computeResidual:  evalInterpolantAndGradient of vn+dv (Lib/MPM/Force/MpmForceBase.cpp:213-248),
+//                   restoreStrain/evolveStrain (FBasedMpmForceHelper.cpp:35-43,99-114), updateImplicitState (:70-97),
+//                   FBased totalEnergy (:116-135) and rasterizeForceToTVStack<false> (MpmForceBase.cpp:100-153).
+//                   The reference runs these as 4 separate particle sweeps with two SVDs per particle and 8 colour
+//                   passes for both the gather and the scatter; here: one launch, one SVD, LDS-staged node tile for the
+//                   gather, LDS accumulators + one global atomic per touched node for the scatter.
+//   k_residual      computeResidual (Projects/multigrid/ImplicitSolver.h:128-155) incl. MassLumpedInertia::addScaledForces
+//                   (Lib/Ziran/Physics/LagrangianForce/Inertia.cpp:33-41), transformResidual (:117-125), project.
+//   k_matfree       matrix-free Hessian product (ImplicitSolver.h:741-758, MpmForceBase.cpp:262-306,
+//                   FBasedMpmForceHelper.cpp:137-160).
+#include "hot_impl.h"
+#include "hot_constitutive.h"
+#include <cmath>
+
+namespace hot {
+
+template <class T>
+__device__ __forceinline__ int tile_slot2(int t, const int32_t* __restrict__ nb8)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2;
+    int tz = t % TZ, ty = (t / TZ) % TY, tx = t / (TZ * TY);
+    int ox = tx >> G::xb, oy = ty >> G::yb, oz = tz >> G::zb;
+    int elem = ((tx & (G::BX - 1)) << (G::yb + G::zb)) | ((ty & (G::BY - 1)) << G::zb) | (tz & (G::BZ - 1));
+    return nb8[ox * 4 + oy * 2 + oz] * G::EPB + elem;
+}
+
+// ------------------------------------------------------------------------------------------------ BCs
+template <class T>
+__global__ void k_hs_flag(const int32_t* __restrict__ id2coord, const double* __restrict__ hs, int nhs, int32_t* flags, int nn, T dx)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nn) return;
+    bool inside = false;
+    for (int h = 0; h < nhs; ++h) {
+        double s = 0;
+        for (int d = 0; d < 3; ++d) s += ((double)((T)id2coord[3 * n + d] * dx) - hs[6 * h + d]) * hs[6 * h + 3 + d];
+        if (s <= 0) inside = true;
+    }
+    flags[n] = inside ? 1 : 0;
+}
+template <class T>
+__global__ void k_hs_fill(const int32_t* __restrict__ flags, const int32_t* __restrict__ scan, int32_t* bcNode, T* P, T* R, T* Rinv, uint8_t* slip, uint8_t* hasdv, int nn)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nn || !flags[n]) return;
+    int c = scan[n];
+    bcNode[c] = n;
+    for (int k = 0; k < 9; ++k) {
+        P[9 * c + k] = (T)0;
+        R[9 * c + k] = Rinv[9 * c + k] = (k % 4 == 0) ? (T)1 : (T)0;
+    }
+    slip[c] = 0;
+    hasdv[c] = 0;
+}
+__global__ void k_bc_index(const int32_t* __restrict__ bcNode, int32_t* bcIdx, int nc)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nc) bcIdx[bcNode[c]] = c;
+}
+template <class T>
+__global__ void k_begin(const T* __restrict__ nodeV, const int32_t* __restrict__ bcIdx, const T* __restrict__ bcDv, const uint8_t* __restrict__ hasdv, T* dv, T* vn, T* dv0,
+    int nn, T g0, T g1, T g2, T dt)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nn) return;
+    T v[3] = { nodeV[3 * n], nodeV[3 * n + 1], nodeV[3 * n + 2] };
+    int c = bcIdx[n];
+    T d[3];
+    if (c >= 0) {
+        if (hasdv[c])
+            d[0] = bcDv[3 * c], d[1] = bcDv[3 * c + 1], d[2] = bcDv[3 * c + 2];
+        else
+            d[0] = -v[0], d[1] = -v[1], d[2] = -v[2];
+    }
+    else
+        d[0] = g0 * dt, d[1] = g1 * dt, d[2] = g2 * dt;
+    for (int k = 0; k < 3; ++k) dv[3 * n + k] = d[k], dv0[3 * n + k] = d[k], vn[3 * n + k] = v[k];
+}
+
+template <class T>
+void Ctx<T>::set_bc(int32_t nc, const int32_t* node_id, const void* P, const void* R, const void* Rinv, const uint8_t* slip, const void* dvc)
+{
+    need(Nn > 0, "hot_set_bc before hot_p2g");
+    need(nc >= 0 && (nc == 0 || (node_id && P)), "hot_set_bc: node_id and P are required");
+    hs_origin.clear(), hs_normal.clear();
+    Nc = nc;
+    size_t n = std::max(nc, 1);
+    bcNode.reserve(n), bcP.reserve(9 * n), bcR.reserve(9 * n), bcRinv.reserve(9 * n), bcDv.reserve(3 * n), bcSlip.reserve(n), bcHasDv.reserve(n);
+    if (nc == 0) return;
+    std::vector<int32_t> ids(nc);
+    HOT_HIP(hipMemcpy(ids.data(), node_id, nc * sizeof(int32_t), hipMemcpyDefault));
+    for (int c = 0; c < nc; ++c) HOT_CHECK(ids[c] >= 0 && ids[c] < Nn, HOT_ERR_INVALID, "collision node id out of range");
+    upload(bcNode, ids.data(), nc);
+    sync();
+    upload(bcP, P, 9 * (size_t)nc);
+    std::vector<T> eye(9 * (size_t)nc, (T)0);
+    for (int c = 0; c < nc; ++c) eye[9 * c] = eye[9 * c + 4] = eye[9 * c + 8] = (T)1;
+    upload(bcR, R ? R : (const void*)eye.data(), 9 * (size_t)nc);
+    upload(bcRinv, Rinv ? Rinv : (const void*)eye.data(), 9 * (size_t)nc);
+    if (slip)
+        upload(bcSlip, slip, nc);
+    else
+        HOT_HIP(hipMemsetAsync(bcSlip.p, 0, nc, stream));
+    HOT_HIP(hipMemsetAsync(bcHasDv.p, dvc ? 1 : 0, nc, stream));
+    if (dvc) upload(bcDv, dvc, 3 * (size_t)nc);
+    sync();
+}
+
+template <class T>
+void Ctx<T>::set_halfspaces(int32_t n, const double* origin, const double* normal)
+{
+    hs_origin.assign(origin, origin + 3 * n);
+    hs_normal.assign(normal, normal + 3 * n);
+}
+
+template <class T>
+void Ctx<T>::eval_halfspaces()
+{
+    if (hs_origin.empty()) return;
+    int nhs = (int)hs_origin.size() / 3;
+    std::vector<double> h(6 * nhs);
+    for (int i = 0; i < nhs; ++i)
+        for (int d = 0; d < 3; ++d) h[6 * i + d] = hs_origin[3 * i + d], h[6 * i + 3 + d] = hs_normal[3 * i + d];
+    upload(d_hs, h.data(), h.size());
+    flags.reserve(Nn), scan.reserve(Nn);
+    HOT_LAUNCH(this, "bc_halfspace_flag", k_hs_flag<T>, div_up(Nn, 256), 256, 0, id2coord.p, d_hs.p, nhs, flags.p, Nn, dx);
+    Nc = exclusive_scan_i32(flags.p, scan.p, Nn);
+    size_t n = std::max(Nc, 1);
+    bcNode.reserve(n), bcP.reserve(9 * n), bcR.reserve(9 * n), bcRinv.reserve(9 * n), bcDv.reserve(3 * n), bcSlip.reserve(n), bcHasDv.reserve(n);
+    HOT_LAUNCH(this, "bc_halfspace_fill", k_hs_fill<T>, div_up(Nn, 256), 256, 0, flags.p, scan.p, bcNode.p, bcP.p, bcR.p, bcRinv.p, bcSlip.p, bcHasDv.p, Nn);
+}
+
+template <class T>
+void Ctx<T>::begin_step(double dt_)
+{
+    need(Nn > 0, "hot_begin_step before hot_p2g");
+    double t0 = wall_ms();
+    dt = (T)dt_;
+    eval_halfspaces();
+    HOT_HIP(hipMemsetAsync(bcIdx.p, 0xff, (size_t)Nn * sizeof(int32_t), stream));
+    if (Nc > 0) HOT_LAUNCH(this, "bc_index", k_bc_index, div_up(Nc, 256), 256, 0, bcNode.p, bcIdx.p, Nc);
+    HOT_LAUNCH(this, "begin_step", k_begin<T>, div_up(Nn, 256), 256, 0, nodeV.p, bcIdx.p, bcDv.p, bcHasDv.p, dv.p, vn.p, dv0.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dt);
+    HOT_HIP(hipMemcpyAsync(pFn.p, pF.p, 9 * (size_t)Np * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    updated = false;
+    for (auto* l : levels) delete l;
+    levels.clear();
+    stats.ms_begin = wall_ms() - t0;
+}
+
+template <class T>
+void Ctx<T>::get_dv(void* out)
+{
+    need(Nn > 0, "no grid");
+    download(out, dv.p, 3 * (size_t)Nn);
+    sync();
+}
+template <class T>
+void Ctx<T>::set_dv(const void* in)
+{
+    need(Nn > 0, "no grid");
+    HOT_HIP(hipMemcpyAsync(dv.p, in, 3 * (size_t)Nn * sizeof(T), hipMemcpyDefault, stream));
+    sync();
+}
+
+// ------------------------------------------------------------------------------------------------ state pass
+template <class T>
+__global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ Vol, const T* __restrict__ Mu, const T* __restrict__ Lam,
+    T* __restrict__ Ft, T* __restrict__ stress_out, T* __restrict__ gradV_out, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
+    const int32_t* __restrict__ group_nb, const int32_t* __restrict__ gIdx, const T* __restrict__ vn, const T* __restrict__ dv, T* gF, int64_t slots, T dx, T one_over_dx, T dt,
+    double* energy, int want_force)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
+    __shared__ T nv[3][TILE];
+    __shared__ T acc[3][TILE];
+    __shared__ int32_t nb8[8];
+    __shared__ double red[4];
+    const int g = blockIdx.x;
+    if (threadIdx.x < 8) nb8[threadIdx.x] = group_nb[g * 8 + threadIdx.x];
+    __syncthreads();
+    for (int t = threadIdx.x; t < TILE; t += 256) {
+        int idx = gIdx[tile_slot2<T>(t, nb8)];
+        T a = 0, b = 0, c = 0;
+        if (idx >= 0) a = vn[3 * idx] + dv[3 * idx], b = vn[3 * idx + 1] + dv[3 * idx + 1], c = vn[3 * idx + 2] + dv[3 * idx + 2];
+        nv[0][t] = a, nv[1][t] = b, nv[2][t] = c;
+        acc[0][t] = acc[1][t] = acc[2][t] = (T)0;
+    }
+    __syncthreads();
+    const int first = group_first[g], last = group_first[g + 1];
+    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
+    double e = 0;
+    for (int p = first + threadIdx.x; p < last; p += 256) {
+        T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
+        int base[3];
+        T w[3][3], dw[3][3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+        const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
+        T gv[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) gv[c] = (T)0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            T wi = w[0][i], dwi = one_over_dx * dw[0][i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                T wij = wi * w[1][j];
+                T dwij_i = dwi * w[1][j], dwij_j = wi * one_over_dx * dw[1][j];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    T g0 = dwij_i * w[2][k], g1 = dwij_j * w[2][k], g2 = wij * one_over_dx * dw[2][k];
+                    int t = ((cx + i) * TY + (cy + j)) * TZ + (cz + k);
+                    T v0 = nv[0][t], v1 = nv[1][t], v2 = nv[2][t];
+                    gv[0] += v0 * g0, gv[1] += v1 * g0, gv[2] += v2 * g0;
+                    gv[3] += v0 * g1, gv[4] += v1 * g1, gv[5] += v2 * g1;
+                    gv[6] += v0 * g2, gv[7] += v1 * g2, gv[8] += v2 * g2;
+                }
+            }
+        }
+        Mat3<T> A, Fo;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) A.a[c] = dt * gv[c] + ((c % 4 == 0) ? (T)1 : (T)0), Fo.a[c] = Fn[(int64_t)c * Np + p];
+        Mat3<T> Fnew = m3_mul(A, Fo);
+        T mu = Mu[p], la = Lam[p], vol = Vol[p];
+        T psi;
+        Mat3<T> P;
+        corotated_state(Fnew, mu, la, psi, P);
+        e += (double)(vol * psi);
+        // stress = V_p P Fn^T
+        Mat3<T> S;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) S(r, c) = vol * (P(r, 0) * Fo(c, 0) + P(r, 1) * Fo(c, 1) + P(r, 2) * Fo(c, 2));
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Ft[(int64_t)c * Np + p] = Fnew.a[c];
+        if (stress_out) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) stress_out[(int64_t)c * Np + p] = S.a[c], gradV_out[(int64_t)c * Np + p] = gv[c];
+        }
+        if (want_force) {
+            int rot = threadIdx.x % 27;
+            for (int n = 0; n < 27; ++n) {
+                int q = n + rot;
+                q = q >= 27 ? q - 27 : q;
+                int i = q / 9, j = (q / 3) % 3, k = q % 3;
+                T g0 = one_over_dx * dw[0][i] * w[1][j] * w[2][k], g1 = w[0][i] * one_over_dx * dw[1][j] * w[2][k], g2 = w[0][i] * w[1][j] * one_over_dx * dw[2][k];
+                int t = ((cx + i) * TY + (cy + j)) * TZ + (cz + k);
+                lds_atomic_add(&acc[0][t], -dt * (S(0, 0) * g0 + S(0, 1) * g1 + S(0, 2) * g2));
+                lds_atomic_add(&acc[1][t], -dt * (S(1, 0) * g0 + S(1, 1) * g1 + S(1, 2) * g2));
+                lds_atomic_add(&acc[2][t], -dt * (S(2, 0) * g0 + S(2, 1) * g1 + S(2, 2) * g2));
+            }
+        }
+    }
+    double tot = block_sum_256<double>(e, red);
+    if (threadIdx.x == 0 && tot != 0.0) atomic_add(energy, tot);
+    if (want_force) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < TILE; t += 256) {
+            T a = acc[0][t], b = acc[1][t], c = acc[2][t];
+            if (a == (T)0 && b == (T)0 && c == (T)0) continue;
+            int64_t s = tile_slot2<T>(t, nb8);
+            atomic_add(&gF[s], a);
+            atomic_add(&gF[slots + s], b);
+            atomic_add(&gF[2 * slots + s], c);
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_inertia_energy(const T* __restrict__ dv, const T* __restrict__ mass, int nn, T g0, T g1, T g2, double* out)
+{
+    __shared__ double red[4];
+    double ke = 0, ge = 0;
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < nn; n += gridDim.x * 256) {
+        T a = dv[3 * n], b = dv[3 * n + 1], c = dv[3 * n + 2], m = mass[n];
+        ke += (double)((a * a + b * b + c * c) * m);
+        ge += (double)((g0 * a + g1 * b + g2 * c) * m);
+    }
+    double k = block_sum_256<double>(ke, red);
+    double gg = block_sum_256<double>(ge, red);
+    if (threadIdx.x == 0) {
+        atomic_add(out, k);
+        atomic_add(out + 1, gg);
+    }
+}
+
+template <class T>
+double Ctx<T>::state_pass(const T* dv_in, bool want_force)
+{
+    int64_t slots = (int64_t)Nb * EPB;
+    HOT_HIP(hipMemsetAsync(dscal.p, 0, 4 * sizeof(double), stream));
+    if (want_force) HOT_HIP(hipMemsetAsync(gF.p, 0, 3 * slots * sizeof(T), stream));
+    HOT_LAUNCH(this, "state_update_force", k_state<T>, Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, pFt.p, keep_debug ? pStress.p : (T*)nullptr, keep_debug ? pGradV.p : (T*)nullptr, Np,
+        group_first.p, group_origin.p, group_nb.p, gIdx.p, vn.p, dv_in, gF.p, slots, dx, (T)1 / dx, dt, dscal.p, want_force ? 1 : 0);
+    HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, std::min(div_up(Nn, 256), 1024), 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1);
+    HOT_HIP(hipMemcpyAsync(hscal, dscal.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    double result = (double)(T)hscal[0];
+    result += hscal[1] / 2;
+    result -= (double)dt * hscal[2];
+    return result;
+}
+
+template <class T>
+void Ctx<T>::update_state(const void* dv_in, double* energy)
+{
+    need(Nn > 0 && dt > 0, "hot_update_state before hot_begin_step");
+    if (dv_in) HOT_HIP(hipMemcpyAsync(dv.p, dv_in, 3 * (size_t)Nn * sizeof(T), hipMemcpyDefault, stream));
+    Ek = state_pass(dv.p, true);
+    if (energy) *energy = Ek;
+}
+
+template <class T>
+void Ctx<T>::get_particle_state(void* F, void* stress, void* gradV)
+{
+    need(Np > 0, "no particles");
+    int64_t n = Np;
+    DBuf<T> tmp;
+    tmp.reserve(9 * n);
+    auto out = [&](const T* src, void* dst) {
+        if (!dst) return;
+        HOT_HIP(hipMemcpyAsync(tmp.p, src, 9 * n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        // scatter to original order on the host side of the ABI: reuse get_particles machinery through spare9
+        std::vector<T> h(9 * n), o(9 * n);
+        std::vector<int32_t> s2o(n);
+        HOT_HIP(hipMemcpyAsync(h.data(), tmp.p, 9 * n * sizeof(T), hipMemcpyDeviceToHost, stream));
+        HOT_HIP(hipMemcpyAsync(s2o.data(), slot2orig.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        sync();
+        for (int64_t p = 0; p < n; ++p)
+            for (int c = 0; c < 9; ++c) o[(int64_t)s2o[p] * 9 + c] = h[(int64_t)c * n + p];
+        HOT_HIP(hipMemcpy(dst, o.data(), 9 * n * sizeof(T), hipMemcpyDefault));
+    };
+    out(pFt.p, F), out(pStress.p, stress), out(pGradV.p, gradV);
+}
+
+// ------------------------------------------------------------------------------------------------ residual / projection
+template <class T>
+__device__ __forceinline__ void mat3_vec(const T* __restrict__ M, const T* v, T* o) // column-major
+{
+    o[0] = M[0] * v[0] + M[3] * v[1] + M[6] * v[2];
+    o[1] = M[1] * v[0] + M[4] * v[1] + M[7] * v[2];
+    o[2] = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+}
+// v <- projected v at a collision node (project lambda, MultigridSimulation.h:105-124)
+template <class T>
+__device__ __forceinline__ void bc_project(int c, const T* __restrict__ P, const uint8_t* __restrict__ slip, bool slipmode, T* v)
+{
+    if (slipmode) {
+        if (slip[c])
+            v[0] = (T)0;
+        else
+            v[0] = v[1] = v[2] = (T)0;
+    }
+    else {
+        T o[3];
+        mat3_vec(P + 9 * c, v, o);
+        v[0] = o[0], v[1] = o[1], v[2] = o[2];
+    }
+}
+
+template <class T>
+__global__ void k_residual(const T* __restrict__ gF, const int32_t* __restrict__ dofSlot, const T* __restrict__ mass, const T* __restrict__ dv, const int32_t* __restrict__ bcIdx,
+    const T* __restrict__ bcP, const T* __restrict__ bcR, const uint8_t* __restrict__ bcSlip, T* r, int nn, int64_t slots, T g0, T g1, T g2, T dt, int slipmode)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nn) return;
+    int64_t s = dofSlot[n];
+    T m = mass[n];
+    T v[3] = { g0 * dt * m + gF[s] - dv[3 * n] * m, g1 * dt * m + gF[slots + s] - dv[3 * n + 1] * m, g2 * dt * m + gF[2 * slots + s] - dv[3 * n + 2] * m };
+    int c = bcIdx[n];
+    if (c >= 0) {
+        if (slipmode && bcSlip[c]) { // transformResidual
+            T o[3];
+            mat3_vec(bcR + 9 * c, v, o);
+            v[0] = o[0], v[1] = o[1], v[2] = o[2];
+        }
+        bc_project(c, bcP, bcSlip, slipmode != 0, v);
+    }
+    r[3 * n] = v[0], r[3 * n + 1] = v[1], r[3 * n + 2] = v[2];
+}
+template <class T>
+__global__ void k_project(const int32_t* __restrict__ bcNode, const T* __restrict__ bcP, const uint8_t* __restrict__ bcSlip, T* v, int nc, int slipmode)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nc) return;
+    int n = bcNode[c];
+    T x[3] = { v[3 * n], v[3 * n + 1], v[3 * n + 2] };
+    bc_project(c, bcP, bcSlip, slipmode != 0, x);
+    v[3 * n] = x[0], v[3 * n + 1] = x[1], v[3 * n + 2] = x[2];
+}
+template <class T>
+__global__ void k_transform(const int32_t* __restrict__ bcNode, const T* __restrict__ M, const uint8_t* __restrict__ bcSlip, T* v, int nc)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nc || !bcSlip[c]) return;
+    int n = bcNode[c];
+    T x[3] = { v[3 * n], v[3 * n + 1], v[3 * n + 2] }, o[3];
+    mat3_vec(M + 9 * c, x, o);
+    v[3 * n] = o[0], v[3 * n + 1] = o[1], v[3 * n + 2] = o[2];
+}
+
+template <class T>
+void Ctx<T>::residual_dev(T* r)
+{
+    int slipmode = (cfg.systemBCProject && cfg.boundaryType == 1) ? 1 : 0;
+    HOT_LAUNCH(this, "residual", k_residual<T>, div_up(Nn, 256), 256, 0, gF.p, dofSlot.p, mass.p, dv.p, bcIdx.p, bcP.p, bcR.p, bcSlip.p, r, Nn, (int64_t)Nb * EPB, (T)cfg.gravity[0],
+        (T)cfg.gravity[1], (T)cfg.gravity[2], dt, slipmode);
+    HOT_HIP(hipMemcpyAsync(rhs.p, r, 3 * (size_t)Nn * sizeof(T), hipMemcpyDeviceToDevice, stream));
+}
+template <class T>
+void Ctx<T>::project_dev(T* v)
+{
+    if (Nc == 0) return;
+    int slipmode = (cfg.systemBCProject && cfg.boundaryType == 1) ? 1 : 0;
+    HOT_LAUNCH(this, "project", k_project<T>, div_up(Nc, 256), 256, 0, bcNode.p, bcP.p, bcSlip.p, v, Nc, slipmode);
+}
+template <class T>
+void Ctx<T>::transform_dev(T* v, bool inverse)
+{
+    if (Nc == 0 || !(cfg.systemBCProject && cfg.boundaryType == 1)) return;
+    HOT_LAUNCH(this, "transform", k_transform<T>, div_up(Nc, 256), 256, 0, bcNode.p, inverse ? bcRinv.p : bcR.p, bcSlip.p, v, Nc);
+}
+
+template <class T>
+void Ctx<T>::residual(void* r)
+{
+    need(Nn > 0 && dt > 0, "hot_residual before hot_begin_step/hot_update_state");
+    residual_dev(work0.p);
+    download(r, work0.p, 3 * (size_t)Nn);
+    sync();
+}
+template <class T>
+void Ctx<T>::project(void* v)
+{
+    need(Nn > 0, "no grid");
+    HOT_HIP(hipMemcpyAsync(work0.p, v, 3 * (size_t)Nn * sizeof(T), hipMemcpyDefault, stream));
+    project_dev(work0.p);
+    download(v, work0.p, 3 * (size_t)Nn);
+    sync();
+}
+
+// ------------------------------------------------------------------------------------------------ CN tolerance
+template <class T>
+__global__ void k_cn_tol(const T* __restrict__ gCN, const int32_t* __restrict__ dofSlot, const T* __restrict__ mass, T* tol, int nn, T scale)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < nn) tol[n] = gCN[dofSlot[n]] * scale / mass[n];
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_max_dpdf(const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t np, unsigned long long* out)
+{
+    __shared__ double red[4];
+    double mx = 0;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < np; p += (int64_t)gridDim.x * 256) {
+        T mu = Mu[p], la = Lam[p];
+        double v = (double)hsqrt((T)3 * ((T)2 * mu + la) * ((T)2 * mu + la) + (T)6 * la * la + (T)12 * mu * mu);
+        mx = v > mx ? v : mx;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        double other = __shfl_xor(mx, o, 64);
+        mx = other > mx ? other : mx;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) mx = red[k] > mx ? red[k] : mx;
+        atomicMax(out, (unsigned long long)__double_as_longlong(mx)); // non-negative doubles order like integers
+    }
+}
+template <class T>
+void Ctx<T>::cn_tolerance_dev()
+{
+    T scale = (T)cfg.cneps * 24 * dx * dx * dt;
+    HOT_LAUNCH(this, "cn_tolerance", k_cn_tol<T>, div_up(Nn, 256), 256, 0, gCN.p, dofSlot.p, mass.p, cnTol.p, Nn, scale);
+    HOT_HIP(hipMemsetAsync(dscal.p + 8, 0, sizeof(double), stream));
+    HOT_LAUNCH(this, "max_dpdf_norm", k_max_dpdf<T>, std::min(div_up(Np, 256), 1024), 256, 0, pMu.p, pLam.p, Np, (unsigned long long*)(dscal.p + 8));
+    HOT_HIP(hipMemcpyAsync(hscal + 8, dscal.p + 8, sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    max_cn_tolerance = (T)cfg.cneps * dt * 24 * (T)std::sqrt((double)Nn) * dx * dx * (T)hscal[8];
+}
+template <class T>
+void Ctx<T>::cn_tolerance(void* tol)
+{
+    need(Nn > 0 && dt > 0, "hot_cn_tolerance before hot_begin_step");
+    need(cfg.useCN, "hot_cn_tolerance needs cfg.useCN (the accumulation is fused into P2G)");
+    cn_tolerance_dev();
+    download(tol, cnTol.p, Nn);
+    sync();
+}
+
+// ------------------------------------------------------------------------------------------------ matrix-free product
+template <class T>
+__global__ __launch_bounds__(256) void k_matfree(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ Ft, const T* __restrict__ Vol, const T* __restrict__ Mu,
+    const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin, const int32_t* __restrict__ group_nb,
+    const int32_t* __restrict__ gIdx, const T* __restrict__ x, T* gOut, int64_t slots, T dx, T one_over_dx, T dt, int project)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
+    __shared__ T nv[3][TILE];
+    __shared__ T acc[3][TILE];
+    __shared__ int32_t nb8[8];
+    const int g = blockIdx.x;
+    if (threadIdx.x < 8) nb8[threadIdx.x] = group_nb[g * 8 + threadIdx.x];
+    __syncthreads();
+    for (int t = threadIdx.x; t < TILE; t += 256) {
+        int idx = gIdx[tile_slot2<T>(t, nb8)];
+        T a = 0, b = 0, c = 0;
+        if (idx >= 0) a = x[3 * idx], b = x[3 * idx + 1], c = x[3 * idx + 2];
+        nv[0][t] = a, nv[1][t] = b, nv[2][t] = c;
+        acc[0][t] = acc[1][t] = acc[2][t] = (T)0;
+    }
+    __syncthreads();
+    const int first = group_first[g], last = group_first[g + 1];
+    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
+    for (int p = first + threadIdx.x; p < last; p += 256) {
+        T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
+        int base[3];
+        T w[3][3], dw[3][3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+        const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
+        Mat3<T> gx;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) gx.a[c] = (T)0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    T g0 = one_over_dx * dw[0][i] * w[1][j] * w[2][k], g1 = w[0][i] * one_over_dx * dw[1][j] * w[2][k], g2 = w[0][i] * w[1][j] * one_over_dx * dw[2][k];
+                    int t = ((cx + i) * TY + (cy + j)) * TZ + (cz + k);
+                    T v0 = nv[0][t], v1 = nv[1][t], v2 = nv[2][t];
+                    gx.a[0] += v0 * g0, gx.a[1] += v1 * g0, gx.a[2] += v2 * g0;
+                    gx.a[3] += v0 * g1, gx.a[4] += v1 * g1, gx.a[5] += v2 * g1;
+                    gx.a[6] += v0 * g2, gx.a[7] += v1 * g2, gx.a[8] += v2 * g2;
+                }
+        Mat3<T> Fo, Fc;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Fo.a[c] = Fn[(int64_t)c * Np + p], Fc.a[c] = Ft[(int64_t)c * Np + p];
+        HessBlocks<T> h;
+        corotated_hessian(Fc, Mu[p], Lam[p], project != 0, h);
+        Mat3<T> dP = hess_apply(h, m3_mul(gx, Fo));
+        T vol = Vol[p];
+        Mat3<T> S;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) S(r, c) = vol * (dP(r, 0) * Fo(c, 0) + dP(r, 1) * Fo(c, 1) + dP(r, 2) * Fo(c, 2));
+        T sc = dt * dt; // -(scale) with scale = -dt^2
+        for (int n = 0; n < 27; ++n) {
+            int i = n / 9, j = (n / 3) % 3, k = n % 3;
+            T g0 = one_over_dx * dw[0][i] * w[1][j] * w[2][k], g1 = w[0][i] * one_over_dx * dw[1][j] * w[2][k], g2 = w[0][i] * w[1][j] * one_over_dx * dw[2][k];
+            int t = ((cx + i) * TY + (cy + j)) * TZ + (cz + k);
+            lds_atomic_add(&acc[0][t], sc * (S(0, 0) * g0 + S(0, 1) * g1 + S(0, 2) * g2));
+            lds_atomic_add(&acc[1][t], sc * (S(1, 0) * g0 + S(1, 1) * g1 + S(1, 2) * g2));
+            lds_atomic_add(&acc[2][t], sc * (S(2, 0) * g0 + S(2, 1) * g1 + S(2, 2) * g2));
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < TILE; t += 256) {
+        T a = acc[0][t], b = acc[1][t], c = acc[2][t];
+        if (a == (T)0 && b == (T)0 && c == (T)0) continue;
+        int64_t s = tile_slot2<T>(t, nb8);
+        atomic_add(&gOut[s], a);
+        atomic_add(&gOut[slots + s], b);
+        atomic_add(&gOut[2 * slots + s], c);
+    }
+}
+template <class T>
+__global__ void k_matfree_finish(const T* __restrict__ gOut, const int32_t* __restrict__ dofSlot, const T* __restrict__ mass, const T* __restrict__ x, T* y, int nn, int64_t slots)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nn) return;
+    int64_t s = dofSlot[n];
+    T m = mass[n];
+    y[3 * n] = m * x[3 * n] + gOut[s], y[3 * n + 1] = m * x[3 * n + 1] + gOut[slots + s], y[3 * n + 2] = m * x[3 * n + 2] + gOut[2 * slots + s];
+}
+
+template <class T>
+void Ctx<T>::matfree_dev(const T* x, T* y)
+{
+    int64_t slots = (int64_t)Nb * EPB;
+    DBuf<T>& tile = ap; // scratch tile array (3*slots); `ap` is otherwise only used while building the hierarchy
+    tile.reserve(3 * slots);
+    HOT_HIP(hipMemsetAsync(tile.p, 0, 3 * slots * sizeof(T), stream));
+    HOT_LAUNCH(this, "matfree_hessian_product", k_matfree<T>, Ng, 256, 0, pX.p, pFn.p, pFt.p, pVol.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gIdx.p, x, tile.p, slots, dx,
+        (T)1 / dx, dt, cfg.project);
+    HOT_LAUNCH(this, "matfree_finish", k_matfree_finish<T>, div_up(Nn, 256), 256, 0, tile.p, dofSlot.p, mass.p, x, y, Nn, slots);
+}
+template <class T>
+void Ctx<T>::matfree_multiply(const void* x, void* y)
+{
+    need(Nn > 0 && dt > 0, "hot_matfree_multiply before hot_update_state");
+    HOT_HIP(hipMemcpyAsync(work0.p, x, 3 * (size_t)Nn * sizeof(T), hipMemcpyDefault, stream));
+    matfree_dev(work0.p, work1.p);
+    download(y, work1.p, 3 * (size_t)Nn);
+    sync();
+}
+
+template struct Ctx<float>;
+template struct Ctx<double>;
+
+} // namespace hot

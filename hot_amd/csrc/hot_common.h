@@ -1,0 +1,241 @@
+// libhotmi355x — common device/host utilities (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include <chrono>
+#include "../../include/hot_mi355x.h"
+
+namespace hot {
+
+struct Error {
+    int code;
+    std::string msg;
+};
+
+#define HOT_HIP(expr)                                                                                             \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess) throw ::hot::Error{ HOT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e) }; \
+    } while (0)
+
+#define HOT_CHECK(cond, code, text)                       \
+    do {                                                  \
+        if (!(cond)) throw ::hot::Error{ (code), (text) }; \
+    } while (0)
+
+// ------------------------------------------------------------------ device buffers (grow-only)
+template <class T>
+struct DBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    DBuf() = default;
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    ~DBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    // ensure capacity >= n elements; contents are NOT preserved on growth
+    void reserve(size_t n, double slack = 1.0)
+    {
+        if (n <= cap) return;
+        if (p) HOT_HIP(hipFree(p));
+        p = nullptr;
+        cap = (size_t)(n * slack) + 64;
+        HOT_HIP(hipMalloc((void**)&p, cap * sizeof(T)));
+    }
+    operator T*() const { return p; }
+};
+
+// ------------------------------------------------------------------ SPGrid address arithmetic
+// Device restatement of SPGrid_Mask<log2_struct, log2_struct, 3, 12> (reference Lib/SPGrid/Core/SPGrid_Mask.h:21-57,
+// 76-80,119-123,150-157,237-245): low 12 bits = element inside the 4 KiB page (x | y | z, z lowest, times the
+// struct size), high bits = block coordinates Morton-interleaved starting at the "left-over" axis.  Instead of
+// the reference's generic software pdep (SPGrid_Utilities.h:80-343) the two concrete layouts are written in
+// closed form with magic-number bit spreads; tests pin them bit-exactly to the compiled reference.
+template <int LOG2_STRUCT>
+struct SpMask {
+    static constexpr int data_bits = LOG2_STRUCT;
+    static constexpr int block_bits = 12 - LOG2_STRUCT;
+    static constexpr int zb = block_bits / 3 + (block_bits % 3 > 0);
+    static constexpr int yb = block_bits / 3 + (block_bits % 3 > 1);
+    static constexpr int xb = block_bits / 3;
+    static constexpr int EPB = 1 << block_bits; // elements (nodes) per block
+    static constexpr int BX = 1 << xb, BY = 1 << yb, BZ = 1 << zb;
+    // position of the lowest page bit of each axis: page masks are (0x9249.. << s) with s = 3 - block_bits % 3,
+    // i.e. z at bits {s, s+3, ..} >= 12 etc.
+    static constexpr int sh = 3 - block_bits % 3;
+    // first bit index >= 12 for each axis
+    static constexpr int first_at_or_above_12(int start)
+    {
+        int b = start;
+        while (b < 12) b += 3;
+        return b;
+    }
+    static constexpr int zlo = first_at_or_above_12(sh + 0), ylo = first_at_or_above_12(sh + 1), xlo = first_at_or_above_12(sh + 2);
+
+    // spread the low 21 bits of v so that bit i lands at bit 3*i
+    __host__ __device__ static inline uint64_t spread3(uint64_t v)
+    {
+        v &= 0x1fffffULL;
+        v = (v | (v << 32)) & 0x1f00000000ffffULL;
+        v = (v | (v << 16)) & 0x1f0000ff0000ffULL;
+        v = (v | (v << 8)) & 0x100f00f00f00f00fULL;
+        v = (v | (v << 4)) & 0x10c30c30c30c30c3ULL;
+        v = (v | (v << 2)) & 0x1249249249249249ULL;
+        return v;
+    }
+    __host__ __device__ static inline uint32_t compact3(uint64_t v)
+    {
+        v &= 0x1249249249249249ULL;
+        v = (v ^ (v >> 2)) & 0x10c30c30c30c30c3ULL;
+        v = (v ^ (v >> 4)) & 0x100f00f00f00f00fULL;
+        v = (v ^ (v >> 8)) & 0x1f0000ff0000ffULL;
+        v = (v ^ (v >> 16)) & 0x1f00000000ffffULL;
+        v = (v ^ (v >> 32)) & 0x1fffffULL;
+        return (uint32_t)v;
+    }
+    __host__ __device__ static inline uint64_t linear_offset(int i, int j, int k)
+    {
+        uint64_t ux = (uint64_t)(int64_t)i, uy = (uint64_t)(int64_t)j, uz = (uint64_t)(int64_t)k;
+        uint64_t elem = ((ux & (BX - 1)) << (data_bits + zb + yb)) | ((uy & (BY - 1)) << (data_bits + zb)) | ((uz & (BZ - 1)) << data_bits);
+        uint64_t page = (spread3(ux >> xb) << xlo) | (spread3(uy >> yb) << ylo) | (spread3(uz >> zb) << zlo);
+        return page | elem;
+    }
+    __host__ __device__ static inline void linear_to_coord(uint64_t o, int& i, int& j, int& k)
+    {
+        int ex = (int)((o >> (data_bits + zb + yb)) & (BX - 1)), ey = (int)((o >> (data_bits + zb)) & (BY - 1)), ez = (int)((o >> data_bits) & (BZ - 1));
+        i = (int)(compact3(o >> xlo) << xb) | ex;
+        j = (int)(compact3(o >> ylo) << yb) | ey;
+        k = (int)(compact3(o >> zlo) << zb) | ez;
+    }
+};
+
+// per-dtype grid geometry: GridState<float,3> = 64 B, GridState<double,3> = 128 B (reference Lib/MPM/MpmGrid.h:15-34)
+template <class T>
+struct Geo;
+template <>
+struct Geo<float> : SpMask<6> {
+};
+template <>
+struct Geo<double> : SpMask<7> {
+};
+
+// reference Lib/Ziran/Math/MathTools.h:21-25 and Lib/Ziran/Math/Splines/BSplines.h:16-20
+template <class T>
+__host__ __device__ inline int int_floor(T x)
+{
+    int i = (int)x;
+    return i - (i > x);
+}
+template <class T>
+__host__ __device__ inline int base_node(T x_index_space) { return int_floor<T>(x_index_space - (T)0.5); }
+
+// quadratic B-spline weights and derivatives of one axis: reference BSplines.h:55-81
+template <class T>
+__device__ inline void bspline(T x, int& base, T (&w)[3], T (&dw)[3])
+{
+    base = base_node<T>(x);
+    T d0 = x - (T)base;
+    T z = ((T)1.5 - d0);
+    w[0] = (T)0.5 * z * z;
+    T d1 = d0 - (T)1;
+    w[1] = (T)0.75 - d1 * d1;
+    T d2 = (T)1 - d1;
+    T zz = (T)1.5 - d2;
+    w[2] = (T)0.5 * zz * zz;
+    dw[0] = -z;
+    dw[1] = -(T)2 * d1;
+    dw[2] = zz;
+}
+
+// ------------------------------------------------------------------ wave / block reductions (wave = 64)
+template <class T>
+__device__ inline T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// block-wide sum for blockDim.x == 256; result valid in thread 0
+template <class T>
+__device__ inline T block_sum_256(T v, T* sm4)
+{
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sm4[w] = v;
+    __syncthreads();
+    T r = 0;
+    if (threadIdx.x == 0) r = sm4[0] + sm4[1] + sm4[2] + sm4[3];
+    __syncthreads();
+    return r;
+}
+
+template <class T>
+__device__ inline void atomic_add(T* p, T v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ inline void lds_atomic_add(T* p, T v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ------------------------------------------------------------------ open-addressing hash map u64 -> (min rank, id)
+struct HashMap {
+    uint64_t* keys = nullptr; // ~0 == empty
+    unsigned long long* minrank = nullptr;
+    int32_t* id = nullptr;
+    uint32_t mask = 0; // capacity - 1
+};
+__host__ __device__ inline uint64_t hash_mix(uint64_t k)
+{
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+__device__ inline uint32_t hash_insert_min(const HashMap& h, uint64_t key, unsigned long long rank)
+{
+    uint32_t s = (uint32_t)hash_mix(key) & h.mask;
+    while (true) {
+        unsigned long long prev = atomicCAS((unsigned long long*)&h.keys[s], ~0ULL, (unsigned long long)key);
+        if (prev == ~0ULL || prev == key) {
+            atomicMin(&h.minrank[s], rank);
+            return s;
+        }
+        s = (s + 1) & h.mask;
+    }
+}
+__device__ inline int32_t hash_find_slot(const HashMap& h, uint64_t key)
+{
+    uint32_t s = (uint32_t)hash_mix(key) & h.mask;
+    while (true) {
+        uint64_t k = h.keys[s];
+        if (k == key) return (int32_t)s;
+        if (k == ~0ULL) return -1;
+        s = (s + 1) & h.mask;
+    }
+}
+__device__ inline int32_t hash_find_id(const HashMap& h, uint64_t key)
+{
+    int32_t s = hash_find_slot(h, key);
+    return s < 0 ? -1 : h.id[s];
+}
+// pack non-negative 3-D integer coordinates (< 2^21) into a map key
+__host__ __device__ inline uint64_t coord_key(int x, int y, int z) { return ((uint64_t)(uint32_t)x << 42) | ((uint64_t)(uint32_t)y << 21) | (uint64_t)(uint32_t)z; }
+
+inline double wall_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace hot

@@ -1,0 +1,184 @@
+// libhotmi355x — typed context.  Member functions are defined in sort.hip / transfer.hip / force.hip /
+// hessian.hip / mg_build.hip / mg_solve.hip / solve.hip and explicitly instantiated there for float and double.
+#pragma once
+#include "hot_ctx.h"
+
+namespace hot {
+
+// one multigrid level: system matrix in 125-slot stencil ELL + transfer tables to the next coarser level
+template <class T>
+struct Level {
+    int n = 0; // rows (nodes)
+    DBuf<int32_t> coord; // 3n
+    DBuf<int32_t> col; // n*125   (entryCol)
+    DBuf<T> val; // n*125*9 (entryVal, 3x3 column-major)
+    DBuf<T> diagVal, diagInv; // n*9: D_i and the scaler (inverse of entries or of the block, by Ainv)
+    DBuf<T> diagBlockInv; // n*9: D_i^{-1} (GS always uses the block inverse)
+    // colouring (markColors): ckey = colour<<28 | blockId<<7 | indexInBlock(1-based), gs_order = nodes sorted by ckey
+    DBuf<uint32_t> ckey;
+    DBuf<int32_t> gs_order; // n
+    DBuf<int32_t> gs_block_start; // nblocks+1 : offsets into gs_order
+    int color_block_begin[9] = { 0 }; // blocks of colour c are [color_block_begin[c], color_block_begin[c+1])
+    int nblocks = 0;
+    // prolongation to this level from the next coarser one (P has 8 slots/row), restriction = P^T as child table
+    DBuf<int32_t> pcol; // n*8  coarse ids (padded slots repeat slot 0, weight 0)
+    DBuf<T> pw; // n*8
+    DBuf<int32_t> child; // ncoarse*27 fine ids of the 3x3x3 children of each coarse node (-1 = absent), on the COARSE level object
+    // coordinate -> id map of this level
+    DBuf<uint64_t> hkeys;
+    DBuf<unsigned long long> hrank;
+    DBuf<int32_t> hid;
+    HashMap map;
+    // V-cycle work vectors (3n each)
+    DBuf<T> residual, initialResidual, sol, du, dAu, tmp;
+};
+
+template <class T>
+struct Ctx : CtxBase {
+    using G = Geo<T>;
+    static constexpr int EPB = G::EPB;
+    static constexpr int TX = G::BX + 2, TY = G::BY + 2, TZ = G::BZ + 2, TILE = TX * TY * TZ; // nodes a particle group touches
+
+    T dx = 0, dt = 0;
+    // ---- particles (sorted order)
+    int64_t Np = 0;
+    DBuf<T> pX, pV, pM, pC, pF, pVol, pMu, pLam, pJp, pFn, pFt, pStress, pGradV;
+    DBuf<int32_t> slot2orig;
+    DBuf<T> spare1, spare3, spare9;
+    DBuf<int32_t> sparei;
+    bool keep_debug = true; // store stress/gradV for hot_get_particle_state
+    // ---- sort
+    DBuf<uint64_t> keys, keys2;
+    DBuf<uint32_t> vals, vals2;
+    DBuf<char> sort_tmp;
+    size_t sort_tmp_bytes = 0;
+    DBuf<int32_t> flags, scan; // generic flag/scan scratch
+    DBuf<char> scan_tmp;
+    size_t scan_tmp_bytes = 0;
+    // ---- groups / blocks
+    int Ng = 0, Nb = 0, Nn = 0;
+    DBuf<int32_t> group_first; // Ng+1
+    DBuf<uint64_t> group_page; // Ng page ids
+    DBuf<int32_t> group_nb; // Ng*8
+    DBuf<int32_t> group_origin; // Ng*3 node coords of the page's first node
+    DBuf<uint64_t> blocks; // Nb page byte offsets
+    DBuf<uint64_t> bh_keys;
+    DBuf<unsigned long long> bh_rank;
+    DBuf<int32_t> bh_id;
+    HashMap block_map;
+    // ---- node tiles (Nb*EPB)
+    DBuf<T> gM, gMV, gF, gCN; // gMV/gF: 3 components, component-major over slots
+    DBuf<int32_t> gIdx;
+    DBuf<int32_t> block_count; // Nb+1
+    // ---- DOFs (Nn)
+    DBuf<int32_t> dofSlot, id2coord, bcIdx;
+    DBuf<T> mass, vn, dv, dv0, cnTol, nodeV;
+    // ---- BC (Nc)
+    int Nc = 0;
+    DBuf<int32_t> bcNode;
+    DBuf<T> bcP, bcR, bcRinv, bcDv;
+    DBuf<uint8_t> bcSlip, bcHasDv;
+    std::vector<double> hs_origin, hs_normal;
+    DBuf<double> d_hs;
+    // ---- objective
+    double Ek = 0;
+    bool updated = false;
+    T max_cn_tolerance = 0;
+    DBuf<T> rhs, work0, work1, work2, work3;
+    DBuf<double> dscal; // device scalars
+    double* hscal = nullptr; // pinned host mirror
+    // ---- L-BFGS history
+    DBuf<T> hist_dx[9], hist_dg[9];
+    // ---- multigrid
+    std::vector<Level<T>*> levels;
+    DBuf<T> ap; // A*P scratch (n*64*9)
+
+    Ctx(const hot_config& c);
+    ~Ctx();
+    template <class U>
+    void upload(DBuf<U>& dst, const void* src, size_t n)
+    {
+        dst.reserve(n);
+        if (n) HOT_HIP(hipMemcpyAsync(dst.p, src, n * sizeof(U), hipMemcpyDefault, stream));
+    }
+    template <class U>
+    void download(void* dst, const U* src, size_t n)
+    {
+        if (dst && n) HOT_HIP(hipMemcpyAsync(dst, src, n * sizeof(U), hipMemcpyDefault, stream));
+    }
+    void sync() { HOT_HIP(hipStreamSynchronize(stream)); }
+    int32_t exclusive_scan_i32(const int32_t* in, int32_t* out, size_t n); // returns total (syncs)
+    void need(bool cond, const char* what) { HOT_CHECK(cond, HOT_ERR_INVALID, what); }
+
+    // CtxBase
+    void set_particles(int64_t Np, const void* X, const void* V, const void* mass, const void* C, const void* F, const void* vol, const void* mu, const void* lambda, const void* Jp) override;
+    void get_particles(void* X, void* V, void* C, void* F, void* mu, void* lambda, void* Jp) override;
+    void sort() override;
+    void get_counts(int64_t* Np, int32_t* Ng, int32_t* Nb, int32_t* Nn) override;
+    void get_indexing(int32_t* order, uint64_t* base_offset, int32_t* group, uint64_t* block_offset, uint64_t* blocks) override;
+    void p2g() override;
+    void get_grid(int32_t* id2coord, void* mass, void* v) override;
+    void set_bc(int32_t Nc, const int32_t* node_id, const void* P, const void* R, const void* Rinv, const uint8_t* slip, const void* dvc) override;
+    void set_halfspaces(int32_t n, const double* origin, const double* normal) override;
+    void begin_step(double dt) override;
+    void get_dv(void* dv) override;
+    void set_dv(const void* dv) override;
+    void update_state(const void* dv, double* energy) override;
+    void get_particle_state(void* F, void* stress, void* gradV) override;
+    void residual(void* r) override;
+    void project(void* v) override;
+    void cn_tolerance(void* tol) override;
+    void build_hessian() override;
+    void matfree_multiply(const void* x, void* y) override;
+    void build_mg() override;
+    void get_level(int32_t level, int32_t* nrows, int32_t* colsize, int32_t* id2coord) override;
+    void get_matrix(int32_t level, int32_t* entryCol, void* entryVal) override;
+    void get_prolongation(int32_t level, int32_t* entryCol, void* weight) override;
+    void spmv(int32_t level, const void* x, void* y) override;
+    void restrict_(int32_t level, const void* fine, void* coarse) override;
+    void prolong(int32_t level, const void* coarse, void* fine) override;
+    void smooth(int32_t level, int32_t kind, int32_t iterations, double tol, void* u, void* r, const void* r0) override;
+    void vcycle(const void* in, void* out) override;
+    void solve(hot_stats* st) override;
+    void g2p(double dt, int32_t* flags) override;
+    void advance(double dt, hot_stats* st) override;
+
+    // ---- device-side building blocks (device pointers)
+    void eval_halfspaces();
+    double state_pass(const T* dv_in, bool want_force); // G2P(vn+dv) -> F, energy, force scatter; returns total energy (syncs)
+    void residual_dev(T* r); // from the force tiles of the last state_pass
+    void project_dev(T* v);
+    void transform_dev(T* v, bool inverse); // transformResidual / recoverSolution
+    void cn_tolerance_dev();
+    void build_diagonal(Level<T>& L);
+    void spmv_dev(Level<T>& L, const T* x, T* y);
+    void restrict_dev(int level, const T* fine, T* coarse);
+    void prolong_dev(int level, const T* coarse, T* fine);
+    void smooth_dev(int level, int kind, int iterations, T tol, T* u, T* r, T* du, T* dAu);
+    void vcycle_dev(const T* in, T* out);
+    void precondition_dev(const T* in, T* out);
+    void matfree_dev(const T* x, T* y);
+    // vector helpers on 3n-long arrays
+    void axpy(size_t n, T a, const T* x, T* y); // y += a x
+    void axpy_dev(size_t n, const double* a, double sign, const T* x, T* y); // y += sign * (*a) * x, scalar on device
+    void copy(size_t n, const T* x, T* y);
+    void zero(size_t n, T* y);
+    void dot_to(size_t n, const T* x, const T* y, double* out); // *out = <x,y> (device scalar)
+    double dot_host(size_t n, const T* x, const T* y);
+    bool should_exit(const T* r);
+    T line_search(T* ddv, T* residual_out, T alpha);
+    bool lbfgs_solve();
+    bool newton_solve();
+};
+
+// launch helpers
+inline int div_up(size_t a, size_t b) { return (int)((a + b - 1) / b); }
+
+#define HOT_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                       \
+    do {                                                                             \
+        (ctx)->prof.begin(name, (ctx)->stream);                                      \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, (ctx)->stream, __VA_ARGS__); \
+        (ctx)->prof.end((ctx)->stream);                                              \
+    } while (0)
+
+} // namespace hot

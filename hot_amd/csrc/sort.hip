@@ -1,0 +1,358 @@
+// libhotmi355x — particle storage, sort/bin, block list, neighbour tables.
+//
+// Replaces MpmSimulationBase::sortParticlesAndPolluteGrid (reference Lib/MPM/MpmSimulationBase.cpp:1066-1137):
+//   key build (:1080-1085)           -> k_make_keys (same float arithmetic: X * (1/dx), baseNode, Linear_Offset)
+//   tbb::parallel_sort (:1087)       -> LSD radix sort of the 64-bit keys (rocPRIM device primitive)
+//   serial group scan (:1089-1097)   -> head flags + exclusive scan
+//   serial Set_Page loop (:1099-1125)-> hash insert with atomicMin(sequence rank): a page's position in the
+//                                       block list is the rank of its FIRST Set_Page call, which is what the
+//                                       reference's insertion-ordered std::vector records (SPGrid_Page_Map.h:61-70)
+//   serial memset (:1126-1136)       -> tile clears
+// MI355X design: the particle arrays are physically permuted into sorted order every step (one gather pass),
+// so every later particle kernel streams them fully coalesced instead of chasing particle_order.
+#include "hot_impl.h"
+#include <rocprim/rocprim.hpp>
+
+namespace hot {
+
+template <class T>
+__global__ void k_aos_to_soa(const T* __restrict__ aos, T* __restrict__ soa, int64_t n, int comps)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * comps) return;
+    int64_t p = i / comps;
+    int c = (int)(i - p * comps);
+    soa[(int64_t)c * n + p] = aos[i];
+}
+// aos[orig*comps + c] = soa[c*n + slot], orig = slot2orig[slot]
+template <class T>
+__global__ void k_soa_to_aos(const T* __restrict__ soa, T* __restrict__ aos, const int32_t* __restrict__ slot2orig, int64_t n, int comps)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * comps) return;
+    int c = (int)(i / n);
+    int64_t p = i - (int64_t)c * n;
+    aos[(int64_t)slot2orig[p] * comps + c] = soa[i];
+}
+template <class T>
+__global__ void k_fill(T* a, int64_t n, T v)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = v;
+}
+__global__ void k_iota(int32_t* a, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (int32_t)i;
+}
+template <class T>
+__global__ void k_identity9(T* a, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 9) return;
+    int c = (int)(i / n);
+    a[i] = (c == 0 || c == 4 || c == 8) ? (T)1 : (T)0;
+}
+
+template <class T>
+__global__ void k_make_keys(const T* __restrict__ X, const int32_t* __restrict__ slot2orig, uint64_t* keys, uint32_t* vals, int64_t n, T one_over_dx)
+{
+    using G = Geo<T>;
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int b0 = base_node<T>(X[p] * one_over_dx), b1 = base_node<T>(X[n + p] * one_over_dx), b2 = base_node<T>(X[2 * n + p] * one_over_dx);
+    uint64_t offset = G::linear_offset(b0, b1, b2);
+    constexpr int index_bits = 32 - G::block_bits;
+    keys[p] = ((offset >> G::data_bits) << index_bits) + (uint64_t)(uint32_t)slot2orig[p];
+    vals[p] = (uint32_t)p;
+}
+
+template <class U>
+__global__ void k_gather(const U* __restrict__ src, U* __restrict__ dst, const uint32_t* __restrict__ perm, int64_t n, int comps)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int64_t q = perm[p];
+    for (int c = 0; c < comps; ++c) dst[(int64_t)c * n + p] = src[(int64_t)c * n + q];
+}
+
+__global__ void k_group_heads(const uint64_t* __restrict__ keys, int32_t* flags, int64_t n)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    flags[p] = (p == 0 || (keys[p] >> 32) != (keys[p - 1] >> 32)) ? 1 : 0;
+}
+template <class T>
+__global__ void k_fill_groups(const uint64_t* __restrict__ keys, const int32_t* __restrict__ flags, const int32_t* __restrict__ scan, int32_t* group_first,
+    uint64_t* group_page, int32_t* group_origin, int64_t n, int ng)
+{
+    using G = Geo<T>;
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (p == 0) group_first[ng] = (int32_t)n;
+    if (!flags[p]) return;
+    int g = scan[p];
+    group_first[g] = (int32_t)p;
+    uint64_t page = keys[p] >> 32;
+    group_page[g] = page;
+    int i, j, k;
+    G::linear_to_coord(page << 12, i, j, k);
+    group_origin[3 * g] = i, group_origin[3 * g + 1] = j, group_origin[3 * g + 2] = k;
+}
+
+__global__ void k_hash_clear(HashMap h)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > h.mask) return;
+    h.keys[i] = ~0ULL;
+    h.minrank[i] = ~0ULL;
+    h.id[i] = -1;
+}
+template <class T>
+__device__ inline uint64_t nb_page(const int32_t* origin, int g, int n)
+{
+    using G = Geo<T>;
+    int a = n >> 2, b = (n >> 1) & 1, c = n & 1;
+    return G::linear_offset(origin[3 * g] + a * G::BX, origin[3 * g + 1] + b * G::BY, origin[3 * g + 2] + c * G::BZ) >> 12;
+}
+template <class T>
+__global__ void k_block_insert(HashMap h, const int32_t* __restrict__ origin, int ng)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ng * 8) return;
+    hash_insert_min(h, nb_page<T>(origin, s >> 3, s & 7), (unsigned long long)s);
+}
+template <class T>
+__global__ void k_block_flag(HashMap h, const int32_t* __restrict__ origin, int32_t* flags, int ng)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ng * 8) return;
+    int32_t slot = hash_find_slot(h, nb_page<T>(origin, s >> 3, s & 7));
+    flags[s] = (h.minrank[slot] == (unsigned long long)s) ? 1 : 0;
+}
+template <class T>
+__global__ void k_block_assign(HashMap h, const int32_t* __restrict__ origin, const int32_t* __restrict__ flags, const int32_t* __restrict__ scan, uint64_t* blocks, int ng)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ng * 8 || !flags[s]) return;
+    uint64_t page = nb_page<T>(origin, s >> 3, s & 7);
+    int32_t slot = hash_find_slot(h, page);
+    h.id[slot] = scan[s];
+    blocks[scan[s]] = page << 12;
+}
+template <class T>
+__global__ void k_group_nb(HashMap h, const int32_t* __restrict__ origin, int32_t* group_nb, int ng)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ng * 8) return;
+    group_nb[s] = hash_find_id(h, nb_page<T>(origin, s >> 3, s & 7));
+}
+template <class T>
+__global__ void k_base_offsets(const T* __restrict__ X, const int32_t* __restrict__ slot2orig, uint64_t* out, int32_t* order, int64_t n, T one_over_dx)
+{
+    using G = Geo<T>;
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int b0 = base_node<T>(X[p] * one_over_dx), b1 = base_node<T>(X[n + p] * one_over_dx), b2 = base_node<T>(X[2 * n + p] * one_over_dx);
+    uint64_t offset = G::linear_offset(b0, b1, b2);
+    offset = (offset >> G::data_bits) << G::data_bits;
+    int32_t o = slot2orig[p];
+    out[o] = offset;
+    order[p] = o;
+}
+__global__ void k_group_ranges(const int32_t* __restrict__ first, int32_t* out, int ng)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    out[2 * g] = first[g];
+    out[2 * g + 1] = first[g + 1] - 1;
+}
+
+// ------------------------------------------------------------------------------------------------ Ctx
+template <class T>
+Ctx<T>::Ctx(const hot_config& c)
+{
+    cfg = c;
+    dx = (T)c.dx;
+    HOT_HIP(hipSetDevice(c.device));
+    HOT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    prof.on = c.profile != 0;
+    dscal.reserve(256);
+    HOT_HIP(hipHostMalloc((void**)&hscal, 256 * sizeof(double)));
+    std::memset(&stats, 0, sizeof(stats));
+}
+template <class T>
+Ctx<T>::~Ctx()
+{
+    for (auto* l : levels) delete l;
+    if (hscal) (void)hipHostFree(hscal);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+template <class T>
+int32_t Ctx<T>::exclusive_scan_i32(const int32_t* in, int32_t* out, size_t n)
+{
+    if (n == 0) return 0;
+    size_t bytes = 0;
+    HOT_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, (int32_t)0, n, rocprim::plus<int32_t>(), stream));
+    if (bytes > scan_tmp_bytes) {
+        scan_tmp.reserve(bytes);
+        scan_tmp_bytes = scan_tmp.cap;
+    }
+    HOT_HIP(rocprim::exclusive_scan(scan_tmp.p, bytes, in, out, (int32_t)0, n, rocprim::plus<int32_t>(), stream));
+    int32_t last_in = 0, last_out = 0;
+    HOT_HIP(hipMemcpyAsync(&last_in, in + n - 1, 4, hipMemcpyDeviceToHost, stream));
+    HOT_HIP(hipMemcpyAsync(&last_out, out + n - 1, 4, hipMemcpyDeviceToHost, stream));
+    sync();
+    return last_in + last_out;
+}
+
+template <class T>
+void Ctx<T>::set_particles(int64_t n, const void* X, const void* V, const void* m, const void* C, const void* F, const void* vol, const void* mu, const void* lam, const void* Jp)
+{
+    constexpr int index_bits = 32 - G::block_bits;
+    HOT_CHECK(n > 0 && n < (1LL << index_bits), HOT_ERR_CAPACITY, "particle count must be in (0, 2^(32-block_bits)) (MpmSimulationBase.cpp:1071-1072)");
+    need(X && V && m && vol && mu && lam, "X, V, mass, vol, mu, lambda are required");
+    Np = n;
+    pX.reserve(3 * n), pV.reserve(3 * n), pM.reserve(n), pC.reserve(9 * n), pF.reserve(9 * n), pVol.reserve(n), pMu.reserve(n), pLam.reserve(n), pJp.reserve(n);
+    pFn.reserve(9 * n), pFt.reserve(9 * n), pStress.reserve(9 * n), pGradV.reserve(9 * n);
+    spare1.reserve(n), spare3.reserve(3 * n), spare9.reserve(9 * n), sparei.reserve(n), slot2orig.reserve(n);
+    auto put = [&](DBuf<T>& dst, const void* src, int comps) {
+        if (comps == 1) {
+            HOT_HIP(hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyDefault, stream));
+            return;
+        }
+        HOT_HIP(hipMemcpyAsync(spare9.p, src, (size_t)n * comps * sizeof(T), hipMemcpyDefault, stream));
+        HOT_LAUNCH(this, "aos_to_soa", k_aos_to_soa<T>, div_up(n * comps, 256), 256, 0, spare9.p, dst.p, n, comps);
+    };
+    put(pX, X, 3), put(pV, V, 3), put(pM, m, 1), put(pVol, vol, 1), put(pMu, mu, 1), put(pLam, lam, 1);
+    if (C)
+        put(pC, C, 9);
+    else
+        HOT_HIP(hipMemsetAsync(pC.p, 0, 9 * n * sizeof(T), stream));
+    if (F)
+        put(pF, F, 9);
+    else
+        HOT_LAUNCH(this, "identity9", k_identity9<T>, div_up(9 * n, 256), 256, 0, pF.p, n);
+    if (Jp)
+        put(pJp, Jp, 1);
+    else
+        HOT_LAUNCH(this, "fill", k_fill<T>, div_up(n, 256), 256, 0, pJp.p, n, (T)1);
+    HOT_LAUNCH(this, "iota", k_iota, div_up(n, 256), 256, 0, slot2orig.p, n);
+    Ng = Nb = Nn = 0;
+    sync();
+}
+
+template <class T>
+void Ctx<T>::get_particles(void* X, void* V, void* C, void* F, void* mu, void* lam, void* Jp)
+{
+    need(Np > 0, "no particles");
+    int64_t n = Np;
+    auto get = [&](const DBuf<T>& src, void* dst, int comps) {
+        if (!dst) return;
+        HOT_LAUNCH(this, "soa_to_aos", k_soa_to_aos<T>, div_up(n * comps, 256), 256, 0, src.p, spare9.p, slot2orig.p, n, comps);
+        HOT_HIP(hipMemcpyAsync(dst, spare9.p, (size_t)n * comps * sizeof(T), hipMemcpyDefault, stream));
+        sync();
+    };
+    get(pX, X, 3), get(pV, V, 3), get(pC, C, 9), get(pF, F, 9), get(pMu, mu, 1), get(pLam, lam, 1), get(pJp, Jp, 1);
+}
+
+template <class T>
+void Ctx<T>::sort()
+{
+    need(Np > 0, "hot_sort: no particles");
+    int64_t n = Np;
+    double t0 = wall_ms();
+    keys.reserve(n), keys2.reserve(n), vals.reserve(n), vals2.reserve(n), flags.reserve(std::max<size_t>(n, 64)), scan.reserve(std::max<size_t>(n, 64));
+    T one_over_dx = (T)1 / dx;
+    HOT_LAUNCH(this, "make_keys", k_make_keys<T>, div_up(n, 256), 256, 0, pX.p, slot2orig.p, keys.p, vals.p, n, one_over_dx);
+    size_t bytes = 0;
+    HOT_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)n, 0, 64, stream));
+    if (bytes > sort_tmp_bytes) {
+        sort_tmp.reserve(bytes);
+        sort_tmp_bytes = sort_tmp.cap;
+    }
+    prof.begin("radix_sort_pairs", stream);
+    HOT_HIP(rocprim::radix_sort_pairs(sort_tmp.p, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)n, 0, 64, stream));
+    prof.end(stream);
+    // physical reorder of every per-particle array into sorted order
+    auto reorder = [&](DBuf<T>& a, DBuf<T>& spare, int comps) {
+        HOT_LAUNCH(this, "reorder_gather", k_gather<T>, div_up(n, 256), 256, 0, a.p, spare.p, vals2.p, n, comps);
+        std::swap(a.p, spare.p);
+        std::swap(a.cap, spare.cap);
+    };
+    reorder(pX, spare3, 3), reorder(pV, spare3, 3), reorder(pM, spare1, 1), reorder(pVol, spare1, 1), reorder(pMu, spare1, 1), reorder(pLam, spare1, 1), reorder(pJp, spare1, 1);
+    reorder(pC, spare9, 9), reorder(pF, spare9, 9);
+    HOT_LAUNCH(this, "reorder_gather", k_gather<int32_t>, div_up(n, 256), 256, 0, slot2orig.p, sparei.p, vals2.p, n, 1);
+    std::swap(slot2orig.p, sparei.p);
+    std::swap(slot2orig.cap, sparei.cap);
+    // groups
+    HOT_LAUNCH(this, "group_heads", k_group_heads, div_up(n, 256), 256, 0, keys2.p, flags.p, n);
+    Ng = exclusive_scan_i32(flags.p, scan.p, n);
+    group_first.reserve(Ng + 1), group_page.reserve(Ng), group_origin.reserve(3 * (size_t)Ng), group_nb.reserve(8 * (size_t)Ng);
+    HOT_LAUNCH(this, "fill_groups", k_fill_groups<T>, div_up(n, 256), 256, 0, keys2.p, flags.p, scan.p, group_first.p, group_page.p, group_origin.p, n, Ng);
+    // block list in Set_Page insertion order
+    size_t cand = (size_t)Ng * 8;
+    uint32_t capn = 1024;
+    while (capn < 2 * cand) capn <<= 1;
+    bh_keys.reserve(capn), bh_rank.reserve(capn), bh_id.reserve(capn);
+    block_map.keys = bh_keys.p, block_map.minrank = bh_rank.p, block_map.id = bh_id.p, block_map.mask = capn - 1;
+    flags.reserve(cand), scan.reserve(cand);
+    HOT_LAUNCH(this, "hash_clear", k_hash_clear, div_up(capn, 256), 256, 0, block_map);
+    HOT_LAUNCH(this, "block_insert", k_block_insert<T>, div_up(cand, 256), 256, 0, block_map, group_origin.p, Ng);
+    HOT_LAUNCH(this, "block_flag", k_block_flag<T>, div_up(cand, 256), 256, 0, block_map, group_origin.p, flags.p, Ng);
+    Nb = exclusive_scan_i32(flags.p, scan.p, cand);
+    blocks.reserve(Nb);
+    HOT_LAUNCH(this, "block_assign", k_block_assign<T>, div_up(cand, 256), 256, 0, block_map, group_origin.p, flags.p, scan.p, blocks.p, Ng);
+    HOT_LAUNCH(this, "group_nb", k_group_nb<T>, div_up(cand, 256), 256, 0, block_map, group_origin.p, group_nb.p, Ng);
+    // node tiles
+    size_t slots = (size_t)Nb * EPB;
+    gM.reserve(slots, 1.25), gMV.reserve(3 * slots, 1.25), gF.reserve(3 * slots, 1.25), gCN.reserve(slots, 1.25), gIdx.reserve(slots, 1.25), block_count.reserve(Nb + 1, 1.25);
+    Nn = 0;
+    Nc = 0;
+    updated = false;
+    stats.ms_sort = wall_ms() - t0;
+}
+
+template <class T>
+void Ctx<T>::get_counts(int64_t* np, int32_t* ng, int32_t* nb, int32_t* nn)
+{
+    if (np) *np = Np;
+    if (ng) *ng = Ng;
+    if (nb) *nb = Nb;
+    if (nn) *nn = Nn;
+}
+
+template <class T>
+void Ctx<T>::get_indexing(int32_t* order, uint64_t* base_offset, int32_t* group, uint64_t* block_offset, uint64_t* blk)
+{
+    need(Ng > 0, "hot_get_indexing before hot_sort");
+    int64_t n = Np;
+    if (order || base_offset) {
+        DBuf<uint64_t> off;
+        DBuf<int32_t> ord;
+        off.reserve(n), ord.reserve(n);
+        HOT_LAUNCH(this, "base_offsets", k_base_offsets<T>, div_up(n, 256), 256, 0, pX.p, slot2orig.p, off.p, ord.p, n, (T)1 / dx);
+        download(order, ord.p, n);
+        download(base_offset, off.p, n);
+        sync();
+    }
+    if (group) {
+        DBuf<int32_t> r;
+        r.reserve(2 * (size_t)Ng);
+        HOT_LAUNCH(this, "group_ranges", k_group_ranges, div_up(Ng, 256), 256, 0, group_first.p, r.p, Ng);
+        download(group, r.p, 2 * (size_t)Ng);
+        sync();
+    }
+    download(block_offset, group_page.p, Ng);
+    download(blk, blocks.p, Nb);
+    sync();
+}
+
+template struct Ctx<float>;
+template struct Ctx<double>;
+
+CtxBase* make_ctx_f32(const hot_config& cfg) { return new Ctx<float>(cfg); }
+CtxBase* make_ctx_f64(const hot_config& cfg) { return new Ctx<double>(cfg); }
+
+} // namespace hot

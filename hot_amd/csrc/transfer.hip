@@ -1,0 +1,302 @@
+// libhotmi355x — APIC particle <-> grid transfers over the SPGrid block grid.
+//
+//   k_p2g          particlesToGridHelper<true,false> (reference Lib/MPM/MpmSimulationBase.cpp:611-656): one particle
+//                  group (= one SPGrid page worth of base cells) per workgroup; the (BX+2)(BY+2)(BZ+2) nodes the
+//                  group can touch are accumulated in LDS with ds_add atomics, then flushed with one global atomic
+//                  per touched node and quantity.  The reference's 8 sequential colour passes (:621-655) exist only
+//                  to avoid write races between pages; atomics make the pass single-launch.
+//   k_block_count / k_number_nodes
+//                  MpmGrid::getNumNodes (Lib/MPM/MpmGrid.h:148-161) — serial in the reference; here a per-block
+//                  ballot + an exclusive scan over the insertion-ordered block list reproduce the ids bit-exactly;
+//                  also v /= m (MpmSimulationBase.cpp:521-532), buildMassMatrix (:817-826) and id2coord
+//                  (ImplicitSolver.h:474-477).
+//   k_g2p          constructNewVelocityFromNewtonResult (:891-901) + gridToParticlesHelper<true,false,false>
+//                  (:930-1007) + evolveStrain (Force/FBasedMpmForceHelper.cpp:99-114) + applyPlasticity (:1044-1064)
+//                  fused: node tile staged in LDS, particle streams fully coalesced.
+#include "hot_impl.h"
+#include "hot_constitutive.h"
+
+namespace hot {
+
+// decode tile node t -> node slot (which of the 8 neighbour pages, which element)
+template <class T>
+__device__ __forceinline__ int tile_slot(int t, const int32_t* __restrict__ nb8)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2;
+    int tz = t % TZ, ty = (t / TZ) % TY, tx = t / (TZ * TY);
+    int ox = tx >> G::xb, oy = ty >> G::yb, oz = tz >> G::zb;
+    int elem = ((tx & (G::BX - 1)) << (G::yb + G::zb)) | ((ty & (G::BY - 1)) << G::zb) | (tz & (G::BZ - 1));
+    return nb8[ox * 4 + oy * 2 + oz] * G::EPB + elem;
+}
+
+template <class T, bool WITH_CN>
+__global__ __launch_bounds__(256) void k_p2g(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C,
+    const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
+    const int32_t* __restrict__ group_nb, T* gM, T* gMV, T* gCN, int64_t slots, T dx, T one_over_dx)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
+    constexpr int NQ = WITH_CN ? 5 : 4;
+    __shared__ T acc[NQ][TILE];
+    __shared__ int32_t nb8[8];
+    const int g = blockIdx.x;
+    for (int t = threadIdx.x; t < NQ * TILE; t += 256) (&acc[0][0])[t] = (T)0;
+    if (threadIdx.x < 8) nb8[threadIdx.x] = group_nb[g * 8 + threadIdx.x];
+    __syncthreads();
+    const int first = group_first[g], last = group_first[g + 1];
+    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
+    for (int p = first + threadIdx.x; p < last; p += 256) {
+        T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
+        T m = M[p];
+        T mom[3] = { m * V[p], m * V[Np + p], m * V[2 * Np + p] };
+        T Cm[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Cm[c] = m * C[(int64_t)c * Np + p];
+        int base[3];
+        T w[3][3], dw[3][3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+        T cn = (T)0;
+        if (WITH_CN) {
+            // |dP/dF(F = I)|_F of the fixed-corotated model: A = 2 mu I + lambda 11^T, B blocks = mu [[1,1],[1,1]]
+            // (already PSD, so --project does not change it): sqrt(3(2mu+l)^2 + 6 l^2 + 12 mu^2)
+            T mu = Mu[p], la = Lam[p];
+            cn = m * hsqrt((T)3 * ((T)2 * mu + la) * ((T)2 * mu + la) + (T)6 * la * la + (T)12 * mu * mu);
+        }
+        const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
+        // rotate the visiting order per lane so that the particles of one cell (adjacent lanes) hit different
+        // LDS addresses in the same instruction
+        int rot = threadIdx.x % 27;
+        for (int n = 0; n < 27; ++n) {
+            int q = n + rot;
+            q = q >= 27 ? q - 27 : q;
+            int i = q / 9, j = (q / 3) % 3, k = q % 3;
+            T wijk = w[0][i] * w[1][j] * w[2][k];
+            T d0 = (T)(base[0] + i) * dx - xp[0], d1 = (T)(base[1] + j) * dx - xp[1], d2 = (T)(base[2] + k) * dx - xp[2];
+            int t = ((cx + i) * TY + (cy + j)) * TZ + (cz + k);
+            lds_atomic_add(&acc[0][t], m * wijk);
+            lds_atomic_add(&acc[1][t], (Cm[0] * d0 + Cm[3] * d1 + Cm[6] * d2 + mom[0]) * wijk);
+            lds_atomic_add(&acc[2][t], (Cm[1] * d0 + Cm[4] * d1 + Cm[7] * d2 + mom[1]) * wijk);
+            lds_atomic_add(&acc[3][t], (Cm[2] * d0 + Cm[5] * d1 + Cm[8] * d2 + mom[2]) * wijk);
+            if (WITH_CN) lds_atomic_add(&acc[NQ - 1][t], cn * wijk);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < TILE; t += 256) {
+        T m = acc[0][t];
+        if (m == (T)0 && acc[1][t] == (T)0 && acc[2][t] == (T)0 && acc[3][t] == (T)0) continue;
+        int64_t s = tile_slot<T>(t, nb8);
+        atomic_add(&gM[s], m);
+        atomic_add(&gMV[s], acc[1][t]);
+        atomic_add(&gMV[slots + s], acc[2][t]);
+        atomic_add(&gMV[2 * slots + s], acc[3][t]);
+        if (WITH_CN) atomic_add(&gCN[s], acc[NQ - 1][t]);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_block_count(const T* __restrict__ gM, int32_t* block_count, int nb)
+{
+    using G = Geo<T>;
+    int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    bool has = false;
+    if (b < nb && lane < G::EPB) has = gM[(int64_t)b * G::EPB + lane] != (T)0;
+    unsigned long long mask = __ballot(has);
+    if (b < nb && lane == 0) block_count[b] = __popcll(mask);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_number_nodes(const T* __restrict__ gM, T* gMV, int32_t* gIdx, const int32_t* __restrict__ block_base,
+    const uint64_t* __restrict__ blocks, int32_t* dofSlot, int32_t* id2coord, T* mass, T* nodeV, int nb, int64_t slots)
+{
+    using G = Geo<T>;
+    int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    bool valid = b < nb && lane < G::EPB;
+    int64_t s = (int64_t)b * G::EPB + lane;
+    T m = valid ? gM[s] : (T)0;
+    bool has = valid && m != (T)0;
+    unsigned long long mask = __ballot(has);
+    if (!valid) return;
+    int idx = -1;
+    T v0 = 0, v1 = 0, v2 = 0;
+    if (has) {
+        idx = block_base[b] + __popcll(mask & ((1ULL << lane) - 1ULL));
+        T inv = (T)1 / m;
+        v0 = gMV[s] * inv, v1 = gMV[slots + s] * inv, v2 = gMV[2 * slots + s] * inv;
+        int bi, bj, bk;
+        G::linear_to_coord(blocks[b], bi, bj, bk);
+        int ez = lane & (G::BZ - 1), ey = (lane >> G::zb) & (G::BY - 1), ex = lane >> (G::zb + G::yb);
+        dofSlot[idx] = (int32_t)s;
+        id2coord[3 * idx] = bi + ex, id2coord[3 * idx + 1] = bj + ey, id2coord[3 * idx + 2] = bk + ez;
+        mass[idx] = m;
+        nodeV[3 * idx] = v0, nodeV[3 * idx + 1] = v1, nodeV[3 * idx + 2] = v2;
+    }
+    gIdx[s] = idx;
+    gMV[s] = v0, gMV[slots + s] = v1, gMV[2 * slots + s] = v2;
+}
+
+template <class T>
+void Ctx<T>::p2g()
+{
+    need(Ng > 0, "hot_p2g before hot_sort");
+    double t0 = wall_ms();
+    int64_t slots = (int64_t)Nb * EPB;
+    HOT_HIP(hipMemsetAsync(gM.p, 0, slots * sizeof(T), stream));
+    HOT_HIP(hipMemsetAsync(gMV.p, 0, 3 * slots * sizeof(T), stream));
+    HOT_HIP(hipMemsetAsync(gCN.p, 0, slots * sizeof(T), stream));
+    T one_over_dx = (T)1 / dx;
+    if (cfg.useCN)
+        HOT_LAUNCH(this, "p2g", (k_p2g<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gM.p, gMV.p, gCN.p, slots, dx, one_over_dx);
+    else
+        HOT_LAUNCH(this, "p2g", (k_p2g<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gM.p, gMV.p, gCN.p, slots, dx, one_over_dx);
+    HOT_LAUNCH(this, "block_count", k_block_count<T>, div_up(Nb, 4), 256, 0, gM.p, block_count.p, Nb);
+    scan.reserve(Nb + 1);
+    Nn = exclusive_scan_i32(block_count.p, scan.p, Nb);
+    HOT_CHECK((int64_t)Nn * 125 < (1LL << 31), HOT_ERR_CAPACITY, "num_nodes*125 overflows int32 (ImplicitSolver.h:479-480)");
+    size_t n = std::max(Nn, 1);
+    dofSlot.reserve(n, 1.25), id2coord.reserve(3 * n, 1.25), mass.reserve(n, 1.25), nodeV.reserve(3 * n, 1.25), bcIdx.reserve(n, 1.25);
+    vn.reserve(3 * n, 1.25), dv.reserve(3 * n, 1.25), dv0.reserve(3 * n, 1.25), cnTol.reserve(n, 1.25), rhs.reserve(3 * n, 1.25);
+    work0.reserve(3 * n, 1.25), work1.reserve(3 * n, 1.25), work2.reserve(3 * n, 1.25), work3.reserve(3 * n, 1.25);
+    HOT_LAUNCH(this, "number_nodes", k_number_nodes<T>, div_up(Nb, 4), 256, 0, gM.p, gMV.p, gIdx.p, scan.p, blocks.p, dofSlot.p, id2coord.p, mass.p, nodeV.p, Nb, slots);
+    stats.ms_p2g = wall_ms() - t0;
+}
+
+template <class T>
+void Ctx<T>::get_grid(int32_t* ic, void* m, void* v)
+{
+    need(Nn > 0, "hot_get_grid before hot_p2g");
+    download(ic, id2coord.p, 3 * (size_t)Nn);
+    download(m, mass.p, Nn);
+    download(v, nodeV.p, 3 * (size_t)Nn);
+    sync();
+}
+
+// ------------------------------------------------------------------------------------------------ G2P
+template <class T, int PLASTIC>
+__global__ __launch_bounds__(256) void k_g2p(T* __restrict__ X, T* __restrict__ V, T* __restrict__ C, T* __restrict__ F, const T* __restrict__ Fn, T* __restrict__ gradV_out,
+    T* __restrict__ Mu, T* __restrict__ Lam, T* __restrict__ Jp, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
+    const int32_t* __restrict__ group_nb, const int32_t* __restrict__ gIdx, const T* __restrict__ nodeV, const T* __restrict__ dv, T dx, T one_over_dx, T dt, T apic_r,
+    T cfl, T yield_stress, T sn0, T sn1, T sn2, T sn3, T sn4, int32_t* flags_out)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
+    __shared__ T nv[3][TILE];
+    __shared__ int32_t nb8[8];
+    const int g = blockIdx.x;
+    if (threadIdx.x < 8) nb8[threadIdx.x] = group_nb[g * 8 + threadIdx.x];
+    __syncthreads();
+    for (int t = threadIdx.x; t < TILE; t += 256) {
+        int idx = gIdx[tile_slot<T>(t, nb8)];
+        T a = 0, b = 0, c = 0;
+        if (idx >= 0) {
+            a = nodeV[3 * idx] + dv[3 * idx], b = nodeV[3 * idx + 1] + dv[3 * idx + 1], c = nodeV[3 * idx + 2] + dv[3 * idx + 2];
+        }
+        nv[0][t] = a, nv[1][t] = b, nv[2][t] = c;
+    }
+    __syncthreads();
+    const int first = group_first[g], last = group_first[g + 1];
+    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
+    const T D_inverse = (T)4 / (dx * dx);
+    int myflags = 0;
+    for (int p = first + threadIdx.x; p < last; p += 256) {
+        T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
+        int base[3];
+        T w[3][3], dw[3][3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+        const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
+        T pic[3] = { 0, 0, 0 };
+        T B[9], gv[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) B[c] = (T)0, gv[c] = (T)0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            T wi = w[0][i], dwi = one_over_dx * dw[0][i];
+            T d0 = (T)(base[0] + i) * dx - xp[0];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                T wij = wi * w[1][j];
+                T dwij_i = dwi * w[1][j], dwij_j = wi * one_over_dx * dw[1][j];
+                T d1 = (T)(base[1] + j) * dx - xp[1];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    T wijk = wij * w[2][k];
+                    T g0 = dwij_i * w[2][k], g1 = dwij_j * w[2][k], g2 = wij * one_over_dx * dw[2][k];
+                    T d2 = (T)(base[2] + k) * dx - xp[2];
+                    int t = ((cx + i) * TY + (cy + j)) * TZ + (cz + k);
+                    T v0 = nv[0][t], v1 = nv[1][t], v2 = nv[2][t];
+                    pic[0] += wijk * v0, pic[1] += wijk * v1, pic[2] += wijk * v2;
+                    T wv0 = wijk * v0, wv1 = wijk * v1, wv2 = wijk * v2;
+                    B[0] += wv0 * d0, B[1] += wv1 * d0, B[2] += wv2 * d0;
+                    B[3] += wv0 * d1, B[4] += wv1 * d1, B[5] += wv2 * d1;
+                    B[6] += wv0 * d2, B[7] += wv1 * d2, B[8] += wv2 * d2;
+                    gv[0] += v0 * g0, gv[1] += v1 * g0, gv[2] += v2 * g0;
+                    gv[3] += v0 * g1, gv[4] += v1 * g1, gv[5] += v2 * g1;
+                    gv[6] += v0 * g2, gv[7] += v1 * g2, gv[8] += v2 * g2;
+                }
+            }
+        }
+        V[p] = pic[0], V[Np + p] = pic[1], V[2 * Np + p] = pic[2];
+        T ra = (apic_r + (T)1) * (T)0.5, rb = (apic_r - (T)1) * (T)0.5;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) C[(int64_t)(c * 3 + r) * Np + p] = ra * (B[c * 3 + r] * D_inverse) + rb * (B[r * 3 + c] * D_inverse);
+        T inc0 = dt * pic[0], inc1 = dt * pic[1], inc2 = dt * pic[2];
+        X[p] = xp[0] + inc0, X[Np + p] = xp[1] + inc1, X[2 * Np + p] = xp[2] + inc2;
+        T inc = inc0 * inc0 + inc1 * inc1 + inc2 * inc2, dx2 = dx * dx;
+        if (inc > dx2) myflags |= 1;
+        if (inc > dx2 * (T)0.25 * (cfl * cfl)) myflags |= 2;
+        if (gradV_out)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) gradV_out[(int64_t)c * Np + p] = gv[c];
+        // F = (I + dt gradV) Fn   (restoreStrain + evolveStrain)
+        Mat3<T> A, Fo, Fnew;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) A.a[c] = dt * gv[c] + ((c % 4 == 0) ? (T)1 : (T)0), Fo.a[c] = Fn[(int64_t)c * Np + p];
+        Fnew = m3_mul(A, Fo);
+        if (PLASTIC == 1) {
+            von_mises_project(Fnew, Mu[p], Lam[p], yield_stress);
+        }
+        else if (PLASTIC == 2) {
+            T mu = Mu[p], la = Lam[p], jp = Jp[p];
+            snow_project(Fnew, mu, la, jp, sn0, sn1, sn2, sn3, sn4);
+            Mu[p] = mu, Lam[p] = la, Jp[p] = jp;
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) F[(int64_t)c * Np + p] = Fnew.a[c];
+    }
+    if (myflags) atomicOr(flags_out, myflags);
+}
+
+template <class T>
+void Ctx<T>::g2p(double dt_, int32_t* flags)
+{
+    need(Nn > 0, "hot_g2p before hot_p2g/hot_begin_step");
+    double t0 = wall_ms();
+    int32_t* dflags = (int32_t*)(dscal.p + 200);
+    HOT_HIP(hipMemsetAsync(dflags, 0, 4, stream));
+    T one_over_dx = (T)1 / dx;
+#define G2P_ARGS pX.p, pV.p, pC.p, pF.p, pFn.p, (keep_debug ? pGradV.p : (T*)nullptr), pMu.p, pLam.p, pJp.p, Np, group_first.p, group_origin.p, group_nb.p, gIdx.p, nodeV.p, dv.p, dx, \
+                 one_over_dx, (T)dt_, (T)cfg.apic_rpic_ratio, (T)cfg.cfl, (T)cfg.yield_stress, (T)cfg.snow[0], (T)cfg.snow[1], (T)cfg.snow[2], (T)cfg.snow[3], (T)cfg.snow[4], dflags
+    if (cfg.plasticity == 1)
+        HOT_LAUNCH(this, "g2p", (k_g2p<T, 1>), Ng, 256, 0, G2P_ARGS);
+    else if (cfg.plasticity == 2)
+        HOT_LAUNCH(this, "g2p", (k_g2p<T, 2>), Ng, 256, 0, G2P_ARGS);
+    else
+        HOT_LAUNCH(this, "g2p", (k_g2p<T, 0>), Ng, 256, 0, G2P_ARGS);
+#undef G2P_ARGS
+    int32_t f = 0;
+    HOT_HIP(hipMemcpyAsync(&f, dflags, 4, hipMemcpyDeviceToHost, stream));
+    sync();
+    if (flags) *flags = f;
+    stats.ms_g2p = wall_ms() - t0;
+}
+
+template struct Ctx<float>;
+template struct Ctx<double>;
+
+} // namespace hot

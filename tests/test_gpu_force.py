@@ -1,0 +1,71 @@
+"""GPU parity: objective pieces (state update, energy, residual, projection, CN tolerances, matrix-free product)
+against the CPU oracle on identical inputs."""
+import numpy as np
+import pytest
+
+from tests import pipeline_checks as pc
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(np.asarray(b, np.float64)).max(), 1e-300)
+
+
+@pytest.mark.parametrize("dtype,tol", [(1, 1e-10), (0, 2e-3)])
+@pytest.mark.parametrize("n", [6, 12])
+def test_objective_pieces_against_oracle(hotlib, oracle, dtype, tol, n):
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=n, dtype=dtype, bc=True)
+        pc.prepare(ctx)
+        dv0 = ctx.get_dv()
+        rng = np.random.default_rng(7)
+        dv = dv0 + 0.02 * rng.standard_normal(dv0.shape).astype(dv0.dtype)
+        dv = ctx.project(dv) if False else dv
+        e = ctx.update_state(dv)
+        st = ctx.particle_state()
+        r = ctx.residual()
+        tol_n = ctx.cn_tolerance()
+        x = rng.standard_normal(dv0.shape)
+        hx = ctx.matfree_multiply(x)
+        pv = ctx.project(x)
+        out[name] = dict(dv0=dv0, e=e, r=r, tol=tol_n, hx=hx, pv=pv, **st)
+    g, c = out["gpu"], out["cpu"]
+    assert rel(g["dv0"], c["dv0"]) < tol
+    assert abs(g["e"] - c["e"]) < tol * max(abs(c["e"]), 1e-6) * 10
+    for k in ("F", "gradV", "stress", "r", "tol", "hx", "pv"):
+        assert rel(g[k], c[k]) < tol * 20, (k, rel(g[k], c[k]))
+
+
+def test_diff_test_on_gpu(hotlib):
+    assert pc.check_diff_test(hotlib) < 1e-5
+
+
+def test_explicit_bc_list_matches_halfspace(hotlib, oracle):
+    """hot_set_bc with an explicit collision-node list (sticky + slip) against the oracle."""
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=6, bc=False, boundaryType=1)
+        ctx.sort()
+        ctx.p2g()
+        coords = ctx.grid()["id2coord"]
+        ymin = coords[:, 1].min()
+        sticky = np.where(coords[:, 1] <= ymin + 1)[0]
+        slip = np.where(coords[:, 0] == coords[:, 0].min())[0]
+        slip = np.setdiff1d(slip, sticky)
+        ids = np.concatenate([sticky, slip]).astype(np.int32)
+        nc = len(ids)
+        P = np.zeros((nc, 9))
+        R = np.tile(np.eye(3).reshape(1, 9), (nc, 1))
+        # slip nodes: normal (1,0,0) -> P = I - n n^T, R = I (already aligned with x)
+        P[len(sticky):] = np.diag([0.0, 1.0, 1.0]).reshape(9)
+        flags = np.zeros(nc, np.uint8)
+        flags[len(sticky):] = 1
+        ctx.set_bc(ids, P, R, R, flags)
+        ctx.begin_step(1.0 / 24)
+        dv = ctx.get_dv()
+        ctx.update_state(dv)
+        out[name] = (dv, ctx.residual())
+    assert rel(out["gpu"][0], out["cpu"][0]) < 1e-10
+    assert rel(out["gpu"][1], out["cpu"][1]) < 1e-9
