@@ -252,12 +252,14 @@ class Context:
         return out
 
     def set_dv(self, dv):
-        self._call("set_dv", _ptr(self._real(dv)))
+        d = self._real(dv)
+        self._call("set_dv", _ptr(d))
 
     # ---- objective
     def update_state(self, dv=None):
         e = C.c_double()
-        self._call("update_state", _ptr(self._real(dv)), C.byref(e))
+        d = self._real(dv)
+        self._call("update_state", _ptr(d), C.byref(e))
         return e.value
 
     def particle_state(self):
@@ -286,7 +288,8 @@ class Context:
 
     def matfree_multiply(self, x):
         y = np.empty((self.Nn, 3), self.T)
-        self._call("matfree_multiply", _ptr(self._real(x)), _ptr(y))
+        xr = self._real(x)
+        self._call("matfree_multiply", _ptr(xr), _ptr(y))
         return y
 
     def build_mg(self):
@@ -319,19 +322,22 @@ class Context:
     def spmv(self, level, x):
         n = self.level(level, coords=False)["nrows"]
         y = np.empty((n, 3), self.T)
-        self._call("spmv", C.c_int32(level), _ptr(self._real(x)), _ptr(y))
+        xr = self._real(x)
+        self._call("spmv", C.c_int32(level), _ptr(xr), _ptr(y))
         return y
 
     def restrict(self, level, fine):
         n = self.level(level + 1, coords=False)["nrows"]
         y = np.empty((n, 3), self.T)
-        self._call("restrict", C.c_int32(level), _ptr(self._real(fine)), _ptr(y))
+        xr = self._real(fine)
+        self._call("restrict", C.c_int32(level), _ptr(xr), _ptr(y))
         return y
 
     def prolong(self, level, coarse):
         n = self.level(level, coords=False)["nrows"]
         y = np.empty((n, 3), self.T)
-        self._call("prolong", C.c_int32(level), _ptr(self._real(coarse)), _ptr(y))
+        xr = self._real(coarse)
+        self._call("prolong", C.c_int32(level), _ptr(xr), _ptr(y))
         return y
 
     def smooth(self, level, kind, iterations, u, r, tolerance=0.0, initial_residual=None):
@@ -343,7 +349,8 @@ class Context:
 
     def vcycle(self, x):
         y = np.empty((self.Nn, 3), self.T)
-        self._call("vcycle", _ptr(self._real(x)), _ptr(y))
+        xr = self._real(x)
+        self._call("vcycle", _ptr(xr), _ptr(y))
         return y
 
     def solve(self):

@@ -152,6 +152,8 @@ struct Ctx : CtxBase {
     void cn_tolerance_dev();
     void build_diagonal(Level<T>& L);
     void spmv_dev(Level<T>& L, const T* x, T* y);
+    void scale_dev(Level<T>& L, const T* in, T* out); // out_i = Dinv_i in_i
+    void scal(size_t n, T a, T* x); // x *= a
     void restrict_dev(int level, const T* fine, T* coarse);
     void prolong_dev(int level, const T* coarse, T* fine);
     void smooth_dev(int level, int kind, int iterations, T tol, T* u, T* r, T* du, T* dAu);

@@ -1,0 +1,403 @@
+// libhotmi355x — Galerkin multigrid hierarchy on the device.
+//
+// Replaces MultigridBuilder::build (reference Projects/multigrid/MultigridPreconditioner.h:554-703), which is serial
+// and std::unordered_map based:
+//   coarse node set + numbering (:619-664)  first-touch order over (fine id, 2x2x2 parent loop) == rank of the first
+//                                           (i*8 + linear_idx) candidate that names a coarse coordinate: hash insert with
+//                                           atomicMin(rank), flag first occurrences, exclusive scan  -> bit-exact ids
+//   P (8 slots/row, trilinear, :445-466)    k_build_P, same slot layout and padding rule (:647-651)
+//   R = P^T (SquareMatrix.h:573-607)        child table of each coarse node (<= 27 fine children), weights 1/.5 per axis
+//   A_{l+1} = R (A_l P) (:526-571)          stencil collapse without hash maps: every level keeps the 125-slot stencil
+//                                           layout, so  AP[i, J] (4^3 coarse window per fine row, k_ap) and
+//                                           RAP[I, slot] (k_rap) are pure gathers — no atomics, deterministic
+//   markColors (:582-605)                   4^3-node blocks, colour = parity bits, first-touch block ids per colour,
+//                                           1-based index in block; the GS processing order is the radix-sorted
+//                                           (colour, block, id) key, so smoothers walk contiguous segments
+#include "hot_impl.h"
+#include "hot_svd.h"
+#include <rocprim/rocprim.hpp>
+
+namespace hot {
+
+__global__ void k_hash_clear2(HashMap h)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > h.mask) return;
+    h.keys[i] = ~0ULL;
+    h.minrank[i] = ~0ULL;
+    h.id[i] = -1;
+}
+__global__ void k_coord_map_insert(HashMap h, const int32_t* __restrict__ coord, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = hash_insert_min(h, coord_key(coord[3 * i], coord[3 * i + 1], coord[3 * i + 2]), (unsigned long long)i);
+    h.id[s] = i;
+}
+
+// candidate s = i*8 + linear_idx  (linear_idx = (dx*4 + dy*2 + dz), parent = coord/2 + d) with non-zero weight
+__device__ __forceinline__ bool parent_of(const int32_t* __restrict__ coord, int s, int& px, int& py, int& pz)
+{
+    int i = s >> 3, l = s & 7;
+    int x = coord[3 * i], y = coord[3 * i + 1], z = coord[3 * i + 2];
+    int dx = l >> 2, dy = (l >> 1) & 1, dz = l & 1;
+    if ((dx && !(x & 1)) || (dy && !(y & 1)) || (dz && !(z & 1))) return false; // weight 0 (even coordinate has one parent)
+    px = x / 2 + dx, py = y / 2 + dy, pz = z / 2 + dz;
+    return true;
+}
+__global__ void k_coarse_insert(HashMap h, const int32_t* __restrict__ coord, int n)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n * 8) return;
+    int px, py, pz;
+    if (parent_of(coord, s, px, py, pz)) hash_insert_min(h, coord_key(px, py, pz), (unsigned long long)s);
+}
+__global__ void k_coarse_flag(HashMap h, const int32_t* __restrict__ coord, int32_t* flags, int n)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n * 8) return;
+    int px, py, pz;
+    int f = 0;
+    if (parent_of(coord, s, px, py, pz)) {
+        int32_t slot = hash_find_slot(h, coord_key(px, py, pz));
+        f = h.minrank[slot] == (unsigned long long)s;
+    }
+    flags[s] = f;
+}
+__global__ void k_coarse_assign(HashMap h, const int32_t* __restrict__ coord, const int32_t* __restrict__ flags, const int32_t* __restrict__ scan, int32_t* ccoord, int n)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n * 8 || !flags[s]) return;
+    int px, py, pz;
+    parent_of(coord, s, px, py, pz);
+    int id = scan[s];
+    h.id[hash_find_slot(h, coord_key(px, py, pz))] = id;
+    ccoord[3 * id] = px, ccoord[3 * id + 1] = py, ccoord[3 * id + 2] = pz;
+}
+// P row: 8 slots, padding repeats slot 0's column with weight 0 (MultigridPreconditioner.h:647-651)
+template <class T>
+__global__ void k_build_P(HashMap cmap, const int32_t* __restrict__ coord, int32_t* pcol, T* pw, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int x = coord[3 * i], y = coord[3 * i + 1], z = coord[3 * i + 2];
+    int first = hash_find_id(cmap, coord_key(x / 2, y / 2, z / 2));
+    for (int l = 0; l < 8; ++l) {
+        int dx = l >> 2, dy = (l >> 1) & 1, dz = l & 1;
+        T wx = (x & 1) ? (T)0.5 : (dx ? (T)0 : (T)1), wy = (y & 1) ? (T)0.5 : (dy ? (T)0 : (T)1), wz = (z & 1) ? (T)0.5 : (dz ? (T)0 : (T)1);
+        T w = wx * wy * wz;
+        int c = first;
+        if (w != (T)0) c = hash_find_id(cmap, coord_key(x / 2 + dx, y / 2 + dy, z / 2 + dz));
+        pcol[8 * (int64_t)i + l] = c;
+        pw[8 * (int64_t)i + l] = w;
+    }
+}
+// children of coarse node I: fine coords 2I + (a-1, b-1, c-1)
+__global__ void k_build_children(HashMap fmap, const int32_t* __restrict__ ccoord, int32_t* child, int nc)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nc * 27) return;
+    int I = e / 27, q = e - I * 27;
+    int a = q / 9 - 1, b = (q / 3) % 3 - 1, c = q % 3 - 1;
+    int x = 2 * ccoord[3 * I] + a, y = 2 * ccoord[3 * I + 1] + b, z = 2 * ccoord[3 * I + 2] + c;
+    child[e] = (x | y | z) < 0 ? -1 : hash_find_id(fmap, coord_key(x, y, z));
+}
+__global__ void k_coarse_cols(HashMap cmap, const int32_t* __restrict__ ccoord, int32_t* col, int nc)
+{
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)nc * 125) return;
+    int n = (int)(e / 125), k = (int)(e - (int64_t)n * 125);
+    int x = ccoord[3 * n] - (k / 25 - 2), y = ccoord[3 * n + 1] - ((k / 5) % 5 - 2), z = ccoord[3 * n + 2] - (k % 5 - 2);
+    int j = (x | y | z) < 0 ? -1 : hash_find_id(cmap, coord_key(x, y, z));
+    col[e] = j >= 0 ? j : (n > 0 ? 0 : 1);
+}
+
+// AP[i][(a,b,c) in 4^3][9]: coarse window origin cb = (coord - 2) >> 1 ;  J = cb + (a,b,c)
+// AP[i,J] = sum_{d in {-1,0,1}^3} w(d) A[i][slot(i - (2J + d))]
+template <class T>
+__global__ __launch_bounds__(256) void k_ap(const int32_t* __restrict__ coord, const T* __restrict__ val, T* ap, int n)
+{
+    __shared__ T row[4][1125];
+    int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int i = blockIdx.x * 4 + w;
+    if (i < n) {
+        const T* src = val + (int64_t)i * 1125;
+        for (int e = lane; e < 1125; e += 64) row[w][e] = src[e];
+    }
+    __syncthreads();
+    if (i >= n) return;
+    int x = coord[3 * i], y = coord[3 * i + 1], z = coord[3 * i + 2];
+    int cbx = (x - 2) >> 1, cby = (y - 2) >> 1, cbz = (z - 2) >> 1;
+    for (int o = lane; o < 576; o += 64) {
+        int js = o / 9, comp = o - js * 9;
+        int a = js >> 4, b = (js >> 2) & 3, c = js & 3;
+        int Jx = cbx + a, Jy = cby + b, Jz = cbz + c;
+        T sum = (T)0;
+#pragma unroll
+        for (int da = -1; da <= 1; ++da) {
+            int ddx = x - (2 * Jx + da); // i - j
+            if (ddx < -2 || ddx > 2) continue;
+#pragma unroll
+            for (int db = -1; db <= 1; ++db) {
+                int ddy = y - (2 * Jy + db);
+                if (ddy < -2 || ddy > 2) continue;
+#pragma unroll
+                for (int dc = -1; dc <= 1; ++dc) {
+                    int ddz = z - (2 * Jz + dc);
+                    if (ddz < -2 || ddz > 2) continue;
+                    T wgt = (da ? (T)0.5 : (T)1) * (db ? (T)0.5 : (T)1) * (dc ? (T)0.5 : (T)1);
+                    sum += wgt * row[w][((ddx + 2) * 25 + (ddy + 2) * 5 + (ddz + 2)) * 9 + comp];
+                }
+            }
+        }
+        ap[(int64_t)i * 576 + o] = sum;
+    }
+}
+// RAP[I][slot k][9] = sum_{d} w(d) AP[child(I,d)][J - cb(child)] ,  J = I - Delta(k)
+template <class T>
+__global__ __launch_bounds__(256) void k_rap(const int32_t* __restrict__ ccoord, const int32_t* __restrict__ child, const T* __restrict__ ap, T* cval, int nc)
+{
+    int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int I = blockIdx.x * 4 + w;
+    if (I >= nc) return;
+    int X = ccoord[3 * I], Y = ccoord[3 * I + 1], Z = ccoord[3 * I + 2];
+    for (int o = lane; o < 1125; o += 64) {
+        int k = o / 9, comp = o - k * 9;
+        int Jx = X - (k / 25 - 2), Jy = Y - ((k / 5) % 5 - 2), Jz = Z - (k % 5 - 2);
+        T sum = (T)0;
+        for (int q = 0; q < 27; ++q) {
+            int ci = child[I * 27 + q];
+            if (ci < 0) continue;
+            int da = q / 9 - 1, db = (q / 3) % 3 - 1, dc = q % 3 - 1;
+            int x = 2 * X + da, y = 2 * Y + db, z = 2 * Z + dc;
+            int a = Jx - ((x - 2) >> 1), b = Jy - ((y - 2) >> 1), c = Jz - ((z - 2) >> 1);
+            if ((unsigned)a > 3u || (unsigned)b > 3u || (unsigned)c > 3u) continue;
+            T wgt = (da ? (T)0.5 : (T)1) * (db ? (T)0.5 : (T)1) * (dc ? (T)0.5 : (T)1);
+            sum += wgt * ap[(int64_t)ci * 576 + ((a << 4) | (b << 2) | c) * 9 + comp];
+        }
+        cval[(int64_t)I * 1125 + o] = sum;
+    }
+}
+
+// ---- colouring
+__global__ void k_color_insert(HashMap h, const int32_t* __restrict__ coord, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    hash_insert_min(h, coord_key(coord[3 * i] >> 2, coord[3 * i + 1] >> 2, coord[3 * i + 2] >> 2), (unsigned long long)i);
+}
+__device__ __forceinline__ int color_of(const int32_t* __restrict__ coord, int i)
+{
+    return (((coord[3 * i] >> 2) & 1) << 2) | (((coord[3 * i + 1] >> 2) & 1) << 1) | ((coord[3 * i + 2] >> 2) & 1);
+}
+__global__ void k_color_flag(HashMap h, const int32_t* __restrict__ coord, int32_t* flags, int n)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 8 * n) return;
+    int c = e / n, i = e - c * n;
+    int f = 0;
+    if (color_of(coord, i) == c) {
+        int32_t slot = hash_find_slot(h, coord_key(coord[3 * i] >> 2, coord[3 * i + 1] >> 2, coord[3 * i + 2] >> 2));
+        f = h.minrank[slot] == (unsigned long long)i;
+    }
+    flags[e] = f;
+}
+__global__ void k_color_assign(HashMap h, const int32_t* __restrict__ coord, const int32_t* __restrict__ flags, const int32_t* __restrict__ scan, int n)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 8 * n || !flags[e]) return;
+    int c = e / n, i = e - c * n;
+    int32_t slot = hash_find_slot(h, coord_key(coord[3 * i] >> 2, coord[3 * i + 1] >> 2, coord[3 * i + 2] >> 2));
+    h.id[slot] = scan[e] - scan[c * n]; // block id inside its colour, first-touch order
+}
+__global__ void k_color_keys(HashMap h, const int32_t* __restrict__ coord, uint64_t* keys, uint32_t* vals, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t bid = hash_find_id(h, coord_key(coord[3 * i] >> 2, coord[3 * i + 1] >> 2, coord[3 * i + 2] >> 2));
+    keys[i] = ((uint64_t)color_of(coord, i) << 56) | ((uint64_t)(uint32_t)bid << 32) | (uint32_t)i;
+    vals[i] = (uint32_t)i;
+}
+__global__ void k_color_heads(const uint64_t* __restrict__ keys, int32_t* flags, int n)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    flags[p] = (p == 0 || (keys[p] >> 32) != (keys[p - 1] >> 32)) ? 1 : 0;
+}
+__global__ void k_color_finish(const uint64_t* __restrict__ keys, const int32_t* __restrict__ flags, const int32_t* __restrict__ scan, int32_t* gs_order, int32_t* block_start,
+    int32_t* color_begin, int n, int nblocks)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    gs_order[p] = (int32_t)(keys[p] & 0xffffffffu);
+    if (p == 0) block_start[nblocks] = n;
+    if (flags[p]) {
+        int b = scan[p];
+        block_start[b] = p;
+        int c = (int)(keys[p] >> 56);
+        int cprev = p == 0 ? -1 : (int)(keys[p - 1] >> 56);
+        for (int cc = cprev + 1; cc <= c; ++cc) color_begin[cc] = b;
+    }
+    if (p == n - 1) {
+        int c = (int)(keys[p] >> 56);
+        for (int cc = c + 1; cc <= 8; ++cc) color_begin[cc] = nblocks;
+    }
+}
+__global__ void k_color_ckey(const uint64_t* __restrict__ keys, const int32_t* __restrict__ scan, const int32_t* __restrict__ block_start, uint32_t* ckey, int n)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int node = (int)(keys[p] & 0xffffffffu);
+    // block rank of position p = number of heads at or before p, minus one
+    // (scan is the exclusive scan of head flags, so rank = scan[p] + flag[p] - 1; recomputed from block_start)
+    int lo = 0, hi = 0;
+    (void)lo, (void)hi;
+    uint32_t color = (uint32_t)(keys[p] >> 56), bid = (uint32_t)((keys[p] >> 32) & 0xffffff);
+    int b = scan[p]; // exclusive count of heads before p
+    int start = block_start[b] == p ? p : block_start[b - 1];
+    ckey[node] = (color << 28) | (bid << 7) | (uint32_t)(p - start + 1);
+}
+
+template <class T>
+static void build_coord_map(Ctx<T>* ctx, Level<T>& L)
+{
+    uint32_t cap = 1024;
+    while (cap < 2u * (uint32_t)L.n + 16u) cap <<= 1;
+    L.hkeys.reserve(cap), L.hrank.reserve(cap), L.hid.reserve(cap);
+    L.map.keys = L.hkeys.p, L.map.minrank = L.hrank.p, L.map.id = L.hid.p, L.map.mask = cap - 1;
+    HOT_LAUNCH(ctx, "mg_hash_clear", k_hash_clear2, div_up(cap, 256), 256, 0, L.map);
+    HOT_LAUNCH(ctx, "mg_coord_map", k_coord_map_insert, div_up(L.n, 256), 256, 0, L.map, L.coord.p, L.n);
+}
+
+template <class T>
+static void mark_colors(Ctx<T>* ctx, Level<T>& L)
+{
+    int n = L.n;
+    // block map (temporary)
+    uint32_t cap = 1024;
+    while (cap < 2u * (uint32_t)n + 16u) cap <<= 1;
+    DBuf<uint64_t> hk;
+    DBuf<unsigned long long> hr;
+    DBuf<int32_t> hi;
+    hk.reserve(cap), hr.reserve(cap), hi.reserve(cap);
+    HashMap h{ hk.p, hr.p, hi.p, cap - 1 };
+    HOT_LAUNCH(ctx, "mg_hash_clear", k_hash_clear2, div_up(cap, 256), 256, 0, h);
+    HOT_LAUNCH(ctx, "color_block_insert", k_color_insert, div_up(n, 256), 256, 0, h, L.coord.p, n);
+    ctx->flags.reserve(8 * (size_t)n), ctx->scan.reserve(8 * (size_t)n);
+    HOT_LAUNCH(ctx, "color_block_flag", k_color_flag, div_up(8 * (size_t)n, 256), 256, 0, h, L.coord.p, ctx->flags.p, n);
+    ctx->exclusive_scan_i32(ctx->flags.p, ctx->scan.p, 8 * (size_t)n);
+    HOT_LAUNCH(ctx, "color_block_assign", k_color_assign, div_up(8 * (size_t)n, 256), 256, 0, h, L.coord.p, ctx->flags.p, ctx->scan.p, n);
+    ctx->keys.reserve(n), ctx->keys2.reserve(n), ctx->vals.reserve(n), ctx->vals2.reserve(n);
+    HOT_LAUNCH(ctx, "color_keys", k_color_keys, div_up(n, 256), 256, 0, h, L.coord.p, ctx->keys.p, ctx->vals.p, n);
+    size_t bytes = 0;
+    HOT_HIP(rocprim::radix_sort_pairs(nullptr, bytes, ctx->keys.p, ctx->keys2.p, ctx->vals.p, ctx->vals2.p, (size_t)n, 0, 64, ctx->stream));
+    if (bytes > ctx->sort_tmp_bytes) {
+        ctx->sort_tmp.reserve(bytes);
+        ctx->sort_tmp_bytes = ctx->sort_tmp.cap;
+    }
+    HOT_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, bytes, ctx->keys.p, ctx->keys2.p, ctx->vals.p, ctx->vals2.p, (size_t)n, 0, 64, ctx->stream));
+    HOT_LAUNCH(ctx, "color_heads", k_color_heads, div_up(n, 256), 256, 0, ctx->keys2.p, ctx->flags.p, n);
+    L.nblocks = ctx->exclusive_scan_i32(ctx->flags.p, ctx->scan.p, n);
+    L.gs_order.reserve(n), L.gs_block_start.reserve(L.nblocks + 1), L.ckey.reserve(n);
+    DBuf<int32_t> cb;
+    cb.reserve(16);
+    HOT_LAUNCH(ctx, "color_finish", k_color_finish, div_up(n, 256), 256, 0, ctx->keys2.p, ctx->flags.p, ctx->scan.p, L.gs_order.p, L.gs_block_start.p, cb.p, n, L.nblocks);
+    HOT_LAUNCH(ctx, "color_ckey", k_color_ckey, div_up(n, 256), 256, 0, ctx->keys2.p, ctx->scan.p, L.gs_block_start.p, L.ckey.p, n);
+    HOT_HIP(hipMemcpyAsync(L.color_block_begin, cb.p, 9 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+}
+
+template <class T>
+static void alloc_work(Level<T>& L)
+{
+    size_t m = 3 * (size_t)L.n;
+    L.residual.reserve(m), L.initialResidual.reserve(m), L.sol.reserve(m), L.du.reserve(m), L.dAu.reserve(m), L.tmp.reserve(m);
+}
+
+template <class T>
+void Ctx<T>::build_mg()
+{
+    need(!levels.empty(), "hot_build_mg before hot_build_hessian");
+    need(!(!cfg.systemBCProject && cfg.levelCnt > 1), "levelCnt > 1 requires systemBCProject (ImplicitSolver.h:339)");
+    need(cfg.levelCnt >= 1 && cfg.levelCnt <= 10, "levelCnt must be in [1,10] (MultigridPreconditioner.h:369)");
+    for (int k : { cfg.smoother, cfg.coarseSolver }) need(k == 0 || k == 1 || k == 2 || k == 5, "smoother/coarseSolver must be 0, 1, 2 or 5 (6/7: SURVEY 8f, not built yet)");
+    double t0 = wall_ms();
+    while (levels.size() > 1) {
+        delete levels.back();
+        levels.pop_back();
+    }
+    bool colors = cfg.smoother == 5 || cfg.coarseSolver == 5;
+    Level<T>& L0 = *levels[0];
+    alloc_work(L0);
+    if (colors) mark_colors(this, L0);
+    for (int level = 0; level < cfg.levelCnt - 1; ++level) {
+        Level<T>& F = *levels[level];
+        int n = F.n;
+        build_coord_map(this, F);
+        Level<T>* Cp = new Level<T>();
+        levels.push_back(Cp);
+        Level<T>& C = *Cp;
+        // ---- coarse node set with first-touch numbering
+        uint32_t cap = 1024;
+        while (cap < 2u * (uint32_t)n + 16u) cap <<= 1;
+        C.hkeys.reserve(cap), C.hrank.reserve(cap), C.hid.reserve(cap);
+        C.map.keys = C.hkeys.p, C.map.minrank = C.hrank.p, C.map.id = C.hid.p, C.map.mask = cap - 1;
+        HOT_LAUNCH(this, "mg_hash_clear", k_hash_clear2, div_up(cap, 256), 256, 0, C.map);
+        size_t cand = 8 * (size_t)n;
+        flags.reserve(cand), scan.reserve(cand);
+        HOT_LAUNCH(this, "mg_coarse_insert", k_coarse_insert, div_up(cand, 256), 256, 0, C.map, F.coord.p, n);
+        HOT_LAUNCH(this, "mg_coarse_flag", k_coarse_flag, div_up(cand, 256), 256, 0, C.map, F.coord.p, flags.p, n);
+        C.n = exclusive_scan_i32(flags.p, scan.p, cand);
+        size_t nc = C.n;
+        C.coord.reserve(3 * nc), C.col.reserve(125 * nc), C.val.reserve(1125 * nc), C.child.reserve(27 * nc);
+        HOT_LAUNCH(this, "mg_coarse_assign", k_coarse_assign, div_up(cand, 256), 256, 0, C.map, F.coord.p, flags.p, scan.p, C.coord.p, n);
+        // ---- transfer tables
+        F.pcol.reserve(8 * (size_t)n), F.pw.reserve(8 * (size_t)n);
+        HOT_LAUNCH(this, "mg_build_P", k_build_P<T>, div_up(n, 256), 256, 0, C.map, F.coord.p, F.pcol.p, F.pw.p, n);
+        HOT_LAUNCH(this, "mg_build_children", k_build_children, div_up(27 * nc, 256), 256, 0, F.map, C.coord.p, C.child.p, C.n);
+        HOT_LAUNCH(this, "mg_coarse_cols", k_coarse_cols, div_up(125 * nc, 256), 256, 0, C.map, C.coord.p, C.col.p, C.n);
+        // ---- A_c = R (A P)
+        ap.reserve(576 * (size_t)n);
+        HOT_LAUNCH(this, "mg_AP", k_ap<T>, div_up(n, 4), 256, 0, F.coord.p, F.val.p, ap.p, n);
+        HOT_LAUNCH(this, "mg_RAP", k_rap<T>, div_up(nc, 4), 256, 0, C.coord.p, C.child.p, ap.p, C.val.p, C.n);
+        build_diagonal(C);
+        alloc_work(C);
+        if (colors) mark_colors(this, C);
+    }
+    sync();
+    stats.ms_mg_build += wall_ms() - t0;
+}
+
+template <class T>
+void Ctx<T>::get_level(int32_t level, int32_t* nrows, int32_t* colsize, int32_t* ic)
+{
+    need(level >= 0 && level < (int)levels.size(), "level out of range");
+    Level<T>& L = *levels[level];
+    if (nrows) *nrows = L.n;
+    if (colsize) *colsize = 125;
+    download(ic, L.coord.p, 3 * (size_t)L.n);
+    sync();
+}
+template <class T>
+void Ctx<T>::get_matrix(int32_t level, int32_t* entryCol, void* entryVal)
+{
+    need(level >= 0 && level < (int)levels.size(), "level out of range");
+    Level<T>& L = *levels[level];
+    download(entryCol, L.col.p, 125 * (size_t)L.n);
+    download(entryVal, L.val.p, 1125 * (size_t)L.n);
+    sync();
+}
+template <class T>
+void Ctx<T>::get_prolongation(int32_t level, int32_t* entryCol, void* weight)
+{
+    need(level >= 0 && level + 1 < (int)levels.size(), "level out of range");
+    Level<T>& L = *levels[level];
+    download(entryCol, L.pcol.p, 8 * (size_t)L.n);
+    download(weight, L.pw.p, 8 * (size_t)L.n);
+    sync();
+}
+
+template struct Ctx<float>;
+template struct Ctx<double>;
+
+} // namespace hot

@@ -1,0 +1,475 @@
+// libhotmi355x — operator applications: block-ELL SpMV, restriction / prolongation, smoothers, V-cycle.
+//
+//   k_spmv          SquareMatrix::multiply (reference Projects/multigrid/SquareMatrix.h:477-487) — THE bandwidth consumer
+//                   (SURVEY §8a row 17/21).  One wavefront per block row: a row is 125 contiguous 3x3 blocks (9000 B fp64),
+//                   lane l owns slots l and l+64, so the 64 lanes stream the row in two fully coalesced sweeps; x is
+//                   gathered per slot, the three row sums are reduced with __shfl_xor.
+//   k_gs_color      MultigridOperator::gs_smooth (Projects/multigrid/MultigridPreconditioner.h:266-318): symmetric coloured
+//                   block Gauss–Seidel in the reference's exact node order (colour, first-touch block, id).  One wavefront
+//                   per 4^3-node block walks its nodes sequentially; the row sweep is the SpMV sweep with the ordering
+//                   predicate on the packed colour key, values of the block's own earlier nodes come from LDS.
+//   restrict/prolong SparseMPMMatrix::transposeMultiply / multiply on the transfer matrices (MPMMultigridMatrix.h:63-70) as
+//                   pure gathers over the child / parent tables with scalar weights (the reference stores 3x3 w*I blocks).
+//   smooth_dev      jacobi_smooth :160-173, optimal_jacobi_smooth :174-189, cg_smooth :190-226, gs_smooth :266-318
+//   vcycle_dev      MultigridOperator::operator() :362-421 with setup_parameters :525-551
+#include "hot_impl.h"
+#include "hot_svd.h"
+
+namespace hot {
+
+// ------------------------------------------------------------------------------------------------ vector ops
+template <class T>
+__global__ void k_axpy(size_t n, T a, const T* __restrict__ x, T* y)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += a * x[i];
+}
+template <class T>
+__global__ void k_axpy_dev(size_t n, const double* a, double sign, const T* __restrict__ x, T* y)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    T s = (T)(sign * (*a));
+    if (i < n) y[i] += s * x[i];
+}
+// y = x + (*a) * y
+template <class T>
+__global__ void k_xpay_dev(size_t n, const double* a, const T* __restrict__ x, T* y)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    T s = (T)(*a);
+    if (i < n) y[i] = x[i] + s * y[i];
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_dot(size_t n, const T* __restrict__ x, const T* __restrict__ y, double* out)
+{
+    __shared__ double red[4];
+    double s = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += (double)(x[i] * y[i]);
+    double t = block_sum_256<double>(s, red);
+    if (threadIdx.x == 0) atomic_add(out, t);
+}
+template <class T>
+void Ctx<T>::axpy(size_t n, T a, const T* x, T* y)
+{
+    HOT_LAUNCH(this, "axpy", k_axpy<T>, div_up(n, 256), 256, 0, n, a, x, y);
+}
+template <class T>
+void Ctx<T>::axpy_dev(size_t n, const double* a, double sign, const T* x, T* y)
+{
+    HOT_LAUNCH(this, "axpy", k_axpy_dev<T>, div_up(n, 256), 256, 0, n, a, sign, x, y);
+}
+template <class T>
+void Ctx<T>::copy(size_t n, const T* x, T* y)
+{
+    HOT_HIP(hipMemcpyAsync(y, x, n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+}
+template <class T>
+void Ctx<T>::zero(size_t n, T* y)
+{
+    HOT_HIP(hipMemsetAsync(y, 0, n * sizeof(T), stream));
+}
+template <class T>
+void Ctx<T>::dot_to(size_t n, const T* x, const T* y, double* out)
+{
+    HOT_HIP(hipMemsetAsync(out, 0, sizeof(double), stream));
+    HOT_LAUNCH(this, "dot", k_dot<T>, std::min(div_up(n, 256), 2048), 256, 0, n, x, y, out);
+}
+template <class T>
+double Ctx<T>::dot_host(size_t n, const T* x, const T* y)
+{
+    dot_to(n, x, y, dscal.p + 100);
+    HOT_HIP(hipMemcpyAsync(hscal + 100, dscal.p + 100, sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    return hscal[100];
+}
+
+// ------------------------------------------------------------------------------------------------ SpMV
+template <class T>
+__global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ col, const T* __restrict__ val, const T* __restrict__ x, T* __restrict__ y, int n)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int32_t* c = col + (int64_t)row * 125;
+    const T* v = val + (int64_t)row * 1125;
+    T s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        int k = lane + 64 * r;
+        if (k < 125) {
+            int j = c[k];
+            const T* b = v + k * 9;
+            T x0 = x[3 * (int64_t)j], x1 = x[3 * (int64_t)j + 1], x2 = x[3 * (int64_t)j + 2];
+            s0 += b[0] * x0 + b[3] * x1 + b[6] * x2;
+            s1 += b[1] * x0 + b[4] * x1 + b[7] * x2;
+            s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
+        }
+    }
+    s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
+    if (lane == 0) y[3 * (int64_t)row] = s0, y[3 * (int64_t)row + 1] = s1, y[3 * (int64_t)row + 2] = s2;
+}
+template <class T>
+__global__ void k_scal_v(size_t n, T a, T* x)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= a;
+}
+template <class T>
+void Ctx<T>::scal(size_t n, T a, T* x)
+{
+    HOT_LAUNCH(this, "scal", k_scal_v<T>, div_up(n, 256), 256, 0, n, a, x);
+}
+template <class T>
+void Ctx<T>::spmv_dev(Level<T>& L, const T* x, T* y)
+{
+    HOT_LAUNCH(this, "spmv", k_spmv<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, x, y, L.n);
+}
+
+// ------------------------------------------------------------------------------------------------ transfers
+template <class T>
+__global__ void k_restrict(const int32_t* __restrict__ child, const T* __restrict__ fine, T* coarse, int nc)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 3 * nc) return;
+    int I = e / 3, d = e - 3 * I;
+    T s = 0;
+    for (int q = 0; q < 27; ++q) {
+        int ci = child[I * 27 + q];
+        if (ci < 0) continue;
+        T w = ((q / 9 != 1) ? (T)0.5 : (T)1) * (((q / 3) % 3 != 1) ? (T)0.5 : (T)1) * ((q % 3 != 1) ? (T)0.5 : (T)1);
+        s += w * fine[3 * (int64_t)ci + d];
+    }
+    coarse[e] = s;
+}
+template <class T>
+__global__ void k_prolong(const int32_t* __restrict__ pcol, const T* __restrict__ pw, const T* __restrict__ coarse, T* fine, int n)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 3 * n) return;
+    int i = e / 3, d = e - 3 * i;
+    T s = 0;
+    for (int l = 0; l < 8; ++l) s += pw[8 * (int64_t)i + l] * coarse[3 * (int64_t)pcol[8 * (int64_t)i + l] + d];
+    fine[e] = s;
+}
+template <class T>
+void Ctx<T>::restrict_dev(int level, const T* fine, T* coarse)
+{
+    Level<T>& C = *levels[level + 1];
+    HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n);
+}
+template <class T>
+void Ctx<T>::prolong_dev(int level, const T* coarse, T* fine)
+{
+    Level<T>& F = *levels[level];
+    HOT_LAUNCH(this, "prolong", k_prolong<T>, div_up(3 * (size_t)F.n, 256), 256, 0, F.pcol.p, F.pw.p, coarse, fine, F.n);
+}
+
+// ------------------------------------------------------------------------------------------------ smoothers
+// mr_i = Dinv_i r_i (scale_diagonal_{entry,block}_inverse, MultigridPreconditioner.h:143-154)
+template <class T>
+__global__ void k_scale(const T* __restrict__ D, const T* __restrict__ r, T* mr, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const T* d = D + 9 * (int64_t)i;
+    T a = r[3 * (int64_t)i], b = r[3 * (int64_t)i + 1], c = r[3 * (int64_t)i + 2];
+    mr[3 * (int64_t)i] = d[0] * a + d[3] * b + d[6] * c;
+    mr[3 * (int64_t)i + 1] = d[1] * a + d[4] * b + d[7] * c;
+    mr[3 * (int64_t)i + 2] = d[2] * a + d[5] * b + d[8] * c;
+}
+
+template <class T>
+void Ctx<T>::scale_dev(Level<T>& L, const T* in, T* out)
+{
+    HOT_LAUNCH(this, "diag_scale", k_scale<T>, div_up(L.n, 256), 256, 0, L.diagInv.p, in, out, L.n);
+}
+
+// One colour of one half-sweep of symmetric block GS.  FWD: h_i = Dinv (rhs_i - sum_{j<i} A_ij h_j), also writes
+// hD_i = D_i h_i ; BWD: du_i = Dinv (rhs_i - sum_{j>i} A_ij du_j).  "<" is the packed (colour, block, index) key.
+template <class T, bool FWD>
+__global__ __launch_bounds__(64) void k_gs_color(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
+    const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, int block0, int nblk)
+{
+    __shared__ T xl[64][3];
+    const int lane = threadIdx.x;
+    const int b = block0 + blockIdx.x;
+    if (blockIdx.x >= nblk) return;
+    const int start = block_start[b], cnt = block_start[b + 1] - start;
+    for (int s = 0; s < cnt; ++s) {
+        const int ii = FWD ? s : cnt - 1 - s;
+        const int i = gs_order[start + ii];
+        const uint32_t keyi = ckey[i];
+        const int32_t* c = col + (int64_t)i * 125;
+        const T* v = val + (int64_t)i * 1125;
+        T s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int k = lane + 64 * r;
+            if (k < 125) {
+                int j = c[k];
+                uint32_t keyj = ckey[j];
+                bool take = FWD ? (keyj < keyi) : (keyj > keyi);
+                if (take) {
+                    T x0, x1, x2;
+                    if ((keyj >> 7) == (keyi >> 7)) {
+                        int lj = (int)(keyj & 127u) - 1;
+                        x0 = xl[lj][0], x1 = xl[lj][1], x2 = xl[lj][2];
+                    }
+                    else {
+                        x0 = x[3 * (int64_t)j], x1 = x[3 * (int64_t)j + 1], x2 = x[3 * (int64_t)j + 2];
+                    }
+                    const T* bb = v + k * 9;
+                    s0 += bb[0] * x0 + bb[3] * x1 + bb[6] * x2;
+                    s1 += bb[1] * x0 + bb[4] * x1 + bb[7] * x2;
+                    s2 += bb[2] * x0 + bb[5] * x1 + bb[8] * x2;
+                }
+            }
+        }
+        s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
+        T r0 = rhs[3 * (int64_t)i] - s0, r1 = rhs[3 * (int64_t)i + 1] - s1, r2 = rhs[3 * (int64_t)i + 2] - s2;
+        const T* di = diagBlockInv + 9 * (int64_t)i;
+        T h0 = di[0] * r0 + di[3] * r1 + di[6] * r2, h1 = di[1] * r0 + di[4] * r1 + di[7] * r2, h2 = di[2] * r0 + di[5] * r1 + di[8] * r2;
+        if (lane == 0) {
+            xl[ii][0] = h0, xl[ii][1] = h1, xl[ii][2] = h2;
+            x[3 * (int64_t)i] = h0, x[3 * (int64_t)i + 1] = h1, x[3 * (int64_t)i + 2] = h2;
+            if (FWD) {
+                const T* d = diagVal + 9 * (int64_t)i;
+                hD[3 * (int64_t)i] = d[0] * h0 + d[3] * h1 + d[6] * h2;
+                hD[3 * (int64_t)i + 1] = d[1] * h0 + d[4] * h1 + d[7] * h2;
+                hD[3 * (int64_t)i + 2] = d[2] * h0 + d[5] * h1 + d[8] * h2;
+            }
+        }
+        __syncthreads(); // single-wave workgroup: orders the LDS write before the next node's reads
+    }
+}
+
+template <class T>
+__global__ void k_cg_scalars(double* s, int what)
+{
+    // s[0]=zTrk  s[1]=dAu.du  s[2]=omega  s[3]=-omega  s[4]=zTrk_new  s[5]=beta
+    if (what == 0) {
+        s[2] = s[0] / s[1];
+        s[3] = -s[2];
+    }
+    else {
+        s[5] = s[4] / s[0];
+        s[0] = s[4];
+    }
+}
+
+template <class T>
+void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, T* r, T* du, T* dAu)
+{
+    Level<T>& L = *levels[level];
+    size_t n3 = 3 * (size_t)L.n;
+    auto Aproject = [&](T* v) {
+        if (level == 0 && !cfg.systemBCProject) project_dev(v);
+    };
+    auto scaler = [&](const T* in, T* out) { scale_dev(L, in, out); };
+    if (kind == 0) {
+        for (; iterations--;) {
+            scaler(r, du);
+            scal(n3, (T)cfg.topomega, du);
+            axpy(n3, (T)1, du, u);
+            spmv_dev(L, du, dAu);
+            Aproject(dAu);
+            axpy(n3, (T)-1, dAu, r);
+        }
+    }
+    else if (kind == 1) {
+        for (; iterations--;) {
+            double rr = dot_host(n3, r, r);
+            if (std::sqrt(rr) < (double)tolerance) break;
+            scaler(r, du);
+            spmv_dev(L, du, dAu);
+            Aproject(dAu);
+            double a = dot_host(n3, du, r), b = dot_host(n3, du, dAu);
+            T omega = (T)(a / b);
+            axpy(n3, omega, du, u);
+            axpy(n3, -omega, dAu, r);
+        }
+    }
+    else if (kind == 2) {
+        T* z = L.tmp.p;
+        double* s = dscal.p + 40;
+        scaler(L.initialResidual.p, z);
+        double zTrk0 = dot_host(n3, z, L.initialResidual.p);
+        scaler(r, z);
+        copy(n3, z, du);
+        double zTrk = dot_host(n3, z, r);
+        double tol = (double)(T)(zTrk0 * 0.25); // cgratio = 0.5 hard-wired (:203-209)
+        HOT_HIP(hipMemcpyAsync(s, &zTrk, sizeof(double), hipMemcpyHostToDevice, stream));
+        int cnt = 0;
+        for (; iterations--;) {
+            if (zTrk < tol) break;
+            spmv_dev(L, du, dAu);
+            Aproject(dAu);
+            dot_to(n3, dAu, du, s + 1);
+            HOT_LAUNCH(this, "cg_scalars", k_cg_scalars<T>, 1, 1, 0, s, 0);
+            axpy_dev(n3, s + 2, 1.0, du, u);
+            axpy_dev(n3, s + 3, 1.0, dAu, r);
+            scaler(r, z);
+            dot_to(n3, z, r, s + 4);
+            HOT_LAUNCH(this, "cg_scalars", k_cg_scalars<T>, 1, 1, 0, s, 1);
+            HOT_LAUNCH(this, "xpay", k_xpay_dev<T>, div_up(n3, 256), 256, 0, n3, s + 5, z, du);
+            HOT_HIP(hipMemcpyAsync(hscal + 40, s, sizeof(double), hipMemcpyDeviceToHost, stream));
+            sync();
+            zTrk = hscal[40];
+            ++cnt;
+        }
+        stats.linear_iterations += cnt;
+    }
+    else if (kind == 5) {
+        HOT_CHECK(L.nblocks > 0, HOT_ERR_INVALID, "GS smoother requested but the level was built without colouring");
+        T* hdu = L.tmp.p;
+        iterations = ((iterations + 1) >> 1);
+        for (; iterations--;) {
+            zero(n3, hdu);
+            for (int c = 0; c < 8; ++c) {
+                int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
+                if (nb > 0)
+                    HOT_LAUNCH(this, "gs_forward", (k_gs_color<T, true>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0, nb);
+            }
+            // dAu now holds D h ; du = backward solve
+            zero(n3, du);
+            for (int c = 7; c >= 0; --c) {
+                int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
+                if (nb > 0)
+                    HOT_LAUNCH(this, "gs_backward", (k_gs_color<T, false>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0, nb);
+            }
+            axpy(n3, (T)1, du, u);
+            spmv_dev(L, du, dAu);
+            Aproject(dAu);
+            axpy(n3, (T)-1, dAu, r);
+        }
+    }
+    else
+        HOT_CHECK(false, HOT_ERR_INVALID, "unsupported smoother kind");
+}
+
+template <class T>
+void Ctx<T>::vcycle_dev(const T* in, T* out)
+{
+    int levelCnt = (int)levels.size();
+    int times = cfg.times, levelscale = cfg.levelscale;
+    int splitLevel;
+    auto downIter = [&](int level) { return times + level * levelscale; };
+    auto upIter = [&](int level) { return cfg.topDownMGS ? 0 : times + level * levelscale; };
+    auto topIter = [&](int level) {
+        if (cfg.topDownMGS) return 10000;
+        if (cfg.levelCnt == 1) return times + level * levelscale;
+        if (!(cfg.coarseSolver == 2 || cfg.coarseSolver == 6)) return (times + level * levelscale) * 3;
+        return 10000;
+    };
+    splitLevel = cfg.topDownMGS ? 1 : cfg.levelCnt - 1;
+    T tolTop = (T)(cfg.cneps * cfg.cneps);
+    auto run = [&](bool regular, int level, T* sol, int its) {
+        Level<T>& L = *levels[level];
+        smooth_dev(level, regular ? cfg.smoother : cfg.coarseSolver, its, regular ? (T)0 : tolTop, sol, L.residual.p, L.du.p, L.dAu.p);
+    };
+    stats.vcycles++;
+    Level<T>& L0 = *levels[0];
+    size_t n0 = 3 * (size_t)L0.n;
+    copy(n0, in, L0.residual.p); // dRhs == 0 (ImplicitSolver.h:483-484,579), correctResidualProjection is the identity
+    zero(n0, out);
+    if (levelCnt > 1)
+        restrict_dev(0, L0.residual.p, levels[1]->initialResidual.p);
+    else
+        copy(n0, L0.residual.p, L0.initialResidual.p);
+    for (int l = 1; l < levelCnt - 1; ++l) restrict_dev(l, levels[l]->initialResidual.p, levels[l + 1]->initialResidual.p);
+    int level;
+    for (level = 0; level < levelCnt - 1; ++level) {
+        T* sol = level == 0 ? out : levels[level]->sol.p;
+        run(level < splitLevel, level, sol, level < splitLevel ? upIter(level) : topIter(level));
+        restrict_dev(level, levels[level]->residual.p, levels[level + 1]->residual.p);
+        zero(3 * (size_t)levels[level + 1]->n, levels[level + 1]->sol.p);
+    }
+    run(false, level, level == 0 ? out : levels[level]->sol.p, topIter(level));
+    for (--level; level >= 0; --level) {
+        Level<T>& L = *levels[level];
+        T* sol = level == 0 ? out : L.sol.p;
+        size_t n3 = 3 * (size_t)L.n;
+        prolong_dev(level, levels[level + 1]->sol.p, L.du.p);
+        axpy(n3, (T)1, L.du.p, sol);
+        spmv_dev(L, L.du.p, L.dAu.p);
+        axpy(n3, (T)-1, L.dAu.p, L.residual.p);
+        run(level < splitLevel, level, sol, level < splitLevel ? downIter(level) : topIter(level));
+    }
+}
+
+template <class T>
+void Ctx<T>::precondition_dev(const T* in, T* out)
+{
+    HOT_CHECK(!levels.empty() && levels[0]->residual.p, HOT_ERR_INVALID, "preconditioner used before hot_build_mg");
+    vcycle_dev(in, out);
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI wrappers
+template <class T>
+void Ctx<T>::spmv(int32_t level, const void* x, void* y)
+{
+    need(level >= 0 && level < (int)levels.size(), "level out of range");
+    Level<T>& L = *levels[level];
+    size_t n3 = 3 * (size_t)L.n;
+    DBuf<T> a, b;
+    a.reserve(n3), b.reserve(n3);
+    HOT_HIP(hipMemcpyAsync(a.p, x, n3 * sizeof(T), hipMemcpyDefault, stream));
+    spmv_dev(L, a.p, b.p);
+    download(y, b.p, n3);
+    sync();
+}
+template <class T>
+void Ctx<T>::restrict_(int32_t level, const void* fine, void* coarse)
+{
+    need(level >= 0 && level + 1 < (int)levels.size(), "level out of range");
+    size_t nf = 3 * (size_t)levels[level]->n, nc = 3 * (size_t)levels[level + 1]->n;
+    DBuf<T> a, b;
+    a.reserve(nf), b.reserve(nc);
+    HOT_HIP(hipMemcpyAsync(a.p, fine, nf * sizeof(T), hipMemcpyDefault, stream));
+    restrict_dev(level, a.p, b.p);
+    download(coarse, b.p, nc);
+    sync();
+}
+template <class T>
+void Ctx<T>::prolong(int32_t level, const void* coarse, void* fine)
+{
+    need(level >= 0 && level + 1 < (int)levels.size(), "level out of range");
+    size_t nf = 3 * (size_t)levels[level]->n, nc = 3 * (size_t)levels[level + 1]->n;
+    DBuf<T> a, b;
+    a.reserve(nc), b.reserve(nf);
+    HOT_HIP(hipMemcpyAsync(a.p, coarse, nc * sizeof(T), hipMemcpyDefault, stream));
+    prolong_dev(level, a.p, b.p);
+    download(fine, b.p, nf);
+    sync();
+}
+template <class T>
+void Ctx<T>::smooth(int32_t level, int32_t kind, int32_t iterations, double tol, void* u, void* r, const void* r0)
+{
+    need(level >= 0 && level < (int)levels.size() && levels[level]->residual.p, "hot_smooth: level not built (hot_build_mg)");
+    Level<T>& L = *levels[level];
+    size_t n3 = 3 * (size_t)L.n;
+    DBuf<T> du_, dr_;
+    du_.reserve(n3), dr_.reserve(n3);
+    HOT_HIP(hipMemcpyAsync(du_.p, u, n3 * sizeof(T), hipMemcpyDefault, stream));
+    HOT_HIP(hipMemcpyAsync(dr_.p, r, n3 * sizeof(T), hipMemcpyDefault, stream));
+    HOT_HIP(hipMemcpyAsync(L.initialResidual.p, r0 ? r0 : r, n3 * sizeof(T), hipMemcpyDefault, stream));
+    smooth_dev(level, kind, iterations, (T)tol, du_.p, dr_.p, L.du.p, L.dAu.p);
+    download(u, du_.p, n3);
+    download(r, dr_.p, n3);
+    sync();
+}
+template <class T>
+void Ctx<T>::vcycle(const void* in, void* out)
+{
+    need(!levels.empty() && levels[0]->residual.p, "hot_vcycle before hot_build_mg");
+    size_t n3 = 3 * (size_t)Nn;
+    HOT_HIP(hipMemcpyAsync(work0.p, in, n3 * sizeof(T), hipMemcpyDefault, stream));
+    vcycle_dev(work0.p, work1.p);
+    download(out, work1.p, n3);
+    sync();
+}
+
+template struct Ctx<float>;
+template struct Ctx<double>;
+
+} // namespace hot

@@ -1,0 +1,303 @@
+// libhotmi355x — nonlinear solvers and the time-step driver (host control flow, device data).
+//
+//   lbfgs_solve     LBFGS::solve (reference Lib/Ziran/Math/Nonlinear/LBFGS.h:300-437): history 8 ring buffer, two-loop
+//                   recursion around the V-cycle, curvature pairs dropped when y^T s <= 0, Hessian + hierarchy rebuilt at
+//                   iteration 0 (or every 16 with useAdaptiveHessian).  The two-loop scalars live on the device
+//                   (k_lbfgs_scalar), so the <= 16 dots + 16 axpys per iteration run without host round trips.
+//   line_search     ImplicitSolverObjective::lineSearch (Projects/multigrid/ImplicitSolver.h:312-333)
+//   should_exit     shouldExitByCN (:174-211) / computeNorm (:158-171)
+//   newton_solve    ExtendedNewtonsMethod::solve (Lib/Ziran/Math/Nonlinear/ExtendedNewtonsMethod.h:39-66) + computeStep
+//                   (ImplicitSolver.h:355-432) + InexactConjugateGradient::solve (Lib/Ziran/Math/Linear/InexactConjugateGradient.h:49-103)
+//   advance         MultigridSimulation::advanceOneTimeStep (Projects/multigrid/MultigridSimulation.h:235-297)
+//
+// Reference quirk kept on purpose (DESIGN.md "reference quirks"): with --linesearch, lineSearch's updateState(dvnew)
+// aliases the solver's x through moveNodes (MpmSimulationBase.cpp:736-747) and `updated` stays true for the rest of
+// the step, so the caller's `x += step` (LBFGS.h:413, ExtendedNewtonsMethod.h:61) lands on top of an x that already
+// contains the step: the dv handed to G2P is (last accepted iterate + last accepted step).
+#include "hot_impl.h"
+#include <cmath>
+
+namespace hot {
+
+template <class T>
+__global__ __launch_bounds__(256) void k_scaled_norm(const T* __restrict__ r, const T* __restrict__ tol, int nn, int useCN, double* out)
+{
+    __shared__ double red[4];
+    double s = 0;
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < nn; n += gridDim.x * 256) {
+        T a = r[3 * n], b = r[3 * n + 1], c = r[3 * n + 2];
+        T q = a * a + b * b + c * c;
+        if (useCN) q = q / (tol[n] * tol[n]);
+        s += (double)q;
+    }
+    double t = block_sum_256<double>(s, red);
+    if (threadIdx.x == 0) atomic_add(out, t);
+}
+// out = dv0 + alpha * ddv
+template <class T>
+__global__ void k_combine(size_t n, const T* __restrict__ a, T alpha, const T* __restrict__ b, T* out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i] * alpha;
+}
+template <class T>
+__global__ void k_scal(size_t n, T alpha, T* x)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= alpha;
+}
+// two-loop scalars: what 0: ksi[i] = tmp * dgTdx[i] ; what 1: coef = ksi[i] - tmp * dgTdx[i]
+__global__ void k_lbfgs_scalar(double* s, int i, int what)
+{
+    if (what == 0)
+        s[50 + i] = s[70] * s[60 + i];
+    else
+        s[80] = s[50 + i] - s[70] * s[60 + i];
+}
+
+template <class T>
+bool Ctx<T>::should_exit(const T* r)
+{
+    if (Nn == 0) return true;
+    HOT_HIP(hipMemsetAsync(dscal.p + 90, 0, sizeof(double), stream));
+    HOT_LAUNCH(this, "exit_norm", k_scaled_norm<T>, std::min(div_up(Nn, 256), 1024), 256, 0, r, cnTol.p, Nn, cfg.useCN, dscal.p + 90);
+    HOT_HIP(hipMemcpyAsync(hscal + 90, dscal.p + 90, sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    double v = hscal[90];
+    HOT_CHECK(v == v, HOT_ERR_NUMERIC, "NaN in the residual norm");
+    if (!cfg.useCN) {
+        double res = std::sqrt(v);
+        stats.final_scaled_residual = res;
+        return res < cfg.cneps;
+    }
+    stats.final_scaled_residual = std::sqrt(v / Nn);
+    return (T)v < (T)Nn;
+}
+
+template <class T>
+T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
+{
+    size_t n3 = 3 * (size_t)Nn;
+    T* dvnew = work3.p;
+    transform_dev(ddv, true); // recoverSolution
+    double Ek0 = Ek;
+    int guard = 0;
+    do {
+        HOT_LAUNCH(this, "linesearch_combine", k_combine<T>, div_up(n3, 256), 256, 0, n3, dv0.p, alpha, ddv, dvnew);
+        copy(n3, dvnew, dv.p); // moveNodes
+        Ek = state_pass(dv.p, true);
+        HOT_CHECK(Ek == Ek, HOT_ERR_NUMERIC, "NaN energy in line search");
+        stats.linesearch_trials++;
+        alpha *= (T)0.5;
+    } while (Ek > Ek0 && ++guard < 200);
+    alpha *= 2;
+    HOT_LAUNCH(this, "scal", k_scal<T>, div_up(n3, 256), 256, 0, n3, alpha, ddv);
+    transform_dev(ddv, false); // transformResidual
+    residual_dev(residual_out);
+    updated = true;
+    copy(n3, dvnew, dv0.p);
+    return alpha;
+}
+
+template <class T>
+bool Ctx<T>::lbfgs_solve()
+{
+    constexpr int historySize = 8;
+    size_t n3 = 3 * (size_t)Nn;
+    T* x = dv.p;
+    T* residual = work2.p;
+    for (int k = 0; k < historySize + 1; ++k) hist_dx[k].reserve(n3, 1.25), hist_dg[k].reserve(n3, 1.25);
+    if (!updated) {
+        Ek = state_pass(x, true);
+        residual_dev(residual);
+    }
+    std::vector<int> order; // physical slots, oldest first; back() is the working slot
+    std::vector<int> freeSlots;
+    for (int k = historySize; k >= 0; --k) freeSlots.push_back(k);
+    auto push_back = [&]() {
+        if ((int)order.size() == historySize + 1) {
+            freeSlots.push_back(order.front());
+            order.erase(order.begin());
+        }
+        order.push_back(freeSlots.back());
+        freeSlots.pop_back();
+    };
+    auto pop_back = [&]() {
+        freeSlots.push_back(order.back());
+        order.pop_back();
+    };
+    push_back();
+    double* s = dscal.p;
+    for (int it = 0; it < cfg.max_iterations; ++it) {
+        stats.iterations = it;
+        if (should_exit(residual)) {
+            stats.converged = 1;
+            return true;
+        }
+        bool rebuild = cfg.useAdaptiveHessian ? ((it & 0xf) == 0) : (it == 0);
+        if (rebuild) {
+            build_hessian();
+            build_mg();
+            while (!order.empty()) pop_back();
+            push_back();
+        }
+        int wk = order.back();
+        copy(n3, residual, hist_dg[wk].p);
+        for (int i = (int)order.size() - 2; i >= 0; --i) {
+            int ph = order[i];
+            dot_to(n3, hist_dx[ph].p, residual, s + 70);
+            HOT_LAUNCH(this, "lbfgs_scalar", k_lbfgs_scalar, 1, 1, 0, s, ph, 0);
+            axpy_dev(n3, s + 50 + ph, -1.0, hist_dg[ph].p, residual);
+        }
+        precondition_dev(residual, hist_dx[wk].p);
+        project_dev(hist_dx[wk].p);
+        for (int i = 0; i < (int)order.size() - 1; ++i) {
+            int ph = order[i];
+            dot_to(n3, hist_dg[ph].p, hist_dx[wk].p, s + 70);
+            HOT_LAUNCH(this, "lbfgs_scalar", k_lbfgs_scalar, 1, 1, 0, s, ph, 1);
+            axpy_dev(n3, s + 80, 1.0, hist_dx[ph].p, hist_dx[wk].p);
+        }
+        if (cfg.linesearch) line_search(hist_dx[wk].p, residual, (T)1);
+        transform_dev(hist_dx[wk].p, true); // recoverSolution
+        axpy(n3, (T)1, hist_dx[wk].p, x);
+        transform_dev(hist_dx[wk].p, false);
+        if (!updated) {
+            Ek = state_pass(x, true);
+            residual_dev(residual);
+        }
+        axpy(n3, (T)-1, residual, hist_dg[wk].p);
+        double d = dot_host(n3, hist_dg[wk].p, hist_dx[wk].p);
+        T dgTdx = (T)1 / (T)d;
+        if (dgTdx <= (T)0 || !(dgTdx == dgTdx)) {
+            if (!(dgTdx <= (T)0)) HOT_CHECK(false, HOT_ERR_NUMERIC, "NaN curvature in L-BFGS");
+            pop_back();
+            stats.dropped_pairs++;
+        }
+        else {
+            double v = (double)dgTdx;
+            HOT_HIP(hipMemcpyAsync(s + 60 + wk, &v, sizeof(double), hipMemcpyHostToDevice, stream));
+            sync();
+        }
+        push_back();
+    }
+    stats.iterations = cfg.max_iterations;
+    return false;
+}
+
+template <class T>
+__global__ void k_sub(size_t n, const T* __restrict__ a, const T* __restrict__ b, T* out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] - b[i];
+}
+
+template <class T>
+bool Ctx<T>::newton_solve()
+{
+    size_t n3 = 3 * (size_t)Nn;
+    T* x = dv.p;
+    T* residual = work2.p;
+    DBuf<T> step, r, p, q, temp;
+    step.reserve(n3), r.reserve(n3), p.reserve(n3), q.reserve(n3), temp.reserve(n3);
+    T cg_tolerance = cfg.useCN ? max_cn_tolerance : (T)1e-4; // MultigridSimulation.h:201-208 / MultigridInit3D.h:2500-2501
+    DBuf<T> mfdiag;
+    for (int it = 0; it < cfg.max_iterations; ++it) {
+        stats.iterations = it;
+        if (!updated) {
+            Ek = state_pass(x, true);
+            residual_dev(residual);
+        }
+        if (should_exit(residual)) {
+            stats.converged = 1;
+            return true;
+        }
+        zero(n3, step.p);
+        HOT_CHECK(!cfg.matrixFree, HOT_ERR_INVALID, "matrixFree PN needs the matrix-free block diagonal (buildDiagonal, ImplicitSolver.h:605-665): not built yet");
+        build_hessian();
+        build_mg();
+        bool diagPrec = (cfg.levelCnt == 1 && cfg.times == 1);
+        auto prec = [&](const T* in, T* out) {
+            if (diagPrec)
+                scale_dev(*levels[0], in, out); // forced diagonal preconditioner (ImplicitSolver.h:376-391)
+            else
+                vcycle_dev(in, out);
+        };
+        auto Amul = [&](const T* xx, T* bb) { spmv_dev(*levels[0], xx, bb); };
+        // b = residual (+ dRhs == 0)
+        Amul(step.p, temp.p);
+        HOT_LAUNCH(this, "sub", k_sub<T>, div_up(n3, 256), 256, 0, n3, residual, temp.p, r.p);
+        project_dev(r.p);
+        prec(r.p, q.p);
+        copy(n3, q.p, p.p);
+        double zTrk = dot_host(n3, r.p, q.p);
+        T rpn = (T)std::sqrt(zTrk);
+        T forcing = std::min((T)0.5, (T)std::sqrt(std::max(rpn, cg_tolerance)));
+        T local_tol = forcing * rpn;
+        int cnt = 0;
+        for (; cnt < 10000; ++cnt) {
+            if (rpn < local_tol) break;
+            Amul(p.p, temp.p);
+            project_dev(temp.p);
+            T alpha = (T)(zTrk / dot_host(n3, temp.p, p.p));
+            axpy(n3, alpha, p.p, step.p);
+            axpy(n3, -alpha, temp.p, r.p);
+            prec(r.p, q.p);
+            double zlast = zTrk;
+            zTrk = dot_host(n3, q.p, r.p);
+            T beta = (T)(zTrk / zlast);
+            HOT_LAUNCH(this, "scal", k_scal<T>, div_up(n3, 256), 256, 0, n3, beta, p.p);
+            axpy(n3, (T)1, q.p, p.p);
+            rpn = (T)std::sqrt(zTrk);
+        }
+        stats.linear_iterations += cnt;
+        if (cfg.linesearch) line_search(step.p, residual, (T)1);
+        transform_dev(step.p, true);
+        axpy(n3, (T)1, step.p, x);
+        transform_dev(step.p, false);
+    }
+    stats.iterations = cfg.max_iterations;
+    return false;
+}
+
+template <class T>
+void Ctx<T>::solve(hot_stats* st)
+{
+    need(Nn > 0 && dt > 0, "hot_solve before hot_begin_step");
+    double keep_sort = stats.ms_sort, keep_p2g = stats.ms_p2g, keep_begin = stats.ms_begin;
+    std::memset(&stats, 0, sizeof(stats));
+    stats.ms_sort = keep_sort, stats.ms_p2g = keep_p2g, stats.ms_begin = keep_begin;
+    double t0 = wall_ms();
+    if (cfg.useCN) cn_tolerance_dev();
+    for (auto* l : levels) delete l;
+    levels.clear();
+    if (cfg.lsolver == 3)
+        lbfgs_solve();
+    else
+        newton_solve();
+    sync();
+    prof.collect();
+    stats.num_nodes = Nn;
+    stats.num_levels = (int)levels.size();
+    stats.energy = Ek;
+    stats.ms_solve = wall_ms() - t0;
+    if (st) *st = stats;
+}
+
+template <class T>
+void Ctx<T>::advance(double dt_, hot_stats* st)
+{
+    double t0 = wall_ms();
+    sort();
+    p2g();
+    begin_step(dt_);
+    solve(nullptr);
+    int32_t f = 0;
+    g2p(dt_, &f);
+    stats.ms_total = wall_ms() - t0;
+    if (st) *st = stats;
+}
+
+template struct Ctx<float>;
+template struct Ctx<double>;
+
+} // namespace hot

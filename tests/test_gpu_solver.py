@@ -1,0 +1,109 @@
+"""GPU parity: assembled Hessian, Galerkin hierarchy, smoothers, V-cycle, L-BFGS / PN solves and whole time steps
+through the C ABI against the CPU oracle."""
+import numpy as np
+import pytest
+
+from tests import pipeline_checks as pc
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def built(lib, n=8, dtype=1, **kw):
+    ctx, c = pc.make_ctx(lib, n=n, dtype=dtype, **kw)
+    pc.prepare(ctx)
+    ctx.update_state(ctx.get_dv())
+    ctx.build_hessian()
+    ctx.build_mg()
+    return ctx
+
+
+def level_matrices(ctx, nlev):
+    out = []
+    for l in range(nlev):
+        col, val = ctx.matrix(l)
+        out.append(pc.ell_to_scipy(col, val, col.shape[0]))
+    return out
+
+
+@pytest.mark.parametrize("dtype,tol", [(1, 1e-10), (0, 5e-4)])
+def test_hessian_and_hierarchy_against_oracle(hotlib, oracle, dtype, tol):
+    g = built(hotlib, dtype=dtype, levelCnt=3)
+    c = built(oracle, dtype=dtype, levelCnt=3)
+    mg, mc = level_matrices(g, 3), level_matrices(c, 3)
+    for l in range(3):
+        assert np.array_equal(g.level(l)["id2coord"], c.level(l)["id2coord"])  # coarse numbering is bit-exact
+        d = abs(mg[l] - mc[l]).max()
+        assert d < tol * abs(mc[l]).max(), (l, d)
+        assert abs(mg[l] - mg[l].T).max() < tol * abs(mc[l]).max()
+    for l in range(2):
+        gp, cp = g.prolongation(l), c.prolongation(l)
+        assert np.array_equal(gp[0], cp[0]) and np.array_equal(gp[1], cp[1])
+
+
+def test_matrix_vs_matfree_and_galerkin_on_gpu(hotlib):
+    err, sym, pd = pc.check_matrix_vs_matfree(hotlib, project=1)
+    assert err < 1e-10 and sym < 1e-10 and pd > 0
+    err, sym, pd = pc.check_matrix_vs_matfree(hotlib, project=0)
+    assert err < 1e-10
+    pc.check_galerkin(hotlib)
+    sym, energies = pc.check_vcycle_spd(hotlib)
+    assert sym < 1e-8 and all(b < a for a, b in zip(energies, energies[1:]))
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 5])
+@pytest.mark.parametrize("level", [0, 1])
+def test_smoothers_against_oracle(hotlib, oracle, kind, level):
+    g, c = built(hotlib, levelCnt=2), built(oracle, levelCnt=2)
+    n = g.level(level, coords=False)["nrows"]
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal((n, 3))
+    if level == 0:
+        b = c.project(b)
+    its = 6 if kind != 5 else 4
+    ug, rg = g.smooth(level, kind, its, np.zeros_like(b), b, tolerance=0.0)
+    uc, rc = c.smooth(level, kind, its, np.zeros_like(b), b, tolerance=0.0)
+    assert rel(ug, uc) < 1e-9, rel(ug, uc)
+    assert rel(rg, rc) < 1e-8
+
+
+@pytest.mark.parametrize("cfg", [dict(levelCnt=3, coarseSolver=2), dict(levelCnt=2, coarseSolver=5), dict(levelCnt=1, coarseSolver=2), dict(levelCnt=3, smoother=0, coarseSolver=2)])
+def test_vcycle_against_oracle(hotlib, oracle, cfg):
+    g, c = built(hotlib, **cfg), built(oracle, **cfg)
+    x = c.project(np.random.default_rng(5).standard_normal((c.Nn, 3)))
+    assert rel(g.vcycle(x), c.vcycle(x)) < 1e-8
+
+
+@pytest.mark.parametrize("kw", [dict(lsolver=3, levelCnt=3), dict(lsolver=3, levelCnt=1), dict(lsolver=2, levelCnt=2), dict(lsolver=2, levelCnt=1, smoother=0, coarseSolver=0)])
+def test_solve_against_oracle(hotlib, oracle, kw):
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=8, cneps=1e-7, **kw)
+        pc.prepare(ctx)
+        st = ctx.solve()
+        out[name] = (ctx.get_dv(), st, ctx.grid()["mass"])
+    sg, sc = out["gpu"][1], out["cpu"][1]
+    assert sg["converged"] == 1 and sc["converged"] == 1
+    assert abs(sg["iterations"] - sc["iterations"]) <= max(1, sc["iterations"] // 20), (sg, sc)
+    m = out["cpu"][2][:, None]
+    a, b = out["gpu"][0], out["cpu"][0]
+    assert np.sqrt((m * (a - b) ** 2).sum()) < 1e-6 * np.sqrt((m * b ** 2).sum())
+    assert abs(sg["energy"] - sc["energy"]) < 1e-8 * max(abs(sc["energy"]), 1e-6)
+
+
+@pytest.mark.parametrize("dtype,tol", [(1, 1e-7), (0, 5e-3)])
+def test_three_time_steps_against_oracle(hotlib, oracle, dtype, tol):
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=8, dtype=dtype, levelCnt=2, cneps=1e-6 if dtype == 1 else 1e-4)
+        its = []
+        for _ in range(3):
+            its.append(ctx.advance(1.0 / 24)["iterations"])
+        out[name] = (ctx.get_particles(), its)
+    pg, pcpu = out["gpu"][0], out["cpu"][0]
+    for k in ("X", "V", "F"):
+        assert rel(pg[k], pcpu[k]) < tol, (k, rel(pg[k], pcpu[k]), out["gpu"][1], out["cpu"][1])
