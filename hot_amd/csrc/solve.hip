@@ -16,6 +16,7 @@
 // contains the step: the dv handed to G2P is (last accepted iterate + last accepted step).
 #include "hot_impl.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace hot {
 
@@ -89,7 +90,8 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
         HOT_CHECK(Ek == Ek, HOT_ERR_NUMERIC, "NaN energy in line search");
         stats.linesearch_trials++;
         alpha *= (T)0.5;
-    } while (Ek > Ek0 && ++guard < 200);
+        if (getenv("HOT_DEBUG")) fprintf(stderr, "[hot]   linesearch alpha=%g Ek=%.12e Ek0=%.12e\n", (double)alpha * 2, Ek, Ek0);
+    } while (Ek > Ek0 && ++guard < 60);
     alpha *= 2;
     HOT_LAUNCH(this, "scal", k_scal<T>, div_up(n3, 256), 256, 0, n3, alpha, ddv);
     transform_dev(ddv, false); // transformResidual
@@ -130,7 +132,9 @@ bool Ctx<T>::lbfgs_solve()
     double* s = dscal.p;
     for (int it = 0; it < cfg.max_iterations; ++it) {
         stats.iterations = it;
-        if (should_exit(residual)) {
+        bool ex = should_exit(residual);
+        if (getenv("HOT_DEBUG")) fprintf(stderr, "[hot] lbfgs it=%d scaled_res=%.6e Ek=%.12e hist=%d\n", it, stats.final_scaled_residual, Ek, (int)order.size() - 1);
+        if (ex) {
             stats.converged = 1;
             return true;
         }

@@ -6,6 +6,12 @@ import subprocess
 
 import numpy as np
 
+# The oracle is OpenMP code full of short parallel loops: on a many-core GPU host (possibly with a smaller
+# cgroup quota than nproc reports) an unbounded team makes it orders of magnitude slower.  Bound the team
+# before libgomp is loaded; bench.py's cpu_baseline leg sets its own value and reports it.
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, len(os.sched_getaffinity(0))))))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 _cached = None
