@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "default_config", "create", "destroy", "last_error", "sync", "set_particles", "get_particles", "sort",
     "get_counts", "get_indexing", "p2g", "get_grid", "set_bc", "set_sticky_halfspaces", "begin_step", "get_dv",
     "set_dv", "update_state", "get_particle_state", "residual", "project", "cn_tolerance", "build_hessian",
-    "matfree_multiply", "build_mg", "get_level", "get_matrix", "get_prolongation", "spmv", "restrict", "prolong",
+    "matfree_multiply", "build_mg", "get_level", "get_matrix", "get_level_nnzb", "get_prolongation", "spmv", "restrict", "prolong",
     "smooth", "vcycle", "solve", "g2p", "advance", "profile_reset", "profile_count", "profile_get", "version",
 ]
 
@@ -100,6 +100,7 @@ class HotLib:
             "build_mg": (C.c_int, [vp]),
             "get_level": (C.c_int, [vp, i32, P(i32), P(i32), vp]),
             "get_matrix": (C.c_int, [vp, i32, vp, vp]),
+            "get_level_nnzb": (C.c_int, [vp, i32, P(i64)]),
             "get_prolongation": (C.c_int, [vp, i32, vp, vp]),
             "spmv": (C.c_int, [vp, i32, vp, vp]),
             "restrict": (C.c_int, [vp, i32, vp, vp]),
@@ -311,6 +312,11 @@ class Context:
         val = np.empty((info["nrows"], info["colsize"], 9), self.T)
         self._call("get_matrix", C.c_int32(level), _ptr(col), _ptr(val))
         return col, val
+
+    def level_nnzb(self, level):
+        v = C.c_int64()
+        self._call("get_level_nnzb", C.c_int32(level), C.byref(v))
+        return v.value
 
     def prolongation(self, level):
         n = self.level(level, coords=False)["nrows"]

@@ -293,6 +293,33 @@ void Ctx<T>::build_diagonal(Level<T>& L)
 }
 
 template <class T>
+__global__ __launch_bounds__(256) void k_count_nnzb(const T* __restrict__ val, int64_t nblocks, unsigned long long* out)
+{
+    __shared__ double red[4];
+    double c = 0;
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nblocks; b += (int64_t)gridDim.x * 256) {
+        const T* v = val + b * 9;
+        bool nz = false;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) nz = nz || v[k] != (T)0;
+        c += nz ? 1.0 : 0.0;
+    }
+    double t = block_sum_256<double>(c, red);
+    if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)t);
+}
+template <class T>
+void Ctx<T>::count_nnzb(Level<T>& L)
+{
+    unsigned long long* d = (unsigned long long*)(dscal.p + 120);
+    HOT_HIP(hipMemsetAsync(d, 0, 8, stream));
+    HOT_LAUNCH(this, "count_nnzb", k_count_nnzb<T>, std::min(div_up((size_t)L.n * 125, 256), 2048), 256, 0, L.val.p, (int64_t)L.n * 125, d);
+    unsigned long long h = 0;
+    HOT_HIP(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream));
+    sync();
+    L.nnzb = (long long)h;
+}
+
+template <class T>
 void Ctx<T>::build_hessian()
 {
     need(Nn > 0 && dt > 0, "hot_build_hessian before hot_update_state");
@@ -311,6 +338,7 @@ void Ctx<T>::build_hessian()
     if (cfg.systemBCProject && Nc > 0)
         HOT_LAUNCH(this, "hessian_bc_project", k_bc_project_matrix<T>, div_up(ne, 256), 256, 0, L->col.p, L->val.p, bcIdx.p, bcR.p, bcRinv.p, bcSlip.p, Nn);
     build_diagonal(*L);
+    count_nnzb(*L);
     sync();
     stats.ms_hessian += wall_ms() - t0;
 }

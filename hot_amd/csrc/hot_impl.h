@@ -9,6 +9,8 @@ namespace hot {
 template <class T>
 struct Level {
     int n = 0; // rows (nodes)
+    int id = 0; // level index
+    long long nnzb = 0; // structurally non-zero 3x3 blocks (for the roofline's algorithmic bytes)
     DBuf<int32_t> coord; // 3n
     DBuf<int32_t> col; // n*125   (entryCol)
     DBuf<T> val; // n*125*9 (entryVal, 3x3 column-major)
@@ -133,6 +135,7 @@ struct Ctx : CtxBase {
     void build_mg() override;
     void get_level(int32_t level, int32_t* nrows, int32_t* colsize, int32_t* id2coord) override;
     void get_matrix(int32_t level, int32_t* entryCol, void* entryVal) override;
+    long long get_level_nnzb(int32_t level) override { need(level >= 0 && level < (int)levels.size(), "level out of range"); return levels[level]->nnzb; }
     void get_prolongation(int32_t level, int32_t* entryCol, void* weight) override;
     void spmv(int32_t level, const void* x, void* y) override;
     void restrict_(int32_t level, const void* fine, void* coarse) override;
@@ -151,6 +154,8 @@ struct Ctx : CtxBase {
     void transform_dev(T* v, bool inverse); // transformResidual / recoverSolution
     void cn_tolerance_dev();
     void build_diagonal(Level<T>& L);
+    void count_nnzb(Level<T>& L);
+    std::string lname(const char* base, int level) { return std::string(base) + "_L" + std::to_string(level); }
     void spmv_dev(Level<T>& L, const T* x, T* y);
     void scale_dev(Level<T>& L, const T* in, T* out); // out_i = Dinv_i in_i
     void scal(size_t n, T a, T* x); // x *= a

@@ -337,6 +337,7 @@ void Ctx<T>::build_mg()
         Level<T>* Cp = new Level<T>();
         levels.push_back(Cp);
         Level<T>& C = *Cp;
+        C.id = level + 1;
         // ---- coarse node set with first-touch numbering
         uint32_t cap = 1024;
         while (cap < 2u * (uint32_t)n + 16u) cap <<= 1;
@@ -361,6 +362,7 @@ void Ctx<T>::build_mg()
         HOT_LAUNCH(this, "mg_AP", k_ap<T>, div_up(n, 4), 256, 0, F.coord.p, F.val.p, ap.p, n);
         HOT_LAUNCH(this, "mg_RAP", k_rap<T>, div_up(nc, 4), 256, 0, C.coord.p, C.child.p, ap.p, C.val.p, C.n);
         build_diagonal(C);
+        count_nnzb(C);
         alloc_work(C);
         if (colors) mark_colors(this, C);
     }

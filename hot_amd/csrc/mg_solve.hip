@@ -122,7 +122,7 @@ void Ctx<T>::scal(size_t n, T a, T* x)
 template <class T>
 void Ctx<T>::spmv_dev(Level<T>& L, const T* x, T* y)
 {
-    HOT_LAUNCH(this, "spmv", k_spmv<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, x, y, L.n);
+    HOT_LAUNCH(this, lname("spmv", L.id).c_str(), k_spmv<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, x, y, L.n);
 }
 
 // ------------------------------------------------------------------------------------------------ transfers
@@ -328,14 +328,14 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             for (int c = 0; c < 8; ++c) {
                 int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
                 if (nb > 0)
-                    HOT_LAUNCH(this, "gs_forward", (k_gs_color<T, true>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0, nb);
+                    HOT_LAUNCH(this, lname("gs_forward", L.id).c_str(), (k_gs_color<T, true>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0, nb);
             }
             // dAu now holds D h ; du = backward solve
             zero(n3, du);
             for (int c = 7; c >= 0; --c) {
                 int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
                 if (nb > 0)
-                    HOT_LAUNCH(this, "gs_backward", (k_gs_color<T, false>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0, nb);
+                    HOT_LAUNCH(this, lname("gs_backward", L.id).c_str(), (k_gs_color<T, false>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0, nb);
             }
             axpy(n3, (T)1, du, u);
             spmv_dev(L, du, dAu);

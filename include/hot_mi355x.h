@@ -144,6 +144,8 @@ int hot_get_level(hot_ctx*, int32_t level, int32_t* nrows, int32_t* colsize, int
  * (row-major slots, 3x3 column-major) — SquareMatrix.h:27-34.  Slot order inside a coarse row is
  * implementation-defined (the reference's is std::unordered_map iteration order, SquareMatrix.h:560-564). */
 int hot_get_matrix(hot_ctx*, int32_t level, int32_t* entryCol, void* entryVal);
+/* structurally non-zero 3x3 blocks of the level's system matrix (used for the roofline's algorithmic bytes) */
+int hot_get_level_nnzb(hot_ctx*, int32_t level, int64_t* nnzb);
 int hot_get_prolongation(hot_ctx*, int32_t level, int32_t* entryCol /*8*nrows(level)*/, void* weight /*8*nrows(level)*/);
 
 /* ---- operators */

@@ -294,6 +294,20 @@ int hoto_get_matrix(hoto_ctx* c, int32_t level, int32_t* entryCol, void* entryVa
     });
     return 0;
 }
+int hoto_get_level_nnzb(hoto_ctx* c, int32_t level, int64_t* nnzb)
+{
+    DISPATCH(c, {
+        auto& m = S.sysmats[level];
+        int64_t cnt = 0;
+        for (auto& v : m.entryVal) {
+            bool nz = false;
+            for (int k = 0; k < 9; ++k) nz = nz || v.a[k] != 0;
+            cnt += nz;
+        }
+        *nnzb = cnt;
+    });
+    return 0;
+}
 int hoto_get_prolongation(hoto_ctx* c, int32_t level, int32_t* entryCol, void* weight)
 {
     DISPATCH(c, {
