@@ -171,16 +171,25 @@ void Ctx<T>::set_dv(const void* in)
 }
 
 // ------------------------------------------------------------------------------------------------ state pass
+// rotate the (j,k) visiting order per lane with compile-time loop structure: the particles of one cell sit in
+// adjacent lanes and would otherwise hit the same LDS address in the same ds_add instruction
+template <class T>
+__device__ __forceinline__ void rot3(const T (&in)[3], int r, T (&out)[3])
+{
+    out[0] = r == 0 ? in[0] : (r == 1 ? in[1] : in[2]);
+    out[1] = r == 0 ? in[1] : (r == 1 ? in[2] : in[0]);
+    out[2] = r == 0 ? in[2] : (r == 1 ? in[0] : in[1]);
+}
+
+// pass A: gather grad(vn+dv) from the LDS node tile -> trial F -> one SVD -> psi, P -> stress = V_p P Fn^T, energy
 template <class T>
 __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ Vol, const T* __restrict__ Mu, const T* __restrict__ Lam,
     T* __restrict__ Ft, T* __restrict__ stress_out, T* __restrict__ gradV_out, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
-    const int32_t* __restrict__ group_nb, const int32_t* __restrict__ gIdx, const T* __restrict__ vn, const T* __restrict__ dv, T* gF, int64_t slots, T dx, T one_over_dx, T dt,
-    double* energy, int want_force)
+    const int32_t* __restrict__ group_nb, const int32_t* __restrict__ gIdx, const T* __restrict__ vn, const T* __restrict__ dv, T dx, T one_over_dx, T dt, double* energy)
 {
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
     __shared__ T nv[3][TILE];
-    __shared__ T acc[3][TILE];
     __shared__ int32_t nb8[8];
     __shared__ double red[4];
     const int g = blockIdx.x;
@@ -191,87 +200,129 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
         T a = 0, b = 0, c = 0;
         if (idx >= 0) a = vn[3 * idx] + dv[3 * idx], b = vn[3 * idx + 1] + dv[3 * idx + 1], c = vn[3 * idx + 2] + dv[3 * idx + 2];
         nv[0][t] = a, nv[1][t] = b, nv[2][t] = c;
-        acc[0][t] = acc[1][t] = acc[2][t] = (T)0;
     }
     __syncthreads();
     const int first = group_first[g], last = group_first[g + 1];
     const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
     double e = 0;
     for (int p = first + threadIdx.x; p < last; p += 256) {
+        Mat3<T> Fnew;
+        {
+            T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
+            int base[3];
+            T w[3][3], dw[3][3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+            const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
+            T gv[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) gv[c] = (T)0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                T wi = w[0][i], dwi = one_over_dx * dw[0][i];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    T wij = wi * w[1][j];
+                    T dwij_i = dwi * w[1][j], dwij_j = wi * one_over_dx * dw[1][j];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        T g0 = dwij_i * w[2][k], g1 = dwij_j * w[2][k], g2 = wij * one_over_dx * dw[2][k];
+                        int t = ((cx + i) * TY + (cy + j)) * TZ + (cz + k);
+                        T v0 = nv[0][t], v1 = nv[1][t], v2 = nv[2][t];
+                        gv[0] += v0 * g0, gv[1] += v1 * g0, gv[2] += v2 * g0;
+                        gv[3] += v0 * g1, gv[4] += v1 * g1, gv[5] += v2 * g1;
+                        gv[6] += v0 * g2, gv[7] += v1 * g2, gv[8] += v2 * g2;
+                    }
+                }
+            }
+            if (gradV_out) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) gradV_out[(int64_t)c * Np + p] = gv[c];
+            }
+            Mat3<T> A, Fo;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) A.a[c] = dt * gv[c] + ((c % 4 == 0) ? (T)1 : (T)0), Fo.a[c] = Fn[(int64_t)c * Np + p];
+            Fnew = m3_mul(A, Fo);
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Ft[(int64_t)c * Np + p] = Fnew.a[c];
+        T mu = Mu[p], la = Lam[p];
+        T psi;
+        Mat3<T> P;
+        corotated_state(Fnew, mu, la, psi, P);
+        T vol = Vol[p];
+        e += (double)(vol * psi);
+        // stress = V_p P Fn^T  (Fn re-read after the SVD instead of being kept live across it)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            T f0 = Fn[(int64_t)(0 * 3 + c) * Np + p], f1 = Fn[(int64_t)(1 * 3 + c) * Np + p], f2 = Fn[(int64_t)(2 * 3 + c) * Np + p]; // Fn(c, 0..2)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) stress_out[(int64_t)(c * 3 + r) * Np + p] = vol * (P(r, 0) * f0 + P(r, 1) * f1 + P(r, 2) * f2);
+        }
+    }
+    double tot = block_sum_256<double>(e, red);
+    if (threadIdx.x == 0 && tot != 0.0) atomic_add(energy, tot);
+}
+
+// pass B: rasterizeForceToTVStack — f_i -= dt * stress grad w_i, LDS accumulators, one global atomic per touched node
+template <class T>
+__global__ __launch_bounds__(256) void k_force_scatter(const T* __restrict__ X, const T* __restrict__ stress, int64_t Np, const int32_t* __restrict__ group_first,
+    const int32_t* __restrict__ group_origin, const int32_t* __restrict__ group_nb, T* gF, int64_t slots, T one_over_dx, T scale)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
+    __shared__ T acc[3][TILE];
+    __shared__ int32_t nb8[8];
+    const int g = blockIdx.x;
+    if (threadIdx.x < 8) nb8[threadIdx.x] = group_nb[g * 8 + threadIdx.x];
+    for (int t = threadIdx.x; t < TILE; t += 256) acc[0][t] = acc[1][t] = acc[2][t] = (T)0;
+    __syncthreads();
+    const int first = group_first[g], last = group_first[g + 1];
+    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
+    const int rk = threadIdx.x % 3, rj = (threadIdx.x / 3) % 3;
+    for (int p = first + threadIdx.x; p < last; p += 256) {
         T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
         int base[3];
         T w[3][3], dw[3][3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
-        const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
-        T gv[9];
+        T S[9];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) gv[c] = (T)0;
+        for (int c = 0; c < 9; ++c) S[c] = scale * stress[(int64_t)c * Np + p];
+        // rotated y / z weight tables and tile offsets
+        T wy[3], dwy[3], wz[3], dwz[3];
+        rot3(w[1], rj, wy), rot3(dw[1], rj, dwy), rot3(w[2], rk, wz), rot3(dw[2], rk, dwz);
+        const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             T wi = w[0][i], dwi = one_over_dx * dw[0][i];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                T wij = wi * w[1][j];
-                T dwij_i = dwi * w[1][j], dwij_j = wi * one_over_dx * dw[1][j];
+                int jj = j + rj;
+                jj = jj >= 3 ? jj - 3 : jj;
+                T wij = wi * wy[j], dwij_i = dwi * wy[j], dwij_j = wi * one_over_dx * dwy[j];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    T g0 = dwij_i * w[2][k], g1 = dwij_j * w[2][k], g2 = wij * one_over_dx * dw[2][k];
-                    int t = ((cx + i) * TY + (cy + j)) * TZ + (cz + k);
-                    T v0 = nv[0][t], v1 = nv[1][t], v2 = nv[2][t];
-                    gv[0] += v0 * g0, gv[1] += v1 * g0, gv[2] += v2 * g0;
-                    gv[3] += v0 * g1, gv[4] += v1 * g1, gv[5] += v2 * g1;
-                    gv[6] += v0 * g2, gv[7] += v1 * g2, gv[8] += v2 * g2;
+                    int kk = k + rk;
+                    kk = kk >= 3 ? kk - 3 : kk;
+                    T g0 = dwij_i * wz[k], g1 = dwij_j * wz[k], g2 = wij * one_over_dx * dwz[k];
+                    int t = ((cx + i) * TY + (cy + jj)) * TZ + (cz + kk);
+                    lds_atomic_add(&acc[0][t], -(S[0] * g0 + S[3] * g1 + S[6] * g2));
+                    lds_atomic_add(&acc[1][t], -(S[1] * g0 + S[4] * g1 + S[7] * g2));
+                    lds_atomic_add(&acc[2][t], -(S[2] * g0 + S[5] * g1 + S[8] * g2));
                 }
             }
         }
-        Mat3<T> A, Fo;
-#pragma unroll
-        for (int c = 0; c < 9; ++c) A.a[c] = dt * gv[c] + ((c % 4 == 0) ? (T)1 : (T)0), Fo.a[c] = Fn[(int64_t)c * Np + p];
-        Mat3<T> Fnew = m3_mul(A, Fo);
-        T mu = Mu[p], la = Lam[p], vol = Vol[p];
-        T psi;
-        Mat3<T> P;
-        corotated_state(Fnew, mu, la, psi, P);
-        e += (double)(vol * psi);
-        // stress = V_p P Fn^T
-        Mat3<T> S;
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int r = 0; r < 3; ++r) S(r, c) = vol * (P(r, 0) * Fo(c, 0) + P(r, 1) * Fo(c, 1) + P(r, 2) * Fo(c, 2));
-#pragma unroll
-        for (int c = 0; c < 9; ++c) Ft[(int64_t)c * Np + p] = Fnew.a[c];
-        if (stress_out) {
-#pragma unroll
-            for (int c = 0; c < 9; ++c) stress_out[(int64_t)c * Np + p] = S.a[c], gradV_out[(int64_t)c * Np + p] = gv[c];
-        }
-        if (want_force) {
-            int rot = threadIdx.x % 27;
-            for (int n = 0; n < 27; ++n) {
-                int q = n + rot;
-                q = q >= 27 ? q - 27 : q;
-                int i = q / 9, j = (q / 3) % 3, k = q % 3;
-                T g0 = one_over_dx * dw[0][i] * w[1][j] * w[2][k], g1 = w[0][i] * one_over_dx * dw[1][j] * w[2][k], g2 = w[0][i] * w[1][j] * one_over_dx * dw[2][k];
-                int t = ((cx + i) * TY + (cy + j)) * TZ + (cz + k);
-                lds_atomic_add(&acc[0][t], -dt * (S(0, 0) * g0 + S(0, 1) * g1 + S(0, 2) * g2));
-                lds_atomic_add(&acc[1][t], -dt * (S(1, 0) * g0 + S(1, 1) * g1 + S(1, 2) * g2));
-                lds_atomic_add(&acc[2][t], -dt * (S(2, 0) * g0 + S(2, 1) * g1 + S(2, 2) * g2));
-            }
-        }
     }
-    double tot = block_sum_256<double>(e, red);
-    if (threadIdx.x == 0 && tot != 0.0) atomic_add(energy, tot);
-    if (want_force) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < TILE; t += 256) {
-            T a = acc[0][t], b = acc[1][t], c = acc[2][t];
-            if (a == (T)0 && b == (T)0 && c == (T)0) continue;
-            int64_t s = tile_slot2<T>(t, nb8);
-            atomic_add(&gF[s], a);
-            atomic_add(&gF[slots + s], b);
-            atomic_add(&gF[2 * slots + s], c);
-        }
+    __syncthreads();
+    for (int t = threadIdx.x; t < TILE; t += 256) {
+        T a = acc[0][t], b = acc[1][t], c = acc[2][t];
+        if (a == (T)0 && b == (T)0 && c == (T)0) continue;
+        int64_t s = tile_slot2<T>(t, nb8);
+        atomic_add(&gF[s], a);
+        atomic_add(&gF[slots + s], b);
+        atomic_add(&gF[2 * slots + s], c);
     }
 }
 
@@ -299,8 +350,10 @@ double Ctx<T>::state_pass(const T* dv_in, bool want_force)
     int64_t slots = (int64_t)Nb * EPB;
     HOT_HIP(hipMemsetAsync(dscal.p, 0, 4 * sizeof(double), stream));
     if (want_force) HOT_HIP(hipMemsetAsync(gF.p, 0, 3 * slots * sizeof(T), stream));
-    HOT_LAUNCH(this, "state_update_force", k_state<T>, Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, pFt.p, keep_debug ? pStress.p : (T*)nullptr, keep_debug ? pGradV.p : (T*)nullptr, Np,
-        group_first.p, group_origin.p, group_nb.p, gIdx.p, vn.p, dv_in, gF.p, slots, dx, (T)1 / dx, dt, dscal.p, want_force ? 1 : 0);
+    HOT_LAUNCH(this, "state_update", k_state<T>, Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, pFt.p, pStress.p, keep_debug ? pGradV.p : (T*)nullptr, Np, group_first.p, group_origin.p,
+        group_nb.p, gIdx.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p);
+    if (want_force)
+        HOT_LAUNCH(this, "force_scatter", k_force_scatter<T>, Ng, 256, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_nb.p, gF.p, slots, (T)1 / dx, dt);
     HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, std::min(div_up(Nn, 256), 1024), 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1);
     HOT_HIP(hipMemcpyAsync(hscal, dscal.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();

@@ -17,6 +17,7 @@
 //   k_bc_project    the per-row BC projection (:554-593); k_diag buildDiagonal (Projects/multigrid/SquareMatrix.h:301-324).
 #include "hot_impl.h"
 #include "hot_constitutive.h"
+#include <cstdlib>
 
 namespace hot {
 
@@ -33,7 +34,7 @@ __device__ __forceinline__ int32_t node_dof(const HashMap& bm, const int32_t* __
 }
 
 template <class T>
-__global__ void k_fill_cols(HashMap bm, const int32_t* __restrict__ gIdx, const int32_t* __restrict__ id2coord, const T* __restrict__ mass, int32_t* col, T* val, int nn)
+__global__ void k_fill_cols(HashMap bm, const int32_t* __restrict__ gIdx, const int32_t* __restrict__ id2coord, const T* __restrict__ mass, int32_t* col, T* val, int nn, int init_val)
 {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)nn * 125) return;
@@ -41,6 +42,7 @@ __global__ void k_fill_cols(HashMap bm, const int32_t* __restrict__ gIdx, const 
     int dx = k / 25 - 2, dy = (k / 5) % 5 - 2, dz = k % 5 - 2;
     int32_t j = node_dof<T>(bm, gIdx, id2coord[3 * n] - dx, id2coord[3 * n + 1] - dy, id2coord[3 * n + 2] - dz);
     col[e] = j >= 0 ? j : (n > 0 ? 0 : 1);
+    if (!init_val) return;
     T m = (k == 62) ? mass[n] : (T)0;
     T* v = val + e * 9;
 #pragma unroll
@@ -332,9 +334,13 @@ void Ctx<T>::build_hessian()
     size_t ne = (size_t)Nn * 125;
     L->col.reserve(ne), L->val.reserve(ne * 9), L->coord.reserve(3 * (size_t)Nn);
     HOT_HIP(hipMemcpyAsync(L->coord.p, id2coord.p, 3 * (size_t)Nn * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
-    HOT_LAUNCH(this, "hessian_fill_cols", k_fill_cols<T>, div_up(ne, 256), 256, 0, block_map, gIdx.p, id2coord.p, mass.p, L->col.p, L->val.p, Nn);
-    HOT_LAUNCH(this, "hessian_assemble", k_hessian<T>, Ng, 256, 0, pX.p, pFn.p, pFt.p, pVol.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gIdx.p, L->val.p, dx, (T)1 / dx, dt,
-        cfg.project);
+    static const bool v1 = getenv("HOT_HESSIAN_V1") != nullptr; // A/B switch: per-cell global-atomic scatter kernel
+    HOT_LAUNCH(this, "hessian_fill_cols", k_fill_cols<T>, div_up(ne, 256), 256, 0, block_map, gIdx.p, id2coord.p, mass.p, L->col.p, L->val.p, Nn, v1 ? 1 : 0);
+    if (v1)
+        HOT_LAUNCH(this, "hessian_assemble_v1", k_hessian<T>, Ng, 256, 0, pX.p, pFn.p, pFt.p, pVol.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gIdx.p, L->val.p, dx, (T)1 / dx,
+            dt, cfg.project);
+    else
+        assemble_tiles(*L);
     if (cfg.systemBCProject && Nc > 0)
         HOT_LAUNCH(this, "hessian_bc_project", k_bc_project_matrix<T>, div_up(ne, 256), 256, 0, L->col.p, L->val.p, bcIdx.p, bcR.p, bcRinv.p, bcSlip.p, Nn);
     build_diagonal(*L);

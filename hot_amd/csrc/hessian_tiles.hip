@@ -1,0 +1,282 @@
+// libhotmi355x — Hessian assembly, production kernel: "row-tile owns its rows", no global atomics.
+//
+// Same mathematics as hessian.hip's k_hessian (reference Projects/multigrid/ImplicitSolver.h:498-552): every ordered
+// node pair (i, j) of every particle contributes  V_p dt^2 sum_{v,q} dP_{(a,v),(b,q)} g_i[v] g_j[q]  to row dof_i,
+// slot linearOffset(node_i - node_j).  The first version scattered those blocks with global fp64 atomics
+// (1.7e9 of them at 2 M particles: atomic-throughput bound, 76 ms).  Here:
+//   pass 1  k_dpdf45        per particle: SVD, PSD-projected A/B blocks, rotate the 21 couplings into the symmetric
+//                           9x9 V_p dt^2 dP/dF, stored as 45 scalars (SoA).
+//   pass 2  k_hessian_tiles one workgroup per aligned 2x2x2 tile of grid nodes.  The 8 rows x 125 slots x 9 values
+//                           live in LDS (72 KB fp64).  Only particles whose base cell lies in the 4x4x4 cells around
+//                           the tile touch these rows; they are fetched cell by cell through the per-cell ranges of
+//                           the sorted particle array.  A thread takes one (particle, row-in-tile) item, forms
+//                           T_i = dPdF . g_i (27 registers) and adds the 27 blocks (i, j) with ds_add (LDS atomics).
+//                           At the end the tile is written to HBM with plain coalesced stores (mass term folded in).
+//   Each (particle, i, j) block is computed exactly once in the whole launch (by the tile owning row i); a particle's
+//   45 scalars are re-read by the <= 8 tiles its 3x3x3 support intersects.
+#include "hot_impl.h"
+#include "hot_constitutive.h"
+
+namespace hot {
+
+__host__ __device__ constexpr int sym45(int a, int b) { return a <= b ? (a * 9 - (a * (a - 1)) / 2 + (b - a)) : (b * 9 - (b * (b - 1)) / 2 + (a - b)); }
+
+template <class T>
+__global__ __launch_bounds__(256) void k_dpdf45(const T* __restrict__ Ft, const T* __restrict__ Vol, const T* __restrict__ Mu, const T* __restrict__ Lam, T* __restrict__ dp, int64_t Np,
+    T dt, int project)
+{
+    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= Np) return;
+    Mat3<T> Fc;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Fc.a[c] = Ft[(int64_t)c * Np + p];
+    HessBlocks<T> h;
+    corotated_hessian(Fc, Mu[p], Lam[p], project != 0, h);
+    const T sc = Vol[p] * dt * dt;
+    // W[(a',b'),(r,s)] = sum_{c,d} K_{a'b',cd} U(r,c) V(s,d): first rotate the right index pair, then the left one
+    // (2 x 9 x 21 / 9 x 9 x 9 multiply-adds instead of 45 x 21 four-factor products)
+    const Mat3<T>& U = h.U;
+    const Mat3<T>& V = h.V;
+    // K is non-zero only for (aa,cc) [A], (ab,ab) and (ab,ba) [B blocks]
+    auto Kval = [&](int a, int b, int c, int d) -> T {
+        if (a == b && c == d) return h.A(a, c);
+        if (a != b && ((a == c && b == d) || (a == d && b == c))) {
+            int lo = a < b ? a : b, hi = a < b ? b : a;
+            const T* B = (lo == 0 && hi == 1) ? h.B01 : ((lo == 1 && hi == 2) ? h.B12 : h.B20);
+            // B01: rows/cols ordered (01, 10); B12: (12, 21); B20: (20, 02)
+            int ia, ic;
+            if (lo == 0 && hi == 2) {
+                ia = (a == 2) ? 0 : 1, ic = (c == 2) ? 0 : 1;
+            }
+            else {
+                ia = (a == lo) ? 0 : 1, ic = (c == lo) ? 0 : 1;
+            }
+            return B[ia + ic];
+        }
+        return (T)0;
+    };
+#pragma unroll
+    for (int ij = 0; ij < 9; ++ij) {
+        const int jj = ij / 3, ii = ij - jj * 3;
+#pragma unroll
+        for (int rs = ij; rs < 9; ++rs) {
+            const int ss = rs / 3, rr = rs - ss * 3;
+            T v = (T)0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    T ub = U(ii, a) * V(jj, b);
+                    if (a == b) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) v += Kval(a, a, c, c) * ub * U(rr, c) * V(ss, c);
+                    }
+                    else {
+                        v += Kval(a, b, a, b) * ub * U(rr, a) * V(ss, b) + Kval(a, b, b, a) * ub * U(rr, b) * V(ss, a);
+                    }
+                }
+            dp[(int64_t)sym45(ij, rs) * Np + p] = v * sc;
+        }
+    }
+}
+
+// ---- cell table: particles sorted by cell key; (key -> [first, next))
+__global__ void k_cell_heads(const uint64_t* __restrict__ keys, int32_t* flags, int64_t n, int index_bits)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    flags[p] = (p == 0 || (keys[p] >> index_bits) != (keys[p - 1] >> index_bits)) ? 1 : 0;
+}
+__global__ void k_cell_fill(const uint64_t* __restrict__ keys, const int32_t* __restrict__ flags, const int32_t* __restrict__ scan, int32_t* cell_first, HashMap h, int64_t n,
+    int ncell, int index_bits)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (p == 0) cell_first[ncell] = (int32_t)n;
+    if (!flags[p]) return;
+    int c = scan[p];
+    cell_first[c] = (int32_t)p;
+    uint32_t s = hash_insert_min(h, keys[p] >> index_bits, (unsigned long long)c);
+    h.id[s] = c;
+}
+__global__ void k_hash_clear3(HashMap h)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > h.mask) return;
+    h.keys[i] = ~0ULL;
+    h.minrank[i] = ~0ULL;
+    h.id[i] = -1;
+}
+
+template <class T>
+void Ctx<T>::build_cell_table()
+{
+    constexpr int index_bits = 32 - G::block_bits;
+    int64_t n = Np;
+    // keys2 still holds the sorted keys of this step's hot_sort
+    flags.reserve(n), scan.reserve(n);
+    HOT_LAUNCH(this, "cell_heads", k_cell_heads, div_up(n, 256), 256, 0, keys2.p, flags.p, n, index_bits);
+    Ncell = exclusive_scan_i32(flags.p, scan.p, n);
+    uint32_t cap = 1024;
+    while (cap < 2u * (uint32_t)Ncell + 16u) cap <<= 1;
+    cell_first.reserve(Ncell + 1), ch_keys.reserve(cap), ch_rank.reserve(cap), ch_id.reserve(cap);
+    cell_map.keys = ch_keys.p, cell_map.minrank = ch_rank.p, cell_map.id = ch_id.p, cell_map.mask = cap - 1;
+    HOT_LAUNCH(this, "hash_clear", k_hash_clear3, div_up(cap, 256), 256, 0, cell_map);
+    HOT_LAUNCH(this, "cell_fill", k_cell_fill, div_up(n, 256), 256, 0, keys2.p, flags.p, scan.p, cell_first.p, cell_map, n, Ncell, index_bits);
+}
+
+template <class T>
+struct TileLds {
+    static constexpr int CH = 64; // particles per chunk
+    static constexpr size_t bytes = (size_t)8 * 1125 * sizeof(T) /*tile*/ + (size_t)CH * 45 * sizeof(T) /*dP*/ + (size_t)CH * 81 * sizeof(T) /*g*/ + (64 + 65 + 8 + CH * 3 + CH * 8 + 4) * sizeof(int32_t);
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void k_hessian_tiles(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ dp, int64_t Np, const uint64_t* __restrict__ blocks,
+    const int32_t* __restrict__ gIdx, const int32_t* __restrict__ cell_first, HashMap cmap, const T* __restrict__ mass, T* __restrict__ val, T one_over_dx)
+{
+    using G = Geo<T>;
+    constexpr int CH = TileLds<T>::CH;
+    constexpr int TPBX = G::BX / 2, TPBY = G::BY / 2, TPBZ = G::BZ / 2, TPB = TPBX * TPBY * TPBZ; // 2x2x2 tiles per block
+    extern __shared__ __attribute__((aligned(16))) char ht_smem[];
+    T* tile = (T*)ht_smem; // [8][1125]
+    T* sdp = tile + 8 * 1125; // [CH][45]
+    T* sg = sdp + CH * 45; // [CH][27][3]
+    int32_t* cstart = (int32_t*)(sg + CH * 81); // [64] first particle of each contributing cell
+    int32_t* cpref = cstart + 64; // [65] prefix of particle counts
+    int32_t* rdof = cpref + 65; // [8]
+    int32_t* pbase = rdof + 8; // [CH][3] base node relative to the tile origin
+    int32_t* items = pbase + CH * 3; // [CH*8] packed (particle-in-chunk << 3 | row)
+    int32_t* nitems = items + CH * 8;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / TPB, tt = blockIdx.x % TPB;
+    int bx, by, bz;
+    G::linear_to_coord(blocks[b], bx, by, bz);
+    const int tx0 = bx + 2 * (tt / (TPBY * TPBZ)), ty0 = by + 2 * ((tt / TPBZ) % TPBY), tz0 = bz + 2 * (tt % TPBZ); // tile origin (node coords)
+    if (tid < 8) {
+        int ex = (tx0 - bx) + (tid >> 2), ey = (ty0 - by) + ((tid >> 1) & 1), ez = (tz0 - bz) + (tid & 1);
+        int elem = (ex << (G::yb + G::zb)) | (ey << G::zb) | ez;
+        rdof[tid] = gIdx[(int64_t)b * G::EPB + elem];
+    }
+    if (tid < 64) {
+        // contributing base cells: tile origin + (-2..1)^3
+        int cx = tx0 - 2 + (tid >> 4), cy = ty0 - 2 + ((tid >> 2) & 3), cz = tz0 - 2 + (tid & 3);
+        int first = 0, cnt = 0;
+        if ((cx | cy | cz) >= 0) {
+            int32_t c = hash_find_id(cmap, G::linear_offset(cx, cy, cz) >> G::data_bits);
+            if (c >= 0) first = cell_first[c], cnt = cell_first[c + 1] - first;
+        }
+        cstart[tid] = first;
+        cpref[tid + 1] = cnt;
+    }
+    for (int e = tid; e < 8 * 1125; e += 256) tile[e] = (T)0;
+    __syncthreads();
+    bool any = false;
+    for (int r = 0; r < 8; ++r) any = any || rdof[r] >= 0;
+    if (!any) return;
+    if (tid == 0) {
+        cpref[0] = 0;
+        for (int c = 0; c < 64; ++c) cpref[c + 1] += cpref[c];
+    }
+    __syncthreads();
+    const int total = cpref[64];
+    for (int chunk = 0; chunk < total; chunk += CH) {
+        const int cnt = min(CH, total - chunk);
+        if (tid == 0) *nitems = 0;
+        __syncthreads();
+        // ---- stage the chunk: dP (45), g = Fn^T grad w (27 x 3), tile-relative base node, work items
+        for (int e = tid; e < cnt * 45; e += 256) {
+            int l = e / 45, q = e - l * 45;
+            int flat = chunk + l;
+            int c = 0;
+            while (cpref[c + 1] <= flat) ++c; // 64 cells: short linear search
+            int p = cstart[c] + (flat - cpref[c]);
+            sdp[l * 45 + q] = dp[(int64_t)q * Np + p];
+        }
+        for (int e = tid; e < cnt * 27; e += 256) {
+            int l = e / 27, nd = e - l * 27;
+            int flat = chunk + l;
+            int c = 0;
+            while (cpref[c + 1] <= flat) ++c;
+            int p = cstart[c] + (flat - cpref[c]);
+            T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
+            int base[3];
+            T w[3][3], dw[3][3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+            int i = nd / 9, j = (nd / 3) % 3, k = nd % 3;
+            T wi = i == 0 ? w[0][0] : (i == 1 ? w[0][1] : w[0][2]), dwi = i == 0 ? dw[0][0] : (i == 1 ? dw[0][1] : dw[0][2]);
+            T wj = j == 0 ? w[1][0] : (j == 1 ? w[1][1] : w[1][2]), dwj = j == 0 ? dw[1][0] : (j == 1 ? dw[1][1] : dw[1][2]);
+            T wk = k == 0 ? w[2][0] : (k == 1 ? w[2][1] : w[2][2]), dwk = k == 0 ? dw[2][0] : (k == 1 ? dw[2][1] : dw[2][2]);
+            T g0 = one_over_dx * dwi * wj * wk, g1 = wi * one_over_dx * dwj * wk, g2 = wi * wj * one_over_dx * dwk;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+                sg[(l * 27 + nd) * 3 + cc] = Fn[(int64_t)(cc * 3 + 0) * Np + p] * g0 + Fn[(int64_t)(cc * 3 + 1) * Np + p] * g1 + Fn[(int64_t)(cc * 3 + 2) * Np + p] * g2;
+            if (nd == 0) pbase[l * 3] = base[0] - tx0, pbase[l * 3 + 1] = base[1] - ty0, pbase[l * 3 + 2] = base[2] - tz0;
+        }
+        __syncthreads();
+        // ---- work items: (particle l, tile row r) with row r inside the particle's 3x3x3 support and an active dof
+        for (int e = tid; e < cnt * 8; e += 256) {
+            int l = e >> 3, r = e & 7;
+            int ax = (r >> 2) - pbase[l * 3], ay = ((r >> 1) & 1) - pbase[l * 3 + 1], az = (r & 1) - pbase[l * 3 + 2]; // node index inside the kernel
+            if ((unsigned)ax < 3u && (unsigned)ay < 3u && (unsigned)az < 3u && rdof[r] >= 0) items[atomicAdd(nitems, 1)] = e;
+        }
+        __syncthreads();
+        const int ni = *nitems;
+        for (int it = tid; it < ni; it += 256) {
+            const int e = items[it];
+            const int l = e >> 3, r = e & 7;
+            const int pbx = pbase[l * 3], pby = pbase[l * 3 + 1], pbz = pbase[l * 3 + 2];
+            const int ax = (r >> 2) - pbx, ay = ((r >> 1) & 1) - pby, az = (r & 1) - pbz;
+            const int i = ax * 9 + ay * 3 + az;
+            const T* D = sdp + l * 45;
+            const T gi0 = sg[(l * 27 + i) * 3], gi1 = sg[(l * 27 + i) * 3 + 1], gi2 = sg[(l * 27 + i) * 3 + 2];
+            // T_i[a + 3*(b + 3 q)] = sum_v dP[(a + 3 v), (b + 3 q)] g_i[v]
+            T Tm[27];
+#pragma unroll
+            for (int bq = 0; bq < 9; ++bq)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) Tm[a + 3 * bq] = D[sym45(a, bq)] * gi0 + D[sym45(a + 3, bq)] * gi1 + D[sym45(a + 6, bq)] * gi2;
+            T* row = tile + r * 1125;
+            for (int j = 0; j < 27; ++j) {
+                const int jx = j / 9, jy = (j / 3) % 3, jz = j % 3;
+                const T g0 = sg[(l * 27 + j) * 3], g1 = sg[(l * 27 + j) * 3 + 1], g2 = sg[(l * 27 + j) * 3 + 2];
+                const int slot = (ax - jx + 2) * 25 + (ay - jy + 2) * 5 + (az - jz + 2);
+                T* o = row + slot * 9;
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) lds_atomic_add(o + bb * 3 + a, Tm[a + 3 * (bb + 0)] * g0 + Tm[a + 3 * (bb + 3)] * g1 + Tm[a + 3 * (bb + 6)] * g2);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- write the tile: inertia term M on the diagonal slot (ImplicitSolver.h:486-496)
+    for (int e = tid; e < 8 * 1125; e += 256) {
+        int r = e / 1125, q = e - r * 1125;
+        int dof = rdof[r];
+        if (dof < 0) continue;
+        T v = tile[e];
+        if (q >= 62 * 9 && q < 63 * 9 && ((q - 62 * 9) % 4 == 0)) v += mass[dof];
+        val[(int64_t)dof * 1125 + q] = v;
+    }
+}
+
+template <class T>
+void Ctx<T>::assemble_tiles(Level<T>& L)
+{
+    pDP.reserve(45 * (size_t)Np);
+    HOT_LAUNCH(this, "hessian_dpdf", k_dpdf45<T>, div_up(Np, 256), 256, 0, pFt.p, pVol.p, pMu.p, pLam.p, pDP.p, Np, dt, cfg.project);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HOT_HIP(hipFuncSetAttribute((const void*)k_hessian_tiles<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileLds<T>::bytes));
+        attr_set = true;
+    }
+    constexpr int TPB = (G::BX / 2) * (G::BY / 2) * (G::BZ / 2);
+    HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles<T>, Nb * TPB, 256, TileLds<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx);
+}
+
+template struct Ctx<float>;
+template struct Ctx<double>;
+
+} // namespace hot

@@ -68,6 +68,16 @@ struct Ctx : CtxBase {
     DBuf<unsigned long long> bh_rank;
     DBuf<int32_t> bh_id;
     HashMap block_map;
+    // ---- per-cell particle ranges (particles are sorted by page, then by base cell inside the page)
+    int Ncell = 0;
+    DBuf<int32_t> cell_first; // Ncell+1
+    DBuf<uint64_t> ch_keys;
+    DBuf<unsigned long long> ch_rank;
+    DBuf<int32_t> ch_id;
+    HashMap cell_map; // (Linear_Offset(base cell) >> data_bits) -> cell id
+    DBuf<T> pDP; // 45*Np: symmetric 9x9 V_p dt^2 dP/dF per particle (Hessian assembly)
+    void build_cell_table();
+    void assemble_tiles(Level<T>& L);
     // ---- node tiles (Nb*EPB)
     DBuf<T> gM, gMV, gF, gCN; // gMV/gF: 3 components, component-major over slots
     DBuf<int32_t> gIdx;

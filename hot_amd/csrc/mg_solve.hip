@@ -14,6 +14,7 @@
 //   vcycle_dev      MultigridOperator::operator() :362-421 with setup_parameters :525-551
 #include "hot_impl.h"
 #include "hot_svd.h"
+#include <cstdlib>
 
 namespace hot {
 
@@ -243,6 +244,126 @@ __global__ __launch_bounds__(64) void k_gs_color(const int32_t* __restrict__ col
     }
 }
 
+// Two-phase block GS (the production path; k_gs_color above is the simple reference kernel kept for A/B checks).
+// One 512-thread workgroup per 4^3-node block of the current colour:
+//   phase A (8 waves, bandwidth-bound): every wave streams whole matrix rows of the block (lane = stencil slot).
+//           Couplings to nodes OUTSIDE the block that precede the row in the sweep order are folded into
+//           s_i = rhs_i - sum A_ij x_j ; couplings INSIDE the block that precede it are copied into an LDS
+//           triangular array laid out by (column, row) so that phase B reads it conflict-free.
+//   phase B (1 wave, latency-bound but LDS/register only): right-looking block substitution, lane = row:
+//           step c: lane c finalises h_c = Dinv_c s_c, broadcasts it, every later row subtracts L[row][c] h_c.
+// The node order inside a block, the colour order and the predicate are exactly those of k_gs_color, i.e. the
+// reference's gs_smooth (MultigridPreconditioner.h:266-318); only the association order of the row sums differs.
+template <class T>
+struct GsLds {
+    static constexpr int TRI = 2016; // 64*63/2 ordered pairs
+    static constexpr size_t bytes = (size_t)9 * TRI * sizeof(T) + 64 * 3 * sizeof(T) + 64 * sizeof(int32_t);
+};
+__device__ __forceinline__ int gs_tri_fwd(int row, int colm) { return 63 * colm - (colm * (colm - 1)) / 2 + (row - colm - 1); } // row > colm
+__device__ __forceinline__ int gs_tri_bwd(int row, int colm) { return (colm * (colm - 1)) / 2 + row; } // row < colm
+
+template <class T, bool FWD>
+__global__ __launch_bounds__(512) void k_gs_block(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
+    const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, int block0)
+{
+    extern __shared__ __attribute__((aligned(16))) char gs_smem[];
+    constexpr int TRI = GsLds<T>::TRI;
+    T* tri = (T*)gs_smem; // [9][TRI]
+    T* sv = tri + 9 * TRI; // [64][3]
+    int32_t* nodes = (int32_t*)(sv + 192);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = block0 + blockIdx.x;
+    const int start = block_start[b], cnt = block_start[b + 1] - start;
+    for (int e = tid; e < 9 * TRI; e += 512) tri[e] = (T)0;
+    if (tid < 64) nodes[tid] = tid < cnt ? gs_order[start + tid] : -1;
+    __syncthreads();
+    // ---------------- phase A
+    for (int ii = w; ii < cnt; ii += 8) {
+        const int i = nodes[ii];
+        const uint32_t keyi = ckey[i];
+        const int32_t* c = col + (int64_t)i * 125;
+        const T* v = val + (int64_t)i * 1125;
+        T s0 = 0, s1 = 0, s2 = 0;
+        // issue every load of the row up front (both slot rounds): the 3x3 blocks do not depend on the
+        // col -> ckey -> x chain, so the whole row (9 KB per wave) is in flight at once
+        T bv[2][9];
+        int jj[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int k = lane + 64 * r;
+            jj[r] = k < 125 ? c[k] : -1;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) bv[r][e] = k < 125 ? v[k * 9 + e] : (T)0;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int j = jj[r];
+            if (j >= 0) {
+                uint32_t keyj = ckey[j];
+                bool take = FWD ? (keyj < keyi) : (keyj > keyi);
+                if (take) {
+                    if ((keyj >> 7) == (keyi >> 7)) {
+                        int lj = (int)(keyj & 127u) - 1;
+                        int idx = FWD ? gs_tri_fwd(ii, lj) : gs_tri_bwd(ii, lj);
+                        // padded slots alias column 0/1 with an all-zero block (SquareMatrix.h:563-566): they must not
+                        // overwrite the real (row, column) entry, so only non-zero blocks are stored
+                        bool nz = false;
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) nz = nz || bv[r][e] != (T)0;
+                        if (nz) {
+#pragma unroll
+                            for (int e = 0; e < 9; ++e) tri[e * TRI + idx] = bv[r][e];
+                        }
+                    }
+                    else {
+                        T x0 = x[3 * (int64_t)j], x1 = x[3 * (int64_t)j + 1], x2 = x[3 * (int64_t)j + 2];
+                        s0 += bv[r][0] * x0 + bv[r][3] * x1 + bv[r][6] * x2;
+                        s1 += bv[r][1] * x0 + bv[r][4] * x1 + bv[r][7] * x2;
+                        s2 += bv[r][2] * x0 + bv[r][5] * x1 + bv[r][8] * x2;
+                    }
+                }
+            }
+        }
+        s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
+        if (lane == 0) {
+            sv[ii * 3] = rhs[3 * (int64_t)i] - s0, sv[ii * 3 + 1] = rhs[3 * (int64_t)i + 1] - s1, sv[ii * 3 + 2] = rhs[3 * (int64_t)i + 2] - s2;
+        }
+    }
+    __syncthreads();
+    if (w != 0) return;
+    // ---------------- phase B: lane = row
+    const int me = lane;
+    const int i = me < cnt ? nodes[me] : -1;
+    T d[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) d[e] = i >= 0 ? diagBlockInv[9 * (int64_t)i + e] : (T)0;
+    T a0 = me < cnt ? sv[me * 3] : (T)0, a1 = me < cnt ? sv[me * 3 + 1] : (T)0, a2 = me < cnt ? sv[me * 3 + 2] : (T)0;
+    T h0 = 0, h1 = 0, h2 = 0;
+    for (int s = 0; s < cnt; ++s) {
+        const int cidx = FWD ? s : cnt - 1 - s;
+        // candidate solution of every row from its current partial sum; only lane cidx's is final
+        T c0 = d[0] * a0 + d[3] * a1 + d[6] * a2, c1 = d[1] * a0 + d[4] * a1 + d[7] * a2, c2 = d[2] * a0 + d[5] * a1 + d[8] * a2;
+        if (me == cidx) h0 = c0, h1 = c1, h2 = c2;
+        T b0 = __shfl(c0, cidx, 64), b1 = __shfl(c1, cidx, 64), b2 = __shfl(c2, cidx, 64);
+        bool act = FWD ? (me > cidx && me < cnt) : (me < cidx);
+        if (act) {
+            int idx = FWD ? gs_tri_fwd(me, cidx) : gs_tri_bwd(me, cidx);
+            a0 -= tri[0 * TRI + idx] * b0 + tri[3 * TRI + idx] * b1 + tri[6 * TRI + idx] * b2;
+            a1 -= tri[1 * TRI + idx] * b0 + tri[4 * TRI + idx] * b1 + tri[7 * TRI + idx] * b2;
+            a2 -= tri[2 * TRI + idx] * b0 + tri[5 * TRI + idx] * b1 + tri[8 * TRI + idx] * b2;
+        }
+    }
+    if (i >= 0) {
+        x[3 * (int64_t)i] = h0, x[3 * (int64_t)i + 1] = h1, x[3 * (int64_t)i + 2] = h2;
+        if (FWD) {
+            const T* dd = diagVal + 9 * (int64_t)i;
+            hD[3 * (int64_t)i] = dd[0] * h0 + dd[3] * h1 + dd[6] * h2;
+            hD[3 * (int64_t)i + 1] = dd[1] * h0 + dd[4] * h1 + dd[7] * h2;
+            hD[3 * (int64_t)i + 2] = dd[2] * h0 + dd[5] * h1 + dd[8] * h2;
+        }
+    }
+}
+
 template <class T>
 __global__ void k_cg_scalars(double* s, int what)
 {
@@ -322,20 +443,35 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
     else if (kind == 5) {
         HOT_CHECK(L.nblocks > 0, HOT_ERR_INVALID, "GS smoother requested but the level was built without colouring");
         T* hdu = L.tmp.p;
+        static const bool simple_gs = getenv("HOT_SIMPLE_GS") != nullptr; // A/B switch: one-wave-per-block reference kernel
+        static bool attr_set = false;
+        if (!attr_set) {
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T>::bytes));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T>::bytes));
+            attr_set = true;
+        }
         iterations = ((iterations + 1) >> 1);
         for (; iterations--;) {
             zero(n3, hdu);
             for (int c = 0; c < 8; ++c) {
                 int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
-                if (nb > 0)
-                    HOT_LAUNCH(this, lname("gs_forward", L.id).c_str(), (k_gs_color<T, true>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0, nb);
+                if (nb > 0) {
+                    if (simple_gs)
+                        HOT_LAUNCH(this, lname("gs_forward", L.id).c_str(), (k_gs_color<T, true>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0, nb);
+                    else
+                        HOT_LAUNCH(this, lname("gs_forward", L.id).c_str(), (k_gs_block<T, true>), nb, 512, GsLds<T>::bytes, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0);
+                }
             }
             // dAu now holds D h ; du = backward solve
             zero(n3, du);
             for (int c = 7; c >= 0; --c) {
                 int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
-                if (nb > 0)
-                    HOT_LAUNCH(this, lname("gs_backward", L.id).c_str(), (k_gs_color<T, false>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0, nb);
+                if (nb > 0) {
+                    if (simple_gs)
+                        HOT_LAUNCH(this, lname("gs_backward", L.id).c_str(), (k_gs_color<T, false>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0, nb);
+                    else
+                        HOT_LAUNCH(this, lname("gs_backward", L.id).c_str(), (k_gs_block<T, false>), nb, 512, GsLds<T>::bytes, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0);
+                }
             }
             axpy(n3, (T)1, du, u);
             spmv_dev(L, du, dAu);

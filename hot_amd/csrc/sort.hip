@@ -308,6 +308,7 @@ void Ctx<T>::sort()
     // node tiles
     size_t slots = (size_t)Nb * EPB;
     gM.reserve(slots, 1.25), gMV.reserve(3 * slots, 1.25), gF.reserve(3 * slots, 1.25), gCN.reserve(slots, 1.25), gIdx.reserve(slots, 1.25), block_count.reserve(Nb + 1, 1.25);
+    build_cell_table();
     Nn = 0;
     Nc = 0;
     updated = false;
