@@ -128,7 +128,7 @@ void Ctx<T>::build_cell_table()
 template <class T>
 struct TileLds {
     static constexpr int CH = 64; // particles per chunk
-    static constexpr size_t bytes = (size_t)8 * 1125 * sizeof(T) /*tile*/ + (size_t)CH * 45 * sizeof(T) /*dP*/ + (size_t)CH * 81 * sizeof(T) /*g*/ + (64 + 65 + 8 + CH * 3 + CH * 8 + 4) * sizeof(int32_t);
+    static constexpr size_t bytes = (size_t)8 * 1125 * sizeof(T) /*tile*/ + (size_t)CH * 45 * sizeof(T) /*dP*/ + (size_t)CH * 81 * sizeof(T) /*g*/ + (64 + 65 + 8 + CH * 3 + CH * 8 + 4 + CH) * sizeof(int32_t);
 };
 
 template <class T>
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void k_hessian_tiles(const T* __restrict__ X, 
     int32_t* pbase = rdof + 8; // [CH][3] base node relative to the tile origin
     int32_t* items = pbase + CH * 3; // [CH*8] packed (particle-in-chunk << 3 | row)
     int32_t* nitems = items + CH * 8;
+    int32_t* pidx = nitems + 4; // [CH] global particle index of each chunk member
     const int tid = threadIdx.x;
     const int b = blockIdx.x / TPB, tt = blockIdx.x % TPB;
     int bx, by, bz;
@@ -183,22 +184,28 @@ __global__ __launch_bounds__(256) void k_hessian_tiles(const T* __restrict__ X, 
     for (int chunk = 0; chunk < total; chunk += CH) {
         const int cnt = min(CH, total - chunk);
         if (tid == 0) *nitems = 0;
+        if (tid < cnt) {
+            int flat = chunk + tid;
+            int lo = 0, hi = 64; // cpref[lo] <= flat < cpref[hi]
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (cpref[mid] <= flat)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            pidx[tid] = cstart[lo] + (flat - cpref[lo]);
+        }
         __syncthreads();
         // ---- stage the chunk: dP (45), g = Fn^T grad w (27 x 3), tile-relative base node, work items
         for (int e = tid; e < cnt * 45; e += 256) {
             int l = e / 45, q = e - l * 45;
-            int flat = chunk + l;
-            int c = 0;
-            while (cpref[c + 1] <= flat) ++c; // 64 cells: short linear search
-            int p = cstart[c] + (flat - cpref[c]);
+            int p = pidx[l];
             sdp[l * 45 + q] = dp[(int64_t)q * Np + p];
         }
         for (int e = tid; e < cnt * 27; e += 256) {
             int l = e / 27, nd = e - l * 27;
-            int flat = chunk + l;
-            int c = 0;
-            while (cpref[c + 1] <= flat) ++c;
-            int p = cstart[c] + (flat - cpref[c]);
+            int p = pidx[l];
             T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
             int base[3];
             T w[3][3], dw[3][3];

@@ -176,6 +176,15 @@ __device__ inline T block_sum_256(T v, T* sm4)
     return r;
 }
 
+// broadcast lane `src` (wave-uniform) of v to every lane through SGPRs (v_readlane_b32), no LDS round trip
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ double lane_bcast(double v, int src)
+{
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 template <class T>
 __device__ inline void atomic_add(T* p, T v)
 {

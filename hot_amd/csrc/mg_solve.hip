@@ -256,15 +256,15 @@ __global__ __launch_bounds__(64) void k_gs_color(const int32_t* __restrict__ col
 // reference's gs_smooth (MultigridPreconditioner.h:266-318); only the association order of the row sums differs.
 template <class T>
 struct GsLds {
-    static constexpr int TRI = 2016; // 64*63/2 ordered pairs
+    static constexpr int TRI = 2017; // 64*63/2 ordered pairs + one always-zero entry (index 2016) for masked lanes
     static constexpr size_t bytes = (size_t)9 * TRI * sizeof(T) + 64 * 3 * sizeof(T) + 64 * sizeof(int32_t);
 };
 __device__ __forceinline__ int gs_tri_fwd(int row, int colm) { return 63 * colm - (colm * (colm - 1)) / 2 + (row - colm - 1); } // row > colm
 __device__ __forceinline__ int gs_tri_bwd(int row, int colm) { return (colm * (colm - 1)) / 2 + row; } // row < colm
 
 template <class T, bool FWD>
-__global__ __launch_bounds__(512) void k_gs_block(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
-    const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, int block0)
+__global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
+    const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, int block0, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     constexpr int TRI = GsLds<T>::TRI;
@@ -274,11 +274,12 @@ __global__ __launch_bounds__(512) void k_gs_block(const int32_t* __restrict__ co
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = block0 + blockIdx.x;
     const int start = block_start[b], cnt = block_start[b + 1] - start;
-    for (int e = tid; e < 9 * TRI; e += 512) tri[e] = (T)0;
+    const int nthreads = blockDim.x, nwaves = blockDim.x >> 6;
+    if (!(dbg & 2)) for (int e = tid; e < 9 * TRI; e += nthreads) tri[e] = (T)0;
     if (tid < 64) nodes[tid] = tid < cnt ? gs_order[start + tid] : -1;
     __syncthreads();
     // ---------------- phase A
-    for (int ii = w; ii < cnt; ii += 8) {
+    for (int ii = w; ii < cnt; ii += nwaves) {
         const int i = nodes[ii];
         const uint32_t keyi = ckey[i];
         const int32_t* c = col + (int64_t)i * 125;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(512) void k_gs_block(const int32_t* __restrict__ co
         }
     }
     __syncthreads();
-    if (w != 0) return;
+    if (w != 0 || (dbg & 1)) return;
     // ---------------- phase B: lane = row
     const int me = lane;
     const int i = me < cnt ? nodes[me] : -1;
@@ -339,19 +340,28 @@ __global__ __launch_bounds__(512) void k_gs_block(const int32_t* __restrict__ co
     for (int e = 0; e < 9; ++e) d[e] = i >= 0 ? diagBlockInv[9 * (int64_t)i + e] : (T)0;
     T a0 = me < cnt ? sv[me * 3] : (T)0, a1 = me < cnt ? sv[me * 3 + 1] : (T)0, a2 = me < cnt ? sv[me * 3 + 2] : (T)0;
     T h0 = 0, h1 = 0, h2 = 0;
+    // column `cidx` of the in-block triangle for this lane's row (zero where the row does not follow the column);
+    // the next column is fetched from LDS while the current step's dependent arithmetic runs
+    auto load_col = [&](int cidx, T (&L)[9]) {
+        bool act = FWD ? (me > cidx && me < cnt) : (me < cidx);
+        int idx = act ? (FWD ? gs_tri_fwd(me, cidx) : gs_tri_bwd(me, cidx)) : TRI - 1; // masked lanes read the zero entry
+#pragma unroll
+        for (int e = 0; e < 9; ++e) L[e] = tri[e * TRI + idx];
+    };
+    T Lc[9], Ln[9];
+    if (cnt > 0) load_col(FWD ? 0 : cnt - 1, Lc);
     for (int s = 0; s < cnt; ++s) {
         const int cidx = FWD ? s : cnt - 1 - s;
+        if (s + 1 < cnt) load_col(FWD ? s + 1 : cnt - 2 - s, Ln);
         // candidate solution of every row from its current partial sum; only lane cidx's is final
         T c0 = d[0] * a0 + d[3] * a1 + d[6] * a2, c1 = d[1] * a0 + d[4] * a1 + d[7] * a2, c2 = d[2] * a0 + d[5] * a1 + d[8] * a2;
         if (me == cidx) h0 = c0, h1 = c1, h2 = c2;
-        T b0 = __shfl(c0, cidx, 64), b1 = __shfl(c1, cidx, 64), b2 = __shfl(c2, cidx, 64);
-        bool act = FWD ? (me > cidx && me < cnt) : (me < cidx);
-        if (act) {
-            int idx = FWD ? gs_tri_fwd(me, cidx) : gs_tri_bwd(me, cidx);
-            a0 -= tri[0 * TRI + idx] * b0 + tri[3 * TRI + idx] * b1 + tri[6 * TRI + idx] * b2;
-            a1 -= tri[1 * TRI + idx] * b0 + tri[4 * TRI + idx] * b1 + tri[7 * TRI + idx] * b2;
-            a2 -= tri[2 * TRI + idx] * b0 + tri[5 * TRI + idx] * b1 + tri[8 * TRI + idx] * b2;
-        }
+        T b0 = lane_bcast(c0, cidx), b1 = lane_bcast(c1, cidx), b2 = lane_bcast(c2, cidx); // v_readlane: cidx is wave-uniform
+        a0 -= Lc[0] * b0 + Lc[3] * b1 + Lc[6] * b2;
+        a1 -= Lc[1] * b0 + Lc[4] * b1 + Lc[7] * b2;
+        a2 -= Lc[2] * b0 + Lc[5] * b1 + Lc[8] * b2;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Lc[e] = Ln[e];
     }
     if (i >= 0) {
         x[3 * (int64_t)i] = h0, x[3 * (int64_t)i + 1] = h1, x[3 * (int64_t)i + 2] = h2;
@@ -444,6 +454,8 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         HOT_CHECK(L.nblocks > 0, HOT_ERR_INVALID, "GS smoother requested but the level was built without colouring");
         T* hdu = L.tmp.p;
         static const bool simple_gs = getenv("HOT_SIMPLE_GS") != nullptr; // A/B switch: one-wave-per-block reference kernel
+        static const int gs_threads = getenv("HOT_GS_THREADS") ? atoi(getenv("HOT_GS_THREADS")) : 1024;
+        static const int gs_dbg = getenv("HOT_GS_DBG") ? atoi(getenv("HOT_GS_DBG")) : 0; // timing experiments only (wrong results)
         static bool attr_set = false;
         if (!attr_set) {
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T>::bytes));
@@ -459,7 +471,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                     if (simple_gs)
                         HOT_LAUNCH(this, lname("gs_forward", L.id).c_str(), (k_gs_color<T, true>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0, nb);
                     else
-                        HOT_LAUNCH(this, lname("gs_forward", L.id).c_str(), (k_gs_block<T, true>), nb, 512, GsLds<T>::bytes, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0);
+                        HOT_LAUNCH(this, lname("gs_forward", L.id).c_str(), (k_gs_block<T, true>), nb, gs_threads, GsLds<T>::bytes, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0, gs_dbg);
                 }
             }
             // dAu now holds D h ; du = backward solve
@@ -470,7 +482,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                     if (simple_gs)
                         HOT_LAUNCH(this, lname("gs_backward", L.id).c_str(), (k_gs_color<T, false>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0, nb);
                     else
-                        HOT_LAUNCH(this, lname("gs_backward", L.id).c_str(), (k_gs_block<T, false>), nb, 512, GsLds<T>::bytes, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0);
+                        HOT_LAUNCH(this, lname("gs_backward", L.id).c_str(), (k_gs_block<T, false>), nb, gs_threads, GsLds<T>::bytes, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0, gs_dbg);
                 }
             }
             axpy(n3, (T)1, du, u);
