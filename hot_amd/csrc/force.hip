@@ -150,8 +150,7 @@ void Ctx<T>::begin_step(double dt_)
     HOT_LAUNCH(this, "begin_step", k_begin<T>, div_up(Nn, 256), 256, 0, nodeV.p, bcIdx.p, bcDv.p, bcHasDv.p, dv.p, vn.p, dv0.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dt);
     HOT_HIP(hipMemcpyAsync(pFn.p, pF.p, 9 * (size_t)Np * sizeof(T), hipMemcpyDeviceToDevice, stream));
     updated = false;
-    for (auto* l : levels) delete l;
-    levels.clear();
+    release_levels();
     stats.ms_begin = wall_ms() - t0;
 }
 
@@ -268,7 +267,7 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
 // pass B: rasterizeForceToTVStack — f_i -= dt * stress grad w_i, LDS accumulators, one global atomic per touched node
 template <class T>
 __global__ __launch_bounds__(256) void k_force_scatter(const T* __restrict__ X, const T* __restrict__ stress, int64_t Np, const int32_t* __restrict__ group_first,
-    const int32_t* __restrict__ group_origin, const int32_t* __restrict__ group_nb, T* gF, int64_t slots, T one_over_dx, T scale)
+    const int32_t* __restrict__ group_origin, const int32_t* __restrict__ group_nb, T* __restrict__ part, T one_over_dx, T scale)
 {
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
@@ -316,14 +315,8 @@ __global__ __launch_bounds__(256) void k_force_scatter(const T* __restrict__ X, 
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < TILE; t += 256) {
-        T a = acc[0][t], b = acc[1][t], c = acc[2][t];
-        if (a == (T)0 && b == (T)0 && c == (T)0) continue;
-        int64_t s = tile_slot2<T>(t, nb8);
-        atomic_add(&gF[s], a);
-        atomic_add(&gF[slots + s], b);
-        atomic_add(&gF[2 * slots + s], c);
-    }
+    T* out = part + (int64_t)g * 3 * TILE; // partial tile, summed per node by k_tile_reduce
+    for (int t = threadIdx.x; t < 3 * TILE; t += 256) out[t] = (&acc[0][0])[t];
 }
 
 template <class T>
@@ -349,11 +342,13 @@ double Ctx<T>::state_pass(const T* dv_in, bool want_force)
 {
     int64_t slots = (int64_t)Nb * EPB;
     HOT_HIP(hipMemsetAsync(dscal.p, 0, 4 * sizeof(double), stream));
-    if (want_force) HOT_HIP(hipMemsetAsync(gF.p, 0, 3 * slots * sizeof(T), stream));
     HOT_LAUNCH(this, "state_update", k_state<T>, Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, pFt.p, pStress.p, keep_debug ? pGradV.p : (T*)nullptr, Np, group_first.p, group_origin.p,
         group_nb.p, gIdx.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p);
     if (want_force)
-        HOT_LAUNCH(this, "force_scatter", k_force_scatter<T>, Ng, 256, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_nb.p, gF.p, slots, (T)1 / dx, dt);
+    {
+        HOT_LAUNCH(this, "force_scatter", k_force_scatter<T>, Ng, 256, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, (T)1 / dx, dt);
+        reduce_tiles(3, gF.p, gF.p + slots, gF.p + 2 * slots, nullptr, nullptr, "force_reduce");
+    }
     HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, std::min(div_up(Nn, 256), 1024), 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1);
     HOT_HIP(hipMemcpyAsync(hscal, dscal.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
@@ -554,7 +549,7 @@ void Ctx<T>::cn_tolerance(void* tol)
 template <class T>
 __global__ __launch_bounds__(256) void k_matfree(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ Ft, const T* __restrict__ Vol, const T* __restrict__ Mu,
     const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin, const int32_t* __restrict__ group_nb,
-    const int32_t* __restrict__ gIdx, const T* __restrict__ x, T* gOut, int64_t slots, T dx, T one_over_dx, T dt, int project)
+    const int32_t* __restrict__ gIdx, const T* __restrict__ x, T* __restrict__ part, T dx, T one_over_dx, T dt, int project)
 {
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
@@ -620,14 +615,8 @@ __global__ __launch_bounds__(256) void k_matfree(const T* __restrict__ X, const 
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < TILE; t += 256) {
-        T a = acc[0][t], b = acc[1][t], c = acc[2][t];
-        if (a == (T)0 && b == (T)0 && c == (T)0) continue;
-        int64_t s = tile_slot2<T>(t, nb8);
-        atomic_add(&gOut[s], a);
-        atomic_add(&gOut[slots + s], b);
-        atomic_add(&gOut[2 * slots + s], c);
-    }
+    T* out = part + (int64_t)g * 3 * TILE;
+    for (int t = threadIdx.x; t < 3 * TILE; t += 256) out[t] = (&acc[0][0])[t];
 }
 template <class T>
 __global__ void k_matfree_finish(const T* __restrict__ gOut, const int32_t* __restrict__ dofSlot, const T* __restrict__ mass, const T* __restrict__ x, T* y, int nn, int64_t slots)
@@ -645,9 +634,9 @@ void Ctx<T>::matfree_dev(const T* x, T* y)
     int64_t slots = (int64_t)Nb * EPB;
     DBuf<T>& tile = ap; // scratch tile array (3*slots); `ap` is otherwise only used while building the hierarchy
     tile.reserve(3 * slots);
-    HOT_HIP(hipMemsetAsync(tile.p, 0, 3 * slots * sizeof(T), stream));
-    HOT_LAUNCH(this, "matfree_hessian_product", k_matfree<T>, Ng, 256, 0, pX.p, pFn.p, pFt.p, pVol.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gIdx.p, x, tile.p, slots, dx,
+    HOT_LAUNCH(this, "matfree_hessian_product", k_matfree<T>, Ng, 256, 0, pX.p, pFn.p, pFt.p, pVol.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gIdx.p, x, gPart.p, dx,
         (T)1 / dx, dt, cfg.project);
+    reduce_tiles(3, tile.p, tile.p + slots, tile.p + 2 * slots, nullptr, nullptr, "matfree_reduce");
     HOT_LAUNCH(this, "matfree_finish", k_matfree_finish<T>, div_up(Nn, 256), 256, 0, tile.p, dofSlot.p, mass.p, x, y, Nn, slots);
 }
 template <class T>

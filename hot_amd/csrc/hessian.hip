@@ -326,9 +326,8 @@ void Ctx<T>::build_hessian()
 {
     need(Nn > 0 && dt > 0, "hot_build_hessian before hot_update_state");
     double t0 = wall_ms();
-    for (auto* l : levels) delete l;
-    levels.clear();
-    Level<T>* L = new Level<T>();
+    release_levels();
+    Level<T>* L = acquire_level(0);
     levels.push_back(L);
     L->n = Nn;
     size_t ne = (size_t)Nn * 125;

@@ -10,6 +10,7 @@ template <class T>
 struct Level {
     int n = 0; // rows (nodes)
     int id = 0; // level index
+    bool built = false; // work vectors / colouring valid (set by build_mg)
     long long nnzb = 0; // structurally non-zero 3x3 blocks (for the roofline's algorithmic bytes)
     DBuf<int32_t> coord; // 3n
     DBuf<int32_t> col; // n*125   (entryCol)
@@ -20,6 +21,11 @@ struct Level {
     DBuf<uint32_t> ckey;
     DBuf<int32_t> gs_order; // n
     DBuf<int32_t> gs_block_start; // nblocks+1 : offsets into gs_order
+    // after build_mg every row's slots are regrouped as [nl entries preceding the row in the GS order | diagonal |
+    // nu entries following it | structural zeros], so each half sweep streams only the half it needs
+    DBuf<int32_t> rowcnt; // 2n: (nl, nu)
+    DBuf<int32_t> gsmeta; // n*125 slot descriptor for the GS kernels: j >= 0 column outside the row's block, -2-lj inside it
+    bool split = false;
     int color_block_begin[9] = { 0 }; // blocks of colour c are [color_block_begin[c], color_block_begin[c+1])
     int nblocks = 0;
     // prolongation to this level from the next coarser one (P has 8 slots/row), restriction = P^T as child table
@@ -78,6 +84,12 @@ struct Ctx : CtxBase {
     DBuf<T> pDP; // 45*Np: symmetric 9x9 V_p dt^2 dP/dF per particle (Hessian assembly)
     void build_cell_table();
     void assemble_tiles(Level<T>& L);
+    // ---- atomic-free scatter: every particle group writes its (BX+2)(BY+2)(BZ+2) partial tile, then each node sums
+    //      the <= 8 partial tiles that cover it in a fixed order (deterministic; global fp64 atomics top out at ~2e10/s)
+    DBuf<int32_t> block_group; // Nb: group whose page is this block, or -1
+    DBuf<int32_t> block_rev; // Nb*8: group at page(b) - (a BX, b BY, c BZ), or -1
+    DBuf<T> gPart; // Ng * Q * TILE
+    void reduce_tiles(int Q, T* o0, T* o1, T* o2, T* o3, T* o4, const char* name);
     // ---- node tiles (Nb*EPB)
     DBuf<T> gM, gMV, gF, gCN; // gMV/gF: 3 components, component-major over slots
     DBuf<int32_t> gIdx;
@@ -103,6 +115,29 @@ struct Ctx : CtxBase {
     DBuf<T> hist_dx[9], hist_dg[9];
     // ---- multigrid
     std::vector<Level<T>*> levels;
+    // Level objects (and their multi-GB device buffers) are recycled across time steps: hipMalloc/hipFree of the
+    // 2.6 GB level-0 matrix every step costs more than assembling it
+    std::vector<Level<T>*> level_pool[12];
+    Level<T>* acquire_level(int id)
+    {
+        Level<T>* l;
+        if (!level_pool[id].empty()) {
+            l = level_pool[id].back();
+            level_pool[id].pop_back();
+        }
+        else
+            l = new Level<T>();
+        l->id = id, l->n = 0, l->nnzb = 0, l->nblocks = 0, l->built = false, l->split = false;
+        return l;
+    }
+    void release_levels(size_t keep = 0)
+    {
+        while (levels.size() > keep) {
+            Level<T>* l = levels.back();
+            levels.pop_back();
+            level_pool[l->id < 12 ? l->id : 11].push_back(l);
+        }
+    }
     DBuf<T> ap; // A*P scratch (n*64*9)
 
     Ctx(const hot_config& c);

@@ -307,11 +307,83 @@ static void mark_colors(Ctx<T>* ctx, Level<T>& L)
     ctx->sync();
 }
 
+// Regroup the slots of every row as [precede | diagonal | follow | structural zeros] w.r.t. the GS order (stable inside
+// each class).  One wavefront per row, the row is staged in LDS and rewritten in place.
+template <class T>
+__global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col, T* __restrict__ val, const uint32_t* __restrict__ ckey, int32_t* __restrict__ rowcnt, int32_t* __restrict__ meta, int n)
+{
+    __shared__ T sval[4][1125];
+    __shared__ int32_t scol[4][125];
+    __shared__ int32_t smeta[4][125];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i0 = blockIdx.x * 4 + w;
+    const bool valid = i0 < n; // no early return: the workgroup barrier below must be reached by all four waves
+    const int i = valid ? i0 : n - 1;
+    const uint32_t keyi = ckey[i];
+    int32_t* c = col + (int64_t)i * 125;
+    T* v = val + (int64_t)i * 1125;
+    int cls[2], jj[2];
+    T bv[2][9];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        int k = lane + 64 * r;
+        cls[r] = 4; // lane has no slot
+        jj[r] = 0;
+        if (k < 125 && valid) {
+            jj[r] = c[k];
+            bool nz = false;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) bv[r][e] = v[k * 9 + e], nz = nz || bv[r][e] != (T)0;
+            if (!nz)
+                cls[r] = 3;
+            else if (jj[r] == i)
+                cls[r] = 1;
+            else
+                cls[r] = ckey[jj[r]] < keyi ? 0 : 2;
+        }
+    }
+    // stable positions: class-major, then round, then lane
+    int cnt[4], base = 0, pos[2] = { 0, 0 };
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        unsigned long long m0 = __ballot(cls[0] == cc), m1 = __ballot(cls[1] == cc);
+        unsigned long long below = (1ULL << lane) - 1ULL;
+        if (cls[0] == cc) pos[0] = base + __popcll(m0 & below);
+        if (cls[1] == cc) pos[1] = base + __popcll(m0) + __popcll(m1 & below);
+        cnt[cc] = __popcll(m0) + __popcll(m1);
+        base += cnt[cc];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (cls[r] < 4) {
+            scol[w][pos[r]] = jj[r];
+            uint32_t keyj = ckey[jj[r]];
+            smeta[w][pos[r]] = ((keyj >> 7) == (keyi >> 7) && jj[r] != i && (cls[r] == 0 || cls[r] == 2)) ? (-2 - ((int)(keyj & 127u) - 1)) : jj[r];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) sval[w][pos[r] * 9 + e] = bv[r][e];
+        }
+    }
+    __syncthreads();
+    if (!valid) return;
+    for (int e = lane; e < 1125; e += 64) v[e] = sval[w][e];
+    for (int k = lane; k < 125; k += 64) c[k] = scol[w][k], meta[(int64_t)i * 125 + k] = smeta[w][k];
+    if (lane == 0) rowcnt[2 * i] = cnt[0], rowcnt[2 * i + 1] = cnt[2];
+}
+
+template <class T>
+static void split_rows(Ctx<T>* ctx, Level<T>& L)
+{
+    L.rowcnt.reserve(2 * (size_t)L.n), L.gsmeta.reserve(125 * (size_t)L.n);
+    HOT_LAUNCH(ctx, "gs_split_rows", k_gs_split_rows<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.ckey.p, L.rowcnt.p, L.gsmeta.p, L.n);
+    L.split = true;
+}
+
 template <class T>
 static void alloc_work(Level<T>& L)
 {
     size_t m = 3 * (size_t)L.n;
     L.residual.reserve(m), L.initialResidual.reserve(m), L.sol.reserve(m), L.du.reserve(m), L.dAu.reserve(m), L.tmp.reserve(m);
+    L.built = true;
 }
 
 template <class T>
@@ -322,10 +394,7 @@ void Ctx<T>::build_mg()
     need(cfg.levelCnt >= 1 && cfg.levelCnt <= 10, "levelCnt must be in [1,10] (MultigridPreconditioner.h:369)");
     for (int k : { cfg.smoother, cfg.coarseSolver }) need(k == 0 || k == 1 || k == 2 || k == 5, "smoother/coarseSolver must be 0, 1, 2 or 5 (6/7: SURVEY 8f, not built yet)");
     double t0 = wall_ms();
-    while (levels.size() > 1) {
-        delete levels.back();
-        levels.pop_back();
-    }
+    release_levels(1);
     bool colors = cfg.smoother == 5 || cfg.coarseSolver == 5;
     Level<T>& L0 = *levels[0];
     alloc_work(L0);
@@ -334,10 +403,9 @@ void Ctx<T>::build_mg()
         Level<T>& F = *levels[level];
         int n = F.n;
         build_coord_map(this, F);
-        Level<T>* Cp = new Level<T>();
+        Level<T>* Cp = acquire_level(level + 1);
         levels.push_back(Cp);
         Level<T>& C = *Cp;
-        C.id = level + 1;
         // ---- coarse node set with first-touch numbering
         uint32_t cap = 1024;
         while (cap < 2u * (uint32_t)n + 16u) cap <<= 1;
@@ -365,7 +433,9 @@ void Ctx<T>::build_mg()
         count_nnzb(C);
         alloc_work(C);
         if (colors) mark_colors(this, C);
+        if (colors) split_rows(this, F); // level `level` is no longer needed in stencil-slot order
     }
+    if (colors) split_rows(this, *levels.back());
     sync();
     stats.ms_mg_build += wall_ms() - t0;
 }

@@ -73,7 +73,7 @@ template <class T>
 void Ctx<T>::dot_to(size_t n, const T* x, const T* y, double* out)
 {
     HOT_HIP(hipMemsetAsync(out, 0, sizeof(double), stream));
-    HOT_LAUNCH(this, "dot", k_dot<T>, std::min(div_up(n, 256), 2048), 256, 0, n, x, y, out);
+    HOT_LAUNCH(this, "dot", k_dot<T>, std::min(div_up(n, 1024), 256), 256, 0, n, x, y, out); // <= 256 same-address atomics
 }
 template <class T>
 double Ctx<T>::dot_host(size_t n, const T* x, const T* y)
@@ -264,7 +264,8 @@ __device__ __forceinline__ int gs_tri_bwd(int row, int colm) { return (colm * (c
 
 template <class T, bool FWD>
 __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
-    const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, int block0, int dbg)
+    const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, int block0, int dbg,
+    const int32_t* __restrict__ rowcnt, const int32_t* __restrict__ meta)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     constexpr int TRI = GsLds<T>::TRI;
@@ -278,7 +279,78 @@ __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ c
     if (!(dbg & 2)) for (int e = tid; e < 9 * TRI; e += nthreads) tri[e] = (T)0;
     if (tid < 64) nodes[tid] = tid < cnt ? gs_order[start + tid] : -1;
     __syncthreads();
-    // ---------------- phase A
+    // ---------------- phase A, fast path for regrouped rows: every load of the (<= 4) rows of this wave is issued
+    // before any is used, and the precomputed slot descriptor (meta >= 0: column j outside the block, meta <= -2:
+    // local index -2-meta inside the block) removes the col -> ckey -> x dependent-load chain
+    if (rowcnt != nullptr && meta != nullptr) {
+        constexpr int RQ = 4;
+        for (int q0 = 0; q0 * nwaves < cnt; q0 += RQ) {
+            T bv[RQ][9];
+            int mm[RQ], kb[RQ], ke[RQ];
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const int ii = w + nwaves * (q0 + q);
+                mm[q] = -1, kb[q] = 0, ke[q] = 0;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) bv[q][e] = (T)0;
+                if (ii < cnt) {
+                    const int i = nodes[ii];
+                    const int nl = rowcnt[2 * i], nu = rowcnt[2 * i + 1];
+                    kb[q] = FWD ? 0 : nl + 1, ke[q] = FWD ? nl : nl + 1 + nu;
+                    const int k = kb[q] + lane;
+                    if (k < ke[q]) {
+                        mm[q] = meta[(int64_t)i * 125 + k];
+                        const T* bb = val + ((int64_t)i * 125 + k) * 9;
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) bv[q][e] = bb[e];
+                    }
+                }
+            }
+            T xs[RQ][3];
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const int m = mm[q];
+                xs[q][0] = xs[q][1] = xs[q][2] = (T)0;
+                if (m >= 0) xs[q][0] = x[3 * (int64_t)m], xs[q][1] = x[3 * (int64_t)m + 1], xs[q][2] = x[3 * (int64_t)m + 2];
+            }
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const int ii = w + nwaves * (q0 + q);
+                if (ii >= cnt) continue; // wave-uniform
+                const int i = nodes[ii];
+                T s0 = bv[q][0] * xs[q][0] + bv[q][3] * xs[q][1] + bv[q][6] * xs[q][2];
+                T s1 = bv[q][1] * xs[q][0] + bv[q][4] * xs[q][1] + bv[q][7] * xs[q][2];
+                T s2 = bv[q][2] * xs[q][0] + bv[q][5] * xs[q][1] + bv[q][8] * xs[q][2];
+                if (mm[q] <= -2) {
+                    const int lj = -2 - mm[q];
+                    const int idx = FWD ? gs_tri_fwd(ii, lj) : gs_tri_bwd(ii, lj);
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) tri[e * TRI + idx] = bv[q][e];
+                }
+                // half rows longer than one wave (cannot happen for interior 4^3 blocks): plain strided tail
+                for (int k = kb[q] + 64 + lane; k < ke[q]; k += 64) {
+                    const int m = meta[(int64_t)i * 125 + k];
+                    const T* bb = val + ((int64_t)i * 125 + k) * 9;
+                    if (m >= 0) {
+                        T x0 = x[3 * (int64_t)m], x1 = x[3 * (int64_t)m + 1], x2 = x[3 * (int64_t)m + 2];
+                        s0 += bb[0] * x0 + bb[3] * x1 + bb[6] * x2;
+                        s1 += bb[1] * x0 + bb[4] * x1 + bb[7] * x2;
+                        s2 += bb[2] * x0 + bb[5] * x1 + bb[8] * x2;
+                    }
+                    else if (m <= -2) {
+                        const int lj = -2 - m;
+                        const int idx = FWD ? gs_tri_fwd(ii, lj) : gs_tri_bwd(ii, lj);
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) tri[e * TRI + idx] = bb[e];
+                    }
+                }
+                s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
+                if (lane == 0) sv[ii * 3] = rhs[3 * (int64_t)i] - s0, sv[ii * 3 + 1] = rhs[3 * (int64_t)i + 1] - s1, sv[ii * 3 + 2] = rhs[3 * (int64_t)i + 2] - s2;
+            }
+        }
+    }
+    else
+    // ---------------- phase A, generic path (rows in any slot order, predicate on the packed key)
     for (int ii = w; ii < cnt; ii += nwaves) {
         const int i = nodes[ii];
         const uint32_t keyi = ckey[i];
@@ -289,12 +361,19 @@ __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ c
         // col -> ckey -> x chain, so the whole row (9 KB per wave) is in flight at once
         T bv[2][9];
         int jj[2];
+        // rows regrouped by k_gs_split_rows: the forward sweep needs slots [0, nl), the backward sweep
+        // [nl + 1, nl + 1 + nu); without the split every slot is visited and filtered by the key predicate
+        int kbeg = 0, kend = 125;
+        if (rowcnt) {
+            int nl = rowcnt[2 * i], nu = rowcnt[2 * i + 1];
+            kbeg = FWD ? 0 : nl + 1, kend = FWD ? nl : nl + 1 + nu;
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            int k = lane + 64 * r;
-            jj[r] = k < 125 ? c[k] : -1;
+            int k = kbeg + lane + 64 * r;
+            jj[r] = k < kend ? c[k] : -1;
 #pragma unroll
-            for (int e = 0; e < 9; ++e) bv[r][e] = k < 125 ? v[k * 9 + e] : (T)0;
+            for (int e = 0; e < 9; ++e) bv[r][e] = k < kend ? v[k * 9 + e] : (T)0;
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -372,6 +451,30 @@ __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ c
             hD[3 * (int64_t)i + 2] = dd[2] * h0 + dd[5] * h1 + dd[8] * h2;
         }
     }
+}
+
+// r_i = sum over the nl slots preceding row i of A_ik (h - du)_k   (rows regrouped by k_gs_split_rows)
+template <class T>
+__global__ __launch_bounds__(256) void k_gs_residual(const int32_t* __restrict__ col, const T* __restrict__ val, const int32_t* __restrict__ rowcnt, const T* __restrict__ h,
+    const T* __restrict__ du, T* __restrict__ r, int n)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int nl = rowcnt[2 * row];
+    const int32_t* c = col + (int64_t)row * 125;
+    const T* v = val + (int64_t)row * 1125;
+    T s0 = 0, s1 = 0, s2 = 0;
+    for (int k = lane; k < nl; k += 64) {
+        int j = c[k];
+        const T* b = v + k * 9;
+        T x0 = h[3 * (int64_t)j] - du[3 * (int64_t)j], x1 = h[3 * (int64_t)j + 1] - du[3 * (int64_t)j + 1], x2 = h[3 * (int64_t)j + 2] - du[3 * (int64_t)j + 2];
+        s0 += b[0] * x0 + b[3] * x1 + b[6] * x2;
+        s1 += b[1] * x0 + b[4] * x1 + b[7] * x2;
+        s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
+    }
+    s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
+    if (lane == 0) r[3 * (int64_t)row] = s0, r[3 * (int64_t)row + 1] = s1, r[3 * (int64_t)row + 2] = s2;
 }
 
 template <class T>
@@ -455,6 +558,8 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         T* hdu = L.tmp.p;
         static const bool simple_gs = getenv("HOT_SIMPLE_GS") != nullptr; // A/B switch: one-wave-per-block reference kernel
         static const int gs_threads = getenv("HOT_GS_THREADS") ? atoi(getenv("HOT_GS_THREADS")) : 1024;
+        static const bool no_meta = getenv("HOT_GS_NO_META") != nullptr; // A/B switch: generic phase A on split rows
+        static const bool no_lres = getenv("HOT_GS_FULL_RESIDUAL") != nullptr; // A/B switch: r -= A du by a full SpMV
         static const int gs_dbg = getenv("HOT_GS_DBG") ? atoi(getenv("HOT_GS_DBG")) : 0; // timing experiments only (wrong results)
         static bool attr_set = false;
         if (!attr_set) {
@@ -471,7 +576,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                     if (simple_gs)
                         HOT_LAUNCH(this, lname("gs_forward", L.id).c_str(), (k_gs_color<T, true>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0, nb);
                     else
-                        HOT_LAUNCH(this, lname("gs_forward", L.id).c_str(), (k_gs_block<T, true>), nb, gs_threads, GsLds<T>::bytes, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0, gs_dbg);
+                        HOT_LAUNCH(this, lname("gs_forward", L.id).c_str(), (k_gs_block<T, true>), nb, gs_threads, GsLds<T>::bytes, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0, gs_dbg, L.split ? L.rowcnt.p : (const int32_t*)nullptr, (L.split && !no_meta) ? L.gsmeta.p : (const int32_t*)nullptr);
                 }
             }
             // dAu now holds D h ; du = backward solve
@@ -482,13 +587,20 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                     if (simple_gs)
                         HOT_LAUNCH(this, lname("gs_backward", L.id).c_str(), (k_gs_color<T, false>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0, nb);
                     else
-                        HOT_LAUNCH(this, lname("gs_backward", L.id).c_str(), (k_gs_block<T, false>), nb, gs_threads, GsLds<T>::bytes, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0, gs_dbg);
+                        HOT_LAUNCH(this, lname("gs_backward", L.id).c_str(), (k_gs_block<T, false>), nb, gs_threads, GsLds<T>::bytes, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0, gs_dbg, L.split ? L.rowcnt.p : (const int32_t*)nullptr, (L.split && !no_meta) ? L.gsmeta.p : (const int32_t*)nullptr);
                 }
             }
             axpy(n3, (T)1, du, u);
-            spmv_dev(L, du, dAu);
-            Aproject(dAu);
-            axpy(n3, (T)-1, dAu, r);
+            if (L.split && !simple_gs && !(level == 0 && !cfg.systemBCProject) && !no_lres) {
+                // r - A du = L (h - du): with (D+L) h = r and (D+U) du = D h the full product A du collapses to the
+                // strictly-preceding half of the matrix applied to (h - du) (same value, half the bytes of an SpMV)
+                HOT_LAUNCH(this, lname("gs_residual", L.id).c_str(), k_gs_residual<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.rowcnt.p, hdu, du, r, L.n);
+            }
+            else {
+                spmv_dev(L, du, dAu);
+                Aproject(dAu);
+                axpy(n3, (T)-1, dAu, r);
+            }
         }
     }
     else
@@ -548,7 +660,7 @@ void Ctx<T>::vcycle_dev(const T* in, T* out)
 template <class T>
 void Ctx<T>::precondition_dev(const T* in, T* out)
 {
-    HOT_CHECK(!levels.empty() && levels[0]->residual.p, HOT_ERR_INVALID, "preconditioner used before hot_build_mg");
+    HOT_CHECK(!levels.empty() && levels[0]->built, HOT_ERR_INVALID, "preconditioner used before hot_build_mg");
     vcycle_dev(in, out);
 }
 
@@ -593,7 +705,7 @@ void Ctx<T>::prolong(int32_t level, const void* coarse, void* fine)
 template <class T>
 void Ctx<T>::smooth(int32_t level, int32_t kind, int32_t iterations, double tol, void* u, void* r, const void* r0)
 {
-    need(level >= 0 && level < (int)levels.size() && levels[level]->residual.p, "hot_smooth: level not built (hot_build_mg)");
+    need(level >= 0 && level < (int)levels.size() && levels[level]->built, "hot_smooth: level not built (hot_build_mg)");
     Level<T>& L = *levels[level];
     size_t n3 = 3 * (size_t)L.n;
     DBuf<T> du_, dr_;
@@ -609,7 +721,7 @@ void Ctx<T>::smooth(int32_t level, int32_t kind, int32_t iterations, double tol,
 template <class T>
 void Ctx<T>::vcycle(const void* in, void* out)
 {
-    need(!levels.empty() && levels[0]->residual.p, "hot_vcycle before hot_build_mg");
+    need(!levels.empty() && levels[0]->built, "hot_vcycle before hot_build_mg");
     size_t n3 = 3 * (size_t)Nn;
     HOT_HIP(hipMemcpyAsync(work0.p, in, n3 * sizeof(T), hipMemcpyDefault, stream));
     vcycle_dev(work0.p, work1.p);

@@ -272,8 +272,7 @@ void Ctx<T>::solve(hot_stats* st)
     stats.ms_sort = keep_sort, stats.ms_p2g = keep_p2g, stats.ms_begin = keep_begin;
     double t0 = wall_ms();
     if (cfg.useCN) cn_tolerance_dev();
-    for (auto* l : levels) delete l;
-    levels.clear();
+    release_levels();
     if (cfg.lsolver == 3)
         lbfgs_solve();
     else

@@ -160,6 +160,56 @@ __global__ void k_base_offsets(const T* __restrict__ X, const int32_t* __restric
     out[o] = offset;
     order[p] = o;
 }
+__global__ void k_block_group(const int32_t* __restrict__ group_nb, int32_t* block_group, int ng)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < ng) block_group[group_nb[g * 8]] = g; // slot 0 of a group's neighbour table is its own page
+}
+template <class T>
+__global__ void k_block_rev(HashMap h, const uint64_t* __restrict__ blocks, const int32_t* __restrict__ block_group, int32_t* block_rev, int nb)
+{
+    using G = Geo<T>;
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nb * 8) return;
+    int b = s >> 3, n = s & 7;
+    int i, j, k;
+    G::linear_to_coord(blocks[b], i, j, k);
+    i -= (n >> 2) * G::BX, j -= ((n >> 1) & 1) * G::BY, k -= (n & 1) * G::BZ;
+    int r = -1;
+    if ((i | j | k) >= 0) {
+        int32_t bid = hash_find_id(h, G::linear_offset(i, j, k) >> 12);
+        if (bid >= 0) r = block_group[bid];
+    }
+    block_rev[s] = r;
+}
+
+// out_q[slot] = sum over the <= 8 particle groups whose partial tile covers the node, fixed order n = 0..7
+template <class T>
+__global__ void k_tile_reduce(const T* __restrict__ part, int Q, const int32_t* __restrict__ block_rev, T* o0, T* o1, T* o2, T* o3, T* o4, int nb)
+{
+    using G = Geo<T>;
+    constexpr int TX = G::BX + 2, TY = G::BY + 2, TZ = G::BZ + 2, TILE = TX * TY * TZ;
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= (int64_t)nb * G::EPB) return;
+    int b = (int)(s / G::EPB), e = (int)(s - (int64_t)b * G::EPB);
+    int ez = e & (G::BZ - 1), ey = (e >> G::zb) & (G::BY - 1), ex = e >> (G::zb + G::yb);
+    T acc[5] = { 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        int g = block_rev[b * 8 + n];
+        if (g < 0) continue;
+        int tx = ex + (n >> 2) * G::BX, ty = ey + ((n >> 1) & 1) * G::BY, tz = ez + (n & 1) * G::BZ;
+        if (tx >= TX || ty >= TY || tz >= TZ) continue;
+        const T* p = part + (int64_t)g * Q * TILE + (tx * TY + ty) * TZ + tz;
+        for (int q = 0; q < Q; ++q) acc[q] += p[q * TILE];
+    }
+    o0[s] = acc[0];
+    if (Q > 1) o1[s] = acc[1];
+    if (Q > 2) o2[s] = acc[2];
+    if (Q > 3) o3[s] = acc[3];
+    if (Q > 4) o4[s] = acc[4];
+}
+
 __global__ void k_group_ranges(const int32_t* __restrict__ first, int32_t* out, int ng)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,6 +227,7 @@ Ctx<T>::Ctx(const hot_config& c)
     HOT_HIP(hipSetDevice(c.device));
     HOT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     prof.on = c.profile != 0;
+    keep_debug = c.debug_store != 0;
     dscal.reserve(256);
     HOT_HIP(hipHostMalloc((void**)&hscal, 256 * sizeof(double)));
     std::memset(&stats, 0, sizeof(stats));
@@ -185,6 +236,8 @@ template <class T>
 Ctx<T>::~Ctx()
 {
     for (auto* l : levels) delete l;
+    for (auto& pool : level_pool)
+        for (auto* l : pool) delete l;
     if (hscal) (void)hipHostFree(hscal);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -308,11 +361,21 @@ void Ctx<T>::sort()
     // node tiles
     size_t slots = (size_t)Nb * EPB;
     gM.reserve(slots, 1.25), gMV.reserve(3 * slots, 1.25), gF.reserve(3 * slots, 1.25), gCN.reserve(slots, 1.25), gIdx.reserve(slots, 1.25), block_count.reserve(Nb + 1, 1.25);
+    block_group.reserve(Nb, 1.25), block_rev.reserve(8 * (size_t)Nb, 1.25), gPart.reserve((size_t)Ng * 5 * TILE, 1.25);
+    HOT_HIP(hipMemsetAsync(block_group.p, 0xff, (size_t)Nb * sizeof(int32_t), stream));
+    HOT_LAUNCH(this, "block_group", k_block_group, div_up(Ng, 256), 256, 0, group_nb.p, block_group.p, Ng);
+    HOT_LAUNCH(this, "block_rev", k_block_rev<T>, div_up((size_t)Nb * 8, 256), 256, 0, block_map, blocks.p, block_group.p, block_rev.p, Nb);
     build_cell_table();
     Nn = 0;
     Nc = 0;
     updated = false;
     stats.ms_sort = wall_ms() - t0;
+}
+
+template <class T>
+void Ctx<T>::reduce_tiles(int Q, T* o0, T* o1, T* o2, T* o3, T* o4, const char* name)
+{
+    HOT_LAUNCH(this, name, k_tile_reduce<T>, div_up((size_t)Nb * EPB, 256), 256, 0, gPart.p, Q, block_rev.p, o0, o1, o2, o3, o4, Nb);
 }
 
 template <class T>

@@ -33,7 +33,7 @@ __device__ __forceinline__ int tile_slot(int t, const int32_t* __restrict__ nb8)
 template <class T, bool WITH_CN>
 __global__ __launch_bounds__(256) void k_p2g(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C,
     const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
-    const int32_t* __restrict__ group_nb, T* gM, T* gMV, T* gCN, int64_t slots, T dx, T one_over_dx)
+    const int32_t* __restrict__ group_nb, T* __restrict__ part, T dx, T one_over_dx)
 {
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
@@ -83,16 +83,9 @@ __global__ __launch_bounds__(256) void k_p2g(const T* __restrict__ X, const T* _
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < TILE; t += 256) {
-        T m = acc[0][t];
-        if (m == (T)0 && acc[1][t] == (T)0 && acc[2][t] == (T)0 && acc[3][t] == (T)0) continue;
-        int64_t s = tile_slot<T>(t, nb8);
-        atomic_add(&gM[s], m);
-        atomic_add(&gMV[s], acc[1][t]);
-        atomic_add(&gMV[slots + s], acc[2][t]);
-        atomic_add(&gMV[2 * slots + s], acc[3][t]);
-        if (WITH_CN) atomic_add(&gCN[s], acc[NQ - 1][t]);
-    }
+    // partial tile of this group, coalesced; summed per node by k_tile_reduce (no global atomics)
+    T* out = part + (int64_t)g * NQ * TILE;
+    for (int t = threadIdx.x; t < NQ * TILE; t += 256) out[t] = (&acc[0][0])[t];
 }
 
 template <class T>
@@ -144,14 +137,15 @@ void Ctx<T>::p2g()
     need(Ng > 0, "hot_p2g before hot_sort");
     double t0 = wall_ms();
     int64_t slots = (int64_t)Nb * EPB;
-    HOT_HIP(hipMemsetAsync(gM.p, 0, slots * sizeof(T), stream));
-    HOT_HIP(hipMemsetAsync(gMV.p, 0, 3 * slots * sizeof(T), stream));
-    HOT_HIP(hipMemsetAsync(gCN.p, 0, slots * sizeof(T), stream));
     T one_over_dx = (T)1 / dx;
-    if (cfg.useCN)
-        HOT_LAUNCH(this, "p2g", (k_p2g<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gM.p, gMV.p, gCN.p, slots, dx, one_over_dx);
-    else
-        HOT_LAUNCH(this, "p2g", (k_p2g<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gM.p, gMV.p, gCN.p, slots, dx, one_over_dx);
+    if (cfg.useCN) {
+        HOT_LAUNCH(this, "p2g", (k_p2g<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, dx, one_over_dx);
+        reduce_tiles(5, gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p, "p2g_reduce");
+    }
+    else {
+        HOT_LAUNCH(this, "p2g", (k_p2g<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, dx, one_over_dx);
+        reduce_tiles(4, gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p, "p2g_reduce");
+    }
     HOT_LAUNCH(this, "block_count", k_block_count<T>, div_up(Nb, 4), 256, 0, gM.p, block_count.p, Nb);
     scan.reserve(Nb + 1);
     Nn = exclusive_scan_i32(block_count.p, scan.p, Nb);
@@ -269,7 +263,13 @@ __global__ __launch_bounds__(256) void k_g2p(T* __restrict__ X, T* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 9; ++c) F[(int64_t)c * Np + p] = Fnew.a[c];
     }
-    if (myflags) atomicOr(flags_out, myflags);
+    // one global atomic per wavefront at most (2 M same-address atomics cost more than the whole transfer)
+    unsigned long long m1 = __ballot(myflags & 1), m2 = __ballot(myflags & 2);
+    if ((threadIdx.x & 63) == 0 && (m1 | m2)) {
+        int bits = (m1 ? 1 : 0) | (m2 ? 2 : 0);
+        int cur = __hip_atomic_load(flags_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((cur & bits) != bits) atomicOr(flags_out, bits); // already-set bits need no further traffic
+    }
 }
 
 template <class T>

@@ -11,6 +11,7 @@ from hot_amd import synth
 def make_ctx(lib, n=6, dtype=1, bc=True, seed=123, noise=0.1, E=5e4, ppc=8, cells=None, **kw):
     T = np.float64 if dtype == 1 else np.float32
     c = synth.cube_cloud(n, ppc=ppc, dtype=T, seed=seed, noise=noise, E=E, cells=cells)
+    kw.setdefault("debug_store", 1)  # tests read back per-particle grad v
     ctx = lib.context(dtype=dtype, dx=c["dx"], gravity=(0, -9.8, 0), **kw)
     ctx.set_particles(c["X"], c["V"], c["mass"], c["vol"], c["mu"], c["lam"])
     if bc:
