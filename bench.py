@@ -5,13 +5,14 @@ fp64, 3 MG levels, -lsolver 3 -smoother 5 -coarseSolver 2 --project --linesearch
 
 Prints ONE JSON line on rank 0.  `value` = ms per nonlinear (L-BFGS) iteration, Hessian + hierarchy build excluded
 (reported separately and amortised); extra keys carry the P2G+G2P Mparticles/s half of the metric.
-`roofline` = the kernel with the largest share of the timed region, from HIP events recorded on the library's
-launch stream (hot_config.profile); `cpu_baseline` = the CPU oracle (a port of the reference's TBB decomposition to
+`roofline` = the kernel (device symbol) with the largest share of the timed region, from HIP events recorded on the
+library's launch stream (hot_config.profile); its `avg_launch_ms` is what rocprofv3 --kernel-trace --stats reports
+for the same symbol (profiles/).  `cpu_baseline` = the CPU oracle (a port of the reference's TBB decomposition to
 OpenMP) on a bounded sample, with the GPU timed on that same sample next to it.
 
-N > 1: one process per GPU (torch.distributed / RCCL for the barriers and the max-over-ranks clock); every rank
-advances its own spatial shard of the same size (weak scaling).  The shards are not yet coupled by halo exchange
- — `config.parallelism` says so.
+N > 1: one process per GPU (torch.distributed / RCCL for the barriers and the max-over-ranks clock); the scene is N
+non-touching bodies, one per rank (hot_amd/parallel.py): bodies further apart than the kernel support share no grid
+node, so the by-body partition needs no halo exchange (weak scaling).
 """
 import argparse
 import json
@@ -24,7 +25,13 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+
+SYMBOL = {  # profile-record prefix -> device symbol as rocprofv3 names it
+    "gs_forward": "hot::k_gs_block<T,true>", "gs_backward": "hot::k_gs_block<T,false>", "spmv": "hot::k_spmv<T>",
+    "gs_residual": "hot::k_gs_residual<T>", "hessian_assemble": "hot::k_hessian_tiles<T>", "state_update": "hot::k_state<T>",
+    "force_scatter": "hot::k_force_scatter<T>", "p2g": "hot::k_p2g<T,true>", "g2p": "hot::k_g2p<T,0>",
+}
 
 
 def host_cores():
@@ -50,24 +57,28 @@ def make_ctx(lib, cloud, cfg, device=0, profile=0, **over):
 
 
 def algorithmic_bytes(name, s, Np, levels):
-    """SURVEY.md §8(d) per-launch algorithmic bytes of the named kernel (None if not modelled)."""
+    """SURVEY.md §8(d) per-launch algorithmic (compulsory) bytes of one profile record; None if not modelled."""
     base, _, lv = name.rpartition("_L")
-    if base in ("spmv", "gs_forward", "gs_backward") and lv.isdigit():
+    if base in ("spmv", "gs_forward", "gs_backward", "gs_residual") and lv.isdigit():
         N, nnzb = levels[int(lv)]
+        off = max(nnzb - N, 0) / 2.0  # blocks strictly preceding (or following) the row in the sweep order
         if base == "spmv":
             return nnzb * (9 * s + 4) + N * 6 * s
-        off = max(nnzb - N, 0) / 2.0  # strictly lower (or upper) blocks
+        if base == "gs_residual":
+            return off * (9 * s + 4) + N * 9 * s
         per_half_sweep = off * (9 * s + 4) + N * ((18 if base == "gs_forward" else 9) * s + 6 * s)
         return per_half_sweep / 8.0  # one launch per colour
     Nn = levels[0][0]
     if name == "p2g":
         return Np * 16 * s + Nn * 4 * s
     if name == "g2p":
-        return Nn * 3 * s + Np * (3 * s + 24 * s) + Np * 18 * s  # + F in/out (evolveStrain is fused into the kernel)
-    if name == "state_update_force":
-        return Np * 24 * s + Nn * 6 * s
+        return Nn * 3 * s + Np * (3 * s + 24 * s) + Np * 18 * s  # + F in/out: evolveStrain is fused into the kernel
+    if name == "state_update":
+        return Np * (3 + 9 + 3 + 9 + 9) * s + Nn * 3 * s
+    if name == "force_scatter":
+        return Np * 12 * s + Nn * 3 * s
     if name == "hessian_assemble":
-        return Np * 24 * s + levels[0][1] * 9 * s
+        return Np * (45 + 12) * s + levels[0][1] * 9 * s
     return None
 
 
@@ -79,7 +90,7 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--cells", type=int, default=0, help="override the cube edge (cells) for quick runs")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-cells", type=int, default=24)
+    ap.add_argument("--cpu-cells", type=int, default=32)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,7 +102,7 @@ def main():
 
     import torch
     import hot_amd
-    from hot_amd import synth
+    from hot_amd import parallel, synth
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP library has no CPU fallback)"
     torch.cuda.set_device(local)
@@ -109,10 +120,7 @@ def main():
     lib = hot_amd.load()
     cfg = dict(synth.CONFIGS[args.config])
     n = args.cells or cfg["n"]
-    # weak scaling: rank r owns the block of cells shifted by r*(n+8) cells in x (disjoint sub-domains)
-    corner = (5.0 + rank * (n + 8) * 0.01, 5.0, 5.0)
-    cloud = synth.cube_cloud(n, ppc=cfg["ppc"], dtype=cfg["dtype"], E=cfg["E"], nu=cfg["nu"], rho=cfg["rho"], corner=corner, seed=123 + rank)
-    cloud["corner"] = corner
+    cloud = parallel.shard_cloud(cfg, rank, world, n=n)
     Np = cloud["X"].shape[0]
     s = 8 if cfg["dtype"] == np.float64 else 4
     dt = cfg["dt"]
@@ -127,50 +135,52 @@ def main():
         stats.append(ctx.advance(dt))
     ctx.sync()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dist, "cuda")
 
     iters = sum(st["iterations"] for st in stats)
     build_ms = sum(st["ms_hessian"] + st["ms_mg_build"] for st in stats)
     solve_ms = sum(st["ms_solve"] for st in stats)
-    ms_per_iter = (solve_ms - build_ms) / max(iters, 1)
-    if dist is not None:
-        t = torch.tensor([ms_per_iter], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms_per_iter = float(t.item())
+    ms_per_iter = parallel.max_over_ranks((solve_ms - build_ms) / max(iters, 1), dist, "cuda")
+    total_particles = parallel.sum_over_ranks(Np, dist, "cuda")
 
     # ---- profiled pass (HIP events on the launch stream) for the roofline and the transfer half of the metric
-    roof, transfers, prof_table = None, None, {}
+    roof, transfers, prof_top = None, None, None
     if rank == 0:
         pctx = make_ctx(lib, cloud, cfg, device=local, profile=1)
         pctx.advance(dt)
         pctx.profile_reset()
         nprof = max(1, min(2, args.steps))
         pst = [pctx.advance(dt) for _ in range(nprof)]
-        prof_table = pctx.profile()
-        levels = []
-        for l in range(pst[-1]["num_levels"]):
-            levels.append((pctx.level(l, coords=False)["nrows"], pctx.level_nnzb(l)))
-        total_ms = sum(v["total_ms"] for v in prof_table.values())
-        name = max(prof_table, key=lambda k: prof_table[k]["total_ms"])
-        # group the per-colour GS launches / levels under the dominant name as recorded
-        rec = prof_table[name]
-        avg_ms = rec["total_ms"] / rec["calls"]
-        ab = algorithmic_bytes(name, s, Np, levels)
-        achieved = (ab / (avg_ms * 1e-3)) / 1e9 if ab else None
-        roof = {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": None, "avg_launch_ms": avg_ms, "launches": rec["calls"], "algorithmic_bytes_per_launch": ab, "share_of_kernel_time": rec["total_ms"] / total_ms}
-        tp = prof_table.get("p2g", {"total_ms": 0, "calls": 1})
-        tg = prof_table.get("g2p", {"total_ms": 0, "calls": 1})
-        t_p2g, t_g2p = tp["total_ms"] / tp["calls"], tg["total_ms"] / tg["calls"]
+        table = pctx.profile()
+        levels = [(pctx.level(l, coords=False)["nrows"], pctx.level_nnzb(l)) for l in range(pst[-1]["num_levels"])]
+        total_ms = sum(v["total_ms"] for v in table.values())
+        groups = {}
+        for name, rec in table.items():
+            base = name.rpartition("_L")[0] if name.rpartition("_L")[2].isdigit() else name
+            g = groups.setdefault(base, dict(ms=0.0, calls=0, bytes=0.0, modelled=True, records={}))
+            g["ms"] += rec["total_ms"]
+            g["calls"] += rec["calls"]
+            ab = algorithmic_bytes(name, s, Np, levels)
+            if ab is None:
+                g["modelled"] = False
+            else:
+                g["bytes"] += ab * rec["calls"]
+            g["records"][name] = dict(calls=rec["calls"], avg_ms=rec["total_ms"] / rec["calls"], algorithmic_bytes_per_launch=ab)
+        top = max((k for k in groups if groups[k]["modelled"]), key=lambda k: groups[k]["ms"])
+        g = groups[top]
+        avg_ms = g["ms"] / g["calls"]
+        achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+        roof = {"kernel": SYMBOL.get(top, top), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": avg_ms, "launches": g["calls"], "algorithmic_bytes_per_launch": g["bytes"] / g["calls"], "share_of_kernel_time": g["ms"] / total_ms,
+                "per_level": g["records"]}
+        tp, tr, tg = table.get("p2g"), table.get("p2g_reduce"), table.get("g2p")
+        t_p2g = tp["total_ms"] / tp["calls"] + (tr["total_ms"] / tr["calls"] if tr else 0.0)
+        t_g2p = tg["total_ms"] / tg["calls"]
         Nn = levels[0][0]
         tb = 43 * s * Np + 7 * s * Nn
         transfers = {"p2g_ms": t_p2g, "g2p_ms": t_g2p, "mparticles_per_s": Np / ((t_p2g + t_g2p) * 1e-3) / 1e6, "algorithmic_bytes": tb,
                      "achieved_GBps": tb / ((t_p2g + t_g2p) * 1e-3) / 1e9, "frac_of_hbm_peak": tb / ((t_p2g + t_g2p) * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        prof_top = sorted(((k, v["total_ms"] / nprof, v["calls"] // nprof) for k, v in prof_table.items()), key=lambda x: -x[1])[:12]
+        prof_top = sorted(((k, round(v["ms"] / nprof, 3), v["calls"] // nprof) for k, v in groups.items()), key=lambda x: -x[1])[:14]
         del pctx
 
     # ---- CPU baseline: the oracle on a bounded sample, and the GPU on that same sample
@@ -179,21 +189,20 @@ def main():
         from tests.oracle_lib import load_oracle
         ora = load_oracle()
         nc = args.cpu_cells
-        sample = synth.cube_cloud(nc, ppc=cfg["ppc"], dtype=cfg["dtype"], E=cfg["E"], nu=cfg["nu"], rho=cfg["rho"])
-        sample["corner"] = (5.0, 5.0, 5.0)
+        sample = parallel.shard_cloud(cfg, 0, 1, n=nc)
         res = {}
         for nm, L in (("cpu", ora), ("gpu", lib)):
             c = make_ctx(L, sample, cfg, device=local)
-            c.advance(dt)  # warm-up step (first-touch, thread pool)
-            st = c.advance(dt)
-            res[nm] = st
+            c.advance(dt)  # warm-up step (first touch, thread pool)
+            res[nm] = c.advance(dt)
             del c
+
         def per_iter(st):
             return (st["ms_solve"] - st["ms_hessian"] - st["ms_mg_build"]) / max(st["iterations"], 1)
         cpu = {"value": per_iter(res["cpu"]), "unit": "ms per L-BFGS iteration", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
                "sample": f"{nc}^3-cell cube, {sample['X'].shape[0]} particles, {res['cpu']['num_nodes']} nodes, 1 timed step of {res['cpu']['iterations']} iterations (same solver knobs)",
                "gpu_same_sample_ms_per_iter": per_iter(res["gpu"]), "speedup_same_sample": per_iter(res["cpu"]) / max(per_iter(res["gpu"]), 1e-9),
-               "cpu_step_ms": res["cpu"]["ms_total"], "gpu_step_ms": res["gpu"]["ms_total"],
+               "cpu_step_ms": res["cpu"]["ms_total"], "gpu_step_ms": res["gpu"]["ms_total"], "step_speedup_same_sample": res["cpu"]["ms_total"] / res["gpu"]["ms_total"],
                "cpu_p2g_g2p_mparticles_per_s": sample["X"].shape[0] / ((res["cpu"]["ms_p2g"] + res["cpu"]["ms_g2p"]) * 1e-3) / 1e6,
                "cpu_build_ms": res["cpu"]["ms_hessian"] + res["cpu"]["ms_mg_build"], "gpu_build_ms": res["gpu"]["ms_hessian"] + res["gpu"]["ms_mg_build"]}
 
@@ -205,14 +214,13 @@ def main():
             "dtype": "f64" if s == 8 else "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n}^3-cell cube x {cfg['ppc']} ppc per GPU, fixed-corotated E={cfg['E']:g} nu={cfg['nu']}, dx=0.01, dt=1/24, "
                                    f"-lsolver 3 -mg_level {cfg['levelCnt']} -smoother 5 -coarseSolver 2 --project --linesearch --bcproject --usecn -cneps 1e-7",
-                       "particles_per_gpu": Np, "nodes_per_gpu": stats[-1]["num_nodes"], "levels": stats[-1]["num_levels"],
-                       "parallelism": "1 GPU" if world == 1 else f"{world} independent spatial shards (one per GPU, no halo coupling yet)"},
+                       "particles_per_gpu": Np, "particles_total": int(total_particles), "nodes_per_gpu": stats[-1]["num_nodes"], "levels": stats[-1]["num_levels"],
+                       "parallelism": "1 GPU" if world == 1 else f"{world} non-touching bodies, one per GPU (by-body partition, no halo needed)"},
             "iterations_per_step": iters / max(args.steps, 1),
             "hessian_mg_build_ms_per_step": build_ms / max(args.steps, 1),
             "ms_per_iter_build_amortised": solve_ms / max(iters, 1),
             "p2g_g2p_mparticles_per_s": (transfers["mparticles_per_s"] * world) if transfers else None,
-            "roofline": roof, "transfers": transfers, "cpu_baseline": cpu,
-            "kernel_ms_per_step_top": prof_top if prof_table else None,
+            "roofline": roof, "transfers": transfers, "cpu_baseline": cpu, "kernel_ms_per_step_top": prof_top,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -1,0 +1,155 @@
+// hot_adapter.hpp — header-only C++ adapter over the C ABI of libhotmi355x (include/hot_mi355x.h).
+//
+// It re-exposes the accelerated hot path under the member names of the reference objects that own it, so that
+// the reference's solver templates (LBFGS<Objective>, ExtendedNewtonsMethod<Objective>, InexactConjugateGradient,
+// MultigridOperator's smoother plug point) can be pointed at it:
+//
+//   hotmi::Simulation<T>   <->  MultigridSimulation<T,3> / MpmSimulationBase<T,3>
+//        sortParticlesAndPolluteGrid()          Lib/MPM/MpmSimulationBase.cpp:1066-1137
+//        particlesToGrid()                      Lib/MPM/MpmSimulationBase.cpp:461-533
+//        startBackwardEuler(dt)                 Projects/multigrid/MultigridSimulation.h:167-186
+//        backwardEulerStep()                    Projects/multigrid/MultigridSimulation.h:188-233  (whole solve on the device)
+//        gridToParticles(dt)                    Lib/MPM/MpmSimulationBase.cpp:903-1042
+//        advanceOneTimeStep(dt)                 Projects/multigrid/MultigridSimulation.h:235-297
+//   hotmi::Objective<T>    <->  ImplicitSolverObjective<Simulation>  (Projects/multigrid/ImplicitSolver.h)
+//        updateState / totalEnergy / computeResidual / multiply / precondition / project / innerProduct
+//   hotmi::smoothFunc      <->  MultigridOperator::regular.smoothFunc (Projects/multigrid/MultigridPreconditioner.h:67-79)
+//
+// Vectors are "TVStack" (3 x N column-major == xyz interleaved) exactly like the reference's
+// Eigen::Matrix<T,3,Dynamic>; pass `stack.data()`.  Errors: the reference asserts/throws (ZIRAN_ASSERT,
+// Lib/Ziran/CS/Util/Debug.h:19); here every non-zero hot_status becomes std::runtime_error with hot_last_error().
+#pragma once
+#include "hot_mi355x.h"
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+
+// HOTSettings is a namespace of inline statics on the reference side (Projects/multigrid/Configurations.h:18-42),
+// so the copy into hot_config is a macro; field names are identical on both sides.
+#define HOTMI_CONFIG_FROM_HOTSETTINGS(cfg)                                                                 \
+    do {                                                                                                   \
+        (cfg).lsolver = HOTSettings::lsolver, (cfg).Ainv = HOTSettings::Ainv;                              \
+        (cfg).smoother = HOTSettings::smoother, (cfg).coarseSolver = HOTSettings::coarseSolver;            \
+        (cfg).levelCnt = HOTSettings::levelCnt, (cfg).times = HOTSettings::times;                          \
+        (cfg).levelscale = HOTSettings::levelscale, (cfg).omega = HOTSettings::omega;                      \
+        (cfg).topomega = HOTSettings::topomega, (cfg).cneps = HOTSettings::cneps;                          \
+        (cfg).useCN = HOTSettings::useCN, (cfg).project = HOTSettings::project;                            \
+        (cfg).systemBCProject = HOTSettings::systemBCProject, (cfg).linesearch = HOTSettings::linesearch;  \
+        (cfg).matrixFree = HOTSettings::matrixFree, (cfg).boundaryType = HOTSettings::boundaryType;        \
+        (cfg).useAdaptiveHessian = HOTSettings::useAdaptiveHessian;                                        \
+        (cfg).topDownMGS = HOTSettings::topDownMGS;                                                        \
+    } while (0)
+
+namespace hotmi {
+
+inline void check(hot_ctx* c, int rc, const char* what)
+{
+    if (rc != HOT_OK) throw std::runtime_error(std::string(what) + ": " + (c ? hot_last_error(c) : "no context") + " (status " + std::to_string(rc) + ")");
+}
+
+template <class T>
+class Simulation {
+    static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value, "T must be float or double");
+
+public:
+    hot_ctx* ctx = nullptr;
+    hot_config cfg;
+    hot_stats stats;
+
+    explicit Simulation(hot_config c)
+        : cfg(c)
+    {
+        cfg.dtype = std::is_same<T, double>::value ? 1 : 0;
+        int rc = hot_create(&cfg, &ctx);
+        if (rc != HOT_OK) throw std::runtime_error("hot_create failed (no GPU? there is no CPU fallback), status " + std::to_string(rc));
+    }
+    Simulation(const Simulation&) = delete;
+    Simulation& operator=(const Simulation&) = delete;
+    ~Simulation() { hot_destroy(ctx); }
+
+    static hot_config defaults()
+    {
+        hot_config c;
+        hot_default_config(&c);
+        return c;
+    }
+    // particles.X / V / mass / C / F / "element measure" / CorotatedIsotropic(mu, lambda)
+    void setParticles(int64_t Np, const T* X, const T* V, const T* mass, const T* C, const T* F, const T* vol, const T* mu, const T* lambda, const T* Jp = nullptr)
+    {
+        check(ctx, hot_set_particles(ctx, Np, X, V, mass, C, F, vol, mu, lambda, Jp), "hot_set_particles");
+    }
+    void getParticles(T* X, T* V, T* C, T* F, T* mu = nullptr, T* lambda = nullptr, T* Jp = nullptr) { check(ctx, hot_get_particles(ctx, X, V, C, F, mu, lambda, Jp), "hot_get_particles"); }
+    void sortParticlesAndPolluteGrid() { check(ctx, hot_sort(ctx), "hot_sort"); }
+    void particlesToGrid() { check(ctx, hot_p2g(ctx), "hot_p2g"); }
+    int numNodes()
+    {
+        int32_t nn = 0;
+        check(ctx, hot_get_counts(ctx, nullptr, nullptr, nullptr, &nn), "hot_get_counts");
+        return nn;
+    }
+    // MpmGrid::iterateGrid replacement for host-side collision queries: id2coord[3*id + d] is the integer node
+    // coordinate of DOF `id` (world position = coord * dx); mass / v may be null.
+    void gridNodes(int32_t* id2coord, T* mass = nullptr, T* v = nullptr) { check(ctx, hot_get_grid(ctx, id2coord, mass, v), "hot_get_grid"); }
+    // collision_nodes as produced by buildInitialDvAndVnForNewton's collision query (host geometry code)
+    void setCollisionNodes(int Nc, const int32_t* node_id, const T* P, const T* R, const T* Rinv, const uint8_t* shouldRotate, const T* dv = nullptr)
+    {
+        check(ctx, hot_set_bc(ctx, Nc, node_id, P, R, Rinv, shouldRotate, dv), "hot_set_bc");
+    }
+    void startBackwardEuler(double dt) { check(ctx, hot_begin_step(ctx, dt), "hot_begin_step"); }
+    void backwardEulerStep() { check(ctx, hot_solve(ctx, &stats), "hot_solve"); }
+    void gridToParticles(double dt)
+    {
+        int32_t flags = 0;
+        check(ctx, hot_g2p(ctx, dt, &flags), "hot_g2p");
+        faster_than_grid_cell = flags & 1, faster_than_half_grid_cell = (flags & 2) != 0;
+    }
+    void advanceOneTimeStep(double dt) { check(ctx, hot_advance(ctx, dt, &stats), "hot_advance"); }
+    bool faster_than_grid_cell = false, faster_than_half_grid_cell = false;
+};
+
+// The operator concept LBFGS / ExtendedNewtonsMethod / InexactConjugateGradient / Minres are templated on.
+template <class T>
+class Objective {
+public:
+    using Scalar = T;
+    Simulation<T>& simulation;
+    bool matrix_free = false;
+    T Ek = 0;
+    explicit Objective(Simulation<T>& s)
+        : simulation(s) {}
+    hot_ctx* c() const { return simulation.ctx; }
+    void updateState(const T* dv)
+    {
+        double e = 0;
+        check(c(), hot_update_state(c(), dv, &e), "hot_update_state");
+        Ek = (T)e;
+    }
+    T totalEnergy() const { return Ek; }
+    void computeResidual(T* residual) { check(c(), hot_residual(c(), residual), "hot_residual"); }
+    void HinvApproxInit()
+    {
+        check(c(), hot_build_hessian(c()), "hot_build_hessian");
+        check(c(), hot_build_mg(c()), "hot_build_mg");
+    }
+    void multiply(const T* x, T* b) const { check(c(), matrix_free ? hot_matfree_multiply(c(), x, b) : hot_spmv(c(), 0, x, b), "multiply"); }
+    void precondition(const T* in, T* out) const { check(c(), hot_vcycle(c(), in, out), "hot_vcycle"); }
+    void project(T* v) const { check(c(), hot_project(c(), v), "hot_project"); }
+    // evaluatePerNodeCNTolerance (ImplicitSolver.h:667-696): per-node characteristic-norm tolerance
+    void cnTolerance(T* node_tol) const { check(c(), hot_cn_tolerance(c(), node_tol), "hot_cn_tolerance"); }
+    T innerProduct(const T* a, const T* b, int64_t numNodes) const
+    {
+        T s = 0;
+        for (int64_t i = 0; i < 3 * numNodes; ++i) s += a[i] * b[i];
+        return s;
+    }
+};
+
+// void (*smoothFunc)(TVStack& u, TVStack& r, TVStack& du, TVStack& dAu, MPMSpMat& A, int iterations, T tolerance):
+// `A` is replaced by (context, level); du / dAu are library-internal work vectors.
+template <class T>
+inline void smoothFunc(hot_ctx* ctx, int level, int kind /* -smoother numbering */, T* u, T* r, int iterations, T tolerance, const T* initialResidual = nullptr)
+{
+    check(ctx, hot_smooth(ctx, level, kind, iterations, (double)tolerance, u, r, initialResidual), "hot_smooth");
+}
+
+} // namespace hotmi

@@ -39,3 +39,36 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower() or f == "__init__.py" and "oracle" not in txt.replace("no CPU fallback", "").lower(), (dirpath, f)
+
+
+def _build_adapter(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "adapter_smoke")
+    libdir = os.path.join(ROOT, "hot_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adapter_smoke.cpp"),
+                           "-L" + libdir, "-lhotmi355x", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_cpp_adapter_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """include/hot_adapter.hpp (the reference-shaped C++ surface) compiles against the C ABI; on a GPU-less box the
+    constructor throws instead of falling back to anything."""
+    import subprocess
+    import torch
+    if not os.path.exists(hot_amd.LIB_PATH):
+        hot_amd.build()
+    exe = _build_adapter(tmp_path)
+    rc = subprocess.call([exe])
+    assert rc == (0 if torch.cuda.is_available() else 42)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_cpp_adapter_runs_on_gpu(tmp_path):
+    import subprocess
+    exe = _build_adapter(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "adapter ok" in out.stdout
