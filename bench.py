@@ -34,6 +34,25 @@ SYMBOL = {  # profile-record prefix -> device symbol as rocprofv3 names it
 }
 
 
+def pmc_traffic(symbol, dtype_name):
+    """HBM bytes per launch of `symbol` from the newest committed PMC summary (profiles/*_pmc_summary.json, produced
+    by profiles/run_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled
+    for gfx950).  PMC counters cannot be collected from inside the timed process, so this is a recorded value; None
+    if there is no summary for this symbol."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    want = symbol.replace("<T", "<" + dtype_name).replace(" ", "")
+    with open(files[-1]) as fh:
+        table = json.load(fh)
+    for name, rec in table.items():
+        if want in name.replace(" ", "") and "hbm_bytes_per_launch" in rec:
+            return rec["hbm_bytes_per_launch"], os.path.relpath(files[-1], here)
+    return None, None
+
+
 def host_cores():
     n = len(os.sched_getaffinity(0))
     try:
@@ -170,7 +189,9 @@ def main():
         g = groups[top]
         avg_ms = g["ms"] / g["calls"]
         achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
-        roof = {"kernel": SYMBOL.get(top, top), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        traffic, traffic_src = pmc_traffic(SYMBOL.get(top, top), "double" if s == 8 else "float") if args.config == "C2" and not args.cells else (None, None)
+        roof = {"kernel": SYMBOL.get(top, top), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src,
                 "avg_launch_ms": avg_ms, "launches": g["calls"], "algorithmic_bytes_per_launch": g["bytes"] / g["calls"], "share_of_kernel_time": g["ms"] / total_ms,
                 "per_level": g["records"]}
         tp, tr, tg = table.get("p2g"), table.get("p2g_reduce"), table.get("g2p")
