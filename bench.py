@@ -75,7 +75,7 @@ def make_ctx(lib, cloud, cfg, device=0, profile=0, **over):
     return ctx
 
 
-def algorithmic_bytes(name, s, Np, levels):
+def algorithmic_bytes(name, s, Np, levels, launches_per_half_sweep=8.0):
     """SURVEY.md §8(d) per-launch algorithmic (compulsory) bytes of one profile record; None if not modelled."""
     base, _, lv = name.rpartition("_L")
     if base in ("spmv", "gs_forward", "gs_backward", "gs_residual") and lv.isdigit():
@@ -86,7 +86,7 @@ def algorithmic_bytes(name, s, Np, levels):
         if base == "gs_residual":
             return off * (9 * s + 4) + N * 9 * s
         per_half_sweep = off * (9 * s + 4) + N * ((18 if base == "gs_forward" else 9) * s + 6 * s)
-        return per_half_sweep / 8.0  # one launch per colour
+        return per_half_sweep / launches_per_half_sweep  # one launch per (colour, sub-block)
     Nn = levels[0][0]
     if name == "p2g":
         return Np * 16 * s + Nn * 4 * s
@@ -179,7 +179,8 @@ def main():
             g = groups.setdefault(base, dict(ms=0.0, calls=0, bytes=0.0, modelled=True, records={}))
             g["ms"] += rec["total_ms"]
             g["calls"] += rec["calls"]
-            ab = algorithmic_bytes(name, s, Np, levels)
+            sweeps = table.get("gs_residual_L" + name.rpartition("_L")[2])
+            ab = algorithmic_bytes(name, s, Np, levels, rec["calls"] / sweeps["calls"] if sweeps and name.startswith("gs_") else 8.0)
             if ab is None:
                 g["modelled"] = False
             else:

@@ -23,8 +23,7 @@ struct Level {
     DBuf<int32_t> gs_block_start; // nblocks+1 : offsets into gs_order
     // after build_mg every row's slots are regrouped as [nl entries preceding the row in the GS order | diagonal |
     // nu entries following it | structural zeros], so each half sweep streams only the half it needs
-    DBuf<int32_t> rowcnt; // 2n: (nl, nu)
-    DBuf<int32_t> gsmeta; // n*125 slot descriptor for the GS kernels: j >= 0 column outside the row's block, -2-lj inside it
+    DBuf<int32_t> rowcnt; // 4n: (precede-off, precede-in, follow-in, follow-off) slot counts of the regrouped rows
     bool split = false;
     int color_block_begin[9] = { 0 }; // blocks of colour c are [color_block_begin[c], color_block_begin[c+1])
     int nblocks = 0;
@@ -110,6 +109,7 @@ struct Ctx : CtxBase {
     T max_cn_tolerance = 0;
     DBuf<T> rhs, work0, work1, work2, work3;
     DBuf<double> dscal; // device scalars
+    DBuf<int> gs_done; // [0,40) pass counters of k_gs_sweep (the sticky wait-timeout flag lives in pinned host memory, hscal[250])
     double* hscal = nullptr; // pinned host mirror
     // ---- L-BFGS history
     DBuf<T> hist_dx[9], hist_dg[9];
@@ -153,7 +153,11 @@ struct Ctx : CtxBase {
     {
         if (dst && n) HOT_HIP(hipMemcpyAsync(dst, src, n * sizeof(U), hipMemcpyDefault, stream));
     }
-    void sync() { HOT_HIP(hipStreamSynchronize(stream)); }
+    void sync()
+    {
+        HOT_HIP(hipStreamSynchronize(stream));
+        HOT_CHECK(*(volatile int*)(hscal + 250) == 0, HOT_ERR_DEVICE, "k_gs_sweep: wait on the previous pass timed out (workgroup dispatch order assumption violated)");
+    }
     int32_t exclusive_scan_i32(const int32_t* in, int32_t* out, size_t n); // returns total (syncs)
     void need(bool cond, const char* what) { HOT_CHECK(cond, HOT_ERR_INVALID, what); }
 

@@ -307,14 +307,14 @@ static void mark_colors(Ctx<T>* ctx, Level<T>& L)
     ctx->sync();
 }
 
-// Regroup the slots of every row as [precede | diagonal | follow | structural zeros] w.r.t. the GS order (stable inside
-// each class).  One wavefront per row, the row is staged in LDS and rewritten in place.
+// Regroup the slots of every row as [precede-off | precede-in | diagonal | follow-in | follow-off | structural zeros]
+// w.r.t. the GS order ("in" = column inside the row's own 4^3 colour block), stable inside each class.  One wavefront
+// per row, the row is staged in LDS and rewritten in place.  rowcnt[4 i ..] = the four off-diagonal class sizes.
 template <class T>
-__global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col, T* __restrict__ val, const uint32_t* __restrict__ ckey, int32_t* __restrict__ rowcnt, int32_t* __restrict__ meta, int n)
+__global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col, T* __restrict__ val, const uint32_t* __restrict__ ckey, int32_t* __restrict__ rowcnt, int n)
 {
     __shared__ T sval[4][1125];
     __shared__ int32_t scol[4][125];
-    __shared__ int32_t smeta[4][125];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = blockIdx.x * 4 + w;
     const bool valid = i0 < n; // no early return: the workgroup barrier below must be reached by all four waves
@@ -322,12 +322,13 @@ __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col
     const uint32_t keyi = ckey[i];
     int32_t* c = col + (int64_t)i * 125;
     T* v = val + (int64_t)i * 1125;
+    constexpr int NCLS = 6; // 0 pre-off, 1 pre-in, 2 diagonal, 3 follow-in, 4 follow-off, 5 structural zero ; 6 = lane has no slot
     int cls[2], jj[2];
     T bv[2][9];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         int k = lane + 64 * r;
-        cls[r] = 4; // lane has no slot
+        cls[r] = NCLS;
         jj[r] = 0;
         if (k < 125 && valid) {
             jj[r] = c[k];
@@ -335,17 +336,20 @@ __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col
 #pragma unroll
             for (int e = 0; e < 9; ++e) bv[r][e] = v[k * 9 + e], nz = nz || bv[r][e] != (T)0;
             if (!nz)
-                cls[r] = 3;
+                cls[r] = 5;
             else if (jj[r] == i)
-                cls[r] = 1;
-            else
-                cls[r] = ckey[jj[r]] < keyi ? 0 : 2;
+                cls[r] = 2;
+            else {
+                const uint32_t keyj = ckey[jj[r]];
+                const bool in = (keyj >> 7) == (keyi >> 7);
+                cls[r] = keyj < keyi ? (in ? 1 : 0) : (in ? 3 : 4);
+            }
         }
     }
     // stable positions: class-major, then round, then lane
-    int cnt[4], base = 0, pos[2] = { 0, 0 };
+    int cnt[NCLS], base = 0, pos[2] = { 0, 0 };
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
+    for (int cc = 0; cc < NCLS; ++cc) {
         unsigned long long m0 = __ballot(cls[0] == cc), m1 = __ballot(cls[1] == cc);
         unsigned long long below = (1ULL << lane) - 1ULL;
         if (cls[0] == cc) pos[0] = base + __popcll(m0 & below);
@@ -355,10 +359,8 @@ __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        if (cls[r] < 4) {
+        if (cls[r] < NCLS) {
             scol[w][pos[r]] = jj[r];
-            uint32_t keyj = ckey[jj[r]];
-            smeta[w][pos[r]] = ((keyj >> 7) == (keyi >> 7) && jj[r] != i && (cls[r] == 0 || cls[r] == 2)) ? (-2 - ((int)(keyj & 127u) - 1)) : jj[r];
 #pragma unroll
             for (int e = 0; e < 9; ++e) sval[w][pos[r] * 9 + e] = bv[r][e];
         }
@@ -366,15 +368,15 @@ __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col
     __syncthreads();
     if (!valid) return;
     for (int e = lane; e < 1125; e += 64) v[e] = sval[w][e];
-    for (int k = lane; k < 125; k += 64) c[k] = scol[w][k], meta[(int64_t)i * 125 + k] = smeta[w][k];
-    if (lane == 0) rowcnt[2 * i] = cnt[0], rowcnt[2 * i + 1] = cnt[2];
+    for (int k = lane; k < 125; k += 64) c[k] = scol[w][k];
+    if (lane == 0) rowcnt[4 * i] = cnt[0], rowcnt[4 * i + 1] = cnt[1], rowcnt[4 * i + 2] = cnt[3], rowcnt[4 * i + 3] = cnt[4];
 }
 
 template <class T>
 static void split_rows(Ctx<T>* ctx, Level<T>& L)
 {
-    L.rowcnt.reserve(2 * (size_t)L.n), L.gsmeta.reserve(125 * (size_t)L.n);
-    HOT_LAUNCH(ctx, "gs_split_rows", k_gs_split_rows<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.ckey.p, L.rowcnt.p, L.gsmeta.p, L.n);
+    L.rowcnt.reserve(4 * (size_t)L.n);
+    HOT_LAUNCH(ctx, "gs_split_rows", k_gs_split_rows<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.ckey.p, L.rowcnt.p, L.n);
     L.split = true;
 }
 

@@ -245,212 +245,331 @@ __global__ __launch_bounds__(64) void k_gs_color(const int32_t* __restrict__ col
 }
 
 // Two-phase block GS (the production path; k_gs_color above is the simple reference kernel kept for A/B checks).
-// One 512-thread workgroup per 4^3-node block of the current colour:
-//   phase A (8 waves, bandwidth-bound): every wave streams whole matrix rows of the block (lane = stencil slot).
-//           Couplings to nodes OUTSIDE the block that precede the row in the sweep order are folded into
-//           s_i = rhs_i - sum A_ij x_j ; couplings INSIDE the block that precede it are copied into an LDS
-//           triangular array laid out by (column, row) so that phase B reads it conflict-free.
+// The reference sweeps the nodes of one 4^3 colour block sequentially (MultigridPreconditioner.h:266-318).  Here a
+// colour block is cut into 64/SB consecutive sub-blocks of SB nodes; sub-block h of every block of a colour is one
+// launch (one workgroup per block), launches ordered (colour, h).  Nodes of the same block that belong to an earlier
+// sub-block are final in global memory by then and are treated like any other preceding node, so the sequence of
+// updates each node sees is the reference's.  SB = 32 keeps the LDS footprint at 36 KB (fp64), several workgroups
+// per CU overlap their phases, and one launch fits the chip in a single round.
+//   phase A (all waves, bandwidth-bound): every wave streams the preceding half of whole matrix rows (rows are
+//           regrouped by k_gs_split_rows, lane = slot).  Couplings to nodes outside the sub-block are folded into
+//           s_i = rhs_i - sum A_ij x_j ; couplings inside it are copied into an LDS triangular array laid out by
+//           (column, row) so that phase B reads it conflict-free.
 //   phase B (1 wave, latency-bound but LDS/register only): right-looking block substitution, lane = row:
 //           step c: lane c finalises h_c = Dinv_c s_c, broadcasts it, every later row subtracts L[row][c] h_c.
-// The node order inside a block, the colour order and the predicate are exactly those of k_gs_color, i.e. the
-// reference's gs_smooth (MultigridPreconditioner.h:266-318); only the association order of the row sums differs.
-template <class T>
+// Only the association order of the row sums differs from k_gs_color.
+template <class T, int SB>
 struct GsLds {
-    static constexpr int TRI = 2017; // 64*63/2 ordered pairs + one always-zero entry (index 2016) for masked lanes
-    static constexpr size_t bytes = (size_t)9 * TRI * sizeof(T) + 64 * 3 * sizeof(T) + 64 * sizeof(int32_t);
+    static constexpr int TRI = SB * (SB - 1) / 2 + 1; // ordered pairs + one always-zero entry (last) for masked lanes
+    static constexpr size_t bytes = (size_t)9 * TRI * sizeof(T) + SB * 3 * sizeof(T) + SB * sizeof(int32_t);
 };
-__device__ __forceinline__ int gs_tri_fwd(int row, int colm) { return 63 * colm - (colm * (colm - 1)) / 2 + (row - colm - 1); } // row > colm
+template <int SB>
+__device__ __forceinline__ int gs_tri_fwd(int row, int colm) { return (SB - 1) * colm - (colm * (colm - 1)) / 2 + (row - colm - 1); } // row > colm
 __device__ __forceinline__ int gs_tri_bwd(int row, int colm) { return (colm * (colm - 1)) / 2 + row; } // row < colm
 
-template <class T, bool FWD>
+// The LDS triangle holds -(Dinv_i A_ij) and the right-hand sides Dinv_i s_i, so that the substitution phase is a pure
+// multiply-add chain: h_i = Dinv_i s_i + sum_j (-(Dinv_i A_ij)) h_j  (same value as Dinv_i (s_i - sum_j A_ij h_j) up to
+// the association of the 3x3 products).
+template <class T>
+__device__ __forceinline__ void gs_store_tri(T* tri, int TRI, int idx, const T* __restrict__ di, const T (&b)[9])
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) tri[(r + 3 * c) * TRI + idx] = -(di[r] * b[3 * c] + di[r + 3] * b[3 * c + 1] + di[r + 6] * b[3 * c + 2]);
+}
+template <class T>
+__device__ __forceinline__ void gs_store_rhs(T* sv, int ii, const T* __restrict__ di, T r0, T r1, T r2)
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) sv[ii * 3 + r] = di[r] * r0 + di[r + 3] * r1 + di[r + 6] * r2;
+}
+
+template <class T, bool FWD, int SB, bool WT = false>
+__device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int32_t* nodes, int cnt, int lane, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, T* x, T* hD);
+
+template <class T, bool FWD, int SB>
 __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
-    const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, int block0, int dbg,
-    const int32_t* __restrict__ rowcnt, const int32_t* __restrict__ meta)
+    const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, int block0, int sub,
+    const int32_t* __restrict__ rowcnt)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
-    constexpr int TRI = GsLds<T>::TRI;
+    constexpr int TRI = GsLds<T, SB>::TRI;
     T* tri = (T*)gs_smem; // [9][TRI]
-    T* sv = tri + 9 * TRI; // [64][3]
-    int32_t* nodes = (int32_t*)(sv + 192);
+    T* sv = tri + 9 * TRI; // [SB][3]
+    int32_t* nodes = (int32_t*)(sv + 3 * SB);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = block0 + blockIdx.x;
-    const int start = block_start[b], cnt = block_start[b + 1] - start;
+    const int dbg = sub >> 8; // timing experiments only (wrong results): 1 skip phase B, 2 skip phase A
+    sub &= 255;
+    const int lo = sub * SB; // first local index of this sub-block
+    const int start = block_start[b] + lo, cnt = min(SB, block_start[b + 1] - start);
+    if (cnt <= 0) return; // workgroup-uniform
     const int nthreads = blockDim.x, nwaves = blockDim.x >> 6;
-    if (!(dbg & 2)) for (int e = tid; e < 9 * TRI; e += nthreads) tri[e] = (T)0;
-    if (tid < 64) nodes[tid] = tid < cnt ? gs_order[start + tid] : -1;
+    for (int e = tid; e < 9 * TRI; e += nthreads) tri[e] = (T)0;
+    if (tid < SB) nodes[tid] = tid < cnt ? gs_order[start + tid] : -1;
     __syncthreads();
-    // ---------------- phase A, fast path for regrouped rows: every load of the (<= 4) rows of this wave is issued
-    // before any is used, and the precomputed slot descriptor (meta >= 0: column j outside the block, meta <= -2:
-    // local index -2-meta inside the block) removes the col -> ckey -> x dependent-load chain
-    if (rowcnt != nullptr && meta != nullptr) {
-        constexpr int RQ = 4;
-        for (int q0 = 0; q0 * nwaves < cnt; q0 += RQ) {
-            T bv[RQ][9];
-            int mm[RQ], kb[RQ], ke[RQ];
+    // ---------------- phase A: RQ rows of this wave are in flight at once (lane = slot of the needed half row)
+    constexpr int RQ = 2;
+    for (int t0 = 0; w + nwaves * t0 < cnt && !(dbg & 2); t0 += RQ) {
+        T bv[RQ][9];
+        int jj[RQ], rowi[RQ], kb[RQ], ke[RQ], ib[RQ], ie[RQ];
 #pragma unroll
-            for (int q = 0; q < RQ; ++q) {
-                const int ii = w + nwaves * (q0 + q);
-                mm[q] = -1, kb[q] = 0, ke[q] = 0;
+        for (int q = 0; q < RQ; ++q) {
+            const int ii = w + nwaves * (t0 + q);
+            rowi[q] = -1, jj[q] = -1, kb[q] = ke[q] = ib[q] = ie[q] = 0;
 #pragma unroll
-                for (int e = 0; e < 9; ++e) bv[q][e] = (T)0;
-                if (ii < cnt) {
-                    const int i = nodes[ii];
-                    const int nl = rowcnt[2 * i], nu = rowcnt[2 * i + 1];
-                    kb[q] = FWD ? 0 : nl + 1, ke[q] = FWD ? nl : nl + 1 + nu;
-                    const int k = kb[q] + lane;
-                    if (k < ke[q]) {
-                        mm[q] = meta[(int64_t)i * 125 + k];
-                        const T* bb = val + ((int64_t)i * 125 + k) * 9;
+            for (int e = 0; e < 9; ++e) bv[q][e] = (T)0;
+            if (ii < cnt) { // wave-uniform
+                const int i = __builtin_amdgcn_readfirstlane(nodes[ii]); // row id in an SGPR: its metadata loads are scalar
+                rowi[q] = i;
+                const int po = rowcnt[4 * i], pi = rowcnt[4 * i + 1], fi = rowcnt[4 * i + 2], fo = rowcnt[4 * i + 3];
+                const int kbeg = FWD ? 0 : po + pi + 1, kend = FWD ? po + pi : po + pi + 1 + fi + fo;
+                kb[q] = kbeg, ke[q] = kend, ib[q] = FWD ? po : kbeg, ie[q] = FWD ? po + pi : kbeg + fi;
+                // unconditional loads from a clamped slot: predicated loads made the compiler serialise the value loads
+                // behind s_waitcnt vmcnt(0); lanes past the range re-read its last slot and are dropped via jj < 0
+                const int k = kbeg + lane, kc = max(min(k, kend - 1), 0);
+                const int jl = col[(int64_t)i * 125 + kc];
+                const T* bb = val + ((int64_t)i * 125 + kc) * 9;
 #pragma unroll
-                        for (int e = 0; e < 9; ++e) bv[q][e] = bb[e];
-                    }
-                }
-            }
-            T xs[RQ][3];
-#pragma unroll
-            for (int q = 0; q < RQ; ++q) {
-                const int m = mm[q];
-                xs[q][0] = xs[q][1] = xs[q][2] = (T)0;
-                if (m >= 0) xs[q][0] = x[3 * (int64_t)m], xs[q][1] = x[3 * (int64_t)m + 1], xs[q][2] = x[3 * (int64_t)m + 2];
-            }
-#pragma unroll
-            for (int q = 0; q < RQ; ++q) {
-                const int ii = w + nwaves * (q0 + q);
-                if (ii >= cnt) continue; // wave-uniform
-                const int i = nodes[ii];
-                T s0 = bv[q][0] * xs[q][0] + bv[q][3] * xs[q][1] + bv[q][6] * xs[q][2];
-                T s1 = bv[q][1] * xs[q][0] + bv[q][4] * xs[q][1] + bv[q][7] * xs[q][2];
-                T s2 = bv[q][2] * xs[q][0] + bv[q][5] * xs[q][1] + bv[q][8] * xs[q][2];
-                if (mm[q] <= -2) {
-                    const int lj = -2 - mm[q];
-                    const int idx = FWD ? gs_tri_fwd(ii, lj) : gs_tri_bwd(ii, lj);
-#pragma unroll
-                    for (int e = 0; e < 9; ++e) tri[e * TRI + idx] = bv[q][e];
-                }
-                // half rows longer than one wave (cannot happen for interior 4^3 blocks): plain strided tail
-                for (int k = kb[q] + 64 + lane; k < ke[q]; k += 64) {
-                    const int m = meta[(int64_t)i * 125 + k];
-                    const T* bb = val + ((int64_t)i * 125 + k) * 9;
-                    if (m >= 0) {
-                        T x0 = x[3 * (int64_t)m], x1 = x[3 * (int64_t)m + 1], x2 = x[3 * (int64_t)m + 2];
-                        s0 += bb[0] * x0 + bb[3] * x1 + bb[6] * x2;
-                        s1 += bb[1] * x0 + bb[4] * x1 + bb[7] * x2;
-                        s2 += bb[2] * x0 + bb[5] * x1 + bb[8] * x2;
-                    }
-                    else if (m <= -2) {
-                        const int lj = -2 - m;
-                        const int idx = FWD ? gs_tri_fwd(ii, lj) : gs_tri_bwd(ii, lj);
-#pragma unroll
-                        for (int e = 0; e < 9; ++e) tri[e * TRI + idx] = bb[e];
-                    }
-                }
-                s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
-                if (lane == 0) sv[ii * 3] = rhs[3 * (int64_t)i] - s0, sv[ii * 3 + 1] = rhs[3 * (int64_t)i + 1] - s1, sv[ii * 3 + 2] = rhs[3 * (int64_t)i + 2] - s2;
+                for (int e = 0; e < 9; ++e) bv[q][e] = bb[e];
+                jj[q] = k < kend ? jl : -1;
             }
         }
-    }
-    else
-    // ---------------- phase A, generic path (rows in any slot order, predicate on the packed key)
-    for (int ii = w; ii < cnt; ii += nwaves) {
-        const int i = nodes[ii];
-        const uint32_t keyi = ckey[i];
-        const int32_t* c = col + (int64_t)i * 125;
-        const T* v = val + (int64_t)i * 1125;
-        T s0 = 0, s1 = 0, s2 = 0;
-        // issue every load of the row up front (both slot rounds): the 3x3 blocks do not depend on the
-        // col -> ckey -> x chain, so the whole row (9 KB per wave) is in flight at once
-        T bv[2][9];
-        int jj[2];
-        // rows regrouped by k_gs_split_rows: the forward sweep needs slots [0, nl), the backward sweep
-        // [nl + 1, nl + 1 + nu); without the split every slot is visited and filtered by the key predicate
-        int kbeg = 0, kend = 125;
-        if (rowcnt) {
-            int nl = rowcnt[2 * i], nu = rowcnt[2 * i + 1];
-            kbeg = FWD ? 0 : nl + 1, kend = FWD ? nl : nl + 1 + nu;
-        }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            int k = kbeg + lane + 64 * r;
-            jj[r] = k < kend ? c[k] : -1;
+        for (int q = 0; q < RQ; ++q) {
+            const int i = rowi[q], ii = w + nwaves * (t0 + q);
+            if (i < 0) continue; // wave-uniform
+            T di[9];
 #pragma unroll
-            for (int e = 0; e < 9; ++e) bv[r][e] = k < kend ? v[k * 9 + e] : (T)0;
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            int j = jj[r];
-            if (j >= 0) {
-                uint32_t keyj = ckey[j];
-                bool take = FWD ? (keyj < keyi) : (keyj > keyi);
-                if (take) {
-                    if ((keyj >> 7) == (keyi >> 7)) {
-                        int lj = (int)(keyj & 127u) - 1;
-                        int idx = FWD ? gs_tri_fwd(ii, lj) : gs_tri_bwd(ii, lj);
-                        // padded slots alias column 0/1 with an all-zero block (SquareMatrix.h:563-566): they must not
-                        // overwrite the real (row, column) entry, so only non-zero blocks are stored
-                        bool nz = false;
-#pragma unroll
-                        for (int e = 0; e < 9; ++e) nz = nz || bv[r][e] != (T)0;
-                        if (nz) {
-#pragma unroll
-                            for (int e = 0; e < 9; ++e) tri[e * TRI + idx] = bv[r][e];
-                        }
-                    }
-                    else {
-                        T x0 = x[3 * (int64_t)j], x1 = x[3 * (int64_t)j + 1], x2 = x[3 * (int64_t)j + 2];
-                        s0 += bv[r][0] * x0 + bv[r][3] * x1 + bv[r][6] * x2;
-                        s1 += bv[r][1] * x0 + bv[r][4] * x1 + bv[r][7] * x2;
-                        s2 += bv[r][2] * x0 + bv[r][5] * x1 + bv[r][8] * x2;
-                    }
+            for (int e = 0; e < 9; ++e) di[e] = diagBlockInv[9 * (int64_t)i + e];
+            T s0 = 0, s1 = 0, s2 = 0;
+            // couplings inside the sub-block go to the LDS triangle (the in-block slots of a regrouped row hold only
+            // non-zero blocks, so the padded alias slots of SquareMatrix.h:563-566 cannot clobber an entry), the rest
+            // is folded into the row sum
+            auto entry = [&](int k, int j, const T (&b9)[9]) {
+                int lj = -1;
+                if (k >= ib[q] && k < ie[q]) {
+                    const int l = (int)(ckey[j] & 127u) - 1 - lo;
+                    if (l >= 0 && l < SB) lj = l;
                 }
+                if (lj >= 0)
+                    gs_store_tri<T>(tri, TRI, FWD ? gs_tri_fwd<SB>(ii, lj) : gs_tri_bwd(ii, lj), di, b9);
+                else {
+                    const T x0 = x[3 * (int64_t)j], x1 = x[3 * (int64_t)j + 1], x2 = x[3 * (int64_t)j + 2];
+                    s0 += b9[0] * x0 + b9[3] * x1 + b9[6] * x2;
+                    s1 += b9[1] * x0 + b9[4] * x1 + b9[7] * x2;
+                    s2 += b9[2] * x0 + b9[5] * x1 + b9[8] * x2;
+                }
+            };
+            if (jj[q] >= 0) entry(kb[q] + lane, jj[q], bv[q]);
+            for (int k = kb[q] + 64 + lane; k < ke[q]; k += 64) { // half rows longer than one wave: boundary-free interior rows never are
+                T bt[9];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) bt[e] = val[((int64_t)i * 125 + k) * 9 + e];
+                entry(k, col[(int64_t)i * 125 + k], bt);
             }
-        }
-        s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
-        if (lane == 0) {
-            sv[ii * 3] = rhs[3 * (int64_t)i] - s0, sv[ii * 3 + 1] = rhs[3 * (int64_t)i + 1] - s1, sv[ii * 3 + 2] = rhs[3 * (int64_t)i + 2] - s2;
+            s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
+            if (lane == 0) gs_store_rhs<T>(sv, ii, di, rhs[3 * (int64_t)i] - s0, rhs[3 * (int64_t)i + 1] - s1, rhs[3 * (int64_t)i + 2] - s2);
         }
     }
     __syncthreads();
     if (w != 0 || (dbg & 1)) return;
-    // ---------------- phase B: lane = row
+    gs_phase_b<T, FWD, SB>(tri, sv, nodes, cnt, lane, diagVal, diagBlockInv, x, hD);
+}
+
+// ---------------- phase B of the block GS kernels: lane = row, executed by one wavefront.  WT: publish x with
+// write-through (sc1) stores so that other workgroups of the same launch can read it with sc1 loads
+template <class T, bool FWD, int SB, bool WT>
+__device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int32_t* nodes, int cnt, int lane, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, T* x, T* hD)
+{
+    constexpr int TRI = GsLds<T, SB>::TRI;
     const int me = lane;
     const int i = me < cnt ? nodes[me] : -1;
-    T d[9];
-#pragma unroll
-    for (int e = 0; e < 9; ++e) d[e] = i >= 0 ? diagBlockInv[9 * (int64_t)i + e] : (T)0;
     T a0 = me < cnt ? sv[me * 3] : (T)0, a1 = me < cnt ? sv[me * 3 + 1] : (T)0, a2 = me < cnt ? sv[me * 3 + 2] : (T)0;
-    T h0 = 0, h1 = 0, h2 = 0;
-    // column `cidx` of the in-block triangle for this lane's row (zero where the row does not follow the column);
-    // the next column is fetched from LDS while the current step's dependent arithmetic runs
+    // column `cidx` of the triangle for this lane's row (zero where the row does not follow the column); the next
+    // column is fetched from LDS while the current step's dependent arithmetic runs
     auto load_col = [&](int cidx, T (&L)[9]) {
         bool act = FWD ? (me > cidx && me < cnt) : (me < cidx);
-        int idx = act ? (FWD ? gs_tri_fwd(me, cidx) : gs_tri_bwd(me, cidx)) : TRI - 1; // masked lanes read the zero entry
+        int idx = act ? (FWD ? gs_tri_fwd<SB>(me, cidx) : gs_tri_bwd(me, cidx)) : TRI - 1; // masked lanes read the zero entry
 #pragma unroll
         for (int e = 0; e < 9; ++e) L[e] = tri[e * TRI + idx];
     };
-    T Lc[9], Ln[9];
-    if (cnt > 0) load_col(FWD ? 0 : cnt - 1, Lc);
-    for (int s = 0; s < cnt; ++s) {
-        const int cidx = FWD ? s : cnt - 1 - s;
-        if (s + 1 < cnt) load_col(FWD ? s + 1 : cnt - 2 - s, Ln);
-        // candidate solution of every row from its current partial sum; only lane cidx's is final
-        T c0 = d[0] * a0 + d[3] * a1 + d[6] * a2, c1 = d[1] * a0 + d[4] * a1 + d[7] * a2, c2 = d[2] * a0 + d[5] * a1 + d[8] * a2;
-        if (me == cidx) h0 = c0, h1 = c1, h2 = c2;
-        T b0 = lane_bcast(c0, cidx), b1 = lane_bcast(c1, cidx), b2 = lane_bcast(c2, cidx); // v_readlane: cidx is wave-uniform
-        a0 -= Lc[0] * b0 + Lc[3] * b1 + Lc[6] * b2;
-        a1 -= Lc[1] * b0 + Lc[4] * b1 + Lc[7] * b2;
-        a2 -= Lc[2] * b0 + Lc[5] * b1 + Lc[8] * b2;
+    // step: row cidx is final (every earlier column has been applied); broadcast it and apply its column
+    auto step = [&](int cidx, const T (&L)[9]) {
+        T b0 = lane_bcast(a0, cidx), b1 = lane_bcast(a1, cidx), b2 = lane_bcast(a2, cidx); // v_readlane: cidx is wave-uniform
+        a0 = fma(L[0], b0, a0), a1 = fma(L[1], b0, a1), a2 = fma(L[2], b0, a2);
+        a0 = fma(L[3], b1, a0), a1 = fma(L[4], b1, a1), a2 = fma(L[5], b1, a2);
+        a0 = fma(L[6], b2, a0), a1 = fma(L[7], b2, a1), a2 = fma(L[8], b2, a2);
+    };
+    auto colof = [&](int s) { return FWD ? s : cnt - 1 - s; };
+    T LA[9], LB[9];
+    if (cnt > 0) load_col(colof(0), LA);
+    int s = 0;
+    for (; s + 1 < cnt; s += 2) { // two steps per trip: the column buffers alternate without register copies
+        load_col(colof(s + 1), LB);
+        step(colof(s), LA);
+        if (s + 2 < cnt) load_col(colof(s + 2), LA);
+        step(colof(s + 1), LB);
+    }
+    if (s < cnt) step(colof(s), LA);
+    const T h0 = a0, h1 = a1, h2 = a2;
+    T dd[9]; // D_i for hD = D h (forward sweep only); loaded here, not before the loop, to keep the kernel under 80
+             // VGPRs (three 512-thread workgroups per CU, i.e. one round per launch on the finest level)
+    if (FWD) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e) Lc[e] = Ln[e];
+        for (int e = 0; e < 9; ++e) dd[e] = i >= 0 ? diagVal[9 * (int64_t)i + e] : (T)0;
     }
     if (i >= 0) {
-        x[3 * (int64_t)i] = h0, x[3 * (int64_t)i + 1] = h1, x[3 * (int64_t)i + 2] = h2;
+        if (WT) {
+            __hip_atomic_store(x + 3 * (int64_t)i, h0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(x + 3 * (int64_t)i + 1, h1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(x + 3 * (int64_t)i + 2, h2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        else
+            x[3 * (int64_t)i] = h0, x[3 * (int64_t)i + 1] = h1, x[3 * (int64_t)i + 2] = h2;
         if (FWD) {
-            const T* dd = diagVal + 9 * (int64_t)i;
             hD[3 * (int64_t)i] = dd[0] * h0 + dd[3] * h1 + dd[6] * h2;
             hD[3 * (int64_t)i + 1] = dd[1] * h0 + dd[4] * h1 + dd[7] * h2;
             hD[3 * (int64_t)i + 2] = dd[2] * h0 + dd[5] * h1 + dd[8] * h2;
         }
     }
+}
+
+// A whole half sweep (all colours, all sub-blocks) in ONE launch.  Workgroups are ordered by pass = (colour, sub-block)
+// in sweep order; a workgroup of pass p
+//   1. streams the preceding half of its rows into registers and files the in-sub-block couplings into the LDS
+//      triangle — none of this depends on the unknowns, so it overlaps with the substitution phase of pass p-1;
+//   2. waits until every workgroup of pass p-1 has published its nodes (device-scope counter, acquire);
+//   3. gathers x, reduces the row sums, runs phase B, publishes (release + counter increment).
+// Progress: workgroups are dispatched in index order (per XCD), so every workgroup of the lowest unfinished pass is
+// resident and waits on nothing; the spin is bounded anyway and reports through `err` instead of hanging.
+struct GsPasses {
+    int npass;
+    int wg_begin[34]; // first workgroup of pass p ; wg_begin[npass] = grid size
+    int block0[33]; // first colour block of the pass
+    int sub[33]; // sub-block index of the pass
+};
+
+template <class T, bool FWD, int SB>
+__global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
+    const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, GsPasses P,
+    const int32_t* __restrict__ rowcnt, int* done, int* err)
+{
+    extern __shared__ __attribute__((aligned(16))) char gs_smem[];
+    constexpr int TRI = GsLds<T, SB>::TRI;
+    constexpr int RQ = 4, NW = SB / RQ; // rows per wave, waves per workgroup (blockDim.x == 64 * NW)
+    T* tri = (T*)gs_smem; // [9][TRI]
+    T* sv = tri + 9 * TRI; // [SB][3]
+    int32_t* nodes = (int32_t*)(sv + 3 * SB);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int p = 0;
+    while (p + 1 < P.npass && (int)blockIdx.x >= P.wg_begin[p + 1]) ++p;
+    const int b = P.block0[p] + ((int)blockIdx.x - P.wg_begin[p]);
+    const int lo = P.sub[p] * SB;
+    const int start = block_start[b] + lo, cnt = max(0, min(SB, block_start[b + 1] - start));
+    for (int e = tid; e < 9 * TRI; e += 64 * NW) tri[e] = (T)0;
+    if (tid < SB) nodes[tid] = tid < cnt ? gs_order[start + tid] : -1;
+    __syncthreads();
+    // ---- 1. stream the half rows (lane = slot), keep what couples to nodes outside the sub-block
+    T bv[RQ][9];
+    int jj[RQ], node[RQ], kb2[RQ], ke[RQ];
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+        const int ii = w + NW * q;
+        jj[q] = -1, node[q] = -1, kb2[q] = 0, ke[q] = 0;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) bv[q][e] = (T)0;
+        if (ii < cnt) {
+            const int i = nodes[ii];
+            node[q] = i;
+            const int po = rowcnt[4 * i], pi = rowcnt[4 * i + 1], fi = rowcnt[4 * i + 2], fo = rowcnt[4 * i + 3];
+            const int kbeg = FWD ? 0 : po + pi + 1, kend = FWD ? po + pi : po + pi + 1 + fi + fo;
+            const int ibeg = FWD ? po : kbeg, iend = FWD ? po + pi : kbeg + fi;
+            kb2[q] = kbeg + 64, ke[q] = kend;
+            const int k = kbeg + lane;
+            if (k < kend) {
+                const int j = col[(int64_t)i * 125 + k];
+                const T* bb = val + ((int64_t)i * 125 + k) * 9;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) bv[q][e] = bb[e];
+                jj[q] = j;
+                if (k >= ibeg && k < iend) {
+                    const int l = (int)(ckey[j] & 127u) - 1 - lo;
+                    if (l >= 0 && l < SB) {
+                        const int idx = FWD ? gs_tri_fwd<SB>(ii, l) : gs_tri_bwd(ii, l);
+                        gs_store_tri<T>(tri, TRI, idx, diagBlockInv + 9 * (int64_t)i, bv[q]);
+                        jj[q] = -1;
+                    }
+                }
+            }
+        }
+    }
+    // ---- 2. wait for the previous pass
+    if (p > 0) {
+        if (tid == 0) {
+            const int need = P.wg_begin[p] - P.wg_begin[p - 1];
+            int spins = 0;
+            while (__hip_atomic_load(done + p - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(16);
+                ++spins;
+                if ((spins & 1023) == 0 && *(volatile int*)err) break; // some workgroup already gave up: drain quickly
+                if (spins > (1 << 20)) {
+                    *(volatile int*)err = 1;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // x of other workgroups was published with write-through stores and is read with sc1 loads below: no cache
+    // maintenance (buffer_wbl2 / buffer_inv) on either side
+    // ---- 3. row sums against the now final unknowns
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+        const int ii = w + NW * q;
+        if (ii >= cnt) continue; // wave-uniform
+        const int i = node[q];
+        T s0 = 0, s1 = 0, s2 = 0;
+        if (jj[q] >= 0) {
+            const int64_t j = jj[q];
+            const T x0 = __hip_atomic_load(x + 3 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(x + 3 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                    x2 = __hip_atomic_load(x + 3 * j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s0 = bv[q][0] * x0 + bv[q][3] * x1 + bv[q][6] * x2;
+            s1 = bv[q][1] * x0 + bv[q][4] * x1 + bv[q][7] * x2;
+            s2 = bv[q][2] * x0 + bv[q][5] * x1 + bv[q][8] * x2;
+        }
+        // half rows longer than one wave (boundary-free interior rows never are): plain strided tail; the in-block
+        // slots come first (FWD: last) in the range, so the tail may still hold sub-block couplings
+        for (int k = kb2[q] + lane; k < ke[q]; k += 64) {
+            const int j = col[(int64_t)i * 125 + k];
+            const T* bb = val + ((int64_t)i * 125 + k) * 9;
+            const uint32_t keyj = ckey[j], keyi = ckey[i];
+            const int l = (int)(keyj & 127u) - 1 - lo;
+            if ((keyj >> 7) == (keyi >> 7) && l >= 0 && l < SB) {
+                const int idx = FWD ? gs_tri_fwd<SB>(ii, l) : gs_tri_bwd(ii, l);
+                T bt[9];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) bt[e] = bb[e];
+                gs_store_tri<T>(tri, TRI, idx, diagBlockInv + 9 * (int64_t)i, bt);
+            }
+            else {
+                const T x0 = __hip_atomic_load(x + 3 * (int64_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(x + 3 * (int64_t)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                        x2 = __hip_atomic_load(x + 3 * (int64_t)j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s0 += bb[0] * x0 + bb[3] * x1 + bb[6] * x2;
+                s1 += bb[1] * x0 + bb[4] * x1 + bb[7] * x2;
+                s2 += bb[2] * x0 + bb[5] * x1 + bb[8] * x2;
+            }
+        }
+        s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
+        if (lane == 0) gs_store_rhs<T>(sv, ii, diagBlockInv + 9 * (int64_t)i, rhs[3 * (int64_t)i] - s0, rhs[3 * (int64_t)i + 1] - s1, rhs[3 * (int64_t)i + 2] - s2);
+    }
+    __syncthreads();
+    if (w != 0) return;
+    if (cnt > 0) gs_phase_b<T, FWD, SB, true>(tri, sv, nodes, cnt, lane, diagVal, diagBlockInv, x, hD);
+    // ---- publish: the write-through stores of every lane have left the CU before lane 0 bumps the pass counter
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(done + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // r_i = sum over the nl slots preceding row i of A_ik (h - du)_k   (rows regrouped by k_gs_split_rows)
@@ -461,7 +580,7 @@ __global__ __launch_bounds__(256) void k_gs_residual(const int32_t* __restrict__
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
-    const int nl = rowcnt[2 * row];
+    const int nl = rowcnt[4 * row] + rowcnt[4 * row + 1];
     const int32_t* c = col + (int64_t)row * 125;
     const T* v = val + (int64_t)row * 1125;
     T s0 = 0, s1 = 0, s2 = 0;
@@ -557,39 +676,118 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         HOT_CHECK(L.nblocks > 0, HOT_ERR_INVALID, "GS smoother requested but the level was built without colouring");
         T* hdu = L.tmp.p;
         static const bool simple_gs = getenv("HOT_SIMPLE_GS") != nullptr; // A/B switch: one-wave-per-block reference kernel
-        static const int gs_threads = getenv("HOT_GS_THREADS") ? atoi(getenv("HOT_GS_THREADS")) : 1024;
-        static const bool no_meta = getenv("HOT_GS_NO_META") != nullptr; // A/B switch: generic phase A on split rows
+        static const int env_threads = getenv("HOT_GS_THREADS") ? atoi(getenv("HOT_GS_THREADS")) : 0;
+        static const int env_sb = getenv("HOT_GS_SB") ? atoi(getenv("HOT_GS_SB")) : 0; // sub-block size 16 / 32 / 64
         static const bool no_lres = getenv("HOT_GS_FULL_RESIDUAL") != nullptr; // A/B switch: r -= A du by a full SpMV
         static const int gs_dbg = getenv("HOT_GS_DBG") ? atoi(getenv("HOT_GS_DBG")) : 0; // timing experiments only (wrong results)
         static bool attr_set = false;
         if (!attr_set) {
-            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T>::bytes));
-            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T>::bytes));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
             attr_set = true;
         }
+        // sub-block size: levels whose colours hold more blocks than the chip has CUs run half blocks (36 KB LDS, 4
+        // workgroups per CU, one round per launch); small levels are latency-bound per launch and keep whole blocks
+        int max_nb = 0;
+        for (int c = 0; c < 8; ++c) max_nb = std::max(max_nb, L.color_block_begin[c + 1] - L.color_block_begin[c]);
+        const int sb = env_sb ? env_sb : (max_nb > 256 ? 32 : 64);
+        const int gs_threads = env_threads ? env_threads : (sb == 64 ? 1024 : 512);
+        const int nsub = 64 / sb;
+        HOT_CHECK(L.split || simple_gs, HOT_ERR_INVALID, "block GS kernels need the regrouped rows (k_gs_split_rows)");
+        const int32_t* rc = L.rowcnt.p;
+        auto pass = [&](bool fwd, int c, int h) {
+            int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
+            if (nb <= 0) return;
+            const char* nm = fwd ? "gs_forward" : "gs_backward";
+            const T* rhs = fwd ? r : dAu;
+            T* xx = fwd ? hdu : du;
+            T* hD = fwd ? dAu : (T*)nullptr;
+            if (simple_gs) {
+                if (h != 0) return;
+                if (fwd)
+                    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_color<T, true>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, b0, nb);
+                else
+                    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_color<T, false>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, b0, nb);
+                return;
+            }
+#define HOT_GS_CASE(F, S)                                                                                                                                      \
+    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_block<T, F, S>), nb, gs_threads, (GsLds<T, S>::bytes), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
+        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, b0, h | (gs_dbg << 8), rc)
+            if (fwd) {
+                if (sb == 64) HOT_GS_CASE(true, 64);
+                else if (sb == 32) HOT_GS_CASE(true, 32);
+                else HOT_GS_CASE(true, 16);
+            }
+            else {
+                if (sb == 64) HOT_GS_CASE(false, 64);
+                else if (sb == 32) HOT_GS_CASE(false, 32);
+                else HOT_GS_CASE(false, 16);
+            }
+#undef HOT_GS_CASE
+        };
+        HOT_CHECK(sb == 16 || sb == 32 || sb == 64, HOT_ERR_INVALID, "HOT_GS_SB must be 16, 32 or 64");
+        // one launch per half sweep (k_gs_sweep, passes chained by device-scope counters) unless the A/B switches ask
+        // for one launch per pass
+        static const bool multilaunch = getenv("HOT_GS_MULTILAUNCH") != nullptr;
+        static const bool force_dataflow = getenv("HOT_GS_DATAFLOW") != nullptr;
+        // measured (C2, fp64): the chained launch wins on levels whose colours fit the chip in one round (latency-bound
+        // passes, no launch gaps); on the finest level the waiting workgroups cost more than the kernel boundaries
+        const bool dataflow = !multilaunch && !simple_gs && L.split && !gs_dbg && (force_dataflow || max_nb <= 256);
+        GsPasses PF{}, PB{};
+        if (dataflow) {
+            auto add = [&](GsPasses& P, int c, int h) {
+                int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
+                if (nb <= 0) return;
+                P.block0[P.npass] = b0, P.sub[P.npass] = h, P.wg_begin[P.npass + 1] = P.wg_begin[P.npass] + nb;
+                ++P.npass;
+            };
+            for (int c = 0; c < 8; ++c)
+                for (int h = 0; h < nsub; ++h) add(PF, c, h);
+            for (int c = 7; c >= 0; --c)
+                for (int h = nsub - 1; h >= 0; --h) add(PB, c, h);
+            gs_done.reserve(64);
+        }
+        auto sweep = [&](bool fwd) {
+            const GsPasses& P = fwd ? PF : PB;
+            if (P.npass == 0) return;
+            const char* nm = fwd ? "gs_forward" : "gs_backward";
+            const T* rhs = fwd ? r : dAu;
+            T* xx = fwd ? hdu : du;
+            T* hD = fwd ? dAu : (T*)nullptr;
+            HOT_HIP(hipMemsetAsync(gs_done.p, 0, 40 * sizeof(int), stream));
+            const int grid = P.wg_begin[P.npass];
+#define HOT_GS_CASE(F, S)                                                                                                                                              \
+    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_sweep<T, F, S>), grid, 16 * S, (GsLds<T, S>::bytes), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
+        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, P, rc, gs_done.p, (int*)(hscal + 250))
+            if (fwd) {
+                if (sb == 64) HOT_GS_CASE(true, 64);
+                else if (sb == 32) HOT_GS_CASE(true, 32);
+                else HOT_GS_CASE(true, 16);
+            }
+            else {
+                if (sb == 64) HOT_GS_CASE(false, 64);
+                else if (sb == 32) HOT_GS_CASE(false, 32);
+                else HOT_GS_CASE(false, 16);
+            }
+#undef HOT_GS_CASE
+        };
         iterations = ((iterations + 1) >> 1);
         for (; iterations--;) {
             zero(n3, hdu);
-            for (int c = 0; c < 8; ++c) {
-                int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
-                if (nb > 0) {
-                    if (simple_gs)
-                        HOT_LAUNCH(this, lname("gs_forward", L.id).c_str(), (k_gs_color<T, true>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0, nb);
-                    else
-                        HOT_LAUNCH(this, lname("gs_forward", L.id).c_str(), (k_gs_block<T, true>), nb, gs_threads, GsLds<T>::bytes, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, r, hdu, dAu, b0, gs_dbg, L.split ? L.rowcnt.p : (const int32_t*)nullptr, (L.split && !no_meta) ? L.gsmeta.p : (const int32_t*)nullptr);
-                }
-            }
+            if (dataflow)
+                sweep(true);
+            else
+                for (int c = 0; c < 8; ++c)
+                    for (int h = 0; h < nsub; ++h) pass(true, c, h);
             // dAu now holds D h ; du = backward solve
             zero(n3, du);
-            for (int c = 7; c >= 0; --c) {
-                int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
-                if (nb > 0) {
-                    if (simple_gs)
-                        HOT_LAUNCH(this, lname("gs_backward", L.id).c_str(), (k_gs_color<T, false>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0, nb);
-                    else
-                        HOT_LAUNCH(this, lname("gs_backward", L.id).c_str(), (k_gs_block<T, false>), nb, gs_threads, GsLds<T>::bytes, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, dAu, du, (T*)nullptr, b0, gs_dbg, L.split ? L.rowcnt.p : (const int32_t*)nullptr, (L.split && !no_meta) ? L.gsmeta.p : (const int32_t*)nullptr);
-                }
-            }
+            if (dataflow)
+                sweep(false);
+            else
+                for (int c = 7; c >= 0; --c)
+                    for (int h = nsub - 1; h >= 0; --h) pass(false, c, h);
             axpy(n3, (T)1, du, u);
             if (L.split && !simple_gs && !(level == 0 && !cfg.systemBCProject) && !no_lres) {
                 // r - A du = L (h - du): with (D+L) h = r and (D+U) du = D h the full product A du collapses to the

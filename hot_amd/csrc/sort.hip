@@ -230,6 +230,7 @@ Ctx<T>::Ctx(const hot_config& c)
     keep_debug = c.debug_store != 0;
     dscal.reserve(256);
     HOT_HIP(hipHostMalloc((void**)&hscal, 256 * sizeof(double)));
+    std::memset(hscal, 0, 256 * sizeof(double)); // hscal[250] doubles as the device-written k_gs_sweep wait-timeout flag
     std::memset(&stats, 0, sizeof(stats));
 }
 template <class T>
