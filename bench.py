@@ -28,7 +28,8 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
 
 SYMBOL = {  # profile-record prefix -> device symbol as rocprofv3 names it
-    "gs_forward": "hot::k_gs_block<T,true>", "gs_backward": "hot::k_gs_block<T,false>", "spmv": "hot::k_spmv<T>",
+    "gs_forward": "hot::k_gs_block<T,true,32>", "gs_backward": "hot::k_gs_block<T,false,32>", "spmv": "hot::k_spmv<T>",
+    "gs_forward_chained": "hot::k_gs_sweep<T,true,64>", "gs_backward_chained": "hot::k_gs_sweep<T,false,64>",
     "gs_residual": "hot::k_gs_residual<T>", "hessian_assemble": "hot::k_hessian_tiles<T>", "state_update": "hot::k_state<T>",
     "force_scatter": "hot::k_force_scatter<T>", "p2g": "hot::k_p2g<T,true>", "g2p": "hot::k_g2p<T,0>",
 }
@@ -176,11 +177,14 @@ def main():
         groups = {}
         for name, rec in table.items():
             base = name.rpartition("_L")[0] if name.rpartition("_L")[2].isdigit() else name
+            sweeps = table.get("gs_symsweeps_L" + name.rpartition("_L")[2])
+            lph = rec["calls"] / sweeps["calls"] if sweeps and base in ("gs_forward", "gs_backward") else 8.0  # launches per half sweep
+            if base in ("gs_forward", "gs_backward") and lph < 1.5:
+                base += "_chained"  # coarse levels: the whole half sweep is one k_gs_sweep launch (a different device symbol)
             g = groups.setdefault(base, dict(ms=0.0, calls=0, bytes=0.0, modelled=True, records={}))
             g["ms"] += rec["total_ms"]
             g["calls"] += rec["calls"]
-            sweeps = table.get("gs_residual_L" + name.rpartition("_L")[2])
-            ab = algorithmic_bytes(name, s, Np, levels, rec["calls"] / sweeps["calls"] if sweeps and name.startswith("gs_") else 8.0)
+            ab = algorithmic_bytes(name, s, Np, levels, lph)
             if ab is None:
                 g["modelled"] = False
             else:

@@ -108,6 +108,22 @@ __global__ void k_hash_clear3(HashMap h)
     h.id[i] = -1;
 }
 
+// groups start on cell boundaries: the first cell of group g is the cell whose first particle is group_first[g]
+__global__ void k_group_cell0(const int32_t* __restrict__ group_first, const int32_t* __restrict__ cell_first, int32_t* group_cell0, int ng, int ncell)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > ng) return;
+    int target = group_first[g], lo = 0, hi = ncell; // cell_first[lo] <= target ; cell_first[ncell] = Np
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (cell_first[mid] <= target)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    group_cell0[g] = g == ng ? ncell : lo;
+}
+
 template <class T>
 void Ctx<T>::build_cell_table()
 {
@@ -123,16 +139,20 @@ void Ctx<T>::build_cell_table()
     cell_map.keys = ch_keys.p, cell_map.minrank = ch_rank.p, cell_map.id = ch_id.p, cell_map.mask = cap - 1;
     HOT_LAUNCH(this, "hash_clear", k_hash_clear3, div_up(cap, 256), 256, 0, cell_map);
     HOT_LAUNCH(this, "cell_fill", k_cell_fill, div_up(n, 256), 256, 0, keys2.p, flags.p, scan.p, cell_first.p, cell_map, n, Ncell, index_bits);
+    group_cell0.reserve(Ng + 1);
+    HOT_LAUNCH(this, "group_cell0", k_group_cell0, div_up(Ng + 1, 256), 256, 0, group_first.p, cell_first.p, group_cell0.p, Ng, Ncell);
 }
+
+constexpr int HT_THREADS = 1024; // one workgroup per CU (the LDS tile), so the workgroup itself must supply the waves
 
 template <class T>
 struct TileLds {
     static constexpr int CH = 64; // particles per chunk
-    static constexpr size_t bytes = (size_t)8 * 1125 * sizeof(T) /*tile*/ + (size_t)CH * 45 * sizeof(T) /*dP*/ + (size_t)CH * 81 * sizeof(T) /*g*/ + (64 + 65 + 8 + CH * 3 + CH * 8 + 4 + CH) * sizeof(int32_t);
+    static constexpr size_t bytes = (size_t)8 * 1125 * sizeof(T) /*tile*/ + (size_t)CH * 45 * sizeof(T) /*dP*/ + (size_t)CH * 81 * sizeof(T) /*g*/ + (64 + 65 + 8 + CH * 3 + CH * 8 + 4 + CH + 67) * sizeof(int32_t) + (size_t)CH * 12 * sizeof(T);
 };
 
 template <class T>
-__global__ __launch_bounds__(256) void k_hessian_tiles(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ dp, int64_t Np, const uint64_t* __restrict__ blocks,
+__global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ dp, int64_t Np, const uint64_t* __restrict__ blocks,
     const int32_t* __restrict__ gIdx, const int32_t* __restrict__ cell_first, HashMap cmap, const T* __restrict__ mass, T* __restrict__ val, T one_over_dx)
 {
     using G = Geo<T>;
@@ -149,6 +169,8 @@ __global__ __launch_bounds__(256) void k_hessian_tiles(const T* __restrict__ X, 
     int32_t* items = pbase + CH * 3; // [CH*8] packed (particle-in-chunk << 3 | row)
     int32_t* nitems = items + CH * 8;
     int32_t* pidx = nitems + 4; // [CH] global particle index of each chunk member
+    int32_t* segs = pidx + CH; // [64] cell segments of the chunk: cell | first << 8 | end << 16
+    T* sxf = (T*)(segs + 67); // [CH][12] X and Fn of the chunk members (67: keeps the int area a multiple of 8 bytes)
     const int tid = threadIdx.x;
     const int b = blockIdx.x / TPB, tt = blockIdx.x % TPB;
     int bx, by, bz;
@@ -170,7 +192,7 @@ __global__ __launch_bounds__(256) void k_hessian_tiles(const T* __restrict__ X, 
         cstart[tid] = first;
         cpref[tid + 1] = cnt;
     }
-    for (int e = tid; e < 8 * 1125; e += 256) tile[e] = (T)0;
+    for (int e = tid; e < 8 * 1125; e += HT_THREADS) tile[e] = (T)0;
     __syncthreads();
     bool any = false;
     for (int r = 0; r < 8; ++r) any = any || rdof[r] >= 0;
@@ -183,7 +205,7 @@ __global__ __launch_bounds__(256) void k_hessian_tiles(const T* __restrict__ X, 
     const int total = cpref[64];
     for (int chunk = 0; chunk < total; chunk += CH) {
         const int cnt = min(CH, total - chunk);
-        if (tid == 0) *nitems = 0;
+        if (tid == 0) nitems[0] = 0, nitems[1] = 0;
         if (tid < cnt) {
             int flat = chunk + tid;
             int lo = 0, hi = 64; // cpref[lo] <= flat < cpref[hi]
@@ -198,68 +220,91 @@ __global__ __launch_bounds__(256) void k_hessian_tiles(const T* __restrict__ X, 
         }
         __syncthreads();
         // ---- stage the chunk: dP (45), g = Fn^T grad w (27 x 3), tile-relative base node, work items
-        for (int e = tid; e < cnt * 45; e += 256) {
+        for (int e = tid; e < cnt * 45; e += HT_THREADS) {
             int l = e / 45, q = e - l * 45;
             int p = pidx[l];
             sdp[l * 45 + q] = dp[(int64_t)q * Np + p];
         }
-        for (int e = tid; e < cnt * 27; e += 256) {
-            int l = e / 27, nd = e - l * 27;
+        for (int e = tid; e < cnt * 12; e += HT_THREADS) { // X (3) and Fn (9) of every chunk member, once
+            int l = e / 12, q = e - l * 12;
             int p = pidx[l];
-            T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
+            sxf[l * 12 + q] = q < 3 ? X[(int64_t)q * Np + p] : Fn[(int64_t)(q - 3) * Np + p];
+        }
+        __syncthreads();
+        for (int e = tid; e < cnt * 27; e += HT_THREADS) {
+            int l = e / 27, nd = e - l * 27;
+            const T* xf = sxf + l * 12;
             int base[3];
             T w[3][3], dw[3][3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+            for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xf[d], base[d], w[d], dw[d]);
             int i = nd / 9, j = (nd / 3) % 3, k = nd % 3;
             T wi = i == 0 ? w[0][0] : (i == 1 ? w[0][1] : w[0][2]), dwi = i == 0 ? dw[0][0] : (i == 1 ? dw[0][1] : dw[0][2]);
             T wj = j == 0 ? w[1][0] : (j == 1 ? w[1][1] : w[1][2]), dwj = j == 0 ? dw[1][0] : (j == 1 ? dw[1][1] : dw[1][2]);
             T wk = k == 0 ? w[2][0] : (k == 1 ? w[2][1] : w[2][2]), dwk = k == 0 ? dw[2][0] : (k == 1 ? dw[2][1] : dw[2][2]);
             T g0 = one_over_dx * dwi * wj * wk, g1 = wi * one_over_dx * dwj * wk, g2 = wi * wj * one_over_dx * dwk;
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc)
-                sg[(l * 27 + nd) * 3 + cc] = Fn[(int64_t)(cc * 3 + 0) * Np + p] * g0 + Fn[(int64_t)(cc * 3 + 1) * Np + p] * g1 + Fn[(int64_t)(cc * 3 + 2) * Np + p] * g2;
-            if (nd == 0) pbase[l * 3] = base[0] - tx0, pbase[l * 3 + 1] = base[1] - ty0, pbase[l * 3 + 2] = base[2] - tz0;
+            for (int cc = 0; cc < 3; ++cc) sg[(l * 27 + nd) * 3 + cc] = xf[3 + cc * 3] * g0 + xf[3 + cc * 3 + 1] * g1 + xf[3 + cc * 3 + 2] * g2;
         }
         __syncthreads();
-        // ---- work items: (particle l, tile row r) with row r inside the particle's 3x3x3 support and an active dof
-        for (int e = tid; e < cnt * 8; e += 256) {
-            int l = e >> 3, r = e & 7;
-            int ax = (r >> 2) - pbase[l * 3], ay = ((r >> 1) & 1) - pbase[l * 3 + 1], az = (r & 1) - pbase[l * 3 + 2]; // node index inside the kernel
+        // ---- work items.  The particles of one base cell share their 27 support nodes, so for a (cell segment, tile
+        // row r, column node jl) item the 3x3 block of every particle lands in the same (row, slot): it is summed in
+        // registers over the segment and added to the LDS tile ONCE (9 ds_add per item instead of 9 per particle).
+        if (tid < 64) {
+            const int s0 = max(cpref[tid], chunk), s1 = min(cpref[tid + 1], chunk + cnt);
+            if (s1 > s0) {
+                const int k = atomicAdd(nitems + 1, 1);
+                segs[k] = tid | ((s0 - chunk) << 8) | ((s1 - chunk) << 16); // cell, first, end (chunk-relative, <= CH)
+            }
+        }
+        __syncthreads();
+        const int nseg = nitems[1];
+        for (int e = tid; e < nseg * 8; e += HT_THREADS) {
+            const int sg_ = e >> 3, r = e & 7, cell = segs[sg_] & 255;
+            const int ax = (r >> 2) - ((cell >> 4) - 2), ay = ((r >> 1) & 1) - (((cell >> 2) & 3) - 2), az = (r & 1) - ((cell & 3) - 2); // node index inside the kernel
             if ((unsigned)ax < 3u && (unsigned)ay < 3u && (unsigned)az < 3u && rdof[r] >= 0) items[atomicAdd(nitems, 1)] = e;
         }
         __syncthreads();
-        const int ni = *nitems;
-        for (int it = tid; it < ni; it += 256) {
-            const int e = items[it];
-            const int l = e >> 3, r = e & 7;
-            const int pbx = pbase[l * 3], pby = pbase[l * 3 + 1], pbz = pbase[l * 3 + 2];
-            const int ax = (r >> 2) - pbx, ay = ((r >> 1) & 1) - pby, az = (r & 1) - pbz;
+        const int ni = *nitems * 27;
+        for (int it = tid; it < ni; it += HT_THREADS) {
+            const int e = items[it / 27], j = it % 27;
+            const int sd = segs[e >> 3], r = e & 7, cell = sd & 255, l0 = (sd >> 8) & 255, l1 = sd >> 16;
+            const int ax = (r >> 2) - ((cell >> 4) - 2), ay = ((r >> 1) & 1) - (((cell >> 2) & 3) - 2), az = (r & 1) - ((cell & 3) - 2);
             const int i = ax * 9 + ay * 3 + az;
-            const T* D = sdp + l * 45;
-            const T gi0 = sg[(l * 27 + i) * 3], gi1 = sg[(l * 27 + i) * 3 + 1], gi2 = sg[(l * 27 + i) * 3 + 2];
-            // T_i[a + 3*(b + 3 q)] = sum_v dP[(a + 3 v), (b + 3 q)] g_i[v]
-            T Tm[27];
+            const int jx = j / 9, jy = (j / 3) % 3, jz = j % 3;
+            T acc[9];
 #pragma unroll
-            for (int bq = 0; bq < 9; ++bq)
+            for (int q = 0; q < 9; ++q) acc[q] = (T)0;
+            for (int l = l0; l < l1; ++l) {
+                const T* D = sdp + l * 45;
+                const T* gi = sg + (l * 27 + i) * 3;
+                const T* gj = sg + (l * 27 + j) * 3;
+                T Gm[9]; // G[v + 3 q] = g_i[v] g_j[q]
 #pragma unroll
-                for (int a = 0; a < 3; ++a) Tm[a + 3 * bq] = D[sym45(a, bq)] * gi0 + D[sym45(a + 3, bq)] * gi1 + D[sym45(a + 6, bq)] * gi2;
-            T* row = tile + r * 1125;
-            for (int j = 0; j < 27; ++j) {
-                const int jx = j / 9, jy = (j / 3) % 3, jz = j % 3;
-                const T g0 = sg[(l * 27 + j) * 3], g1 = sg[(l * 27 + j) * 3 + 1], g2 = sg[(l * 27 + j) * 3 + 2];
-                const int slot = (ax - jx + 2) * 25 + (ay - jy + 2) * 5 + (az - jz + 2);
-                T* o = row + slot * 9;
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) Gm[v + 3 * q] = gi[v] * gj[q];
+                // block(a, b) = sum_{v,q} dP[(a + 3 v), (b + 3 q)] G[v][q]
 #pragma unroll
                 for (int bb = 0; bb < 3; ++bb)
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) lds_atomic_add(o + bb * 3 + a, Tm[a + 3 * (bb + 0)] * g0 + Tm[a + 3 * (bb + 3)] * g1 + Tm[a + 3 * (bb + 6)] * g2);
+                    for (int a = 0; a < 3; ++a) {
+                        T t = acc[a + 3 * bb];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+#pragma unroll
+                            for (int v = 0; v < 3; ++v) t += D[sym45(a + 3 * v, bb + 3 * q)] * Gm[v + 3 * q];
+                        acc[a + 3 * bb] = t;
+                    }
             }
+            T* o = tile + r * 1125 + ((ax - jx + 2) * 25 + (ay - jy + 2) * 5 + (az - jz + 2)) * 9;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) lds_atomic_add(o + q, acc[q]);
         }
         __syncthreads();
     }
     // ---- write the tile: inertia term M on the diagonal slot (ImplicitSolver.h:486-496)
-    for (int e = tid; e < 8 * 1125; e += 256) {
+    for (int e = tid; e < 8 * 1125; e += HT_THREADS) {
         int r = e / 1125, q = e - r * 1125;
         int dof = rdof[r];
         if (dof < 0) continue;
@@ -280,7 +325,7 @@ void Ctx<T>::assemble_tiles(Level<T>& L)
         attr_set = true;
     }
     constexpr int TPB = (G::BX / 2) * (G::BY / 2) * (G::BZ / 2);
-    HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles<T>, Nb * TPB, 256, TileLds<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx);
+    HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles<T>, Nb * TPB, HT_THREADS, TileLds<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx);
 }
 
 template struct Ctx<float>;

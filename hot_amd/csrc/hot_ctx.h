@@ -42,6 +42,10 @@ struct Profiler {
         if (!on) return;
         (void)hipEventRecord(pending.back().second.second, s);
     }
+    void count(const std::string& name) // event-free counter record (0 ms): lets bench.py relate launches to sweeps
+    {
+        if (on) recs[name].calls++;
+    }
     void collect()
     {
         if (!on) return;

@@ -76,6 +76,7 @@ struct Ctx : CtxBase {
     // ---- per-cell particle ranges (particles are sorted by page, then by base cell inside the page)
     int Ncell = 0;
     DBuf<int32_t> cell_first; // Ncell+1
+    DBuf<int32_t> group_cell0; // Ng+1: rank of the first base cell of every particle group
     DBuf<uint64_t> ch_keys;
     DBuf<unsigned long long> ch_rank;
     DBuf<int32_t> ch_id;
@@ -210,7 +211,7 @@ struct Ctx : CtxBase {
     void scal(size_t n, T a, T* x); // x *= a
     void restrict_dev(int level, const T* fine, T* coarse);
     void prolong_dev(int level, const T* coarse, T* fine);
-    void smooth_dev(int level, int kind, int iterations, T tol, T* u, T* r, T* du, T* dAu);
+    void smooth_dev(int level, int kind, int iterations, T tol, T* u, T* r, T* du, T* dAu, bool final_residual = true);
     void vcycle_dev(const T* in, T* out);
     void precondition_dev(const T* in, T* out);
     void matfree_dev(const T* x, T* y);

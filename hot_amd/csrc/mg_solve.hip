@@ -610,8 +610,11 @@ __global__ void k_cg_scalars(double* s, int what)
     }
 }
 
+// final_residual = false: the caller never reads r after this call (the post-smoothing leg of the V-cycle: the
+// reference updates the residual there too, MultigridPreconditioner.h:266-318, but nothing consumes it), so the last
+// residual update of the stationary smoothers is skipped.  The iterates u are unaffected.
 template <class T>
-void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, T* r, T* du, T* dAu)
+void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, T* r, T* du, T* dAu, bool final_residual)
 {
     Level<T>& L = *levels[level];
     size_t n3 = 3 * (size_t)L.n;
@@ -624,6 +627,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             scaler(r, du);
             scal(n3, (T)cfg.topomega, du);
             axpy(n3, (T)1, du, u);
+            if (!final_residual && iterations == 0) break;
             spmv_dev(L, du, dAu);
             Aproject(dAu);
             axpy(n3, (T)-1, dAu, r);
@@ -775,6 +779,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         };
         iterations = ((iterations + 1) >> 1);
         for (; iterations--;) {
+            prof.count(lname("gs_symsweeps", L.id));
             zero(n3, hdu);
             if (dataflow)
                 sweep(true);
@@ -789,6 +794,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 for (int c = 7; c >= 0; --c)
                     for (int h = nsub - 1; h >= 0; --h) pass(false, c, h);
             axpy(n3, (T)1, du, u);
+            if (!final_residual && iterations == 0) break;
             if (L.split && !simple_gs && !(level == 0 && !cfg.systemBCProject) && !no_lres) {
                 // r - A du = L (h - du): with (D+L) h = r and (D+U) du = D h the full product A du collapses to the
                 // strictly-preceding half of the matrix applied to (h - du) (same value, half the bytes of an SpMV)
@@ -821,9 +827,9 @@ void Ctx<T>::vcycle_dev(const T* in, T* out)
     };
     splitLevel = cfg.topDownMGS ? 1 : cfg.levelCnt - 1;
     T tolTop = (T)(cfg.cneps * cfg.cneps);
-    auto run = [&](bool regular, int level, T* sol, int its) {
+    auto run = [&](bool regular, int level, T* sol, int its, bool final_residual = true) {
         Level<T>& L = *levels[level];
-        smooth_dev(level, regular ? cfg.smoother : cfg.coarseSolver, its, regular ? (T)0 : tolTop, sol, L.residual.p, L.du.p, L.dAu.p);
+        smooth_dev(level, regular ? cfg.smoother : cfg.coarseSolver, its, regular ? (T)0 : tolTop, sol, L.residual.p, L.du.p, L.dAu.p, final_residual);
     };
     stats.vcycles++;
     Level<T>& L0 = *levels[0];
@@ -851,7 +857,7 @@ void Ctx<T>::vcycle_dev(const T* in, T* out)
         axpy(n3, (T)1, L.du.p, sol);
         spmv_dev(L, L.du.p, L.dAu.p);
         axpy(n3, (T)-1, L.dAu.p, L.residual.p);
-        run(level < splitLevel, level, sol, level < splitLevel ? downIter(level) : topIter(level));
+        run(level < splitLevel, level, sol, level < splitLevel ? downIter(level) : topIter(level), false);
     }
 }
 

@@ -1,10 +1,11 @@
 // libhotmi355x — APIC particle <-> grid transfers over the SPGrid block grid.
 //
-//   k_p2g          particlesToGridHelper<true,false> (reference Lib/MPM/MpmSimulationBase.cpp:611-656): one particle
+//   k_p2g_cells    particlesToGridHelper<true,false> (reference Lib/MPM/MpmSimulationBase.cpp:611-656): one particle
 //                  group (= one SPGrid page worth of base cells) per workgroup; the (BX+2)(BY+2)(BZ+2) nodes the
-//                  group can touch are accumulated in LDS with ds_add atomics, then flushed with one global atomic
-//                  per touched node and quantity.  The reference's 8 sequential colour passes (:621-655) exist only
-//                  to avoid write races between pages; atomics make the pass single-launch.
+//                  group can touch are accumulated in LDS ((cell, node) items summed in registers, one ds_add per
+//                  item and quantity) and written as a partial tile; k_tile_reduce sums the <= 8 partial tiles of
+//                  every node in a fixed order.  The reference's 8 sequential colour passes (:621-655) exist only to
+//                  avoid write races between pages.  k_p2g is the first version (one ds_add per particle), kept for A/B.
 //   k_block_count / k_number_nodes
 //                  MpmGrid::getNumNodes (Lib/MPM/MpmGrid.h:148-161) — serial in the reference; here a per-block
 //                  ballot + an exclusive scan over the insertion-ordered block list reproduce the ids bit-exactly;
@@ -15,6 +16,7 @@
 //                  fused: node tile staged in LDS, particle streams fully coalesced.
 #include "hot_impl.h"
 #include "hot_constitutive.h"
+#include <cstdlib>
 
 namespace hot {
 
@@ -88,6 +90,100 @@ __global__ __launch_bounds__(256) void k_p2g(const T* __restrict__ X, const T* _
     for (int t = threadIdx.x; t < NQ * TILE; t += 256) out[t] = (&acc[0][0])[t];
 }
 
+// Production P2G.  The particles of one base cell share their 27 support nodes, so a (cell, node column) work item sums
+// the contributions of the whole cell to its 3 nodes in registers and touches the LDS accumulator once per node and
+// quantity: ~8x fewer ds_add_f64 than one-add-per-particle (k_p2g above, kept for A/B).  Particle data and the per-
+// particle 1-D weights are staged in LDS (coalesced loads, weights computed once per particle instead of once per
+// node) and read back with wave-broadcast reads (all lanes of a cell read the same particle).
+template <class T, bool WITH_CN>
+__global__ __launch_bounds__(256) void k_p2g_cells(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C,
+    const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
+    const int32_t* __restrict__ group_cell0, const int32_t* __restrict__ cell_first, T* __restrict__ part, T dx, T one_over_dx)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
+    constexpr int NQ = WITH_CN ? 5 : 4, NS = 25 + (WITH_CN ? 1 : 0), CH = 256;
+    __shared__ T acc[NQ][TILE];
+    __shared__ T sp[NS][CH]; // x(3) m(1) m*v(3) m*C(9) w(3x3) [cn]
+    __shared__ int32_t sbase[3][CH];
+    __shared__ int32_t segs[G::EPB + 2];
+    __shared__ int32_t nseg;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    for (int t = tid; t < NQ * TILE; t += 256) (&acc[0][0])[t] = (T)0;
+    const int first = group_first[g], last = group_first[g + 1];
+    const int c0 = group_cell0[g], c1 = group_cell0[g + 1];
+    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
+    for (int ch = first; ch < last; ch += CH) {
+        if (tid == 0) nseg = 0;
+        __syncthreads(); // also orders the previous chunk's reads of sp / segs before they are overwritten
+        const int p = ch + tid;
+        if (p < last) {
+            const T m = M[p];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const T x = X[(int64_t)d * Np + p];
+                int base;
+                T w[3], dw[3];
+                bspline<T>(one_over_dx * x, base, w, dw);
+                sp[d][tid] = x, sp[4 + d][tid] = m * V[(int64_t)d * Np + p], sbase[d][tid] = base;
+                sp[16 + 3 * d][tid] = w[0], sp[17 + 3 * d][tid] = w[1], sp[18 + 3 * d][tid] = w[2];
+            }
+            sp[3][tid] = m;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sp[7 + c][tid] = m * C[(int64_t)c * Np + p];
+            if (WITH_CN) {
+                // |dP/dF(F = I)|_F of the fixed-corotated model: A = 2 mu I + lambda 11^T, B blocks = mu [[1,1],[1,1]]
+                // (already PSD, so --project does not change it): sqrt(3(2mu+l)^2 + 6 l^2 + 12 mu^2)
+                const T mu = Mu[p], la = Lam[p];
+                sp[NS - 1][tid] = m * hsqrt((T)3 * ((T)2 * mu + la) * ((T)2 * mu + la) + (T)6 * la * la + (T)12 * mu * mu);
+            }
+        }
+        for (int c = c0 + tid; c < c1; c += 256) {
+            const int s0 = max(cell_first[c], ch), s1 = min(cell_first[c + 1], min(ch + CH, last));
+            if (s1 > s0) segs[atomicAdd(&nseg, 1)] = (s0 - ch) | ((s1 - ch) << 16);
+        }
+        __syncthreads();
+        const int ni = nseg * 9;
+        for (int it = tid; it < ni; it += 256) {
+            const int sd = segs[it / 9], jk = it % 9, l0 = sd & 0xffff, l1 = sd >> 16;
+            const int j = jk / 3, k = jk - 3 * j;
+            T a[3][NQ];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) a[i][q] = (T)0;
+            const int b0 = sbase[0][l0], b1 = sbase[1][l0], b2 = sbase[2][l0]; // the same for every particle of the cell
+            for (int l = l0; l < l1; ++l) {
+                const T d1 = (T)(b1 + j) * dx - sp[1][l], d2 = (T)(b2 + k) * dx - sp[2][l];
+                const T m = sp[3][l];
+                const T c0_ = sp[7][l], c1_ = sp[8][l], c2_ = sp[9][l], m0 = sp[4][l], m1 = sp[5][l], m2 = sp[6][l], xp0 = sp[0][l];
+                T cn = (T)0;
+                if (WITH_CN) cn = sp[NS - 1][l];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const T wijk = sp[16 + i][l] * sp[19 + j][l] * sp[22 + k][l];
+                    const T d0 = (T)(b0 + i) * dx - xp0;
+                    a[i][0] += m * wijk;
+                    a[i][1] += (c0_ * d0 + sp[10][l] * d1 + sp[13][l] * d2 + m0) * wijk;
+                    a[i][2] += (c1_ * d0 + sp[11][l] * d1 + sp[14][l] * d2 + m1) * wijk;
+                    a[i][3] += (c2_ * d0 + sp[12][l] * d1 + sp[15][l] * d2 + m2) * wijk;
+                    if (WITH_CN) a[i][NQ - 1] += cn * wijk;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int t = ((b0 - ox + i) * TY + (b1 - oy + j)) * TZ + (b2 - oz + k);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) lds_atomic_add(&acc[q][t], a[i][q]);
+            }
+        }
+    }
+    __syncthreads();
+    // partial tile of this group, coalesced; summed per node by k_tile_reduce (no global atomics)
+    T* out = part + (int64_t)g * NQ * TILE;
+    for (int t = tid; t < NQ * TILE; t += 256) out[t] = (&acc[0][0])[t];
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void k_block_count(const T* __restrict__ gM, int32_t* block_count, int nb)
 {
@@ -138,12 +234,19 @@ void Ctx<T>::p2g()
     double t0 = wall_ms();
     int64_t slots = (int64_t)Nb * EPB;
     T one_over_dx = (T)1 / dx;
+    static const bool p2g_v1 = getenv("HOT_P2G_V1") != nullptr; // A/B switch: one LDS atomic per particle, node and quantity
     if (cfg.useCN) {
-        HOT_LAUNCH(this, "p2g", (k_p2g<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, dx, one_over_dx);
+        if (p2g_v1)
+            HOT_LAUNCH(this, "p2g", (k_p2g<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, dx, one_over_dx);
+        else
+            HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
         reduce_tiles(5, gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p, "p2g_reduce");
     }
     else {
-        HOT_LAUNCH(this, "p2g", (k_p2g<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, dx, one_over_dx);
+        if (p2g_v1)
+            HOT_LAUNCH(this, "p2g", (k_p2g<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, dx, one_over_dx);
+        else
+            HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
         reduce_tiles(4, gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p, "p2g_reduce");
     }
     HOT_LAUNCH(this, "block_count", k_block_count<T>, div_up(Nb, 4), 256, 0, gM.p, block_count.p, Nb);
