@@ -278,7 +278,19 @@ __global__ void k_diag(const int32_t* __restrict__ col, const T* __restrict__ va
             for (int c = 0; c < 9; ++c) D.a[c] += v[c];
         }
     }
-    Mat3<T> Bi = m3_inverse(D);
+    // block inverse by cofactors like Eigen's 3x3 inverse(), on the block scaled by an exact power of two: bit-identical
+    // in the normal range, and the determinant of a very light node (m ~ 1e-14 => det ~ 1e-42) no longer underflows in
+    // fp32
+    T amax = (T)0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) amax = fmax(amax, habs(D.a[c]));
+    const int ex = (amax > (T)0 && amax < (T)INFINITY) ? ilogb(amax) : 0;
+    Mat3<T> Ds;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Ds.a[c] = scalbn(D.a[c], -ex);
+    Mat3<T> Bi = m3_inverse(Ds);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Bi.a[c] = scalbn(Bi.a[c], -ex);
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
         diagVal[9 * (int64_t)i + c] = D.a[c];

@@ -87,7 +87,13 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
         HOT_LAUNCH(this, "linesearch_combine", k_combine<T>, div_up(n3, 256), 256, 0, n3, dv0.p, alpha, ddv, dvnew);
         copy(n3, dvnew, dv.p); // moveNodes
         Ek = state_pass(dv.p, true);
-        HOT_CHECK(Ek == Ek, HOT_ERR_NUMERIC, "NaN energy in line search");
+        if (!(Ek == Ek)) {
+            // diagnostics for the error message: is the search direction itself already non-finite?
+            double dd = dot_host(n3, ddv, ddv), d0 = dot_host(n3, dv0.p, dv0.p);
+            char msg[256];
+            snprintf(msg, sizeof(msg), "NaN energy in line search (iteration %d, trial %d, alpha %g, |direction|^2 %g, |dv|^2 %g, E0 %g)", stats.iterations, guard, (double)alpha, dd, d0, Ek0);
+            HOT_CHECK(false, HOT_ERR_NUMERIC, msg);
+        }
         stats.linesearch_trials++;
         alpha *= (T)0.5;
         if (getenv("HOT_DEBUG")) fprintf(stderr, "[hot]   linesearch alpha=%g Ek=%.12e Ek0=%.12e\n", (double)alpha * 2, Ek, Ek0);

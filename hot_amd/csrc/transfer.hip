@@ -213,8 +213,9 @@ __global__ __launch_bounds__(256) void k_number_nodes(const T* __restrict__ gM, 
     T v0 = 0, v1 = 0, v2 = 0;
     if (has) {
         idx = block_base[b] + __popcll(mask & ((1ULL << lane) - 1ULL));
-        T inv = (T)1 / m;
-        v0 = gMV[s] * inv, v1 = gMV[slots + s] * inv, v2 = gMV[2 * slots + s] * inv;
+        // g.v /= g.m (MpmSimulationBase.cpp:526): a true division, which also stays finite for the denormal masses
+        // that corner nodes can get in fp32 (1 / m would overflow)
+        v0 = gMV[s] / m, v1 = gMV[slots + s] / m, v2 = gMV[2 * slots + s] / m;
         int bi, bj, bk;
         G::linear_to_coord(blocks[b], bi, bj, bk);
         int ez = lane & (G::BZ - 1), ey = (lane >> G::zb) & (G::BY - 1), ex = lane >> (G::zb + G::yb);

@@ -357,7 +357,7 @@ struct Sim {
         num_nodes = get_num_nodes();
         iterate_grid([&](const int*, Node& g) {
             if (g.m != 0)
-                g.v = g.v * ((T)1 / g.m);
+                for (int d = 0; d < 3; ++d) g.v.a[d] = g.v.a[d] / g.m; // g.v /= g.m (:526)
             else
                 g.v = TV::zero();
         });

@@ -1,0 +1,36 @@
+"""The library picks kernel variants by problem size (block GS: one launch per (colour, sub-block) pass on large levels,
+one chained launch per half sweep on small ones; sub-block size 32 / 64) and keeps first-generation kernels behind
+A/B switches.  The parity tests use small problems, so without this file only the small-problem variants would be
+compared with the oracle.  Each case re-runs the relevant parity tests in a subprocess with the switch set (the
+switches are read once per process)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SOLVER = "tests/test_gpu_solver.py"
+CASES = [
+    ({"HOT_GS_MULTILAUNCH": "1", "HOT_GS_SB": "32"}, SOLVER, "smoothers or vcycle or iterates"),
+    ({"HOT_GS_MULTILAUNCH": "1", "HOT_GS_SB": "16"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_GS_MULTILAUNCH": "1", "HOT_GS_SB": "64"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_GS_DATAFLOW": "1", "HOT_GS_SB": "32"}, SOLVER, "smoothers or vcycle or iterates"),
+    ({"HOT_GS_DATAFLOW": "1", "HOT_GS_SB": "16"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_SIMPLE_GS": "1"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_GS_FULL_RESIDUAL": "1"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_HESSIAN_V1": "1"}, SOLVER, "hessian_and_hierarchy"),
+    ({"HOT_P2G_V1": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,path,expr", CASES, ids=[" ".join(f"{k}={v}" for k, v in c[0].items()) for c in CASES])
+def test_kernel_variant_parity(env, path, expr):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", path, "-x", "-q", "-m", "gpu", "-k", expr, "-p", "no:cacheprovider"], cwd=ROOT, env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout
