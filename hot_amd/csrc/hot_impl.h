@@ -23,6 +23,8 @@ struct Level {
     DBuf<int32_t> gs_block_start; // nblocks+1 : offsets into gs_order
     // after build_mg every row's slots are regrouped as [nl entries preceding the row in the GS order | diagonal |
     // nu entries following it | structural zeros], so each half sweep streams only the half it needs
+    DBuf<T> apv; // n*64*9: A*P of this level (4^3 coarse window per row), kept for the coarse-correction residual update
+    DBuf<int32_t> apc; // n*64: coarse column of every window slot (0 where the coarse node does not exist; its block is 0)
     DBuf<int32_t> rowcnt; // 4n: (precede-off, precede-in, follow-in, follow-off) slot counts of the regrouped rows
     bool split = false;
     int color_block_begin[9] = { 0 }; // blocks of colour c are [color_block_begin[c], color_block_begin[c+1])

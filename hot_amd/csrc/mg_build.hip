@@ -153,6 +153,16 @@ __global__ __launch_bounds__(256) void k_ap(const int32_t* __restrict__ coord, c
         ap[(int64_t)i * 576 + o] = sum;
     }
 }
+// coarse column ids of the AP window slots
+__global__ void k_ap_cols(HashMap cmap, const int32_t* __restrict__ coord, int32_t* apc, int n)
+{
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)n * 64) return;
+    int i = (int)(e >> 6), js = (int)(e & 63);
+    int Jx = ((coord[3 * i] - 2) >> 1) + (js >> 4), Jy = ((coord[3 * i + 1] - 2) >> 1) + ((js >> 2) & 3), Jz = ((coord[3 * i + 2] - 2) >> 1) + (js & 3);
+    int j = (Jx | Jy | Jz) < 0 ? -1 : hash_find_id(cmap, coord_key(Jx, Jy, Jz));
+    apc[e] = j >= 0 ? j : 0;
+}
 // RAP[I][slot k][9] = sum_{d} w(d) AP[child(I,d)][J - cb(child)] ,  J = I - Delta(k)
 template <class T>
 __global__ __launch_bounds__(256) void k_rap(const int32_t* __restrict__ ccoord, const int32_t* __restrict__ child, const T* __restrict__ ap, T* cval, int nc)
@@ -428,9 +438,10 @@ void Ctx<T>::build_mg()
         HOT_LAUNCH(this, "mg_build_children", k_build_children, div_up(27 * nc, 256), 256, 0, F.map, C.coord.p, C.child.p, C.n);
         HOT_LAUNCH(this, "mg_coarse_cols", k_coarse_cols, div_up(125 * nc, 256), 256, 0, C.map, C.coord.p, C.col.p, C.n);
         // ---- A_c = R (A P)
-        ap.reserve(576 * (size_t)n);
-        HOT_LAUNCH(this, "mg_AP", k_ap<T>, div_up(n, 4), 256, 0, F.coord.p, F.val.p, ap.p, n);
-        HOT_LAUNCH(this, "mg_RAP", k_rap<T>, div_up(nc, 4), 256, 0, C.coord.p, C.child.p, ap.p, C.val.p, C.n);
+        F.apv.reserve(576 * (size_t)n), F.apc.reserve(64 * (size_t)n);
+        HOT_LAUNCH(this, "mg_AP", k_ap<T>, div_up(n, 4), 256, 0, F.coord.p, F.val.p, F.apv.p, n);
+        HOT_LAUNCH(this, "mg_AP_cols", k_ap_cols, div_up(64 * (size_t)n, 256), 256, 0, C.map, F.coord.p, F.apc.p, n);
+        HOT_LAUNCH(this, "mg_RAP", k_rap<T>, div_up(nc, 4), 256, 0, C.coord.p, C.child.p, F.apv.p, C.val.p, C.n);
         build_diagonal(C);
         count_nnzb(C);
         alloc_work(C);

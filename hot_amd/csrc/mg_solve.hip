@@ -109,6 +109,24 @@ __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ col, c
     s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
     if (lane == 0) y[3 * (int64_t)row] = s0, y[3 * (int64_t)row + 1] = s1, y[3 * (int64_t)row + 2] = s2;
 }
+// r_i -= sum_J AP[i][J] e_J : the residual update after the coarse-grid correction.  A (P e) and (A P) e are the same
+// vector; A P is a by-product of the Galerkin build with 64 window slots per row instead of the 125 of A, i.e. half
+// the bytes of the SpMV the reference performs here (MultigridPreconditioner.h:362-421).
+template <class T>
+__global__ __launch_bounds__(256) void k_apmv_sub(const int32_t* __restrict__ apc, const T* __restrict__ apv, const T* __restrict__ e, T* __restrict__ r, int n)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int j = apc[(int64_t)row * 64 + lane];
+    const T* b = apv + ((int64_t)row * 64 + lane) * 9;
+    const T x0 = e[3 * (int64_t)j], x1 = e[3 * (int64_t)j + 1], x2 = e[3 * (int64_t)j + 2];
+    T s0 = b[0] * x0 + b[3] * x1 + b[6] * x2;
+    T s1 = b[1] * x0 + b[4] * x1 + b[7] * x2;
+    T s2 = b[2] * x0 + b[5] * x1 + b[8] * x2;
+    s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
+    if (lane == 0) r[3 * (int64_t)row] -= s0, r[3 * (int64_t)row + 1] -= s1, r[3 * (int64_t)row + 2] -= s2;
+}
 template <class T>
 __global__ void k_scal_v(size_t n, T a, T* x)
 {
@@ -855,8 +873,13 @@ void Ctx<T>::vcycle_dev(const T* in, T* out)
         size_t n3 = 3 * (size_t)L.n;
         prolong_dev(level, levels[level + 1]->sol.p, L.du.p);
         axpy(n3, (T)1, L.du.p, sol);
-        spmv_dev(L, L.du.p, L.dAu.p);
-        axpy(n3, (T)-1, L.dAu.p, L.residual.p);
+        static const bool full_spmv = getenv("HOT_MG_FULL_SPMV") != nullptr; // A/B switch: r -= A (P e) like the reference
+        if (full_spmv) {
+            spmv_dev(L, L.du.p, L.dAu.p);
+            axpy(n3, (T)-1, L.dAu.p, L.residual.p);
+        }
+        else
+            HOT_LAUNCH(this, lname("apmv", L.id).c_str(), k_apmv_sub<T>, div_up(L.n, 4), 256, 0, L.apc.p, L.apv.p, levels[level + 1]->sol.p, L.residual.p, L.n);
         run(level < splitLevel, level, sol, level < splitLevel ? downIter(level) : topIter(level), false);
     }
 }
