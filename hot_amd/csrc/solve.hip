@@ -56,6 +56,48 @@ __global__ void k_lbfgs_scalar(double* s, int i, int what)
         s[80] = s[50 + i] - s[70] * s[60 + i];
 }
 
+// One step of the two-loop recursion in one pass over the vectors (LBFGS.h:359-392):
+//   what 0 (first loop):  ksi = rho[ph] * dot_in ; y -= ksi * v ; dot_out += z . y
+//   what 1 (second loop): coef = ksi[ph] - rho[ph] * dot_in ; y += coef * v ; dot_out += z . y
+// dot_in was accumulated by the previous launch (k_dot_only or this kernel), dot_out is the inner product the next
+// step needs, taken on the freshly updated y (z == nullptr on the last step).  Same arithmetic as the unfused
+// dot / k_lbfgs_scalar / axpy sequence, one third of the launches and two thirds of the bytes.
+template <class T>
+__global__ __launch_bounds__(256) void k_lbfgs_fused(size_t n, double* s, int in_slot, int out_slot, int ph, int what, const T* __restrict__ v, T* __restrict__ y, const T* __restrict__ z)
+{
+    __shared__ double red[4];
+    const double tmp = s[in_slot];
+    const double coef = what == 0 ? tmp * s[60 + ph] : s[50 + ph] - tmp * s[60 + ph];
+    if (what == 0 && blockIdx.x == 0 && threadIdx.x == 0) s[50 + ph] = coef;
+    const T c = (T)(what == 0 ? -1.0 * coef : 1.0 * coef);
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        T yn = y[i] + c * v[i];
+        y[i] = yn;
+        if (z) acc += (double)(z[i] * yn);
+    }
+    if (z) { // kernel-uniform
+        double t = block_sum_256<double>(acc, red);
+        if (threadIdx.x == 0) atomic_add(s + out_slot, t);
+    }
+}
+// dst = src (optional) and dot_out += z . src in the same pass
+template <class T>
+__global__ __launch_bounds__(256) void k_copy_dot(size_t n, double* s, int out_slot, const T* __restrict__ src, T* __restrict__ dst, const T* __restrict__ z)
+{
+    __shared__ double red[4];
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        T a = src[i];
+        if (dst) dst[i] = a;
+        if (z) acc += (double)(z[i] * a);
+    }
+    if (z) {
+        double t = block_sum_256<double>(acc, red);
+        if (threadIdx.x == 0) atomic_add(s + out_slot, t);
+    }
+}
+
 template <class T>
 bool Ctx<T>::should_exit(const T* r)
 {
@@ -152,20 +194,45 @@ bool Ctx<T>::lbfgs_solve()
             push_back();
         }
         int wk = order.back();
-        copy(n3, residual, hist_dg[wk].p);
-        for (int i = (int)order.size() - 2; i >= 0; --i) {
-            int ph = order[i];
-            dot_to(n3, hist_dx[ph].p, residual, s + 70);
-            HOT_LAUNCH(this, "lbfgs_scalar", k_lbfgs_scalar, 1, 1, 0, s, ph, 0);
-            axpy_dev(n3, s + 50 + ph, -1.0, hist_dg[ph].p, residual);
+        const int m = (int)order.size() - 1; // stored curvature pairs
+        static const bool unfused = getenv("HOT_LBFGS_UNFUSED") != nullptr; // A/B switch: dot / scalar / axpy as separate launches
+        const int vgrid = (int)std::min<size_t>(div_up(n3, 1024), 512);
+        if (unfused) {
+            copy(n3, residual, hist_dg[wk].p);
+            for (int i = m - 1; i >= 0; --i) {
+                int ph = order[i];
+                dot_to(n3, hist_dx[ph].p, residual, s + 70);
+                HOT_LAUNCH(this, "lbfgs_scalar", k_lbfgs_scalar, 1, 1, 0, s, ph, 0);
+                axpy_dev(n3, s + 50 + ph, -1.0, hist_dg[ph].p, residual);
+            }
+        }
+        else {
+            // dot slots: 140 + k for step k of the first loop, 160 + k for the second
+            HOT_HIP(hipMemsetAsync(s + 140, 0, 40 * sizeof(double), stream));
+            HOT_LAUNCH(this, "lbfgs_copy_dot", k_copy_dot<T>, vgrid, 256, 0, n3, s, 140, residual, hist_dg[wk].p, m > 0 ? hist_dx[order[m - 1]].p : (const T*)nullptr);
+            for (int k = 0; k < m; ++k) {
+                int ph = order[m - 1 - k];
+                const T* znext = k + 1 < m ? hist_dx[order[m - 2 - k]].p : (const T*)nullptr;
+                HOT_LAUNCH(this, "lbfgs_fused", k_lbfgs_fused<T>, vgrid, 256, 0, n3, s, 140 + k, 141 + k, ph, 0, hist_dg[ph].p, residual, znext);
+            }
         }
         precondition_dev(residual, hist_dx[wk].p);
         project_dev(hist_dx[wk].p);
-        for (int i = 0; i < (int)order.size() - 1; ++i) {
-            int ph = order[i];
-            dot_to(n3, hist_dg[ph].p, hist_dx[wk].p, s + 70);
-            HOT_LAUNCH(this, "lbfgs_scalar", k_lbfgs_scalar, 1, 1, 0, s, ph, 1);
-            axpy_dev(n3, s + 80, 1.0, hist_dx[ph].p, hist_dx[wk].p);
+        if (unfused) {
+            for (int i = 0; i < m; ++i) {
+                int ph = order[i];
+                dot_to(n3, hist_dg[ph].p, hist_dx[wk].p, s + 70);
+                HOT_LAUNCH(this, "lbfgs_scalar", k_lbfgs_scalar, 1, 1, 0, s, ph, 1);
+                axpy_dev(n3, s + 80, 1.0, hist_dx[ph].p, hist_dx[wk].p);
+            }
+        }
+        else if (m > 0) {
+            HOT_LAUNCH(this, "lbfgs_copy_dot", k_copy_dot<T>, vgrid, 256, 0, n3, s, 160, hist_dx[wk].p, (T*)nullptr, hist_dg[order[0]].p);
+            for (int k = 0; k < m; ++k) {
+                int ph = order[k];
+                const T* znext = k + 1 < m ? hist_dg[order[k + 1]].p : (const T*)nullptr;
+                HOT_LAUNCH(this, "lbfgs_fused", k_lbfgs_fused<T>, vgrid, 256, 0, n3, s, 160 + k, 161 + k, ph, 1, hist_dx[ph].p, hist_dx[wk].p, znext);
+            }
         }
         if (cfg.linesearch) line_search(hist_dx[wk].p, residual, (T)1);
         transform_dev(hist_dx[wk].p, true); // recoverSolution
