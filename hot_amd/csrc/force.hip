@@ -16,6 +16,7 @@
 //   k_matfree       matrix-free Hessian product (ImplicitSolver.h:741-758, MpmForceBase.cpp:262-306,
 //                   FBasedMpmForceHelper.cpp:137-160).
 #include "hot_impl.h"
+#include <cstdlib>
 #include "hot_constitutive.h"
 #include <cmath>
 
@@ -319,6 +320,86 @@ __global__ __launch_bounds__(256) void k_force_scatter(const T* __restrict__ X, 
     for (int t = threadIdx.x; t < 3 * TILE; t += 256) out[t] = (&acc[0][0])[t];
 }
 
+// Production force scatter: same (cell, node column) work items as k_p2g_cells (transfer.hip) — the particles of a
+// base cell share their 27 nodes, so the three nodes of a column are summed in registers over the cell and added to the
+// LDS tile once.  The 1-D weights and their derivatives are computed once per particle while staging (the first
+// version, k_force_scatter above, recomputed them per node through rotated tables that ended up in scratch memory).
+constexpr int FORCE_THREADS = 256; // see P2G_THREADS (transfer.hip)
+
+template <class T>
+__global__ __launch_bounds__(FORCE_THREADS) void k_force_cells(const T* __restrict__ X, const T* __restrict__ stress, int64_t Np, const int32_t* __restrict__ group_first,
+    const int32_t* __restrict__ group_origin, const int32_t* __restrict__ group_cell0, const int32_t* __restrict__ cell_first, T* __restrict__ part, T one_over_dx, T scale)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
+    constexpr int CH = FORCE_THREADS;
+    __shared__ T acc[3][TILE];
+    __shared__ T sp[27][CH]; // S(9) w(3x3) dw(3x3)
+    __shared__ int32_t sbase[3][CH];
+    __shared__ int32_t segs[G::EPB + 2];
+    __shared__ int32_t nseg;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    for (int t = tid; t < 3 * TILE; t += FORCE_THREADS) (&acc[0][0])[t] = (T)0;
+    const int first = group_first[g], last = group_first[g + 1];
+    const int c0 = group_cell0[g], c1 = group_cell0[g + 1];
+    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
+    for (int ch = first; ch < last; ch += CH) {
+        if (tid == 0) nseg = 0;
+        __syncthreads(); // also orders the previous chunk's reads of sp / segs before they are overwritten
+        const int p = ch + tid;
+        if (p < last) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                int base;
+                T w[3], dw[3];
+                bspline<T>(one_over_dx * X[(int64_t)d * Np + p], base, w, dw);
+                sbase[d][tid] = base;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) sp[9 + 3 * d + q][tid] = w[q], sp[18 + 3 * d + q][tid] = dw[q];
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sp[c][tid] = scale * stress[(int64_t)c * Np + p];
+        }
+        for (int c = c0 + tid; c < c1; c += FORCE_THREADS) {
+            const int s0 = max(cell_first[c], ch), s1 = min(cell_first[c + 1], min(ch + CH, last));
+            if (s1 > s0) segs[atomicAdd(&nseg, 1)] = (s0 - ch) | ((s1 - ch) << 16);
+        }
+        __syncthreads();
+        const int ni = nseg * 9;
+        for (int it = tid; it < ni; it += FORCE_THREADS) {
+            const int sd = segs[it / 9], jk = it % 9, l0 = sd & 0xffff, l1 = sd >> 16;
+            const int j = jk / 3, k = jk - 3 * j;
+            T a[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a[i][0] = a[i][1] = a[i][2] = (T)0;
+            for (int l = l0; l < l1; ++l) {
+                const T wy = sp[12 + j][l], wz = sp[15 + k][l], dwy = sp[21 + j][l], dwz = sp[24 + k][l];
+                T S[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) S[c] = sp[c][l];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const T wi = sp[9 + i][l], dwi = one_over_dx * sp[18 + i][l];
+                    const T wij = wi * wy, dwij_i = dwi * wy, dwij_j = wi * one_over_dx * dwy;
+                    const T g0 = dwij_i * wz, g1 = dwij_j * wz, g2 = wij * one_over_dx * dwz;
+                    a[i][0] += -(S[0] * g0 + S[3] * g1 + S[6] * g2);
+                    a[i][1] += -(S[1] * g0 + S[4] * g1 + S[7] * g2);
+                    a[i][2] += -(S[2] * g0 + S[5] * g1 + S[8] * g2);
+                }
+            }
+            const int b0 = sbase[0][l0], b1 = sbase[1][l0], b2 = sbase[2][l0]; // the same for every particle of the cell
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int t = ((b0 - ox + i) * TY + (b1 - oy + j)) * TZ + (b2 - oz + k);
+                lds_atomic_add(&acc[0][t], a[i][0]), lds_atomic_add(&acc[1][t], a[i][1]), lds_atomic_add(&acc[2][t], a[i][2]);
+            }
+        }
+    }
+    __syncthreads();
+    T* out = part + (int64_t)g * 3 * TILE; // partial tile, summed per node by k_tile_reduce
+    for (int t = tid; t < 3 * TILE; t += FORCE_THREADS) out[t] = (&acc[0][0])[t];
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void k_inertia_energy(const T* __restrict__ dv, const T* __restrict__ mass, int nn, T g0, T g1, T g2, double* out)
 {
@@ -346,7 +427,11 @@ double Ctx<T>::state_pass(const T* dv_in, bool want_force)
         group_nb.p, gIdx.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p);
     if (want_force)
     {
-        HOT_LAUNCH(this, "force_scatter", k_force_scatter<T>, Ng, 256, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, (T)1 / dx, dt);
+        static const bool force_v1 = getenv("HOT_FORCE_V1") != nullptr; // A/B switch: one LDS atomic per particle, node and component
+        if (force_v1)
+            HOT_LAUNCH(this, "force_scatter", k_force_scatter<T>, Ng, 256, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, (T)1 / dx, dt);
+        else
+            HOT_LAUNCH(this, "force_scatter", k_force_cells<T>, Ng, FORCE_THREADS, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, (T)1 / dx, dt);
         reduce_tiles(3, gF.p, gF.p + slots, gF.p + 2 * slots, nullptr, nullptr, "force_reduce");
     }
     HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, std::min(div_up(Nn, 256), 1024), 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1);
