@@ -328,6 +328,96 @@ void Ctx<T>::assemble_tiles(Level<T>& L)
     HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles<T>, Nb * TPB, HT_THREADS, TileLds<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx);
 }
 
+// ------------------------------------------------------------------------------------------------ matrix-free diagonal
+// buildDiagonal (reference Projects/multigrid/ImplicitSolver.h:605-665): the 3x3 diagonal blocks of the matrix-free
+// operator,  D_i = m_i I + dt^2 sum_p V_p sum_{v,q} ddF[(.,v),(.,q)] g_i[v] g_i[q],  g_i = Fn^T grad w_i.  Column `cc`
+// of every block per launch (3 quantities, the same partial-tile + ordered reduce path as the force scatter).
+template <class T>
+__global__ __launch_bounds__(256) void k_mf_diag_col(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ dp, int64_t Np, const int32_t* __restrict__ group_first,
+    const int32_t* __restrict__ group_origin, T* __restrict__ part, T one_over_dx, int cc)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
+    __shared__ T acc[3][TILE];
+    const int g = blockIdx.x;
+    for (int t = threadIdx.x; t < 3 * TILE; t += 256) (&acc[0][0])[t] = (T)0;
+    __syncthreads();
+    const int first = group_first[g], last = group_first[g + 1];
+    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
+    for (int p = first + threadIdx.x; p < last; p += 256) {
+        T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
+        int base[3];
+        T w[3][3], dw[3][3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+        T F9[9], D[45];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) F9[c] = Fn[(int64_t)c * Np + p];
+#pragma unroll
+        for (int q = 0; q < 45; ++q) D[q] = dp[(int64_t)q * Np + p];
+        for (int n = 0; n < 27; ++n) {
+            const int i = n / 9, j = (n / 3) % 3, k = n % 3;
+            const T wi = i == 0 ? w[0][0] : (i == 1 ? w[0][1] : w[0][2]), dwi = i == 0 ? dw[0][0] : (i == 1 ? dw[0][1] : dw[0][2]);
+            const T wj = j == 0 ? w[1][0] : (j == 1 ? w[1][1] : w[1][2]), dwj = j == 0 ? dw[1][0] : (j == 1 ? dw[1][1] : dw[1][2]);
+            const T wk = k == 0 ? w[2][0] : (k == 1 ? w[2][1] : w[2][2]), dwk = k == 0 ? dw[2][0] : (k == 1 ? dw[2][1] : dw[2][2]);
+            const T g0 = one_over_dx * dwi * wj * wk, g1 = wi * one_over_dx * dwj * wk, g2 = wi * wj * one_over_dx * dwk;
+            T gi[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gi[c] = F9[c * 3] * g0 + F9[c * 3 + 1] * g1 + F9[c * 3 + 2] * g2; // (Fn^T grad w)[c] = sum_r Fn(r, c) gw[r]
+            const int t = ((base[0] - ox + i) * TY + (base[1] - oy + j)) * TZ + (base[2] - oz + k);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                T v = (T)0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int vv = 0; vv < 3; ++vv) v += D[sym45(a + 3 * vv, cc + 3 * q)] * gi[vv] * gi[q];
+                lds_atomic_add(&acc[a][t], v);
+            }
+        }
+    }
+    __syncthreads();
+    T* out = part + (int64_t)g * 3 * TILE;
+    for (int t = threadIdx.x; t < 3 * TILE; t += 256) out[t] = (&acc[0][0])[t];
+}
+template <class T>
+__global__ void k_mf_diag_finish(const T* __restrict__ tile /*[9][slots]: column-major blocks*/, const int32_t* __restrict__ dofSlot, const T* __restrict__ mass, T* __restrict__ dinv, int nn,
+    int64_t slots, int Ainv)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nn) return;
+    const int64_t s = dofSlot[n];
+    Mat3<T> D;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) D.a[c] = tile[(int64_t)c * slots + s];
+    const T m = mass[n];
+    D.a[0] += m, D.a[4] += m, D.a[8] += m;
+    Mat3<T> R;
+    if (Ainv == 0) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) R.a[c] = (c % 4 == 0) ? (T)1 / D.a[c] : (T)0;
+    }
+    else
+        R = m3_inverse(D);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) dinv[9 * (int64_t)n + c] = R.a[c];
+}
+
+template <class T>
+void Ctx<T>::matfree_diagonal(T* dinv)
+{
+    int64_t slots = (int64_t)Nb * EPB;
+    pDP.reserve(45 * (size_t)Np);
+    HOT_LAUNCH(this, "hessian_dpdf", k_dpdf45<T>, div_up(Np, 256), 256, 0, pFt.p, pVol.p, pMu.p, pLam.p, pDP.p, Np, dt, cfg.project);
+    DBuf<T>& tile = ap; // scratch (9 * slots)
+    tile.reserve(9 * slots);
+    for (int cc = 0; cc < 3; ++cc) {
+        HOT_LAUNCH(this, "matfree_diag_scatter", k_mf_diag_col<T>, Ng, 256, 0, pX.p, pFn.p, pDP.p, Np, group_first.p, group_origin.p, gPart.p, (T)1 / dx, cc);
+        reduce_tiles(3, tile.p + (3 * cc) * slots, tile.p + (3 * cc + 1) * slots, tile.p + (3 * cc + 2) * slots, nullptr, nullptr, "matfree_diag_reduce");
+    }
+    HOT_LAUNCH(this, "matfree_diag_finish", k_mf_diag_finish<T>, div_up(Nn, 256), 256, 0, tile.p, dofSlot.p, mass.p, dinv, Nn, slots, cfg.Ainv);
+}
+
 template struct Ctx<float>;
 template struct Ctx<double>;
 

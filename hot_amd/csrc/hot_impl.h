@@ -2,6 +2,7 @@
 // hessian.hip / mg_build.hip / mg_solve.hip / solve.hip and explicitly instantiated there for float and double.
 #pragma once
 #include "hot_ctx.h"
+#include <functional>
 
 namespace hot {
 
@@ -85,6 +86,7 @@ struct Ctx : CtxBase {
     HashMap cell_map; // (Linear_Offset(base cell) >> data_bits) -> cell id
     DBuf<T> pDP; // 45*Np: symmetric 9x9 V_p dt^2 dP/dF per particle (Hessian assembly)
     void build_cell_table();
+    void matfree_diagonal(T* dinv); // 9 Nn: inverse (Ainv) of the block diagonal of the matrix-free operator
     void assemble_tiles(Level<T>& L);
     // ---- atomic-free scatter: every particle group writes its (BX+2)(BY+2)(BZ+2) partial tile, then each node sums
     //      the <= 8 partial tiles that cover it in a fixed order (deterministic; global fp64 atomics top out at ~2e10/s)
@@ -210,6 +212,8 @@ struct Ctx : CtxBase {
     std::string lname(const char* base, int level) { return std::string(base) + "_L" + std::to_string(level); }
     void spmv_dev(Level<T>& L, const T* x, T* y);
     void scale_dev(Level<T>& L, const T* in, T* out); // out_i = Dinv_i in_i
+    void block_apply_dev(const T* D, const T* in, T* out, int n);
+    int minres_dev(const std::function<void(const T*, T*)>& Amul, const std::function<void(const T*, T*)>& prec, T* x, const T* b, T relative_tolerance, T tolerance, int max_iterations);
     void scal(size_t n, T a, T* x); // x *= a
     void restrict_dev(int level, const T* fine, T* coarse);
     void prolong_dev(int level, const T* coarse, T* fine);

@@ -268,6 +268,105 @@ __global__ void k_sub(size_t n, const T* __restrict__ a, const T* __restrict__ b
     if (i < n) out[i] = a[i] - b[i];
 }
 
+// out_i = in_i / m_i : the lumped-mass preconditioner (MultigridSimulation.h:170-176, ImplicitSolver.h:365 with Ainv 2)
+template <class T>
+__global__ void k_mass_scale(const T* __restrict__ mass, const T* __restrict__ in, T* out, int nn)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 3 * nn) return;
+    out[e] = in[e] * ((T)1 / mass[e / 3]);
+}
+// y = (y - a x1 - b x2) / c   and   y = y / c   (MINRES three-term recurrences, Minres.h:94-95,127-138)
+template <class T>
+__global__ void k_minres_comb(size_t n, T* y, T a, const T* __restrict__ x1, T b, const T* __restrict__ x2, T c)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (y[i] - a * x1[i] - b * x2[i]) / c;
+}
+template <class T>
+__global__ void k_div2(size_t n, T* y, T* z, T c)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = y[i] / c, z[i] = z[i] / c;
+}
+
+// Minres<T,TM,TV>::solve + applyAllPreviousGivensRotationsAndDetermineNewGivens (reference Lib/Ziran/Math/Linear/Minres.h:69-178)
+template <class T>
+int Ctx<T>::minres_dev(const std::function<void(const T*, T*)>& Amul, const std::function<void(const T*, T*)>& prec, T* x, const T* b, T relative_tolerance, T tolerance, int max_iterations)
+{
+    size_t n3 = 3 * (size_t)Nn;
+    DBuf<T> bufs[7];
+    for (auto& v : bufs) v.reserve(n3), zero(n3, v.p);
+    T *mk = bufs[0].p, *mkm1 = bufs[1].p, *mkm2 = bufs[2].p, *z = bufs[3].p, *qkm1 = bufs[4].p, *qk = bufs[5].p, *qkp1 = bufs[6].p;
+    T gamma = 0, delta = 0, epsilon = 0, beta_kp1 = 0, alpha_k = 0, beta_k = 0, tk = 0;
+    struct G2 {
+        T c = 1, s = 0;
+        void compute(T a, T b)
+        {
+            T d = a * a + b * b;
+            c = 1, s = 0;
+            T sq = std::sqrt(d);
+            if (sq) {
+                T t = 1 / sq;
+                c = a * t, s = -b * t;
+            }
+        }
+        void rot(T& a, T& b) const
+        {
+            T t1 = a, t2 = b;
+            a = c * t1 - s * t2, b = s * t1 + c * t2;
+        }
+    } Gk, Gkm1, Gkm2;
+    Amul(x, qkp1);
+    HOT_LAUNCH(this, "sub", k_sub<T>, div_up(n3, 256), 256, 0, n3, b, qkp1, qkp1);
+    project_dev(qkp1);
+    prec(qkp1, z);
+    T rpn = (T)std::sqrt(dot_host(n3, z, qkp1));
+    beta_kp1 = rpn;
+    HOT_CHECK(beta_kp1 == beta_kp1, HOT_ERR_NUMERIC, "NaN in MINRES");
+    T local_tolerance = std::min(relative_tolerance * rpn, tolerance);
+    if (rpn < local_tolerance) return 0;
+    if (rpn > 0) HOT_LAUNCH(this, "minres_div", k_div2<T>, div_up(n3, 256), 256, 0, n3, qkp1, z, beta_kp1);
+    T rhs0 = rpn, rhs1 = 0;
+    for (int k = 0; k < max_iterations; ++k) {
+        if (rpn < local_tolerance) return k;
+        std::swap(mkm2, mkm1);
+        std::swap(mkm1, mk);
+        copy(n3, z, mk);
+        beta_k = beta_kp1;
+        std::swap(qkm1, qkp1);
+        std::swap(qkm1, qk);
+        Amul(mk, qkp1);
+        project_dev(qkp1);
+        alpha_k = (T)dot_host(n3, mk, qkp1);
+        axpy(n3, -alpha_k, qk, qkp1);
+        axpy(n3, -beta_k, qkm1, qkp1);
+        prec(qkp1, z);
+        beta_kp1 = (T)std::sqrt(std::max(0.0, dot_host(n3, z, qkp1)));
+        if (beta_kp1 > 0) HOT_LAUNCH(this, "minres_div", k_div2<T>, div_up(n3, 256), 256, 0, n3, qkp1, z, beta_kp1);
+        Gkm2 = Gkm1;
+        Gkm1 = Gk;
+        T e0 = 0, e1 = beta_k;
+        Gkm2.rot(e0, e1);
+        epsilon = e0;
+        T d0 = e1, d1 = alpha_k;
+        Gkm1.rot(d0, d1);
+        delta = d0;
+        T t0 = d1, t1 = beta_kp1;
+        Gk.compute(t0, t1);
+        Gk.rot(t0, t1);
+        gamma = t0;
+        Gk.rot(rhs0, rhs1);
+        tk = rhs0;
+        T res = rhs1;
+        rhs0 = res, rhs1 = 0;
+        rpn = res < 0 ? -res : res;
+        HOT_LAUNCH(this, "minres_comb", k_minres_comb<T>, div_up(n3, 256), 256, 0, n3, mk, delta, mkm1, epsilon, mkm2, gamma);
+        axpy(n3, tk, mk, x);
+    }
+    return max_iterations;
+}
+
 template <class T>
 bool Ctx<T>::newton_solve()
 {
@@ -289,17 +388,46 @@ bool Ctx<T>::newton_solve()
             return true;
         }
         zero(n3, step.p);
-        HOT_CHECK(!cfg.matrixFree, HOT_ERR_INVALID, "matrixFree PN needs the matrix-free block diagonal (buildDiagonal, ImplicitSolver.h:605-665): not built yet");
-        build_hessian();
-        build_mg();
+        // computeStep (ImplicitSolver.h:355-432)
+        const bool massPrec = !cfg.matrixFree && (cfg.lsolver == 1 || cfg.lsolver == 2) && cfg.Ainv == 2; // :365
+        if (cfg.matrixFree) {
+            mfdiag.reserve(9 * (size_t)Nn);
+            matfree_diagonal(mfdiag.p); // buildDiagonal :605-665
+        }
+        else {
+            build_hessian();
+            if (!massPrec) build_mg();
+        }
         bool diagPrec = (cfg.levelCnt == 1 && cfg.times == 1);
-        auto prec = [&](const T* in, T* out) {
-            if (diagPrec)
+        std::function<void(const T*, T*)> prec = [&](const T* in, T* out) {
+            if (cfg.matrixFree)
+                block_apply_dev(mfdiag.p, in, out, Nn);
+            else if (massPrec)
+                HOT_LAUNCH(this, "mass_scale", k_mass_scale<T>, div_up(n3, 256), 256, 0, mass.p, in, out, Nn);
+            else if (diagPrec)
                 scale_dev(*levels[0], in, out); // forced diagonal preconditioner (ImplicitSolver.h:376-391)
             else
                 vcycle_dev(in, out);
         };
-        auto Amul = [&](const T* xx, T* bb) { spmv_dev(*levels[0], xx, bb); };
+        std::function<void(const T*, T*)> Amul = [&](const T* xx, T* bb) {
+            if (cfg.matrixFree)
+                matfree_dev(xx, bb);
+            else
+                spmv_dev(*levels[0], xx, bb);
+        };
+        if (cfg.lsolver == 1) {
+            // relative tolerance from the Newton loop (ExtendedNewtonsMethod.h:57), tolerance = maxcntol
+            // (MultigridSimulation.h:204) or the scene value 1e-4 (MultigridInit3D.h:85-86)
+            T residual_norm = (T)std::sqrt(dot_host(n3, residual, residual));
+            T newton_tol = cfg.useCN ? max_cn_tolerance : (T)cfg.cneps;
+            T rel = std::min((T)0.5, (T)std::sqrt(std::max(residual_norm, newton_tol)));
+            stats.linear_iterations += minres_dev(Amul, prec, step.p, residual, rel, cg_tolerance, 10000);
+            if (cfg.linesearch) line_search(step.p, residual, (T)1);
+            transform_dev(step.p, true);
+            axpy(n3, (T)1, step.p, x);
+            transform_dev(step.p, false);
+            continue;
+        }
         // b = residual (+ dRhs == 0)
         Amul(step.p, temp.p);
         HOT_LAUNCH(this, "sub", k_sub<T>, div_up(n3, 256), 256, 0, n3, residual, temp.p, r.p);
@@ -340,6 +468,9 @@ template <class T>
 void Ctx<T>::solve(hot_stats* st)
 {
     need(Nn > 0 && dt > 0, "hot_solve before hot_begin_step");
+    need(cfg.lsolver == 1 || cfg.lsolver == 2 || cfg.lsolver == 3, "lsolver must be 1 (PN + MINRES), 2 (PN + PCG) or 3 (L-BFGS); 0 performs no linear solve in the reference and 4 is the SimplicialLLT direct solver (out of scope)");
+    need(!(cfg.matrixFree && cfg.lsolver == 3), "matrixFree applies to the projected-Newton solvers (lsolver 1 / 2)");
+    need(!(cfg.Ainv == 2 && cfg.lsolver == 3), "Ainv 2 (lumped-mass preconditioner) applies to lsolver 1 / 2 (Configurations.h:30)");
     double keep_sort = stats.ms_sort, keep_p2g = stats.ms_p2g, keep_begin = stats.ms_begin;
     std::memset(&stats, 0, sizeof(stats));
     stats.ms_sort = keep_sort, stats.ms_p2g = keep_p2g, stats.ms_begin = keep_begin;

@@ -49,8 +49,8 @@ typedef struct hot_config {
     double gravity[3];
     double apic_rpic_ratio; /* 1 */
     double cfl; /* 0.6 */
-    int32_t lsolver; /* 2 = projected Newton + (MG-)PCG, 3 = L-BFGS with MG initial Hessian (HOT) */
-    int32_t Ainv; /* 0 inverse diagonal entries, 1 inverse 3x3 diagonal block */
+    int32_t lsolver; /* 1 = projected Newton + MINRES, 2 = projected Newton + inexact (MG-)PCG, 3 = L-BFGS with MG initial Hessian (HOT) */
+    int32_t Ainv; /* 0 inverse diagonal entries, 1 inverse 3x3 diagonal block, 2 lumped mass (lsolver 1 / 2 only, no hierarchy) */
     int32_t smoother; /* 0 damped Jacobi, 1 optimal Jacobi, 2 PCG, 5 symmetric coloured GS, 6 Chebyshev */
     int32_t coarseSolver; /* same option space, applied on the top level */
     int32_t levelCnt; /* -mg_level */
@@ -63,7 +63,7 @@ typedef struct hot_config {
     int32_t project; /* --project: PSD-project dP/dF */
     int32_t systemBCProject; /* --bcproject */
     int32_t linesearch; /* --linesearch */
-    int32_t matrixFree; /* --matfree (lsolver 2 only) */
+    int32_t matrixFree; /* --matfree (lsolver 1 / 2): H x by G2P -> dP -> P2G, block-diagonal preconditioner */
     int32_t boundaryType; /* -bc: 0 all sticky, 1 has slip */
     int32_t useAdaptiveHessian; /* --adaptiveH */
     int32_t topDownMGS;
@@ -80,7 +80,7 @@ typedef struct hot_stats {
     int32_t iterations; /* nonlinear (L-BFGS / Newton) iterations of the last solve */
     int32_t converged;
     int32_t linesearch_trials; /* total updateState calls inside lineSearch */
-    int32_t linear_iterations; /* PCG iterations (lsolver 2) or total top-level PCG iterations (lsolver 3) */
+    int32_t linear_iterations; /* MINRES / PCG iterations (lsolver 1 / 2) or total top-level PCG iterations (lsolver 3) */
     int32_t vcycles;
     int32_t dropped_pairs; /* L-BFGS curvature pairs dropped (y^T s <= 0, LBFGS.h:420-425) */
     int32_t num_nodes;

@@ -9,6 +9,7 @@
 // This file: particle storage, sortParticlesAndPolluteGrid, the sparse block grid, kernel iteration,
 // P2G, DOF numbering, mass vector, BCs, G2P.
 #pragma once
+#include <functional>
 #include "../include/hot_mi355x.h"
 #include "spgrid_index.hpp"
 #include "corotated.hpp"
@@ -578,6 +579,8 @@ struct Sim {
     static void build_product(EllMat<T>& out, const EllMat<T>& l, const EllMat<T>& r);
     static void build_transpose(EllMat<T>& out, const EllMat<T>& l, int rowcnt);
     void build_mg();
+    int minres_solve(const std::function<void(const std::vector<TV>&, std::vector<TV>&)>& Amul, const std::function<void(const std::vector<TV>&, std::vector<TV>&)>& prec,
+        std::vector<TV>& x, const std::vector<TV>& b, T relative_tolerance, T tolerance, int max_iterations);
     void scaler(const std::vector<TV>& r, std::vector<TV>& mr, const EllMat<T>& A) const;
     void smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r, std::vector<TV>& du, std::vector<TV>& dAu, int iterations, T tolerance);
     void vcycle(const std::vector<TV>& in, std::vector<TV>& out);

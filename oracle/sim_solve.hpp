@@ -146,6 +146,78 @@ bool Sim<T>::lbfgs_solve()
 // reference ExtendedNewtonsMethod::solve (Lib/Ziran/Math/Nonlinear/ExtendedNewtonsMethod.h:39-66) +
 // ImplicitSolverObjective::computeStep (ImplicitSolver.h:355-432) + InexactConjugateGradient::solve
 // (Lib/Ziran/Math/Linear/InexactConjugateGradient.h:49-103)
+// reference Minres<T, TM, TV>::solve + applyAllPreviousGivensRotationsAndDetermineNewGivens (Minres.h:69-178)
+template <class T>
+int Sim<T>::minres_solve(const std::function<void(const std::vector<TV>&, std::vector<TV>&)>& Amul,
+    const std::function<void(const std::vector<TV>&, std::vector<TV>&)>& prec, std::vector<TV>& x, const std::vector<TV>& b, T relative_tolerance, T tolerance,
+    int max_iterations)
+{
+    const int n = num_nodes;
+    std::vector<TV> mk(n, TV::zero()), mkm1(n, TV::zero()), mkm2(n, TV::zero()), z(n, TV::zero()), qkm1(n, TV::zero()), qk(n, TV::zero()), qkp1(n, TV::zero());
+    T gamma = 0, delta = 0, epsilon = 0, beta_kp1 = 0, alpha_k = 0, beta_k = 0, tk = 0;
+    Givens<T> Gk(0, 1), Gkm1(0, 1), Gkm2(0, 1);
+    auto rot2 = [](const Givens<T>& G, T& a, T& b2) { // rowRotation on a 2-vector
+        T t1 = a, t2 = b2;
+        a = G.c * t1 - G.s * t2;
+        b2 = G.s * t1 + G.c * t2;
+    };
+    Amul(x, qkp1);
+    for (int i = 0; i < n; ++i) qkp1[i] = b[i] - qkp1[i];
+    project(qkp1);
+    prec(qkp1, z);
+    T rpn = std::sqrt(dot_product(z, qkp1));
+    beta_kp1 = rpn;
+    T local_tolerance = std::min(relative_tolerance * rpn, tolerance);
+    if (rpn < local_tolerance) return 0;
+    if (rpn > 0)
+        for (int i = 0; i < n; ++i)
+                for (int d = 0; d < 3; ++d) qkp1[i].a[d] /= beta_kp1, z[i].a[d] /= beta_kp1;
+    T rhs0 = rpn, rhs1 = 0; // last two components of the Givens-transformed least-squares rhs
+    for (int k = 0; k < max_iterations; ++k) {
+        if (rpn < local_tolerance) return k;
+        mkm2.swap(mkm1);
+        mkm1.swap(mk);
+        mk = z;
+        beta_k = beta_kp1;
+        qkm1.swap(qkp1);
+        qkm1.swap(qk);
+        Amul(mk, qkp1);
+        project(qkp1);
+        alpha_k = dot_product(mk, qkp1);
+        for (int i = 0; i < n; ++i) qkp1[i] = qkp1[i] - qk[i] * alpha_k;
+        for (int i = 0; i < n; ++i) qkp1[i] = qkp1[i] - qkm1[i] * beta_k;
+        prec(qkp1, z);
+        beta_kp1 = std::sqrt(std::max((T)0, dot_product(z, qkp1)));
+        if (beta_kp1 > 0)
+            for (int i = 0; i < n; ++i)
+                for (int d = 0; d < 3; ++d) qkp1[i].a[d] /= beta_kp1, z[i].a[d] /= beta_kp1;
+        // applyAllPreviousGivensRotationsAndDetermineNewGivens
+        Gkm2 = Gkm1;
+        Gkm1 = Gk;
+        T e0 = 0, e1 = beta_k;
+        rot2(Gkm2, e0, e1);
+        epsilon = e0;
+        T d0 = e1, d1 = alpha_k;
+        rot2(Gkm1, d0, d1);
+        delta = d0;
+        T t0 = d1, t1 = beta_kp1;
+        Gk.compute(t0, t1);
+        rot2(Gk, t0, t1);
+        gamma = t0;
+        rot2(Gk, rhs0, rhs1);
+        tk = rhs0;
+        T res = rhs1;
+        rhs0 = res, rhs1 = 0;
+        rpn = res < 0 ? -res : res;
+        for (int i = 0; i < n; ++i) {
+            TV t = mk[i] - mkm1[i] * delta - mkm2[i] * epsilon;
+            for (int d = 0; d < 3; ++d) mk[i].a[d] = t.a[d] / gamma;
+        }
+        for (int i = 0; i < n; ++i) x[i] += mk[i] * tk;
+    }
+    return max_iterations;
+}
+
 template <class T>
 bool Sim<T>::newton_solve()
 {
@@ -170,10 +242,18 @@ bool Sim<T>::newton_solve()
             double t0 = now_ms();
             build_matrix();
             double t1 = now_ms();
-            build_mg();
+            // ImplicitSolver.h:365: with the mass preconditioner (Ainv 2, lsolver 1/2 only) no hierarchy is built and
+            // `precondition` stays the lumped-mass scaling installed by startBackwardEuler
+            const bool massPrec = (cfg.lsolver == 1 || cfg.lsolver == 2) && cfg.Ainv == 2;
+            if (!massPrec) build_mg();
             double t2 = now_ms();
             stats.ms_hessian += t1 - t0, stats.ms_mg_build += t2 - t1;
-            if (cfg.levelCnt == 1 && cfg.times == 1)
+            if (massPrec)
+                prec = [&](const std::vector<TV>& in, std::vector<TV>& out) {
+                    out.resize(in.size());
+                    for (int i = 0; i < num_nodes; ++i) out[i] = in[i] * ((T)1 / mass_matrix[i]);
+                };
+            else if (cfg.levelCnt == 1 && cfg.times == 1)
                 prec = [&](const std::vector<TV>& in, std::vector<TV>& out) { scaler(in, out, sysmats[0]); };
             else
                 prec = [&](const std::vector<TV>& in, std::vector<TV>& out) { vcycle(in, out); };
@@ -225,6 +305,15 @@ bool Sim<T>::newton_solve()
         std::vector<TV> b = residual;
         if (cfg.systemBCProject)
             for (int n = 0; n < num_nodes; ++n) b[n] += dRhs[n];
+        if (cfg.lsolver == 1) {
+            // Minres::solve (Lib/Ziran/Math/Linear/Minres.h:69-149) with relative tolerance from the Newton loop
+            // (ExtendedNewtonsMethod.h:57) and tolerance = maxcntol (MultigridSimulation.h:204) or the scene's 1e-4
+            T residual_norm = std::sqrt(dot_product(residual, residual));
+            T newton_tol = cfg.useCN ? max_cn_tolerance : (T)cfg.cneps;
+            T rel = std::min((T)0.5, std::sqrt(std::max(residual_norm, newton_tol)));
+            stats.linear_iterations += minres_solve(Amul, prec, step, b, rel, cg_tolerance, 10000);
+        }
+        else
         // inexact PCG
         {
             std::vector<TV> r(num_nodes), p(num_nodes), q(num_nodes), temp(num_nodes);

@@ -78,7 +78,11 @@ def test_vcycle_against_oracle(hotlib, oracle, cfg):
     assert rel(g.vcycle(x), c.vcycle(x)) < 1e-8
 
 
-SOLVER_CFGS = [dict(lsolver=3, levelCnt=3), dict(lsolver=3, levelCnt=1), dict(lsolver=2, levelCnt=2), dict(lsolver=2, levelCnt=1, smoother=0, coarseSolver=0)]
+SOLVER_CFGS = [dict(lsolver=3, levelCnt=3), dict(lsolver=3, levelCnt=1), dict(lsolver=2, levelCnt=2), dict(lsolver=2, levelCnt=1, smoother=0, coarseSolver=0),
+               dict(lsolver=1, levelCnt=2, coarseSolver=5),  # projected Newton + MINRES, V-cycle preconditioner (GS on every level: MINRES needs a fixed SPD preconditioner, the PCG coarse solve is not one)
+               dict(lsolver=1, levelCnt=1, Ainv=2),  # ... lumped-mass preconditioner (no hierarchy)
+               dict(lsolver=2, levelCnt=1, matrixFree=1, systemBCProject=0),  # matrix-free PN with the block-diagonal preconditioner
+               dict(lsolver=2, levelCnt=1, matrixFree=1, systemBCProject=0, Ainv=0)]
 
 
 @pytest.mark.parametrize("kw", SOLVER_CFGS)
@@ -91,6 +95,14 @@ def test_solver_iterates_against_oracle(hotlib, oracle, kw):
         st = ctx.solve()
         out[name] = (ctx.get_dv(), st)
     sg, sc = out["gpu"][1], out["cpu"][1]
+    if kw.get("Ainv") == 2:
+        # MINRES behind the lumped-mass preconditioner needs hundreds of Lanczos steps per Newton iteration; its
+        # loss of orthogonality makes the stopping iteration (not the solution) sensitive to round-off
+        assert sg["iterations"] == sc["iterations"] and sg["num_levels"] == sc["num_levels"]
+        assert abs(sg["linear_iterations"] - sc["linear_iterations"]) <= 0.05 * sc["linear_iterations"], (sg, sc)
+        assert rel(out["gpu"][0], out["cpu"][0]) < 1e-2
+        assert abs(sg["energy"] - sc["energy"]) < 1e-3 * max(abs(sc["energy"]), 1e-6)
+        return
     for k in ("iterations", "linesearch_trials", "linear_iterations", "vcycles", "dropped_pairs", "num_levels"):
         assert sg[k] == sc[k], (k, sg, sc)
     assert rel(out["gpu"][0], out["cpu"][0]) < 1e-9

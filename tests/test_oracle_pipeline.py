@@ -37,7 +37,9 @@ def test_vcycle_symmetric_pd(oracle):
 
 def test_solvers_converge_and_agree(oracle):
     res = {}
-    for name, kw in {"lbfgs": dict(lsolver=3, levelCnt=2), "pn": dict(lsolver=2, levelCnt=2), "pn_jacobi": dict(lsolver=2, levelCnt=1, coarseSolver=0, smoother=0)}.items():
+    for name, kw in {"lbfgs": dict(lsolver=3, levelCnt=2), "pn": dict(lsolver=2, levelCnt=2), "pn_jacobi": dict(lsolver=2, levelCnt=1, coarseSolver=0, smoother=0),
+                     "pn_minres": dict(lsolver=1, levelCnt=2, coarseSolver=5), "pn_minres_mass": dict(lsolver=1, levelCnt=1, Ainv=2),
+                     "pn_matfree": dict(lsolver=2, levelCnt=1, matrixFree=1, systemBCProject=0)}.items():
         ctx, c = pc.make_ctx(oracle, n=5, cneps=1e-8, **kw)
         pc.prepare(ctx)
         st = ctx.solve()
@@ -48,7 +50,7 @@ def test_solvers_converge_and_agree(oracle):
     # all three minimise the same energy.  The returned dv is only loosely comparable: low-mass corner nodes
     # are poorly determined at the CN tolerance and the reference applies the last accepted step twice
     # (LBFGS.h:412-413 after lineSearch's moveNodes aliasing, see DESIGN.md "reference quirks").
-    for other in ("pn", "pn_jacobi"):
+    for other in ("pn", "pn_jacobi", "pn_minres", "pn_minres_mass", "pn_matfree"):
         a, b = res["lbfgs"][0], res[other][0]
         m = res["lbfgs"][2][:, None]
         assert np.sqrt((m * (a - b) ** 2).sum()) < 2e-2 * np.sqrt((m * a ** 2).sum())  # kinetic-energy norm
