@@ -24,6 +24,7 @@ struct Level {
     DBuf<int32_t> gs_block_start; // nblocks+1 : offsets into gs_order
     // after build_mg every row's slots are regrouped as [nl entries preceding the row in the GS order | diagonal |
     // nu entries following it | structural zeros], so each half sweep streams only the half it needs
+    double lMin = 1e-8, lMax = 1e2; // spectrum bounds for the Chebyshev smoother (SquareMatrix.h:37, estimate2norm :375-475)
     DBuf<T> apv; // n*64*9: A*P of this level (4^3 coarse window per row), kept for the coarse-correction residual update
     DBuf<int32_t> apc; // n*64: coarse column of every window slot (0 where the coarse node does not exist; its block is 0)
     DBuf<int32_t> rowcnt; // 4n: (precede-off, precede-in, follow-in, follow-off) slot counts of the regrouped rows
@@ -213,6 +214,7 @@ struct Ctx : CtxBase {
     void spmv_dev(Level<T>& L, const T* x, T* y);
     void scale_dev(Level<T>& L, const T* in, T* out); // out_i = Dinv_i in_i
     void block_apply_dev(const T* D, const T* in, T* out, int n);
+    void estimate_2norm(Level<T>& L, double tol);
     int minres_dev(const std::function<void(const T*, T*)>& Amul, const std::function<void(const T*, T*)>& prec, T* x, const T* b, T relative_tolerance, T tolerance, int max_iterations);
     void scal(size_t n, T a, T* x); // x *= a
     void restrict_dev(int level, const T* fine, T* coarse);

@@ -404,13 +404,15 @@ void Ctx<T>::build_mg()
     need(!levels.empty(), "hot_build_mg before hot_build_hessian");
     need(!(!cfg.systemBCProject && cfg.levelCnt > 1), "levelCnt > 1 requires systemBCProject (ImplicitSolver.h:339)");
     need(cfg.levelCnt >= 1 && cfg.levelCnt <= 10, "levelCnt must be in [1,10] (MultigridPreconditioner.h:369)");
-    for (int k : { cfg.smoother, cfg.coarseSolver }) need(k == 0 || k == 1 || k == 2 || k == 5, "smoother/coarseSolver must be 0, 1, 2 or 5 (6/7: SURVEY 8f, not built yet)");
+    for (int k : { cfg.smoother, cfg.coarseSolver })
+        need(k == 0 || k == 1 || k == 2 || k == 5 || k == 6, "smoother/coarseSolver must be 0, 1, 2, 5 or 6 (7 = Eigen IncompleteCholesky: not built; 3/4 are not selectable in the reference either)");
     double t0 = wall_ms();
     release_levels(1);
     bool colors = cfg.smoother == 5 || cfg.coarseSolver == 5;
     Level<T>& L0 = *levels[0];
     alloc_work(L0);
     if (colors) mark_colors(this, L0);
+    if ((cfg.coarseSolver == 6 && cfg.levelCnt == 1) || (cfg.smoother == 6 && cfg.levelCnt > 1)) estimate_2norm(L0, 1e-6); // MultigridPreconditioner.h:610-611
     for (int level = 0; level < cfg.levelCnt - 1; ++level) {
         Level<T>& F = *levels[level];
         int n = F.n;
@@ -446,6 +448,7 @@ void Ctx<T>::build_mg()
         count_nnzb(C);
         alloc_work(C);
         if (colors) mark_colors(this, C);
+        if ((cfg.coarseSolver == 6 && level + 2 == cfg.levelCnt) || (cfg.smoother == 6 && level + 2 < cfg.levelCnt)) estimate_2norm(C, 1e-6); // :682-683
         if (colors) split_rows(this, F); // level `level` is no longer needed in stencil-slot order
     }
     if (colors) split_rows(this, *levels.back());

@@ -197,6 +197,55 @@ __global__ void k_scale(const T* __restrict__ D, const T* __restrict__ r, T* mr,
     mr[3 * (int64_t)i + 2] = d[2] * a + d[5] * b + d[8] * c;
 }
 
+// SquareMatrix::estimate2norm (reference Projects/multigrid/SquareMatrix.h:375-475, active #else branch): power iteration on
+// A*A from a +-1 start vector.  The reference seeds the signs with srand(time(NULL)); here they are a fixed hash of the
+// entry index (identical in the oracle), the converged value does not depend on it within the 1e-6 stopping tolerance.
+template <class T>
+__global__ void k_cheb_start(T* v, size_t n3)
+{
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n3) v[e] = ((((unsigned)e * 2654435761u) >> 16) & 1u) ? (T)1 : (T)-1;
+}
+template <class T>
+__global__ void k_abs(T* v, size_t n3)
+{
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n3) v[e] = v[e] < 0 ? -v[e] : v[e];
+}
+template <class T>
+__global__ void k_div1(T* v, T c, size_t n3)
+{
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n3) v[e] = v[e] / c;
+}
+template <class T>
+void Ctx<T>::estimate_2norm(Level<T>& L, double tol)
+{
+    constexpr int MaxIters = 512;
+    size_t n3 = 3 * (size_t)L.n;
+    T *v = L.du.p, *x = L.dAu.p; // work vectors of the level, free while the hierarchy is being built
+    HOT_LAUNCH(this, "cheb_start", k_cheb_start<T>, div_up(n3, 256), 256, 0, v, n3);
+    spmv_dev(L, v, x);
+    HOT_LAUNCH(this, "cheb_abs", k_abs<T>, div_up(n3, 256), 256, 0, x, n3);
+    T e = (T)std::sqrt(dot_host(n3, x, x));
+    if (e == 0) {
+        L.lMin = L.lMax = 0;
+        return;
+    }
+    HOT_LAUNCH(this, "cheb_div", k_div1<T>, div_up(n3, 256), 256, 0, x, e, n3);
+    T e0 = 0;
+    for (int iter = 0; iter < MaxIters && std::abs(e - e0) > (T)tol * e; ++iter) {
+        e0 = e;
+        spmv_dev(L, x, v);
+        spmv_dev(L, v, x);
+        T normx = (T)std::sqrt(dot_host(n3, x, x));
+        e = normx / (T)std::sqrt(dot_host(n3, v, v));
+        HOT_LAUNCH(this, "cheb_div", k_div1<T>, div_up(n3, 256), 256, 0, x, normx, n3);
+    }
+    L.lMax = e;
+    L.lMin = L.lMax / 30; // "experience" (:473)
+}
+
 // out_i = D_i in_i for an arbitrary array of 3x3 blocks (matrix-free block-diagonal preconditioner)
 template <class T>
 void Ctx<T>::block_apply_dev(const T* D, const T* in, T* out, int n)
@@ -699,6 +748,33 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             ++cnt;
         }
         stats.linear_iterations += cnt;
+    }
+    else if (kind == 6) {
+        // chebyshev_smooth (MultigridPreconditioner.h:227-264); the tolerance argument is unused there
+        T* p = L.tmp.p;
+        T d = (T)((L.lMax + L.lMin) / 2), c = (T)((L.lMax - L.lMin) / 2);
+        int cnt = 1;
+        iterations--;
+        scaler(r, p);
+        T alpha = 1 / d, beta;
+        copy(n3, p, du);
+        spmv_dev(L, du, dAu);
+        Aproject(dAu);
+        axpy(n3, alpha, du, u);
+        axpy(n3, -alpha, dAu, r);
+        for (; iterations-- > 0; ++cnt) {
+            scaler(r, p);
+            beta = (T)0.5 * c * c * alpha * alpha;
+            if (cnt > 1) beta *= (T)0.5;
+            alpha = 1 / (d - beta / alpha);
+            scal(n3, beta, du); // du = p + beta du
+            axpy(n3, (T)1, p, du);
+            spmv_dev(L, du, dAu);
+            Aproject(dAu);
+            axpy(n3, alpha, du, u);
+            if (!final_residual && iterations <= 0) break;
+            axpy(n3, -alpha, dAu, r);
+        }
     }
     else if (kind == 5) {
         HOT_CHECK(L.nblocks > 0, HOT_ERR_INVALID, "GS smoother requested but the level was built without colouring");

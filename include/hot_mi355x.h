@@ -51,7 +51,7 @@ typedef struct hot_config {
     double cfl; /* 0.6 */
     int32_t lsolver; /* 1 = projected Newton + MINRES, 2 = projected Newton + inexact (MG-)PCG, 3 = L-BFGS with MG initial Hessian (HOT) */
     int32_t Ainv; /* 0 inverse diagonal entries, 1 inverse 3x3 diagonal block, 2 lumped mass (lsolver 1 / 2 only, no hierarchy) */
-    int32_t smoother; /* 0 damped Jacobi, 1 optimal Jacobi, 2 PCG, 5 symmetric coloured GS, 6 Chebyshev */
+    int32_t smoother; /* 0 damped Jacobi, 1 optimal Jacobi, 2 PCG, 5 symmetric coloured GS, 6 Chebyshev (7 = Eigen IncompleteCholesky: rejected) */
     int32_t coarseSolver; /* same option space, applied on the top level */
     int32_t levelCnt; /* -mg_level */
     int32_t times; /* -mg_times */

@@ -579,6 +579,7 @@ struct Sim {
     static void build_product(EllMat<T>& out, const EllMat<T>& l, const EllMat<T>& r);
     static void build_transpose(EllMat<T>& out, const EllMat<T>& l, int rowcnt);
     void build_mg();
+    void estimate_2norm(EllMat<T>& A, T tol);
     int minres_solve(const std::function<void(const std::vector<TV>&, std::vector<TV>&)>& Amul, const std::function<void(const std::vector<TV>&, std::vector<TV>&)>& prec,
         std::vector<TV>& x, const std::vector<TV>& b, T relative_tolerance, T tolerance, int max_iterations);
     void scaler(const std::vector<TV>& r, std::vector<TV>& mr, const EllMat<T>& A) const;

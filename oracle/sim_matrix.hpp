@@ -255,6 +255,43 @@ void Sim<T>::build_transpose(EllMat<T>& out, const EllMat<T>& l, int rowcnt)
     }
 }
 
+// reference SquareMatrix::estimate2norm (SquareMatrix.h:375-475, the active #else branch): power iteration on A*A from
+// a +-1 start vector.  The reference seeds the signs with srand(time(NULL)); here they are a fixed hash of the entry
+// index (the converged estimate does not depend on the start within the 1e-6 stopping tolerance).
+static inline int cheb_sign(int i, int d) { return (((unsigned)(3 * i + d) * 2654435761u) >> 16) & 1u ? 1 : -1; }
+template <class T>
+void Sim<T>::estimate_2norm(EllMat<T>& A, T tol)
+{
+    constexpr int MaxIters = 512;
+    int n = A.nrows;
+    std::vector<TV> v(n), x(n);
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) v[i].a[d] = (T)cheb_sign(i, d);
+    multiply(A, v, x);
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) x[i].a[d] = std::abs(x[i].a[d]);
+    T e = std::sqrt(dot_product(x, x));
+    if (e == 0) {
+        A.lMin = A.lMax = 0;
+        return;
+    }
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) x[i].a[d] /= e;
+    T e0 = 0;
+    int iter = 0;
+    for (; iter < MaxIters && std::abs(e - e0) > tol * e; ++iter) {
+        e0 = e;
+        multiply(A, x, v);
+        multiply(A, v, x);
+        T normx = std::sqrt(dot_product(x, x));
+        e = normx / std::sqrt(dot_product(v, v));
+        for (int i = 0; i < n; ++i)
+            for (int d = 0; d < 3; ++d) x[i].a[d] /= normx;
+    }
+    A.lMax = e;
+    A.lMin = A.lMax / 30; // "experience" (:473)
+}
+
 // reference MultigridBuilder::build (MultigridPreconditioner.h:554-703), kernel_range == 2 (trilinear P,
 // linear_weight_template :445-466), R = P^T, A_{l+1} = R (A_l P)
 template <class T>
@@ -269,6 +306,7 @@ void Sim<T>::build_mg()
     bool colors = (cfg.coarseSolver == 5 || cfg.smoother == 5);
     build_diagonal(sysmats[0], cfg.Ainv);
     if (colors) mark_colors(level_coords[0], sysmats[0]);
+    if ((cfg.coarseSolver == 6 && levelCnt == 1) || (cfg.smoother == 6 && levelCnt > 1)) estimate_2norm(sysmats[0], (T)1e-6); // :610-611
     const T w1d[2][3] = { { 0, 1, 0 }, { 0, (T)0.5, (T)0.5 } };
     for (int level = 0; level < levelCnt - 1; ++level) {
         const auto& coords = level_coords[level];
@@ -312,6 +350,7 @@ void Sim<T>::build_mg()
         build_product(RAP, R, AP);
         build_diagonal(RAP, cfg.Ainv);
         if (colors) mark_colors(new_coords, RAP);
+        if ((cfg.coarseSolver == 6 && level + 2 == levelCnt) || (cfg.smoother == 6 && level + 2 < levelCnt)) estimate_2norm(RAP, (T)1e-6); // :682-683
         promats.push_back(std::move(P));
         resmats.push_back(std::move(R));
         sysmats.push_back(std::move(RAP));
