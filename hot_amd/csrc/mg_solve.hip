@@ -199,7 +199,7 @@ __global__ void k_scale(const T* __restrict__ D, const T* __restrict__ r, T* mr,
 
 // SquareMatrix::estimate2norm (reference Projects/multigrid/SquareMatrix.h:375-475, active #else branch): power iteration on
 // A*A from a +-1 start vector.  The reference seeds the signs with srand(time(NULL)); here they are a fixed hash of the
-// entry index (identical in the oracle), the converged value does not depend on it within the 1e-6 stopping tolerance.
+// entry index, the converged value does not depend on it within the 1e-6 stopping tolerance.
 template <class T>
 __global__ void k_cheb_start(T* v, size_t n3)
 {
