@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_force_scatter(const T* __restrict__ X, 
 // base cell share their 27 nodes, so the three nodes of a column are summed in registers over the cell and added to the
 // LDS tile once.  The 1-D weights and their derivatives are computed once per particle while staging (the first
 // version, k_force_scatter above, recomputed them per node through rotated tables that ended up in scratch memory).
-constexpr int FORCE_THREADS = 256; // see P2G_THREADS (transfer.hip)
+constexpr int FORCE_THREADS = 512, FORCE_CHUNK = 256; // see P2G_THREADS (transfer.hip)
 
 template <class T>
 __global__ __launch_bounds__(FORCE_THREADS) void k_force_cells(const T* __restrict__ X, const T* __restrict__ stress, int64_t Np, const int32_t* __restrict__ group_first,
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(FORCE_THREADS) void k_force_cells(const T* __restri
 {
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
-    constexpr int CH = FORCE_THREADS;
+    constexpr int CH = FORCE_CHUNK;
     __shared__ T acc[3][TILE];
     __shared__ T sp[27][CH]; // S(9) w(3x3) dw(3x3)
     __shared__ int32_t sbase[3][CH];
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(FORCE_THREADS) void k_force_cells(const T* __restri
         if (tid == 0) nseg = 0;
         __syncthreads(); // also orders the previous chunk's reads of sp / segs before they are overwritten
         const int p = ch + tid;
-        if (p < last) {
+        if (tid < CH && p < last) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 int base;
@@ -365,9 +365,11 @@ __global__ __launch_bounds__(FORCE_THREADS) void k_force_cells(const T* __restri
             if (s1 > s0) segs[atomicAdd(&nseg, 1)] = (s0 - ch) | ((s1 - ch) << 16);
         }
         __syncthreads();
-        const int ni = nseg * 9;
+        const int ni = nseg * 18; // (segment, node column, half of the segment), see k_p2g_cells
         for (int it = tid; it < ni; it += FORCE_THREADS) {
-            const int sd = segs[it / 9], jk = it % 9, l0 = sd & 0xffff, l1 = sd >> 16;
+            const int sd = segs[it / 18], jk = (it % 18) >> 1, hf = it & 1, s0 = sd & 0xffff, s1 = sd >> 16;
+            const int mid = (s0 + s1 + 1) >> 1, l0 = hf ? mid : s0, l1 = hf ? s1 : mid;
+            if (l0 >= l1) continue;
             const int j = jk / 3, k = jk - 3 * j;
             T a[3][3];
 #pragma unroll

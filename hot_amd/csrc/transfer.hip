@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_p2g(const T* __restrict__ X, const T* _
 // particle 1-D weights are staged in LDS (coalesced loads, weights computed once per particle instead of once per
 // node) and read back with wave-broadcast reads (all lanes of a cell read the same particle).
 // 256 threads measured best (320 = one item round per fp64 page, but lower occupancy: P2G 0.27 vs 0.24 ms at 2 M particles)
-constexpr int P2G_THREADS = 256;
+constexpr int P2G_THREADS = 512, P2G_CHUNK = 256; // particles are staged 256 at a time by the first 256 threads; all 512 work on the items
 
 template <class T, bool WITH_CN>
 __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C,
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
 {
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
-    constexpr int NQ = WITH_CN ? 5 : 4, NS = 25 + (WITH_CN ? 1 : 0), CH = P2G_THREADS;
+    constexpr int NQ = WITH_CN ? 5 : 4, NS = 25 + (WITH_CN ? 1 : 0), CH = P2G_CHUNK;
     __shared__ T acc[NQ][TILE];
     __shared__ T sp[NS][CH]; // x(3) m(1) m*v(3) m*C(9) w(3x3) [cn]
     __shared__ int32_t sbase[3][CH];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
         if (tid == 0) nseg = 0;
         __syncthreads(); // also orders the previous chunk's reads of sp / segs before they are overwritten
         const int p = ch + tid;
-        if (p < last) {
+        if (tid < CH && p < last) {
             const T m = M[p];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -146,9 +146,14 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
             if (s1 > s0) segs[atomicAdd(&nseg, 1)] = (s0 - ch) | ((s1 - ch) << 16);
         }
         __syncthreads();
-        const int ni = nseg * 9;
+        // items: (cell segment, node column, half of the segment).  A full fp64 page has 32 cells x 9 columns = 288
+        // columns, which would be one full round of the 256 threads plus a nearly empty one; splitting every segment in
+        // two gives 576 half-length items = 2.25 short rounds.
+        const int ni = nseg * 18;
         for (int it = tid; it < ni; it += P2G_THREADS) {
-            const int sd = segs[it / 9], jk = it % 9, l0 = sd & 0xffff, l1 = sd >> 16;
+            const int sd = segs[it / 18], jk = (it % 18) >> 1, hf = it & 1, s0 = sd & 0xffff, s1 = sd >> 16;
+            const int mid = (s0 + s1 + 1) >> 1, l0 = hf ? mid : s0, l1 = hf ? s1 : mid;
+            if (l0 >= l1) continue;
             const int j = jk / 3, k = jk - 3 * j;
             T a[3][NQ];
 #pragma unroll
