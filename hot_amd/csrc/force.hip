@@ -4,13 +4,13 @@
 //                   MpmSimulationBase::buildInitialDvAndVnForNewton (Lib/MPM/MpmSimulationBase.cpp:1139-1184, collision
 //                   query result supplied through hot_set_bc or evaluated here for sticky half spaces),
 //                   FBasedMpmForceHelper::backupStrain (Lib/MPM/Force/FBasedMpmForceHelper.cpp:24-33), resetLSFlag.
-//   k_state         ONE fused particle pass for objective.updateState + totalEnergy + the force rasterisation of
-//                   computeResidual:  evalInterpolantAndGradient of vn+dv (Lib/MPM/Force/MpmForceBase.cpp:213-248),
-//                   restoreStrain/evolveStrain (FBasedMpmForceHelper.cpp:35-43,99-114), updateImplicitState (:70-97),
-//                   FBased totalEnergy (:116-135) and rasterizeForceToTVStack<false> (MpmForceBase.cpp:100-153).
-//                   The reference runs these as 4 separate particle sweeps with two SVDs per particle and 8 colour
-//                   passes for both the gather and the scatter; here: one launch, one SVD, LDS-staged node tile for the
-//                   gather, LDS accumulators + one global atomic per touched node for the scatter.
+//   k_state         one particle pass for objective.updateState + totalEnergy:  evalInterpolantAndGradient of vn+dv
+//                   (Lib/MPM/Force/MpmForceBase.cpp:213-248), restoreStrain/evolveStrain (FBasedMpmForceHelper.cpp:35-43,
+//                   99-114), updateImplicitState (:70-97), FBased totalEnergy (:116-135).  The reference runs these as
+//                   separate particle sweeps with two SVDs per particle; here: one launch, one SVD, LDS-staged node tile.
+//   k_force_cells   rasterizeForceToTVStack<false> (MpmForceBase.cpp:100-153): (cell, node column) items summed in
+//                   registers, one partial tile per particle group, ordered reduce (no colour passes, no global
+//                   atomics).  k_force_scatter is the first version (one LDS atomic per particle and node), kept for A/B.
 //   k_residual      computeResidual (Projects/multigrid/ImplicitSolver.h:128-155) incl. MassLumpedInertia::addScaledForces
 //                   (Lib/Ziran/Physics/LagrangianForce/Inertia.cpp:33-41), transformResidual (:117-125), project.
 //   k_matfree       matrix-free Hessian product (ImplicitSolver.h:741-758, MpmForceBase.cpp:262-306,

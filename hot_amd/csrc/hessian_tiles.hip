@@ -9,9 +9,13 @@
 //   pass 2  k_hessian_tiles one workgroup per aligned 2x2x2 tile of grid nodes.  The 8 rows x 125 slots x 9 values
 //                           live in LDS (72 KB fp64).  Only particles whose base cell lies in the 4x4x4 cells around
 //                           the tile touch these rows; they are fetched cell by cell through the per-cell ranges of
-//                           the sorted particle array.  A thread takes one (particle, row-in-tile) item, forms
-//                           T_i = dPdF . g_i (27 registers) and adds the 27 blocks (i, j) with ds_add (LDS atomics).
+//                           the sorted particle array, 64 at a time (dP, X, Fn staged in LDS, g = Fn^T grad w for the
+//                           27 nodes computed once per particle).  The particles of one base cell share their 27
+//                           support nodes, so a (cell segment, tile row, column node) item sums its 3x3 block over
+//                           the segment in registers and adds it to the LDS tile once (9 ds_add per item).
 //                           At the end the tile is written to HBM with plain coalesced stores (mass term folded in).
+//   k_mf_diag_col / k_mf_diag_finish: the block diagonal of the matrix-free operator (buildDiagonal) from the same 45
+//                           scalars, for the --matfree preconditioner.
 //   Each (particle, i, j) block is computed exactly once in the whole launch (by the tile owning row i); a particle's
 //   45 scalars are re-read by the <= 8 tiles its 3x3x3 support intersects.
 #include "hot_impl.h"

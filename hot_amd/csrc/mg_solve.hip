@@ -4,13 +4,16 @@
 //                   (SURVEY §8a row 17/21).  One wavefront per block row: a row is 125 contiguous 3x3 blocks (9000 B fp64),
 //                   lane l owns slots l and l+64, so the 64 lanes stream the row in two fully coalesced sweeps; x is
 //                   gathered per slot, the three row sums are reduced with __shfl_xor.
-//   k_gs_color      MultigridOperator::gs_smooth (Projects/multigrid/MultigridPreconditioner.h:266-318): symmetric coloured
-//                   block Gauss–Seidel in the reference's exact node order (colour, first-touch block, id).  One wavefront
-//                   per 4^3-node block walks its nodes sequentially; the row sweep is the SpMV sweep with the ordering
-//                   predicate on the packed colour key, values of the block's own earlier nodes come from LDS.
+//   k_apmv_sub      the r -= A (P e) of the V-cycle as r -= (A P) e with the A P kept from the Galerkin build (half the bytes).
+//   k_gs_block      MultigridOperator::gs_smooth (Projects/multigrid/MultigridPreconditioner.h:266-318): symmetric coloured
+//                   block Gauss–Seidel in the reference's exact node order (colour, first-touch block, id), one launch per
+//                   (colour, sub-block) pass: streaming phase + LDS-triangle substitution (see the comment at the kernel).
+//   k_gs_sweep      the same passes chained inside one launch (coarse levels).   k_gs_color: the simple one-wavefront-
+//                   per-block version kept as the A/B reference (HOT_SIMPLE_GS).
 //   restrict/prolong SparseMPMMatrix::transposeMultiply / multiply on the transfer matrices (MPMMultigridMatrix.h:63-70) as
 //                   pure gathers over the child / parent tables with scalar weights (the reference stores 3x3 w*I blocks).
-//   smooth_dev      jacobi_smooth :160-173, optimal_jacobi_smooth :174-189, cg_smooth :190-226, gs_smooth :266-318
+//   smooth_dev      jacobi_smooth :160-173, optimal_jacobi_smooth :174-189, cg_smooth :190-226, chebyshev_smooth :227-264
+//                   (+ SquareMatrix::estimate2norm), gs_smooth :266-318
 //   vcycle_dev      MultigridOperator::operator() :362-421 with setup_parameters :525-551
 #include "hot_impl.h"
 #include "hot_svd.h"
