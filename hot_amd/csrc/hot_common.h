@@ -155,12 +155,39 @@ __device__ inline void bspline(T x, int& base, T (&w)[3], T (&dw)[3])
 }
 
 // ------------------------------------------------------------------ wave / block reductions (wave = 64)
+// Sum over the 64 lanes, returned in every lane.  DPP data movement (quad_perm, row_shr, row_bcast) instead of
+// ds_bpermute shuffles: no LDS traffic and a dependent latency of a few VALU ops per step.  The order of the additions
+// is fixed, so the result is deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float wave_last(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ double wave_last(double v)
+{
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 template <class T>
 __device__ inline T wave_sum(T v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_move<0xb1, 0xf>(v); // quad_perm [1,0,3,2]
+    v += dpp_move<0x4e, 0xf>(v); // quad_perm [2,3,0,1]: every lane holds its quad's sum
+    v += dpp_move<0x114, 0xf>(v); // row_shr:4  (lanes without a source add 0)
+    v += dpp_move<0x118, 0xf>(v); // row_shr:8  : lane 15 of every row holds the row's sum
+    v += dpp_move<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v += dpp_move<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+    return wave_last(v);
 }
 // block-wide sum for blockDim.x == 256; result valid in thread 0
 template <class T>
