@@ -485,7 +485,7 @@ __device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int3
     for (; s + 1 < cnt; s += 2) { // two steps per trip: the column buffers alternate without register copies
         load_col(colof(s + 1), LB);
         step(colof(s), LA);
-        if (s + 2 < cnt) load_col(colof(s + 2), LA);
+        load_col(colof(min(s + 2, cnt - 1)), LA); // unconditional (clamped): a conditional load makes the compiler copy the buffers
         step(colof(s + 1), LB);
     }
     if (s < cnt) step(colof(s), LA);
