@@ -883,14 +883,13 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         iterations = ((iterations + 1) >> 1);
         for (; iterations--;) {
             prof.count(lname("gs_symsweeps", L.id));
-            zero(n3, hdu);
+            // no memset of hdu / du: a sweep writes every node before any later node reads it (only preceding nodes are read)
             if (dataflow)
                 sweep(true);
             else
                 for (int c = 0; c < 8; ++c)
                     for (int h = 0; h < nsub; ++h) pass(true, c, h);
             // dAu now holds D h ; du = backward solve
-            zero(n3, du);
             if (dataflow)
                 sweep(false);
             else
