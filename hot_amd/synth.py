@@ -5,7 +5,8 @@ volume = dx^3/ppc, F = I, C = 0 (Lib/MPM/MpmInitializationHelper.h:116-135), Lam
 (Projects/multigrid/MultigridInit3D.h:2483-2524)."""
 import numpy as np
 
-_FACT = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2), 12: (2, 2, 3), 16: (2, 2, 4), 20: (2, 2, 5), 27: (3, 3, 3)}
+_FACT = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2), 12: (2, 2, 3), 16: (2, 2, 4), 20: (2, 2, 5), 27: (3, 3, 3), 64: (4, 4, 4), 80: (4, 4, 5),
+         343: (7, 7, 7)}
 
 
 def lame(E, nu):

@@ -176,3 +176,24 @@ def test_three_time_steps_against_oracle(hotlib, oracle, dtype, cneps, tolX, tol
         print("fp32 3-step |dX|/dx: max %.3g rms %.3g, its gpu %s cpu %s" % (np.abs(dX).max(), np.sqrt((dX ** 2).mean()), out["gpu"][1], out["cpu"][1]))
         assert np.sqrt((dX ** 2).mean()) < 0.5
         assert np.isfinite(pg["F"]).all() and np.isfinite(pg["V"]).all()
+
+
+@pytest.mark.parametrize("ppc", [343, 80, 1])
+def test_dense_and_sparse_cells_against_oracle(hotlib, oracle, ppc):
+    """Cells with hundreds of particles make one cell straddle the 256-particle staging chunks of the scatter kernels
+    and the 64-particle chunks of the Hessian tiles; 1 particle per cell is the other extreme."""
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=4, ppc=ppc, levelCnt=2)
+        pc.prepare(ctx)
+        g = ctx.grid()
+        e = ctx.update_state(ctx.get_dv())
+        r = ctx.residual()
+        ctx.build_hessian()
+        ctx.build_mg()
+        x = np.random.default_rng(1).standard_normal((ctx.Nn, 3))
+        out[name] = (g["mass"], g["v"], r, ctx.spmv(0, x), ctx.vcycle(ctx.project(x)), e)
+    a, b = out["gpu"], out["cpu"]
+    for k in range(5):
+        assert rel(a[k], b[k]) < 1e-11, (k, rel(a[k], b[k]))
+    assert abs(a[5] - b[5]) < 1e-12 * abs(b[5])
