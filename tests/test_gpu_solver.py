@@ -197,3 +197,27 @@ def test_dense_and_sparse_cells_against_oracle(hotlib, oracle, ppc):
     for k in range(5):
         assert rel(a[k], b[k]) < 1e-11, (k, rel(a[k], b[k]))
     assert abs(a[5] - b[5]) < 1e-12 * abs(b[5])
+
+
+def test_irregular_body_against_oracle(hotlib, oracle):
+    """A hollow ball with a bar through it: ragged 4^3 colour blocks, uneven colours, coarse levels with holes."""
+    from hot_amd import synth
+    c = synth.cube_cloud(14, ppc=8)
+    X = c["X"]
+    ctr = X.mean(0)
+    r = np.linalg.norm(X - ctr, axis=1)
+    keep = ((r < 0.066) & (r > 0.03)) | ((np.abs(X[:, 0] - ctr[0]) < 0.012) & (np.abs(X[:, 1] - ctr[1]) < 0.012))
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx = lib.context(dtype=1, dx=c["dx"], gravity=(0, -9.8, 0), levelCnt=3, max_iterations=4, cneps=1e-7)
+        ctx.set_particles(X[keep], c["V"][keep], c["mass"][keep], c["vol"][keep], c["mu"][keep], c["lam"][keep])
+        o, n = synth.sticky_floor(ctr[1] - 0.07, c["dx"])
+        ctx.set_sticky_halfspaces(o, n)
+        ctx.sort(), ctx.p2g(), ctx.begin_step(1 / 24)
+        st = ctx.solve()
+        out[name] = (ctx.get_dv(), st, [ctx.level(l, coords=False)["nrows"] for l in range(st["num_levels"])])
+    a, b = out["gpu"], out["cpu"]
+    assert a[2] == b[2]
+    for k in ("iterations", "linesearch_trials", "linear_iterations", "vcycles", "num_levels"):
+        assert a[1][k] == b[1][k], (k, a[1], b[1])
+    assert rel(a[0], b[0]) < 1e-9
