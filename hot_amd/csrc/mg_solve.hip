@@ -362,7 +362,8 @@ __device__ __forceinline__ void gs_store_rhs(T* sv, int ii, const T* __restrict_
 }
 
 template <class T, bool FWD, int SB, bool WT = false>
-__device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int32_t* nodes, int cnt, int lane, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, T* x, T* hD);
+__device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int32_t* nodes, int cnt, int lane, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, T* x, T* hD,
+    const T* ldsD = nullptr);
 
 template <class T, bool FWD, int SB>
 __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
@@ -457,7 +458,8 @@ __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ c
 // ---------------- phase B of the block GS kernels: lane = row, executed by one wavefront.  WT: publish x with
 // write-through (sc1) stores so that other workgroups of the same launch can read it with sc1 loads
 template <class T, bool FWD, int SB, bool WT>
-__device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int32_t* nodes, int cnt, int lane, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, T* x, T* hD)
+__device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int32_t* nodes, int cnt, int lane, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, T* x, T* hD,
+    const T* ldsD)
 {
     constexpr int TRI = GsLds<T, SB>::TRI;
     const int me = lane;
@@ -494,7 +496,7 @@ __device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int3
              // VGPRs (three 512-thread workgroups per CU, i.e. one round per launch on the finest level)
     if (FWD) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e) dd[e] = i >= 0 ? diagVal[9 * (int64_t)i + e] : (T)0;
+        for (int e = 0; e < 9; ++e) dd[e] = i >= 0 ? (ldsD ? ldsD[9 * me + e] : diagVal[9 * (int64_t)i + e]) : (T)0; // ldsD: staged by the caller
     }
     if (i >= 0) {
         if (WT) {
@@ -544,9 +546,16 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     const int b = P.block0[p] + ((int)blockIdx.x - P.wg_begin[p]);
     const int lo = P.sub[p] * SB;
     const int start = block_start[b] + lo, cnt = max(0, min(SB, block_start[b + 1] - start));
+    T* sDinv = (T*)(nodes + SB); // [SB][9] D_i^-1 and (forward) [SB][9] D_i of the rows: fetched before the wait, so that
+    T* sD = sDinv + 9 * SB; // nothing after it has to go to global memory for them
     for (int e = tid; e < 9 * TRI; e += 64 * NW) tri[e] = (T)0;
     if (tid < SB) nodes[tid] = tid < cnt ? gs_order[start + tid] : -1;
     __syncthreads();
+    for (int e = tid; e < 9 * cnt; e += 64 * NW) {
+        const int64_t i = nodes[e / 9];
+        sDinv[e] = diagBlockInv[9 * i + e % 9];
+        if (FWD) sD[e] = diagVal[9 * i + e % 9];
+    }
     // ---- 1. stream the half rows (lane = slot), keep what couples to nodes outside the sub-block
     T bv[RQ][9];
     int jj[RQ], node[RQ], kb2[RQ], ke[RQ];
@@ -582,21 +591,21 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
         }
     }
     // ---- 2. wait for the previous pass
-    if (p > 0) {
-        if (tid == 0) {
+    {
+        if (p > 0 && tid == 0) {
             const int need = P.wg_begin[p] - P.wg_begin[p - 1];
             int spins = 0;
             while (__hip_atomic_load(done + p - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                __builtin_amdgcn_s_sleep(16);
+                __builtin_amdgcn_s_sleep(4);
                 ++spins;
                 if ((spins & 1023) == 0 && *(volatile int*)err) break; // some workgroup already gave up: drain quickly
-                if (spins > (1 << 20)) {
+                if (spins > (1 << 22)) {
                     *(volatile int*)err = 1;
                     break;
                 }
             }
         }
-        __syncthreads();
+        __syncthreads(); // also for pass 0: orders the staging of D^-1 / D (and the triangle) before their readers
     }
     // x of other workgroups was published with write-through stores and is read with sc1 loads below: no cache
     // maintenance (buffer_wbl2 / buffer_inv) on either side
@@ -638,11 +647,11 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
             }
         }
         s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
-        if (lane == 0) gs_store_rhs<T>(sv, ii, diagBlockInv + 9 * (int64_t)i, rhs[3 * (int64_t)i] - s0, rhs[3 * (int64_t)i + 1] - s1, rhs[3 * (int64_t)i + 2] - s2);
+        if (lane == 0) gs_store_rhs<T>(sv, ii, sDinv + 9 * ii, rhs[3 * (int64_t)i] - s0, rhs[3 * (int64_t)i + 1] - s1, rhs[3 * (int64_t)i + 2] - s2);
     }
     __syncthreads();
     if (w != 0) return;
-    if (cnt > 0) gs_phase_b<T, FWD, SB, true>(tri, sv, nodes, cnt, lane, diagVal, diagBlockInv, x, hD);
+    if (cnt > 0) gs_phase_b<T, FWD, SB, true>(tri, sv, nodes, cnt, lane, diagVal, diagBlockInv, x, hD, sD);
     // ---- publish: the write-through stores of every lane have left the CU before lane 0 bumps the pass counter
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(done + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -791,8 +800,8 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         if (!attr_set) {
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
-            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
-            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 18 * 64 * sizeof(T))));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 18 * 64 * sizeof(T))));
             attr_set = true;
         }
         // sub-block size: levels whose colours hold more blocks than the chip has CUs run half blocks (36 KB LDS, 4
@@ -866,7 +875,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             HOT_HIP(hipMemsetAsync(gs_done.p, 0, 40 * sizeof(int), stream));
             const int grid = P.wg_begin[P.npass];
 #define HOT_GS_CASE(F, S)                                                                                                                                              \
-    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_sweep<T, F, S>), grid, 16 * S, (GsLds<T, S>::bytes), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
+    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_sweep<T, F, S>), grid, 16 * S, (GsLds<T, S>::bytes + 18 * S * sizeof(T)), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
         L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, P, rc, gs_done.p, (int*)(hscal + 250))
             if (fwd) {
                 if (sb == 64) HOT_GS_CASE(true, 64);
