@@ -27,6 +27,7 @@ struct Level {
     double lMin = 1e-8, lMax = 1e2; // spectrum bounds for the Chebyshev smoother (SquareMatrix.h:37, estimate2norm :375-475)
     DBuf<T> apv; // n*64*9: A*P of this level (4^3 coarse window per row), kept for the coarse-correction residual update
     DBuf<int32_t> apc; // n*64: coarse column of every window slot (0 where the coarse node does not exist; its block is 0)
+    DBuf<int32_t> gs_pad; // nblocks*64*8: per (colour block, position) {node or -1, the row's four class counts, pad}: the GS kernels' header in one load
     DBuf<int32_t> rowcnt; // 4n: (precede-off, precede-in, follow-in, follow-off) slot counts of the regrouped rows
     bool split = false;
     int color_block_begin[9] = { 0 }; // blocks of colour c are [color_block_begin[c], color_block_begin[c+1])

@@ -382,11 +382,28 @@ __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col
     if (lane == 0) rowcnt[4 * i] = cnt[0], rowcnt[4 * i + 1] = cnt[1], rowcnt[4 * i + 2] = cnt[3], rowcnt[4 * i + 3] = cnt[4];
 }
 
+// per (colour block, position in block) record {node or -1, the node's four row-class counts}: one 32-byte load gives a GS
+// workgroup everything it needs before it can start streaming rows (instead of block_start -> gs_order -> rowcnt)
+__global__ void k_gs_pad(const int32_t* __restrict__ block_start, const int32_t* __restrict__ gs_order, const int32_t* __restrict__ rowcnt, int32_t* __restrict__ pad, int nblocks)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nblocks * 64) return;
+    int b = e >> 6, t = e & 63;
+    int p = block_start[b] + t;
+    int node = p < block_start[b + 1] ? gs_order[p] : -1;
+    int32_t* o = pad + 8 * (int64_t)e;
+    o[0] = node;
+    for (int k = 0; k < 4; ++k) o[1 + k] = node >= 0 ? rowcnt[4 * node + k] : 0;
+    o[5] = o[6] = o[7] = 0;
+}
+
 template <class T>
 static void split_rows(Ctx<T>* ctx, Level<T>& L)
 {
     L.rowcnt.reserve(4 * (size_t)L.n);
     HOT_LAUNCH(ctx, "gs_split_rows", k_gs_split_rows<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.ckey.p, L.rowcnt.p, L.n);
+    L.gs_pad.reserve(512 * (size_t)L.nblocks);
+    HOT_LAUNCH(ctx, "gs_pad", k_gs_pad, div_up((size_t)L.nblocks * 64, 256), 256, 0, L.gs_block_start.p, L.gs_order.p, L.rowcnt.p, L.gs_pad.p, L.nblocks);
     L.split = true;
 }
 

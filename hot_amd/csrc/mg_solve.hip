@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64) void k_gs_color(const int32_t* __restrict__ col
 template <class T, int SB>
 struct GsLds {
     static constexpr int TRI = SB * (SB - 1) / 2 + 1; // ordered pairs + one always-zero entry (last) for masked lanes
-    static constexpr size_t bytes = (size_t)9 * TRI * sizeof(T) + SB * 3 * sizeof(T) + SB * sizeof(int32_t);
+    static constexpr size_t bytes = (size_t)9 * TRI * sizeof(T) + SB * 3 * sizeof(T) + 5 * SB * sizeof(int32_t);
 };
 template <int SB>
 __device__ __forceinline__ int gs_tri_fwd(int row, int colm) { return (SB - 1) * colm - (colm * (colm - 1)) / 2 + (row - colm - 1); } // row > colm
@@ -368,13 +368,14 @@ __device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int3
 template <class T, bool FWD, int SB>
 __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
     const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, int block0, int sub,
-    const int32_t* __restrict__ rowcnt)
+    const int32_t* __restrict__ rowcnt, const int32_t* __restrict__ gs_pad)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     constexpr int TRI = GsLds<T, SB>::TRI;
     T* tri = (T*)gs_smem; // [9][TRI]
     T* sv = tri + 9 * TRI; // [SB][3]
     int32_t* nodes = (int32_t*)(sv + 3 * SB);
+    int32_t* rcl = nodes + SB; // [SB][4] row class counts (from gs_pad)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = block0 + blockIdx.x;
     const int dbg = sub >> 8; // timing experiments only (wrong results): 1 skip phase B, 2 skip phase A
@@ -384,7 +385,13 @@ __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ c
     if (cnt <= 0) return; // workgroup-uniform
     const int nthreads = blockDim.x, nwaves = blockDim.x >> 6;
     for (int e = tid; e < 9 * TRI; e += nthreads) tri[e] = (T)0;
-    if (tid < SB) nodes[tid] = tid < cnt ? gs_order[start + tid] : -1;
+    if (tid < SB) {
+        // one 32-byte record per position: node id + its row class counts (no block_start -> gs_order -> rowcnt chain)
+        const int4 rec0 = *(const int4*)(gs_pad + 8 * ((int64_t)b * 64 + lo + tid));
+        const int rec1 = gs_pad[8 * ((int64_t)b * 64 + lo + tid) + 4];
+        nodes[tid] = rec0.x;
+        rcl[4 * tid] = rec0.y, rcl[4 * tid + 1] = rec0.z, rcl[4 * tid + 2] = rec0.w, rcl[4 * tid + 3] = rec1;
+    }
     __syncthreads();
     // ---------------- phase A: RQ rows of this wave are in flight at once (lane = slot of the needed half row)
     constexpr int RQ = 2;
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ c
             if (ii < cnt) { // wave-uniform
                 const int i = __builtin_amdgcn_readfirstlane(nodes[ii]); // row id in an SGPR: its metadata loads are scalar
                 rowi[q] = i;
-                const int po = rowcnt[4 * i], pi = rowcnt[4 * i + 1], fi = rowcnt[4 * i + 2], fo = rowcnt[4 * i + 3];
+                const int po = rcl[4 * ii], pi = rcl[4 * ii + 1], fi = rcl[4 * ii + 2], fo = rcl[4 * ii + 3];
                 const int kbeg = FWD ? 0 : po + pi + 1, kend = FWD ? po + pi : po + pi + 1 + fi + fo;
                 kb[q] = kbeg, ke[q] = kend, ib[q] = FWD ? po : kbeg, ie[q] = FWD ? po + pi : kbeg + fi;
                 // unconditional loads from a clamped slot: predicated loads made the compiler serialise the value loads
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     const int b = P.block0[p] + ((int)blockIdx.x - P.wg_begin[p]);
     const int lo = P.sub[p] * SB;
     const int start = block_start[b] + lo, cnt = max(0, min(SB, block_start[b + 1] - start));
-    T* sDinv = (T*)(nodes + SB); // [SB][9] D_i^-1 and (forward) [SB][9] D_i of the rows: fetched before the wait, so that
+    T* sDinv = (T*)(nodes + 5 * SB); // [SB][9] D_i^-1 and (forward) [SB][9] D_i of the rows: fetched before the wait, so that
     T* sD = sDinv + 9 * SB; // nothing after it has to go to global memory for them
     for (int e = tid; e < 9 * TRI; e += 64 * NW) tri[e] = (T)0;
     if (tid < SB) nodes[tid] = tid < cnt ? gs_order[start + tid] : -1;
@@ -830,7 +837,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             }
 #define HOT_GS_CASE(F, S)                                                                                                                                      \
     HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_block<T, F, S>), nb, gs_threads, (GsLds<T, S>::bytes), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
-        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, b0, h | (gs_dbg << 8), rc)
+        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, b0, h | (gs_dbg << 8), rc, L.gs_pad.p)
             if (fwd) {
                 if (sb == 64) HOT_GS_CASE(true, 64);
                 else if (sb == 32) HOT_GS_CASE(true, 32);
