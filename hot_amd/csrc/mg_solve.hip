@@ -427,6 +427,7 @@ __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ c
             T di[9];
 #pragma unroll
             for (int e = 0; e < 9; ++e) di[e] = diagBlockInv[9 * (int64_t)i + e];
+            const T rh0 = rhs[3 * (int64_t)i], rh1 = rhs[3 * (int64_t)i + 1], rh2 = rhs[3 * (int64_t)i + 2]; // requested early: not a dependent load after the reduction
             T s0 = 0, s1 = 0, s2 = 0;
             // couplings inside the sub-block go to the LDS triangle (the in-block slots of a regrouped row hold only
             // non-zero blocks, so the padded alias slots of SquareMatrix.h:563-566 cannot clobber an entry), the rest
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ c
                 entry(k, col[(int64_t)i * 125 + k], bt);
             }
             s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
-            if (lane == 0) gs_store_rhs<T>(sv, ii, di, rhs[3 * (int64_t)i] - s0, rhs[3 * (int64_t)i + 1] - s1, rhs[3 * (int64_t)i + 2] - s2);
+            if (lane == 0) gs_store_rhs<T>(sv, ii, di, rh0 - s0, rh1 - s1, rh2 - s2);
         }
     }
     __syncthreads();
