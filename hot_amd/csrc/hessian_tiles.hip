@@ -157,7 +157,7 @@ struct TileLds {
 
 template <class T>
 __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ dp, int64_t Np, const uint64_t* __restrict__ blocks,
-    const int32_t* __restrict__ gIdx, const int32_t* __restrict__ cell_first, HashMap cmap, const T* __restrict__ mass, T* __restrict__ val, T one_over_dx)
+    const int32_t* __restrict__ gIdx, const int32_t* __restrict__ cell_first, HashMap cmap, const T* __restrict__ mass, T* __restrict__ val, T one_over_dx, int ntiles)
 {
     using G = Geo<T>;
     constexpr int CH = TileLds<T>::CH;
@@ -176,7 +176,11 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles(const T* __restric
     int32_t* segs = pidx + CH; // [64] cell segments of the chunk: cell | first << 8 | end << 16
     T* sxf = (T*)(segs + 67); // [CH][12] X and Fn of the chunk members (67: keeps the int area a multiple of 8 bytes)
     const int tid = threadIdx.x;
-    const int b = blockIdx.x / TPB, tt = blockIdx.x % TPB;
+    // workgroup i runs on XCD i % 8 (MI355X_MICROARCH.md, dispatch).  Runs of 32 consecutive tiles (4-8 SPGrid blocks)
+    // share most of their particle records: give each run to one XCD so that its L2 serves the re-reads.
+    const int id = blockIdx.x, run = (id & 7) + 8 * (id >> 8), tile_id = run * 32 + ((id >> 3) & 31);
+    if (tile_id >= ntiles) return;
+    const int b = tile_id / TPB, tt = tile_id % TPB;
     int bx, by, bz;
     G::linear_to_coord(blocks[b], bx, by, bz);
     const int tx0 = bx + 2 * (tt / (TPBY * TPBZ)), ty0 = by + 2 * ((tt / TPBZ) % TPBY), tz0 = bz + 2 * (tt % TPBZ); // tile origin (node coords)
@@ -329,7 +333,7 @@ void Ctx<T>::assemble_tiles(Level<T>& L)
         attr_set = true;
     }
     constexpr int TPB = (G::BX / 2) * (G::BY / 2) * (G::BZ / 2);
-    HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles<T>, Nb * TPB, HT_THREADS, TileLds<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx);
+    HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles<T>, 256 * div_up(Nb * TPB, 256), HT_THREADS, TileLds<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx, Nb * TPB);
 }
 
 // ------------------------------------------------------------------------------------------------ matrix-free diagonal
