@@ -221,3 +221,24 @@ def test_irregular_body_against_oracle(hotlib, oracle):
     for k in ("iterations", "linesearch_trials", "linear_iterations", "vcycles", "num_levels"):
         assert a[1][k] == b[1][k], (k, a[1], b[1])
     assert rel(a[0], b[0]) < 1e-9
+
+
+def test_tiny_and_empty_inputs(hotlib, oracle):
+    """One particle (27 nodes, nothing to solve), two particles (a 42-node system) and the empty cloud, which the reference
+    rejects with an assertion (MpmSimulationBase.cpp:1071-1072) and the C ABI with HOT_ERR_CAPACITY."""
+    from hot_amd import synth
+    from hot_amd.binding import HotError
+    c = synth.cube_cloud(3, ppc=8)
+    for k, tol in ((1, 1e-12), (2, 1e-5)):
+        out = {}
+        for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+            ctx = lib.context(dtype=1, dx=c["dx"], gravity=(0, -9.8, 0), levelCnt=2, cneps=1e-7)
+            ctx.set_particles(c["X"][:k], c["V"][:k], c["mass"][:k], c["vol"][:k], c["mu"][:k], c["lam"][:k])
+            st = ctx.advance(1 / 24)
+            out[name] = (ctx.get_particles(), st)
+        (pg, sg), (pcpu, sc) = out["gpu"], out["cpu"]
+        assert sg["num_nodes"] == sc["num_nodes"] and sg["iterations"] == sc["iterations"]
+        assert rel(pg["X"], pcpu["X"]) < tol and np.abs(pg["V"] - pcpu["V"]).max() < 1e-3 * max(np.abs(pcpu["V"]).max(), 1e-3)
+    ctx = hotlib.context(dtype=1, dx=c["dx"], gravity=(0, -9.8, 0))
+    with pytest.raises(HotError):
+        ctx.set_particles(c["X"][:0], c["V"][:0], c["mass"][:0], c["vol"][:0], c["mu"][:0], c["lam"][:0])
