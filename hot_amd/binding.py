@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "get_counts", "get_indexing", "p2g", "get_grid", "set_bc", "set_sticky_halfspaces", "begin_step", "get_dv",
     "set_dv", "update_state", "get_particle_state", "residual", "project", "cn_tolerance", "build_hessian",
     "matfree_multiply", "build_mg", "get_level", "get_matrix", "get_level_nnzb", "get_prolongation", "spmv", "restrict", "prolong",
-    "smooth", "vcycle", "solve", "g2p", "advance", "profile_reset", "profile_count", "profile_get", "version",
+    "smooth", "vcycle", "solve", "g2p", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
 ]
 
 
@@ -110,6 +110,8 @@ class HotLib:
             "solve": (C.c_int, [vp, P(hot_stats)]),
             "g2p": (C.c_int, [vp, dbl, P(i32)]),
             "advance": (C.c_int, [vp, dbl, P(hot_stats)]),
+            "calculate_dt": (C.c_int, [vp, dbl, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_double)]),
+            "advance_frame": (C.c_int, [vp, dbl, dbl, dbl, P(C.c_int32), P(C.c_int32), P(hot_stats)]),
             "profile_reset": (C.c_int, [vp]),
             "profile_count": (C.c_int, [vp, P(i32)]),
             "profile_get": (C.c_int, [vp, i32, C.c_char_p, P(i64), P(dbl)]),
@@ -373,6 +375,19 @@ class Context:
         st = hot_stats()
         self._call("advance", C.c_double(dt), C.byref(st))
         return st.as_dict()
+
+    def calculate_dt(self, max_dt=1.0 / 24):
+        """CFL step (MpmSimulationBase::calculateDt): dict(dt, max_speed, min_corner, max_corner)."""
+        dt, ms = C.c_double(), C.c_double()
+        lo, hi = (C.c_double * 3)(), (C.c_double * 3)()
+        self._call("calculate_dt", C.c_double(max_dt), C.byref(dt), C.byref(ms), lo, hi)
+        return dict(dt=dt.value, max_speed=ms.value, min_corner=np.array(lo[:]), max_corner=np.array(hi[:]))
+
+    def advance_frame(self, frame_dt=1.0 / 24, min_dt=1e-6, max_dt=None):
+        """One frame of CFL-limited substeps (SimulationBase::advanceOneFrame): (substeps, total iterations, last stats)."""
+        n, its, st = C.c_int32(), C.c_int32(), hot_stats()
+        self._call("advance_frame", C.c_double(frame_dt), C.c_double(min_dt), C.c_double(frame_dt if max_dt is None else max_dt), C.byref(n), C.byref(its), C.byref(st))
+        return n.value, its.value, st.as_dict()
 
     def sync(self):
         self._call("sync")

@@ -279,6 +279,18 @@ int hot_advance(hot_ctx* ctx, double dt, hot_stats* stats)
     ctx->impl->advance(dt, stats);
     HOT_API_END
 }
+int hot_calculate_dt(hot_ctx* ctx, double max_dt, double* dt, double* max_speed, double* min_corner, double* max_corner)
+{
+    HOT_API_BEGIN
+    ctx->impl->calculate_dt(max_dt, dt, max_speed, min_corner, max_corner);
+    HOT_API_END
+}
+int hot_advance_frame(hot_ctx* ctx, double frame_dt, double min_dt, double max_dt, int32_t* substeps, int32_t* iterations_total, hot_stats* stats)
+{
+    HOT_API_BEGIN
+    ctx->impl->advance_frame(frame_dt, min_dt, max_dt, substeps, iterations_total, stats);
+    HOT_API_END
+}
 int hot_profile_reset(hot_ctx* ctx)
 {
     HOT_API_BEGIN

@@ -101,6 +101,8 @@ struct CtxBase {
     virtual void solve(hot_stats* st) = 0;
     virtual void g2p(double dt, int32_t* flags) = 0;
     virtual void advance(double dt, hot_stats* st) = 0;
+    virtual void calculate_dt(double max_dt, double* dt, double* max_speed, double* min_corner, double* max_corner) = 0;
+    virtual void advance_frame(double frame_dt, double min_dt, double max_dt, int32_t* substeps, int32_t* iterations_total, hot_stats* st) = 0;
 };
 
 CtxBase* make_ctx_f32(const hot_config& cfg);

@@ -201,6 +201,8 @@ struct Ctx : CtxBase {
     void solve(hot_stats* st) override;
     void g2p(double dt, int32_t* flags) override;
     void advance(double dt, hot_stats* st) override;
+    void calculate_dt(double max_dt, double* dt, double* max_speed, double* min_corner, double* max_corner) override;
+    void advance_frame(double frame_dt, double min_dt, double max_dt, int32_t* substeps, int32_t* iterations_total, hot_stats* st) override;
 
     // ---- device-side building blocks (device pointers)
     void eval_halfspaces();

@@ -15,6 +15,7 @@
 // the step, so the caller's `x += step` (LBFGS.h:413, ExtendedNewtonsMethod.h:61) lands on top of an x that already
 // contains the step: the dv handed to G2P is (last accepted iterate + last accepted step).
 #include "hot_impl.h"
+#include "hot_svd.h"
 #include <cmath>
 #include <cstdlib>
 
@@ -502,6 +503,96 @@ void Ctx<T>::advance(double dt_, hot_stats* st)
     g2p(dt_, &f);
     stats.ms_total = wall_ms() - t0;
     if (st) *st = stats;
+}
+
+// evalMaxParticleSpeed (MpmSimulationBase.cpp:1186-1218): max |v_p| and the particle bounding box.  Block maxima are
+// written to a small array and folded by one more workgroup (max is exact, so the order does not matter).
+template <class T>
+__global__ __launch_bounds__(256) void k_max_speed(const T* __restrict__ X, const T* __restrict__ V, int64_t Np, T* __restrict__ part /*[gridDim][8]*/)
+{
+    __shared__ T red[8][4];
+    T r[7];
+    r[0] = (T)0;
+#pragma unroll
+    for (int d = 1; d < 7; ++d) r[d] = -(T)3.4e38;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < Np; p += (int64_t)gridDim.x * 256) {
+        const T vx = V[p], vy = V[Np + p], vz = V[2 * Np + p];
+        r[0] = fmax(r[0], hsqrt(vx * vx + vy * vy + vz * vz));
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const T x = X[(int64_t)d * Np + p];
+            r[1 + d] = fmax(r[1 + d], x), r[4 + d] = fmax(r[4 + d], -x);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        T v = r[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+        if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) part[blockIdx.x * 8 + threadIdx.x] = fmax(fmax(red[threadIdx.x][0], red[threadIdx.x][1]), fmax(red[threadIdx.x][2], red[threadIdx.x][3]));
+}
+template <class T>
+__global__ void k_max_fold(const T* __restrict__ part, int nb, double* out)
+{
+    const int q = threadIdx.x;
+    if (q >= 7) return;
+    T v = part[q];
+    for (int b = 1; b < nb; ++b) v = fmax(v, part[b * 8 + q]);
+    out[q] = (double)v;
+}
+
+template <class T>
+void Ctx<T>::calculate_dt(double max_dt, double* dt_out, double* max_speed, double* min_corner, double* max_corner)
+{
+    need(Np > 0, "hot_calculate_dt before hot_set_particles");
+    const int nb = (int)std::min<int64_t>(div_up(Np, 1024), 256);
+    DBuf<T> part;
+    part.reserve(8 * (size_t)nb);
+    HOT_LAUNCH(this, "max_speed", k_max_speed<T>, nb, 256, 0, pX.p, pV.p, Np, part.p);
+    HOT_LAUNCH(this, "max_speed_fold", k_max_fold<T>, 1, 64, 0, part.p, nb, dscal.p + 200);
+    HOT_HIP(hipMemcpyAsync(hscal + 200, dscal.p + 200, 7 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    const T ms = (T)hscal[200];
+    T dtc = (T)max_dt;
+    if (ms) dtc = (T)cfg.cfl * dx / ms; // :807-809, in the scalar type of the simulation
+    if (dt_out) *dt_out = (double)dtc;
+    if (max_speed) *max_speed = (double)ms;
+    for (int d = 0; d < 3; ++d) {
+        if (max_corner) max_corner[d] = hscal[201 + d];
+        if (min_corner) min_corner[d] = -hscal[204 + d];
+    }
+}
+
+template <class T>
+void Ctx<T>::advance_frame(double frame_dt, double min_dt, double max_dt, int32_t* substeps, int32_t* iterations_total, hot_stats* st)
+{
+    need(frame_dt > 0 && min_dt > 0 && max_dt > 0, "hot_advance_frame: frame_dt, min_dt and max_dt must be positive");
+    double since = 0;
+    int n = 0, its = 0;
+    hot_stats last;
+    std::memset(&last, 0, sizeof(last));
+    for (;;) {
+        double dtc = 0;
+        calculate_dt(max_dt, &dtc, nullptr, nullptr, nullptr);
+        // TimeStepping::nextDt (TimeStepping.h:45-59)
+        HOT_CHECK(dtc > 0, HOT_ERR_NUMERIC, "calculateDt returned a non-positive step");
+        double d = (dtc < min_dt) ? min_dt : (dtc > max_dt) ? max_dt : dtc;
+        if (since + d >= frame_dt)
+            d = frame_dt - since;
+        else if (since + 2 * d > frame_dt)
+            d = (frame_dt - since) / 2;
+        advance(d, &last);
+        its += last.iterations;
+        ++n;
+        since += d; // TimeStepping::advance (:67-76)
+        if (since >= frame_dt) break;
+    }
+    if (substeps) *substeps = n;
+    if (iterations_total) *iterations_total = its;
+    if (st) *st = last;
 }
 
 template struct Ctx<float>;

@@ -104,6 +104,20 @@ public:
         faster_than_grid_cell = flags & 1, faster_than_half_grid_cell = (flags & 2) != 0;
     }
     void advanceOneTimeStep(double dt) { check(ctx, hot_advance(ctx, dt, &stats), "hot_advance"); }
+    // MpmSimulationBase::calculateDt (Lib/MPM/MpmSimulationBase.cpp:789-814); max_dt = step.max_dt
+    double calculateDt(double max_dt)
+    {
+        double dt = 0;
+        check(ctx, hot_calculate_dt(ctx, max_dt, &dt, nullptr, nullptr, nullptr), "hot_calculate_dt");
+        return dt;
+    }
+    // SimulationBase::advanceOneFrame (Lib/Ziran/Sim/SimulationBase.h:291-327): returns the number of substeps
+    int advanceOneFrame(double frame_dt, double min_dt = 1e-6, double max_dt = -1)
+    {
+        int32_t n = 0, its = 0;
+        check(ctx, hot_advance_frame(ctx, frame_dt, min_dt, max_dt > 0 ? max_dt : frame_dt, &n, &its, &stats), "hot_advance_frame");
+        return n;
+    }
     bool faster_than_grid_cell = false, faster_than_half_grid_cell = false;
 };
 

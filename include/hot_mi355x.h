@@ -170,6 +170,15 @@ int hot_g2p(hot_ctx*, double dt, int32_t* flags);
 /* ---- MultigridSimulation::advanceOneTimeStep (MultigridSimulation.h:235-297) with device-side BCs */
 int hot_advance(hot_ctx*, double dt, hot_stats* stats);
 
+/* ---- MpmSimulationBase::calculateDt (Lib/MPM/MpmSimulationBase.cpp:789-814) with evalMaxParticleSpeed (:1186-1218):
+ *      dt = cfl * dx / max_p |v_p| (step.max_dt when nothing moves); the particle bounding box is returned as well.
+ *      Collision objects are static here, so their evalMaxSpeed term is 0. */
+int hot_calculate_dt(hot_ctx*, double max_dt, double* dt, double* max_speed, double* min_corner /*3 or NULL*/, double* max_corner /*3 or NULL*/);
+/* ---- SimulationBase::advanceOneFrame (Lib/Ziran/Sim/SimulationBase.h:291-327) with TimeStepping::nextDt / advance
+ *      (Lib/Ziran/Sim/TimeStepping.h:45-76): substeps of hot_advance with dt = nextDt(calculateDt()) until frame_dt is
+ *      consumed.  stats = the last substep's; iterations_total sums the nonlinear iterations of all substeps. */
+int hot_advance_frame(hot_ctx*, double frame_dt, double min_dt, double max_dt, int32_t* substeps, int32_t* iterations_total, hot_stats* stats);
+
 /* ---- per-kernel timings gathered with HIP events on the launch stream when cfg.profile = 1 */
 int hot_profile_reset(hot_ctx*);
 int hot_profile_count(hot_ctx*, int32_t* n);

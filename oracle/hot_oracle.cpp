@@ -398,6 +398,26 @@ int hoto_advance(hoto_ctx* c, double dt, hot_stats* stats)
     });
     return rc;
 }
+int hoto_calculate_dt(hoto_ctx* c, double max_dt, double* dt, double* max_speed, double* min_corner, double* max_corner)
+{
+    DISPATCH(c, {
+        double d = S.calculate_dt(max_dt, max_speed, min_corner, max_corner);
+        if (dt) *dt = d;
+    });
+    return 0;
+}
+int hoto_advance_frame(hoto_ctx* c, double frame_dt, double min_dt, double max_dt, int32_t* substeps, int32_t* iterations_total, hot_stats* stats)
+{
+    int rc = 0;
+    DISPATCH(c, {
+        int n = 0, its = 0;
+        rc = S.advance_frame(frame_dt, min_dt, max_dt, &n, &its);
+        if (substeps) *substeps = n;
+        if (iterations_total) *iterations_total = its;
+        if (stats) *stats = S.stats;
+    });
+    return rc;
+}
 int hoto_profile_reset(hoto_ctx*) { return 0; }
 int hoto_profile_count(hoto_ctx*, int32_t* n)
 {

@@ -592,6 +592,8 @@ struct Sim {
     bool newton_solve();
     int solve();
     int advance(double dt_);
+    double calculate_dt(double max_dt, double* max_speed, double* min_corner, double* max_corner);
+    int advance_frame(double frame_dt, double min_dt, double max_dt, int* substeps, int* iterations_total);
 };
 
 } // namespace hot_oracle

@@ -389,4 +389,51 @@ int Sim<T>::advance(double dt_)
     return 0;
 }
 
+// reference MpmSimulationBase::calculateDt (Lib/MPM/MpmSimulationBase.cpp:789-814) + evalMaxParticleSpeed (:1186-1218);
+// collision objects are static (their evalMaxSpeed term is 0)
+template <class T>
+double Sim<T>::calculate_dt(double max_dt, double* max_speed, double* min_corner, double* max_corner)
+{
+    T ms = 0;
+    T hi[3] = { -(T)3.4e38, -(T)3.4e38, -(T)3.4e38 }, nlo[3] = { -(T)3.4e38, -(T)3.4e38, -(T)3.4e38 };
+    for (size_t p = 0; p < X.size(); ++p) {
+        ms = std::max(ms, (T)std::sqrt(Vel[p].squaredNorm()));
+        for (int d = 0; d < 3; ++d) hi[d] = std::max(hi[d], X[p](d)), nlo[d] = std::max(nlo[d], -X[p](d));
+    }
+    T dtc = (T)max_dt;
+    if (ms) dtc = (T)cfg.cfl * dx / ms;
+    if (max_speed) *max_speed = (double)ms;
+    for (int d = 0; d < 3; ++d) {
+        if (max_corner) max_corner[d] = (double)hi[d];
+        if (min_corner) min_corner[d] = -(double)nlo[d];
+    }
+    return (double)dtc;
+}
+
+// reference SimulationBase::advanceOneFrame (Lib/Ziran/Sim/SimulationBase.h:291-327) with TimeStepping::nextDt / advance
+// (Lib/Ziran/Sim/TimeStepping.h:45-76)
+template <class T>
+int Sim<T>::advance_frame(double frame_dt, double min_dt, double max_dt, int* substeps, int* iterations_total)
+{
+    double since = 0;
+    int n = 0, its = 0, rc = 0;
+    for (;;) {
+        double dtc = calculate_dt(max_dt, nullptr, nullptr, nullptr);
+        double d = (dtc < min_dt) ? min_dt : (dtc > max_dt) ? max_dt : dtc;
+        if (since + d >= frame_dt)
+            d = frame_dt - since;
+        else if (since + 2 * d > frame_dt)
+            d = (frame_dt - since) / 2;
+        rc = advance(d);
+        if (rc) break;
+        its += stats.iterations;
+        ++n;
+        since += d;
+        if (since >= frame_dt) break;
+    }
+    if (substeps) *substeps = n;
+    if (iterations_total) *iterations_total = its;
+    return rc;
+}
+
 } // namespace hot_oracle

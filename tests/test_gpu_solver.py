@@ -242,3 +242,21 @@ def test_tiny_and_empty_inputs(hotlib, oracle):
     ctx = hotlib.context(dtype=1, dx=c["dx"], gravity=(0, -9.8, 0))
     with pytest.raises(HotError):
         ctx.set_particles(c["X"][:0], c["V"][:0], c["mass"][:0], c["vol"][:0], c["mu"][:0], c["lam"][:0])
+
+
+def test_cfl_step_and_frame_driver_against_oracle(hotlib, oracle):
+    """calculateDt (CFL step from the particle speeds) and advanceOneFrame (TimeStepping::nextDt substeps): a fast
+    cloud needs several substeps per frame; both implementations take the same ones."""
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=6, noise=0.3, levelCnt=2, cneps=1e-7)  # |v| ~ 0.5 => cfl * dx / |v| ~ 1e-2 < 1/24
+        cd = ctx.calculate_dt(1.0 / 24)
+        n, its, st = ctx.advance_frame(1.0 / 24)
+        out[name] = (cd, n, its, ctx.get_particles(), ctx.calculate_dt(1.0 / 24))
+    g, c_ = out["gpu"], out["cpu"]
+    assert abs(g[0]["dt"] - c_[0]["dt"]) < 1e-14 and abs(g[0]["max_speed"] - c_[0]["max_speed"]) < 1e-14
+    assert np.array_equal(g[0]["min_corner"], c_[0]["min_corner"]) and np.array_equal(g[0]["max_corner"], c_[0]["max_corner"])
+    assert g[0]["dt"] < 1.0 / 24 and g[1] == c_[1] and g[1] >= 2, (g[1], c_[1], g[0])
+    assert abs(g[2] - c_[2]) <= max(2, c_[2] // 10)
+    assert np.abs(g[3]["X"] - c_[3]["X"]).max() < 1e-3 * 0.01
+    assert abs(g[4]["dt"] - c_[4]["dt"]) < 1e-3 * c_[4]["dt"]
