@@ -29,6 +29,15 @@ class hot_config(C.Structure):
     ]
 
 
+class hot_collision_object(C.Structure):
+    _fields_ = [("shape", C.c_int32), ("type", C.c_int32), ("p0", C.c_double * 3), ("p1", C.c_double * 3), ("friction", C.c_double),
+                ("b", C.c_double * 3), ("dbdt", C.c_double * 3)]
+
+
+STICKY, SLIP, SEPARATE = 1, 2, 3
+HALFSPACE, SPHERE, BOX = 0, 1, 2
+
+
 class hot_stats(C.Structure):
     _fields_ = [
         ("iterations", C.c_int32), ("converged", C.c_int32), ("linesearch_trials", C.c_int32),
@@ -46,7 +55,7 @@ class hot_stats(C.Structure):
 # every entry point include/hot_mi355x.h declares (tests check each is exported)
 ABI_SYMBOLS = [
     "default_config", "create", "destroy", "last_error", "sync", "set_particles", "get_particles", "sort",
-    "get_counts", "get_indexing", "p2g", "get_grid", "set_bc", "set_sticky_halfspaces", "begin_step", "get_dv",
+    "get_counts", "get_indexing", "p2g", "get_grid", "set_bc", "set_sticky_halfspaces", "set_collision_objects", "begin_step", "get_dv",
     "set_dv", "update_state", "get_particle_state", "residual", "project", "cn_tolerance", "build_hessian",
     "matfree_multiply", "build_mg", "get_level", "get_matrix", "get_level_nnzb", "get_prolongation", "spmv", "restrict", "prolong",
     "smooth", "vcycle", "solve", "g2p", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
@@ -87,6 +96,7 @@ class HotLib:
             "get_grid": (C.c_int, [vp, vp, vp, vp]),
             "set_bc": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp]),
             "set_sticky_halfspaces": (C.c_int, [vp, i32, vp, vp]),
+            "set_collision_objects": (C.c_int, [vp, i32, vp]),
             "begin_step": (C.c_int, [vp, dbl]),
             "get_dv": (C.c_int, [vp, vp]),
             "set_dv": (C.c_int, [vp, vp]),
@@ -245,6 +255,16 @@ class Context:
         o = np.ascontiguousarray(origin, np.float64).reshape(-1, 3)
         n = np.ascontiguousarray(normal, np.float64).reshape(-1, 3)
         self._call("set_sticky_halfspaces", C.c_int32(len(o)), _ptr(o), _ptr(n))
+
+    def set_collision_objects(self, objects):
+        """objects: list of dicts(shape, type, p0, p1, friction=0, b=(0,0,0), dbdt=(0,0,0)) evaluated per node at begin_step."""
+        arr = (hot_collision_object * max(len(objects), 1))()
+        for o, d in zip(arr, objects):
+            o.shape, o.type, o.friction = d["shape"], d["type"], d.get("friction", 0.0)
+            p1 = d["p1"] if np.ndim(d["p1"]) else (d["p1"], 0.0, 0.0)
+            for k in range(3):
+                o.p0[k], o.p1[k], o.b[k], o.dbdt[k] = d["p0"][k], p1[k], d.get("b", (0, 0, 0))[k], d.get("dbdt", (0, 0, 0))[k]
+        self._call("set_collision_objects", C.c_int32(len(objects)), C.cast(arr, C.c_void_p))
 
     def begin_step(self, dt):
         self._call("begin_step", C.c_double(dt))

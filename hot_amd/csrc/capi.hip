@@ -141,6 +141,12 @@ int hot_set_sticky_halfspaces(hot_ctx* ctx, int32_t n, const double* origin, con
     ctx->impl->set_halfspaces(n, origin, normal);
     HOT_API_END
 }
+int hot_set_collision_objects(hot_ctx* ctx, int32_t n, const hot_collision_object* objects)
+{
+    HOT_API_BEGIN
+    ctx->impl->set_collision_objects(n, objects);
+    HOT_API_END
+}
 int hot_begin_step(hot_ctx* ctx, double dt)
 {
     HOT_API_BEGIN

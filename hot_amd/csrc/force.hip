@@ -18,6 +18,7 @@
 #include "hot_impl.h"
 #include <cstdlib>
 #include "hot_constitutive.h"
+#include "hot_collision.h"
 #include <cmath>
 
 namespace hot {
@@ -60,6 +61,48 @@ __global__ void k_hs_fill(const int32_t* __restrict__ flags, const int32_t* __re
     }
     slip[c] = 0;
     hasdv[c] = 0;
+}
+// analytic collision objects (hot_collision.h): pass 1 flags the colliding nodes, pass 2 (after the scan) writes the
+// compacted CollisionNode records {node, P = I - nb nb^T, R, R^-1, isSlip} and the Newton initial guess dv = vi - v
+template <class T>
+__global__ void k_co_flag(const int32_t* __restrict__ id2coord, const T* __restrict__ nodeV, const CollObj<T>* __restrict__ objs, int nobj, int32_t* flags, int nn, T dx)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nn) return;
+    const T x[3] = { (T)id2coord[3 * n] * dx, (T)id2coord[3 * n + 1] * dx, (T)id2coord[3 * n + 2] * dx };
+    T v[3] = { nodeV[3 * n], nodeV[3 * n + 1], nodeV[3 * n + 2] }, nb[9], wn[3];
+    flags[n] = co_multi(objs, nobj, x, v, nb, wn) ? 1 : 0;
+}
+template <class T>
+__global__ void k_co_fill(const int32_t* __restrict__ id2coord, const T* __restrict__ nodeV, const CollObj<T>* __restrict__ objs, int nobj, const int32_t* __restrict__ flags,
+    const int32_t* __restrict__ scan, int32_t* bcNode, T* P, T* R, T* Rinv, T* bcDv, uint8_t* slip, uint8_t* hasdv, int nn, T dx)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nn || !flags[n]) return;
+    const T x[3] = { (T)id2coord[3 * n] * dx, (T)id2coord[3 * n + 1] * dx, (T)id2coord[3 * n + 2] * dx };
+    const T v0[3] = { nodeV[3 * n], nodeV[3 * n + 1], nodeV[3 * n + 2] };
+    T v[3] = { v0[0], v0[1], v0[2] }, nb[9], wn[3];
+    co_multi(objs, nobj, x, v, nb, wn);
+    const int c = scan[n];
+    bcNode[c] = n;
+    // P = I - nb nb^T (column-major)
+    for (int col = 0; col < 3; ++col)
+        for (int row = 0; row < 3; ++row) {
+            T acc = (T)0;
+            for (int k = 0; k < 3; ++k) acc += nb[row + 3 * k] * nb[col + 3 * k];
+            P[9 * c + row + 3 * col] = (row == col ? (T)1 : (T)0) - acc;
+        }
+    const bool isSlip = wn[0] != (T)0 || wn[1] != (T)0 || wn[2] != (T)0;
+    Mat3<T> Rm;
+    if (isSlip)
+        co_rotate_to_x(wn, Rm.a);
+    else
+        for (int k = 0; k < 9; ++k) Rm.a[k] = (k % 4 == 0) ? (T)1 : (T)0;
+    Mat3<T> Ri = m3_inverse(Rm);
+    for (int k = 0; k < 9; ++k) R[9 * c + k] = Rm.a[k], Rinv[9 * c + k] = Ri.a[k];
+    slip[c] = isSlip ? 1 : 0;
+    hasdv[c] = 1;
+    for (int k = 0; k < 3; ++k) bcDv[3 * c + k] = v[k] - v0[k];
 }
 __global__ void k_bc_index(const int32_t* __restrict__ bcNode, int32_t* bcIdx, int nc)
 {
@@ -118,8 +161,45 @@ void Ctx<T>::set_bc(int32_t nc, const int32_t* node_id, const void* P, const voi
 template <class T>
 void Ctx<T>::set_halfspaces(int32_t n, const double* origin, const double* normal)
 {
+    cobjs.clear();
     hs_origin.assign(origin, origin + 3 * n);
     hs_normal.assign(normal, normal + 3 * n);
+}
+
+template <class T>
+void Ctx<T>::set_collision_objects(int32_t n, const hot_collision_object* objs)
+{
+    need(n >= 0 && n <= 64, "hot_set_collision_objects: 0 <= n <= 64");
+    for (int i = 0; i < n; ++i) {
+        need(objs[i].shape >= HOT_SHAPE_HALFSPACE && objs[i].shape <= HOT_SHAPE_BOX, "unknown collision shape");
+        need(objs[i].type >= HOT_COLLISION_STICKY && objs[i].type <= HOT_COLLISION_SEPARATE, "collision type must be STICKY (1), SLIP (2) or SEPARATE (3)");
+        need(!(objs[i].shape == HOT_SHAPE_BOX && objs[i].type != HOT_COLLISION_STICKY), "boxes must be STICKY (the reference's box normal is undefined inside the box)");
+    }
+    cobjs.assign(objs, objs + n);
+    hs_origin.clear(), hs_normal.clear();
+    if (n == 0) Nc = 0;
+}
+
+template <class T>
+void Ctx<T>::eval_collision_objects()
+{
+    if (cobjs.empty()) return;
+    const int nobj = (int)cobjs.size();
+    std::vector<CollObj<T>> h(nobj);
+    for (int i = 0; i < nobj; ++i) {
+        h[i].shape = cobjs[i].shape, h[i].type = cobjs[i].type, h[i].friction = (T)cobjs[i].friction;
+        for (int d = 0; d < 3; ++d) h[i].p0[d] = (T)cobjs[i].p0[d], h[i].p1[d] = (T)cobjs[i].p1[d], h[i].b[d] = (T)cobjs[i].b[d], h[i].dbdt[d] = (T)cobjs[i].dbdt[d];
+    }
+    d_cobjs.reserve(nobj * sizeof(CollObj<T>));
+    HOT_HIP(hipMemcpyAsync(d_cobjs.p, h.data(), nobj * sizeof(CollObj<T>), hipMemcpyHostToDevice, stream));
+    sync(); // h goes out of scope
+    const CollObj<T>* objs = (const CollObj<T>*)d_cobjs.p;
+    flags.reserve(Nn), scan.reserve(Nn);
+    HOT_LAUNCH(this, "bc_objects_flag", k_co_flag<T>, div_up(Nn, 256), 256, 0, id2coord.p, nodeV.p, objs, nobj, flags.p, Nn, dx);
+    Nc = exclusive_scan_i32(flags.p, scan.p, Nn);
+    size_t n = std::max(Nc, 1);
+    bcNode.reserve(n), bcP.reserve(9 * n), bcR.reserve(9 * n), bcRinv.reserve(9 * n), bcDv.reserve(3 * n), bcSlip.reserve(n), bcHasDv.reserve(n);
+    HOT_LAUNCH(this, "bc_objects_fill", k_co_fill<T>, div_up(Nn, 256), 256, 0, id2coord.p, nodeV.p, objs, nobj, flags.p, scan.p, bcNode.p, bcP.p, bcR.p, bcRinv.p, bcDv.p, bcSlip.p, bcHasDv.p, Nn, dx);
 }
 
 template <class T>
@@ -146,6 +226,7 @@ void Ctx<T>::begin_step(double dt_)
     double t0 = wall_ms();
     dt = (T)dt_;
     eval_halfspaces();
+    eval_collision_objects();
     HOT_HIP(hipMemsetAsync(bcIdx.p, 0xff, (size_t)Nn * sizeof(int32_t), stream));
     if (Nc > 0) HOT_LAUNCH(this, "bc_index", k_bc_index, div_up(Nc, 256), 256, 0, bcNode.p, bcIdx.p, Nc);
     HOT_LAUNCH(this, "begin_step", k_begin<T>, div_up(Nn, 256), 256, 0, nodeV.p, bcIdx.p, bcDv.p, bcHasDv.p, dv.p, vn.p, dv0.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dt);

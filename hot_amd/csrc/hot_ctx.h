@@ -78,6 +78,7 @@ struct CtxBase {
     virtual void get_grid(int32_t* id2coord, void* mass, void* v) = 0;
     virtual void set_bc(int32_t Nc, const int32_t* node_id, const void* P, const void* R, const void* Rinv, const uint8_t* slip, const void* dvc) = 0;
     virtual void set_halfspaces(int32_t n, const double* origin, const double* normal) = 0;
+    virtual void set_collision_objects(int32_t n, const hot_collision_object* objs) = 0;
     virtual void begin_step(double dt) = 0;
     virtual void get_dv(void* dv) = 0;
     virtual void set_dv(const void* dv) = 0;

@@ -109,6 +109,8 @@ struct Ctx : CtxBase {
     DBuf<T> bcP, bcR, bcRinv, bcDv;
     DBuf<uint8_t> bcSlip, bcHasDv;
     std::vector<double> hs_origin, hs_normal;
+    std::vector<hot_collision_object> cobjs; // analytic collision objects (hot_set_collision_objects)
+    DBuf<char> d_cobjs;
     DBuf<double> d_hs;
     // ---- objective
     double Ek = 0;
@@ -178,6 +180,7 @@ struct Ctx : CtxBase {
     void get_grid(int32_t* id2coord, void* mass, void* v) override;
     void set_bc(int32_t Nc, const int32_t* node_id, const void* P, const void* R, const void* Rinv, const uint8_t* slip, const void* dvc) override;
     void set_halfspaces(int32_t n, const double* origin, const double* normal) override;
+    void set_collision_objects(int32_t n, const hot_collision_object* objs) override;
     void begin_step(double dt) override;
     void get_dv(void* dv) override;
     void set_dv(const void* dv) override;
@@ -206,6 +209,7 @@ struct Ctx : CtxBase {
 
     // ---- device-side building blocks (device pointers)
     void eval_halfspaces();
+    void eval_collision_objects();
     double state_pass(const T* dv_in, bool want_force); // G2P(vn+dv) -> F, energy, force scatter; returns total energy (syncs)
     void residual_dev(T* r); // from the force tiles of the last state_pass
     void project_dev(T* v);

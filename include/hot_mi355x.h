@@ -123,6 +123,26 @@ int hot_set_bc(hot_ctx*, int32_t Nc, const int32_t* node_id, const void* P /*9Nc
  * (AnalyticCollisionObject + HalfSpace, re-evaluated every hot_begin_step; replaces hot_set_bc). */
 int hot_set_sticky_halfspaces(hot_ctx*, int32_t n, const double* origin /*3n*/, const double* normal /*3n*/);
 
+/* ---- analytic collision objects evaluated per grid node on the device at hot_begin_step: the collision query of
+ *      buildInitialDvAndVnForNewton (MpmSimulationBase.cpp:1139-1184) = AnalyticCollisionObject::multiObjectCollision
+ *      (Lib/Ziran/Math/Geometry/CollisionObject.cpp:107-148) + detectAndResolveCollision (:384-447) over HalfSpace /
+ *      Sphere / AxisAlignedAnalyticBox level sets (AnalyticLevelSet.cpp), RotationExtractor for slip nodes
+ *      (MpmSimulationBase.h:271-281).  Objects translate (b, dbdt) but do not rotate or scale.  type uses the reference's
+ *      enum values (CollisionObject.h:52-57).  Boxes must be STICKY (their normal is not defined inside the box).
+ *      Replaces any half spaces / explicit collision nodes set before; n = 0 clears. */
+enum hot_collision_type { HOT_COLLISION_STICKY = 1, HOT_COLLISION_SLIP = 2, HOT_COLLISION_SEPARATE = 3 };
+enum hot_collision_shape { HOT_SHAPE_HALFSPACE = 0, HOT_SHAPE_SPHERE = 1, HOT_SHAPE_BOX = 2 };
+typedef struct hot_collision_object {
+    int32_t shape; /* hot_collision_shape */
+    int32_t type; /* hot_collision_type */
+    double p0[3]; /* half space: origin ; sphere: centre ; box: min corner */
+    double p1[3]; /* half space: outward normal ; sphere: (radius, -, -) ; box: max corner */
+    double friction;
+    double b[3]; /* translation of the object */
+    double dbdt[3]; /* its velocity */
+} hot_collision_object;
+int hot_set_collision_objects(hot_ctx*, int32_t n, const hot_collision_object* objects);
+
 /* ---- MultigridSimulation::startBackwardEuler (Projects/multigrid/MultigridSimulation.h:167-186):
  *      dv0 = g dt (collider dv on collision nodes), vn = v, Fn = F (backupStrain), resetLSFlag */
 int hot_begin_step(hot_ctx*, double dt);

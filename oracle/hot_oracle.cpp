@@ -184,6 +184,15 @@ int hoto_set_sticky_halfspaces(hoto_ctx* c, int32_t n, const double* origin, con
     });
     return 0;
 }
+int hoto_set_collision_objects(hoto_ctx* c, int32_t n, const hot_collision_object* objects)
+{
+    DISPATCH(c, {
+        S.cobjs.assign(objects, objects + n);
+        S.hs_origin.clear(), S.hs_normal.clear();
+        if (n == 0) S.collision_nodes.clear();
+    });
+    return 0;
+}
 int hoto_begin_step(hoto_ctx* c, double dt)
 {
     DISPATCH(c, S.begin_step((T)dt));

@@ -85,6 +85,7 @@ struct Sim {
     std::vector<CollisionNode> collision_nodes;
     std::vector<int> bc_of_node;
     std::vector<double> hs_origin, hs_normal;
+    std::vector<hot_collision_object> cobjs; // analytic collision objects, evaluated per node in begin_step
     // ---- particle scratch (reference MpmForceBase members scratch_gradV / scratch_vp / scratch_stress)
     std::vector<TM> scratch_gradV, scratch_stress;
     std::vector<TV> scratch_vp;
@@ -452,12 +453,158 @@ struct Sim {
         }
     }
 
+    // ---- analytic collision objects: the collision query of buildInitialDvAndVnForNewton (MpmSimulationBase.cpp:1139-1184)
+    // for objects that translate but neither rotate nor scale
+    // AnalyticCollisionObject::detectAndResolveCollision (Lib/Ziran/Math/Geometry/CollisionObject.cpp:384-447) over
+    // HalfSpace (AnalyticLevelSet.cpp:264-288), Sphere::queryInside (:435-452), AxisAlignedAnalyticBox (:353-363,504-529)
+    static bool detect_and_resolve(const hot_collision_object& o, const TV& x, TV& v, TV& n)
+    {
+        TV b{ { (T)o.b[0], (T)o.b[1], (T)o.b[2] } }, p0{ { (T)o.p0[0], (T)o.p0[1], (T)o.p0[2] } }, p1{ { (T)o.p1[0], (T)o.p1[1], (T)o.p1[2] } };
+        TV X = x - b, N = TV::zero();
+        bool colliding = false;
+        if (o.shape == HOT_SHAPE_HALFSPACE) {
+            T phi = p1.dot(X - p0);
+            colliding = phi <= (T)0;
+            N = p1;
+        }
+        else if (o.shape == HOT_SHAPE_SPHERE) {
+            TV to_center = X - p0;
+            T d2 = to_center.squaredNorm(), r2 = p1(0) * p1(0);
+            if (d2 < r2) {
+                colliding = true;
+                T dist = std::sqrt(d2);
+                if (dist < (T)1e-7)
+                    N = TV{ { 1, 0, 0 } };
+                else
+                    N = to_center * ((T)1 / dist);
+            }
+        }
+        else {
+            T dd = -(T)3.4e38, q2 = 0;
+            for (int k = 0; k < 3; ++k) {
+                T c = (p0(k) + p1(k)) / (T)2, h = (p1(k) - p0(k)) / (T)2;
+                T d = std::abs(X(k) - c) - h;
+                dd = std::max(dd, d);
+                T q = d < (T)0 ? (T)0 : d;
+                q2 += q * q;
+            }
+            colliding = std::min(dd, (T)0) + std::sqrt(q2) <= (T)0;
+        }
+        if (!colliding) return false;
+        TV v_object{ { (T)o.dbdt[0], (T)o.dbdt[1], (T)o.dbdt[2] } };
+        v = v - v_object;
+        if (o.type == HOT_COLLISION_STICKY)
+            v = TV::zero();
+        else if (o.type == HOT_COLLISION_SLIP) {
+            n = N;
+            T dot = v.dot(n);
+            v = v - n * dot;
+            if (o.friction != 0 && dot < 0) {
+                T vn = std::sqrt(v.squaredNorm());
+                if (-dot * (T)o.friction < vn)
+                    for (int k = 0; k < 3; ++k) v.a[k] += (v.a[k] / vn) * dot * (T)o.friction;
+                else
+                    v = TV::zero();
+            }
+        }
+        else { // SEPARATE
+            n = N;
+            T dot = v.dot(n);
+            if (dot < 0) {
+                v = v - n * dot;
+                if (o.friction != 0) {
+                    T vn = std::sqrt(v.squaredNorm());
+                    if (-dot * (T)o.friction < vn)
+                        for (int k = 0; k < 3; ++k) v.a[k] += (v.a[k] / vn) * dot * (T)o.friction;
+                    else
+                        v = TV::zero();
+                }
+            }
+        }
+        v = v + v_object;
+        return true;
+    }
+    // RotationExtractor<T,3>::rotate (MpmSimulationBase.h:271-281): Eigen::Quaternion::setFromTwoVectors(a, e_x) as a matrix
+    static TM rotate_to_x(const TV& a)
+    {
+        T la = std::sqrt(a.squaredNorm());
+        TV v0{ { a(0) / la, a(1) / la, a(2) / la } };
+        T c = v0(0), qx, qy, qz, qw;
+        const T eps = sizeof(T) == 8 ? (T)1e-12 : (T)1e-5;
+        if (c < (T)-1 + eps) {
+            c = std::max(c, (T)-1);
+            T ax1 = v0(2), ax2 = -v0(1), l = std::sqrt(ax1 * ax1 + ax2 * ax2);
+            if (l < (T)1e-30) ax1 = 1, ax2 = 0, l = 1;
+            T w2 = ((T)1 + c) * (T)0.5, s = std::sqrt((T)1 - w2);
+            qw = std::sqrt(w2), qx = 0, qy = ax1 / l * s, qz = ax2 / l * s;
+        }
+        else {
+            T s = std::sqrt(((T)1 + c) * (T)2), invs = (T)1 / s;
+            qx = (T)0 * invs, qy = v0(2) * invs, qz = -v0(1) * invs, qw = s * (T)0.5;
+        }
+        T tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+        T twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+        TM Rm;
+        Rm(0, 0) = 1 - (tyy + tzz), Rm(0, 1) = txy - twz, Rm(0, 2) = txz + twy;
+        Rm(1, 0) = txy + twz, Rm(1, 1) = 1 - (txx + tzz), Rm(1, 2) = tyz - twx;
+        Rm(2, 0) = txz - twy, Rm(2, 1) = tyz + twx, Rm(2, 2) = 1 - (txx + tyy);
+        return Rm;
+    }
+    // multiObjectCollision with wn (CollisionObject.cpp:107-148) + the CollisionNode construction (:1153-1171)
+    void eval_collision_objects()
+    {
+        if (cobjs.empty()) return;
+        collision_nodes.clear();
+        std::vector<TV> gv(num_nodes);
+        iterate_grid([&](const int*, Node& g) { gv[(size_t)g.idx] = g.v; });
+        for (int id = 0; id < num_nodes; ++id) { // serial: the reference pushes into a concurrent_vector (order irrelevant)
+            TV xi{ { (T)id2coord[id][0] * dx, (T)id2coord[id][1] * dx, (T)id2coord[id][2] * dx } };
+            TV old_v = gv[id], vi = gv[id], wn = TV::zero();
+            TM nb = TM::zero();
+            bool any = false;
+            int slip_count = 0;
+            for (const auto& o : cobjs) {
+                TV n = TV::zero();
+                bool collide = detect_and_resolve(o, xi, vi, n);
+                any = any || collide;
+                if (!collide) continue;
+                if (o.type == HOT_COLLISION_STICKY) {
+                    wn = TV::zero();
+                    nb = TM::identity();
+                    break;
+                }
+                for (int c = 0; c < slip_count; ++c) {
+                    TV n_old{ { nb(0, c), nb(1, c), nb(2, c) } };
+                    T dot = n_old.dot(n);
+                    n = n - n_old * dot;
+                }
+                wn = n;
+                T len = std::sqrt(n.squaredNorm());
+                if (len) {
+                    for (int k = 0; k < 3; ++k) nb(k, slip_count) = n(k) / len;
+                    if (++slip_count == 3) break;
+                }
+            }
+            if (!any) continue;
+            CollisionNode z;
+            z.node_id = id;
+            z.P = TM::identity() - nb * nb.transpose();
+            z.shouldRotate = wn(0) != 0 || wn(1) != 0 || wn(2) != 0;
+            z.R = z.shouldRotate ? rotate_to_x(wn) : TM::identity();
+            z.Rinv = inverse(z.R);
+            z.has_dv = true;
+            z.dv = vi - old_v;
+            collision_nodes.push_back(z);
+        }
+    }
+
     // reference MultigridSimulation::startBackwardEuler (MultigridSimulation.h:167-186) +
     // buildInitialDvAndVnForNewton (MpmSimulationBase.cpp:1139-1184) + backupStrain (FBasedMpmForceHelper.cpp:24-33)
     void begin_step(T dt_)
     {
         dt = dt_;
         eval_halfspaces();
+        eval_collision_objects();
         dv.resize(num_nodes), vn.resize(num_nodes);
         bc_of_node.assign(num_nodes, -1);
         for (size_t c = 0; c < collision_nodes.size(); ++c) bc_of_node[collision_nodes[c].node_id] = (int)c;

@@ -260,3 +260,32 @@ def test_cfl_step_and_frame_driver_against_oracle(hotlib, oracle):
     assert abs(g[2] - c_[2]) <= max(2, c_[2] // 10)
     assert np.abs(g[3]["X"] - c_[3]["X"]).max() < 1e-3 * 0.01
     assert abs(g[4]["dt"] - c_[4]["dt"]) < 1e-3 * c_[4]["dt"]
+
+
+@pytest.mark.parametrize("boundaryType", [0, 1])
+def test_analytic_collision_objects_against_oracle(hotlib, oracle, boundaryType):
+    """Collision-node generation on the device: a sticky floor, a slip wall with friction, a moving sticky sphere
+    poking into the body, a separating half space and a sticky box (multiObjectCollision incl. the Gram-Schmidt of two
+    slip normals and the rotation of slip nodes).  boundaryType 1 = the solver's slip mode (rotated dofs)."""
+    from hot_amd.binding import BOX, HALFSPACE, SEPARATE, SLIP, SPHERE, STICKY
+    objs = [
+        dict(shape=HALFSPACE, type=SLIP, p0=(5.0 + 0.0151, 0, 0), p1=(1.0, 0, 0), friction=0.3),  # wall x <= 5.015
+        dict(shape=HALFSPACE, type=SLIP, p0=(0, 0, 5.0 + 0.0151), p1=(0, 0.6, 0.8)),  # a second, oblique slip plane
+        dict(shape=SPHERE, type=STICKY, p0=(5.03, 5.08, 5.03), p1=0.02, dbdt=(0.0, -0.5, 0.0)),  # moving ball pressed into the top
+        dict(shape=HALFSPACE, type=SEPARATE, p0=(0, 5.0 + 0.0049, 0), p1=(0, 1.0, 0), friction=0.1),  # floor that lets go
+        dict(shape=BOX, type=STICKY, p0=(5.05, 4.98, 5.05), p1=(5.08, 5.011, 5.08)),
+    ]
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=8, bc=False, levelCnt=2, cneps=1e-7, max_iterations=4, boundaryType=boundaryType)
+        ctx.set_collision_objects(objs)
+        pc.prepare(ctx)
+        dv0 = ctx.get_dv()
+        st = ctx.solve()
+        out[name] = (dv0, ctx.get_dv(), st)
+    g, c_ = out["gpu"], out["cpu"]
+    assert rel(g[0], c_[0]) < 1e-13  # Newton initial guess = resolved node velocities
+    assert np.abs(g[0] - np.array([0, -9.8 / 24, 0])).max(axis=1).astype(bool).sum() > 50  # many nodes did collide
+    for k in ("iterations", "linesearch_trials", "linear_iterations", "vcycles"):
+        assert g[2][k] == c_[2][k], (k, g[2], c_[2])
+    assert rel(g[1], c_[1]) < 1e-9
