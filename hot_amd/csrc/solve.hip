@@ -197,7 +197,8 @@ bool Ctx<T>::lbfgs_solve()
         int wk = order.back();
         const int m = (int)order.size() - 1; // stored curvature pairs
         static const bool unfused = getenv("HOT_LBFGS_UNFUSED") != nullptr; // A/B switch: dot / scalar / axpy as separate launches
-        const int vgrid = (int)std::min<size_t>(div_up(n3, 1024), 512);
+        static const int vgrid_max = getenv("HOT_LBFGS_GRID") ? atoi(getenv("HOT_LBFGS_GRID")) : 512;
+        const int vgrid = (int)std::min<size_t>(div_up(n3, 1024), vgrid_max);
         if (unfused) {
             copy(n3, residual, hist_dg[wk].p);
             for (int i = m - 1; i >= 0; --i) {
