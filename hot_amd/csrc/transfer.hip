@@ -192,76 +192,6 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
     for (int t = tid; t < NQ * TILE; t += P2G_THREADS) out[t] = (&acc[0][0])[t];
 }
 
-// Variant without LDS staging (experiment): the (cell, node column) items read the particle records straight from
-// global memory (the lanes of a cell read the same addresses; the records of a cell are contiguous in the sorted
-// order), so the workgroup keeps only the 6 KB accumulator tile in LDS and many more workgroups fit a CU.
-template <class T, bool WITH_CN>
-__global__ __launch_bounds__(256) void k_p2g_direct(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C,
-    const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_origin, const int32_t* __restrict__ group_cell0,
-    const int32_t* __restrict__ cell_first, T* __restrict__ part, T dx, T one_over_dx)
-{
-    using G = Geo<T>;
-    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
-    constexpr int NQ = WITH_CN ? 5 : 4;
-    __shared__ T acc[NQ][TILE];
-    const int g = blockIdx.x, tid = threadIdx.x;
-    for (int t = tid; t < NQ * TILE; t += 256) (&acc[0][0])[t] = (T)0;
-    const int c0 = group_cell0[g], c1 = group_cell0[g + 1];
-    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
-    __syncthreads();
-    const int ni = (c1 - c0) * 9;
-    for (int it = tid; it < ni; it += 256) {
-        const int c = c0 + it / 9, jk = it % 9;
-        const int j = jk / 3, k = jk - 3 * j;
-        const int p0 = cell_first[c], p1 = cell_first[c + 1];
-        T a[3][NQ];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) a[i][q] = (T)0;
-        int b0 = 0, b1 = 0, b2 = 0;
-        for (int p = p0; p < p1; ++p) {
-            const T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
-            const T m = M[p];
-            const T m0 = m * V[p], m1 = m * V[Np + p], m2 = m * V[2 * Np + p];
-            T Cm[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) Cm[q] = m * C[(int64_t)q * Np + p];
-            int base[3];
-            T w[3][3], dw[3][3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
-            b0 = base[0], b1 = base[1], b2 = base[2];
-            T cn = (T)0;
-            if (WITH_CN) {
-                const T mu = Mu[p], la = Lam[p];
-                cn = m * hsqrt((T)3 * ((T)2 * mu + la) * ((T)2 * mu + la) + (T)6 * la * la + (T)12 * mu * mu);
-            }
-            const T wj = j == 0 ? w[1][0] : (j == 1 ? w[1][1] : w[1][2]), wk = k == 0 ? w[2][0] : (k == 1 ? w[2][1] : w[2][2]);
-            const T d1 = (T)(b1 + j) * dx - xp[1], d2 = (T)(b2 + k) * dx - xp[2];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const T wijk = w[0][i] * wj * wk;
-                const T d0 = (T)(b0 + i) * dx - xp[0];
-                a[i][0] += m * wijk;
-                a[i][1] += (Cm[0] * d0 + Cm[3] * d1 + Cm[6] * d2 + m0) * wijk;
-                a[i][2] += (Cm[1] * d0 + Cm[4] * d1 + Cm[7] * d2 + m1) * wijk;
-                a[i][3] += (Cm[2] * d0 + Cm[5] * d1 + Cm[8] * d2 + m2) * wijk;
-                if (WITH_CN) a[i][NQ - 1] += cn * wijk;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int t = ((b0 - ox + i) * TY + (b1 - oy + j)) * TZ + (b2 - oz + k);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) lds_atomic_add(&acc[q][t], a[i][q]);
-        }
-    }
-    __syncthreads();
-    T* out = part + (int64_t)g * NQ * TILE;
-    for (int t = tid; t < NQ * TILE; t += 256) out[t] = (&acc[0][0])[t];
-}
-
 template <class T>
 __global__ __launch_bounds__(256) void k_block_count(const T* __restrict__ gM, int32_t* block_count, int nb)
 {
@@ -313,18 +243,8 @@ void Ctx<T>::p2g()
     double t0 = wall_ms();
     int64_t slots = (int64_t)Nb * EPB;
     T one_over_dx = (T)1 / dx;
-    static const bool p2g_direct = getenv("HOT_P2G_DIRECT") != nullptr; // experiment: no LDS staging
-    if (p2g_direct) {
-        if (cfg.useCN)
-            HOT_LAUNCH(this, "p2g", (k_p2g_direct<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
-        else
-            HOT_LAUNCH(this, "p2g", (k_p2g_direct<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
-        reduce_tiles(cfg.useCN ? 5 : 4, gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p, "p2g_reduce");
-    }
     static const bool p2g_v1 = getenv("HOT_P2G_V1") != nullptr; // A/B switch: one LDS atomic per particle, node and quantity
-    if (p2g_direct) {
-    }
-    else if (cfg.useCN) {
+    if (cfg.useCN) {
         if (p2g_v1)
             HOT_LAUNCH(this, "p2g", (k_p2g<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, dx, one_over_dx);
         else
