@@ -157,7 +157,10 @@ def test_three_time_steps_against_oracle(hotlib, oracle, dtype, cneps, tolX, tol
     out = {}
     v0 = None
     for name, lib in (("gpu", hotlib), ("cpu", oracle)):
-        ctx, c = pc.make_ctx(lib, n=8, dtype=dtype, levelCnt=2, cneps=cneps)
+        # fp32: the comparison partner is the fp64 oracle.  A float solve of this cond ~ 1/eps_float system is chaotic, and the
+        # CPU oracle's own float run (OpenMP reductions in varying order) can occasionally fail to converge for minutes;
+        # the bounded iteration count keeps the worst case short on either side.
+        ctx, c = pc.make_ctx(lib, n=8, dtype=dtype if name == "gpu" else 1, levelCnt=2, cneps=cneps, max_iterations=300)
         v0 = np.abs(c["V"]).max()
         its = []
         for _ in range(3):

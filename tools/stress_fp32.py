@@ -11,8 +11,13 @@ for r in range(reps):
     ctx, c = pc.make_ctx(lib, n=8, dtype=0, levelCnt=2, cneps=1e-4)
     its = []
     try:
+        import time
         for s in range(3):
-            its.append(ctx.advance(1.0 / 24)["iterations"])
+            t0 = time.time()
+            st = ctx.advance(1.0 / 24)
+            its.append((st["iterations"], st["converged"], st["linesearch_trials"], round(time.time() - t0, 2)))
+        if max(i[0] for i in its) > 60 or min(i[1] for i in its) == 0:
+            print("rep", r, "SLOW", its, flush=True)
     except Exception as e:
         fails += 1
         print("rep", r, "step", len(its), "its", its, "ERR", e)
