@@ -31,7 +31,7 @@ class hot_config(C.Structure):
 
 class hot_collision_object(C.Structure):
     _fields_ = [("shape", C.c_int32), ("type", C.c_int32), ("p0", C.c_double * 3), ("p1", C.c_double * 3), ("friction", C.c_double),
-                ("b", C.c_double * 3), ("dbdt", C.c_double * 3)]
+                ("b", C.c_double * 3), ("dbdt", C.c_double * 3), ("R", C.c_double * 9), ("omega", C.c_double * 3), ("s", C.c_double), ("dsdt", C.c_double)]
 
 
 STICKY, SLIP, SEPARATE = 1, 2, 3
@@ -257,13 +257,19 @@ class Context:
         self._call("set_sticky_halfspaces", C.c_int32(len(o)), _ptr(o), _ptr(n))
 
     def set_collision_objects(self, objects):
-        """objects: list of dicts(shape, type, p0, p1, friction=0, b=(0,0,0), dbdt=(0,0,0)) evaluated per node at begin_step."""
+        """objects: list of dicts(shape, type, p0, p1, friction=0, b=(0,0,0), dbdt=(0,0,0), R=I (3x3), omega=(0,0,0), s=1, dsdt=0)
+        evaluated per node at begin_step; p0 / p1 are in the object's material space (world x = R s X + b)."""
         arr = (hot_collision_object * max(len(objects), 1))()
         for o, d in zip(arr, objects):
             o.shape, o.type, o.friction = d["shape"], d["type"], d.get("friction", 0.0)
             p1 = d["p1"] if np.ndim(d["p1"]) else (d["p1"], 0.0, 0.0)
             for k in range(3):
                 o.p0[k], o.p1[k], o.b[k], o.dbdt[k] = d["p0"][k], p1[k], d.get("b", (0, 0, 0))[k], d.get("dbdt", (0, 0, 0))[k]
+                o.omega[k] = d.get("omega", (0, 0, 0))[k]
+            R = np.asarray(d.get("R", np.eye(3)), np.float64).reshape(3, 3)
+            for k in range(9):
+                o.R[k] = R[k % 3, k // 3]  # column-major
+            o.s, o.dsdt = d.get("s", 1.0), d.get("dsdt", 0.0)
         self._call("set_collision_objects", C.c_int32(len(objects)), C.cast(arr, C.c_void_p))
 
     def begin_step(self, dt):

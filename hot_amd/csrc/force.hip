@@ -174,6 +174,17 @@ void Ctx<T>::set_collision_objects(int32_t n, const hot_collision_object* objs)
         need(objs[i].shape >= HOT_SHAPE_HALFSPACE && objs[i].shape <= HOT_SHAPE_BOX, "unknown collision shape");
         need(objs[i].type >= HOT_COLLISION_STICKY && objs[i].type <= HOT_COLLISION_SEPARATE, "collision type must be STICKY (1), SLIP (2) or SEPARATE (3)");
         need(!(objs[i].shape == HOT_SHAPE_BOX && objs[i].type != HOT_COLLISION_STICKY), "boxes must be STICKY (the reference's box normal is undefined inside the box)");
+        need(objs[i].s > 0, "collision object scaling s must be > 0 (1 = none)");
+        need(!(objs[i].shape == HOT_SHAPE_HALFSPACE && (objs[i].dsdt != 0 || objs[i].omega[0] != 0 || objs[i].omega[1] != 0 || objs[i].omega[2] != 0)),
+            "a half space cannot turn or scale (no bounds available for its speed: AnalyticLevelSet.cpp:122-125)");
+        double dev = 0; // R^T R = I
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                double g = 0;
+                for (int k = 0; k < 3; ++k) g += objs[i].R[3 * a + k] * objs[i].R[3 * b + k];
+                dev = std::max(dev, std::abs(g - (a == b ? 1.0 : 0.0)));
+            }
+        need(dev < 1e-6, "collision object R must be a rotation matrix (identity when the object does not turn)");
     }
     cobjs.assign(objs, objs + n);
     hs_origin.clear(), hs_normal.clear();
@@ -188,7 +199,9 @@ void Ctx<T>::eval_collision_objects()
     std::vector<CollObj<T>> h(nobj);
     for (int i = 0; i < nobj; ++i) {
         h[i].shape = cobjs[i].shape, h[i].type = cobjs[i].type, h[i].friction = (T)cobjs[i].friction;
-        for (int d = 0; d < 3; ++d) h[i].p0[d] = (T)cobjs[i].p0[d], h[i].p1[d] = (T)cobjs[i].p1[d], h[i].b[d] = (T)cobjs[i].b[d], h[i].dbdt[d] = (T)cobjs[i].dbdt[d];
+        for (int d = 0; d < 3; ++d) h[i].p0[d] = (T)cobjs[i].p0[d], h[i].p1[d] = (T)cobjs[i].p1[d], h[i].b[d] = (T)cobjs[i].b[d], h[i].dbdt[d] = (T)cobjs[i].dbdt[d], h[i].omega[d] = (T)cobjs[i].omega[d];
+        for (int d = 0; d < 9; ++d) h[i].R[d] = (T)cobjs[i].R[d];
+        h[i].inv_s = (T)1 / (T)cobjs[i].s, h[i].dsdt = (T)cobjs[i].dsdt;
     }
     d_cobjs.reserve(nobj * sizeof(CollObj<T>));
     HOT_HIP(hipMemcpyAsync(d_cobjs.p, h.data(), nobj * sizeof(CollObj<T>), hipMemcpyHostToDevice, stream));

@@ -1,6 +1,6 @@
 // libhotmi355x — analytic collision objects evaluated per grid node on the device.
 //
-// Restates, for objects whose rotation / scaling are the identity (translation b with velocity dbdt allowed):
+// Restates (transform x = R s X + b, velocity omega x (x-b) + (ds/dt / s)(x-b) + db/dt):
 //   AnalyticCollisionObject::detectAndResolveCollision   Lib/Ziran/Math/Geometry/CollisionObject.cpp:384-447
 //   AnalyticCollisionObject::multiObjectCollision (wn)    :107-148
 //   HalfSpace / Sphere / AxisAlignedAnalyticBox queries   Lib/Ziran/Math/Geometry/AnalyticLevelSet.cpp:111-118,264-288,353-363,435-452,504-529
@@ -9,6 +9,8 @@
 // reference; only STICKY boxes (no normal needed) are accepted.
 #pragma once
 #include "hot_svd.h"
+#include <algorithm>
+#include <cmath>
 #include "../../include/hot_mi355x.h"
 
 namespace hot {
@@ -17,14 +19,17 @@ template <class T>
 struct CollObj { // device copy of hot_collision_object in the simulation's scalar type
     int32_t shape, type;
     T p0[3], p1[3], friction, b[3], dbdt[3];
+    T R[9], omega[3], inv_s, dsdt; // R column-major; inv_s = 1 / s
 };
 
 // returns whether node position x collides with o; v is replaced by the resolved velocity, n by the world normal (SLIP / SEPARATE)
 template <class T>
 __device__ __forceinline__ bool co_detect_resolve(const CollObj<T>& o, const T (&x)[3], T (&v)[3], T (&n)[3])
 {
-    T X[3] = { x[0] - o.b[0], x[1] - o.b[1], x[2] - o.b[2] };
-    T N[3] = { 0, 0, 0 };
+    const T xb[3] = { x[0] - o.b[0], x[1] - o.b[1], x[2] - o.b[2] };
+    T X[3], N[3] = { 0, 0, 0 }; // material space: X = R^T (x - b) / s
+#pragma unroll
+    for (int k = 0; k < 3; ++k) X[k] = (o.R[3 * k] * xb[0] + o.R[3 * k + 1] * xb[1] + o.R[3 * k + 2] * xb[2]) * o.inv_s;
     bool colliding = false;
     if (o.shape == HOT_SHAPE_HALFSPACE) {
         const T phi = o.p1[0] * (X[0] - o.p0[0]) + o.p1[1] * (X[1] - o.p0[1]) + o.p1[2] * (X[2] - o.p0[2]);
@@ -59,14 +64,17 @@ __device__ __forceinline__ bool co_detect_resolve(const CollObj<T>& o, const T (
         colliding = phi <= (T)0;
     }
     if (!colliding) return false;
-    // v_object = omega x (x - b) + (ds/dt / s)(x - b) + R s V_material + db/dt  with omega = 0, ds/dt = 0, V_material = 0
-    const T vo[3] = { o.dbdt[0], o.dbdt[1], o.dbdt[2] };
+    // v_object = omega x (x - b) + (ds/dt / s)(x - b) + db/dt   (the level sets here have no material velocity)
+    const T ss = o.dsdt * o.inv_s;
+    const T vo[3] = { o.omega[1] * xb[2] - o.omega[2] * xb[1] + ss * xb[0] + o.dbdt[0], o.omega[2] * xb[0] - o.omega[0] * xb[2] + ss * xb[1] + o.dbdt[1],
+        o.omega[0] * xb[1] - o.omega[1] * xb[0] + ss * xb[2] + o.dbdt[2] };
 #pragma unroll
     for (int k = 0; k < 3; ++k) v[k] -= vo[k];
     if (o.type == HOT_COLLISION_STICKY)
         v[0] = v[1] = v[2] = (T)0;
     else {
-        n[0] = N[0], n[1] = N[1], n[2] = N[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) n[k] = o.R[k] * N[0] + o.R[3 + k] * N[1] + o.R[6 + k] * N[2]; // world normal R N
         const T dot = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
         if (o.type == HOT_COLLISION_SLIP || dot < (T)0) {
 #pragma unroll
@@ -85,6 +93,45 @@ __device__ __forceinline__ bool co_detect_resolve(const CollObj<T>& o, const T (
 #pragma unroll
     for (int k = 0; k < 3; ++k) v[k] += vo[k];
     return true;
+}
+
+// AnalyticCollisionObject::evalMaxSpeed (CollisionObject.cpp:200-238): the object's largest speed over the corners of
+// the particle box (expanded by the caller) and of the level set's bounds that pass the reference's overlap test
+// (kept as written there: "any component above the min" and "any component below the max").
+inline double co_max_speed(const hot_collision_object& o, const double (&pmin)[3], const double (&pmax)[3])
+{
+    const double wn = std::sqrt(o.omega[0] * o.omega[0] + o.omega[1] * o.omega[1] + o.omega[2] * o.omega[2]);
+    if (o.dsdt == 0 && wn == 0) return std::sqrt(o.dbdt[0] * o.dbdt[0] + o.dbdt[1] * o.dbdt[1] + o.dbdt[2] * o.dbdt[2]);
+    double lo[3], hi[3]; // ls->getBounds: Sphere (AnalyticLevelSet.cpp:465-469), AxisAlignedAnalyticBox (:371-374)
+    for (int d = 0; d < 3; ++d) {
+        if (o.shape == HOT_SHAPE_SPHERE)
+            lo[d] = o.p0[d] - o.p1[0], hi[d] = o.p0[d] + o.p1[0];
+        else
+            lo[d] = o.p0[d], hi[d] = o.p1[d];
+    }
+    const double one_over_s = 1 / o.s;
+    double best = 0;
+    auto speed_at = [&](const double (&x)[3]) {
+        const double xb[3] = { x[0] - o.b[0], x[1] - o.b[1], x[2] - o.b[2] }, ss = o.dsdt * one_over_s;
+        const double v[3] = { o.omega[1] * xb[2] - o.omega[2] * xb[1] + ss * xb[0] + o.dbdt[0], o.omega[2] * xb[0] - o.omega[0] * xb[2] + ss * xb[1] + o.dbdt[1],
+            o.omega[0] * xb[1] - o.omega[1] * xb[0] + ss * xb[2] + o.dbdt[2] };
+        best = std::max(best, std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]));
+    };
+    for (int i = 0; i < 8; ++i) {
+        double x[3], X[3];
+        for (int d = 0; d < 3; ++d) x[d] = (i & (1 << d)) ? pmin[d] : pmax[d];
+        for (int k = 0; k < 3; ++k) X[k] = (o.R[3 * k] * (x[0] - o.b[0]) + o.R[3 * k + 1] * (x[1] - o.b[1]) + o.R[3 * k + 2] * (x[2] - o.b[2])) * one_over_s;
+        const bool above = lo[0] < X[0] || lo[1] < X[1] || lo[2] < X[2], below = X[0] < hi[0] || X[1] < hi[1] || X[2] < hi[2];
+        if (above && below) speed_at(x);
+    }
+    for (int i = 0; i < 8; ++i) {
+        double X[3], x[3];
+        for (int d = 0; d < 3; ++d) X[d] = (i & (1 << d)) ? lo[d] : hi[d];
+        for (int k = 0; k < 3; ++k) x[k] = (o.R[k] * X[0] + o.R[3 + k] * X[1] + o.R[6 + k] * X[2]) * o.s + o.b[k];
+        const bool above = pmin[0] < x[0] || pmin[1] < x[1] || pmin[2] < x[2], below = x[0] < pmax[0] || x[1] < pmax[1] || x[2] < pmax[2];
+        if (above && below) speed_at(x);
+    }
+    return best;
 }
 
 // multiObjectCollision with wn (CollisionObject.cpp:107-148); nb = normal_basis (column-major 3x3)

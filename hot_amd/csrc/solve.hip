@@ -16,6 +16,7 @@
 // contains the step: the dv handed to G2P is (last accepted iterate + last accepted step).
 #include "hot_impl.h"
 #include "hot_svd.h"
+#include "hot_collision.h"
 #include <cmath>
 #include <cstdlib>
 
@@ -556,11 +557,16 @@ void Ctx<T>::calculate_dt(double max_dt, double* dt_out, double* max_speed, doub
     HOT_LAUNCH(this, "max_speed_fold", k_max_fold<T>, 1, 64, 0, part.p, nb, dscal.p + 200);
     HOT_HIP(hipMemcpyAsync(hscal + 200, dscal.p + 200, 7 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
-    const T ms = (T)hscal[200];
+    T ms = (T)hscal[200];
+    if (!cobjs.empty()) { // :802-806 collision objects inside the particle box expanded by (degree + 2) dx
+        double lo[3], hi[3];
+        for (int d = 0; d < 3; ++d) lo[d] = (double)((T)-hscal[204 + d] - (T)4 * dx), hi[d] = (double)((T)hscal[201 + d] + (T)4 * dx);
+        for (const auto& o : cobjs) ms = std::max(ms, (T)co_max_speed(o, lo, hi));
+    }
     T dtc = (T)max_dt;
     if (ms) dtc = (T)cfg.cfl * dx / ms; // :807-809, in the scalar type of the simulation
     if (dt_out) *dt_out = (double)dtc;
-    if (max_speed) *max_speed = (double)ms;
+    if (max_speed) *max_speed = (double)ms; // max(particles, collision objects), what the step is computed from
     for (int d = 0; d < 3; ++d) {
         if (max_corner) max_corner[d] = hscal[201 + d];
         if (min_corner) min_corner[d] = -hscal[204 + d];

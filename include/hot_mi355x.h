@@ -127,7 +127,8 @@ int hot_set_sticky_halfspaces(hot_ctx*, int32_t n, const double* origin /*3n*/, 
  *      buildInitialDvAndVnForNewton (MpmSimulationBase.cpp:1139-1184) = AnalyticCollisionObject::multiObjectCollision
  *      (Lib/Ziran/Math/Geometry/CollisionObject.cpp:107-148) + detectAndResolveCollision (:384-447) over HalfSpace /
  *      Sphere / AxisAlignedAnalyticBox level sets (AnalyticLevelSet.cpp), RotationExtractor for slip nodes
- *      (MpmSimulationBase.h:271-281).  Objects translate (b, dbdt) but do not rotate or scale.  type uses the reference's
+ *      (MpmSimulationBase.h:271-281).  Objects carry the reference's full transform x = R s X + b with rates (omega, ds/dt, db/dt);
+ *      the caller's updateState callback refreshes them with another hot_set_collision_objects call.  type uses the reference's
  *      enum values (CollisionObject.h:52-57).  Boxes must be STICKY (their normal is not defined inside the box).
  *      Replaces any half spaces / explicit collision nodes set before; n = 0 clears. */
 enum hot_collision_type { HOT_COLLISION_STICKY = 1, HOT_COLLISION_SLIP = 2, HOT_COLLISION_SEPARATE = 3 };
@@ -140,7 +141,11 @@ typedef struct hot_collision_object {
     double friction;
     double b[3]; /* translation of the object */
     double dbdt[3]; /* its velocity */
-} hot_collision_object;
+    double R[9]; /* rotation matrix, column-major (Rotation<T,3>::rotation); identity when the object does not turn */
+    double omega[3]; /* angular velocity (world frame) */
+    double s; /* uniform scaling, > 0 (1 = none) */
+    double dsdt; /* its rate */
+} hot_collision_object; /* world x = R s X + b  (CollisionObject.h:63-69); p0 / p1 are given in material space X */
 int hot_set_collision_objects(hot_ctx*, int32_t n, const hot_collision_object* objects);
 
 /* ---- MultigridSimulation::startBackwardEuler (Projects/multigrid/MultigridSimulation.h:167-186):

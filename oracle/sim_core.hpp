@@ -454,13 +454,15 @@ struct Sim {
     }
 
     // ---- analytic collision objects: the collision query of buildInitialDvAndVnForNewton (MpmSimulationBase.cpp:1139-1184)
-    // for objects that translate but neither rotate nor scale
+    // with the object transform x = R s X + b and its rates (CollisionObject.h:63-69)
     // AnalyticCollisionObject::detectAndResolveCollision (Lib/Ziran/Math/Geometry/CollisionObject.cpp:384-447) over
     // HalfSpace (AnalyticLevelSet.cpp:264-288), Sphere::queryInside (:435-452), AxisAlignedAnalyticBox (:353-363,504-529)
     static bool detect_and_resolve(const hot_collision_object& o, const TV& x, TV& v, TV& n)
     {
         TV b{ { (T)o.b[0], (T)o.b[1], (T)o.b[2] } }, p0{ { (T)o.p0[0], (T)o.p0[1], (T)o.p0[2] } }, p1{ { (T)o.p1[0], (T)o.p1[1], (T)o.p1[2] } };
-        TV X = x - b, N = TV::zero();
+        TV xb = x - b, X, N = TV::zero();
+        const T one_over_s = (T)1 / (T)o.s;
+        for (int k = 0; k < 3; ++k) X.a[k] = ((T)o.R[3 * k] * xb(0) + (T)o.R[3 * k + 1] * xb(1) + (T)o.R[3 * k + 2] * xb(2)) * one_over_s; // R^T (x - b) / s
         bool colliding = false;
         if (o.shape == HOT_SHAPE_HALFSPACE) {
             T phi = p1.dot(X - p0);
@@ -491,7 +493,13 @@ struct Sim {
             colliding = std::min(dd, (T)0) + std::sqrt(q2) <= (T)0;
         }
         if (!colliding) return false;
-        TV v_object{ { (T)o.dbdt[0], (T)o.dbdt[1], (T)o.dbdt[2] } };
+        const T ss = (T)o.dsdt * one_over_s, w0 = (T)o.omega[0], w1 = (T)o.omega[1], w2 = (T)o.omega[2];
+        TV v_object{ { w1 * xb(2) - w2 * xb(1) + ss * xb(0) + (T)o.dbdt[0], w2 * xb(0) - w0 * xb(2) + ss * xb(1) + (T)o.dbdt[1], w0 * xb(1) - w1 * xb(0) + ss * xb(2) + (T)o.dbdt[2] } };
+        { // world normal R N
+            TV Nw;
+            for (int k = 0; k < 3; ++k) Nw.a[k] = (T)o.R[k] * N(0) + (T)o.R[3 + k] * N(1) + (T)o.R[6 + k] * N(2);
+            N = Nw;
+        }
         v = v - v_object;
         if (o.type == HOT_COLLISION_STICKY)
             v = TV::zero();

@@ -400,6 +400,40 @@ double Sim<T>::calculate_dt(double max_dt, double* max_speed, double* min_corner
         ms = std::max(ms, (T)std::sqrt(Vel[p].squaredNorm()));
         for (int d = 0; d < 3; ++d) hi[d] = std::max(hi[d], X[p](d)), nlo[d] = std::max(nlo[d], -X[p](d));
     }
+    for (const auto& o : cobjs) { // MpmSimulationBase.cpp:802-806 with AnalyticCollisionObject::evalMaxSpeed (CollisionObject.cpp:200-238)
+        const double wn = std::sqrt(o.omega[0] * o.omega[0] + o.omega[1] * o.omega[1] + o.omega[2] * o.omega[2]);
+        double best = 0;
+        if (o.dsdt == 0 && wn == 0)
+            best = std::sqrt(o.dbdt[0] * o.dbdt[0] + o.dbdt[1] * o.dbdt[1] + o.dbdt[2] * o.dbdt[2]);
+        else {
+            double pmin[3], pmax[3], blo[3], bhi[3];
+            for (int d = 0; d < 3; ++d) {
+                pmin[d] = (double)(-nlo[d] - (T)4 * dx), pmax[d] = (double)(hi[d] + (T)4 * dx); // particle box expanded by (degree + 2) dx
+                blo[d] = o.shape == HOT_SHAPE_SPHERE ? o.p0[d] - o.p1[0] : o.p0[d];
+                bhi[d] = o.shape == HOT_SHAPE_SPHERE ? o.p0[d] + o.p1[0] : o.p1[d];
+            }
+            std::vector<std::array<double, 3>> corners;
+            for (int i = 0; i < 8; ++i) {
+                std::array<double, 3> x, X;
+                for (int d = 0; d < 3; ++d) x[d] = (i & (1 << d)) ? pmin[d] : pmax[d];
+                for (int k = 0; k < 3; ++k) X[k] = (o.R[3 * k] * (x[0] - o.b[0]) + o.R[3 * k + 1] * (x[1] - o.b[1]) + o.R[3 * k + 2] * (x[2] - o.b[2])) / o.s;
+                if ((blo[0] < X[0] || blo[1] < X[1] || blo[2] < X[2]) && (X[0] < bhi[0] || X[1] < bhi[1] || X[2] < bhi[2])) corners.push_back(x);
+            }
+            for (int i = 0; i < 8; ++i) {
+                std::array<double, 3> x, X;
+                for (int d = 0; d < 3; ++d) X[d] = (i & (1 << d)) ? blo[d] : bhi[d];
+                for (int k = 0; k < 3; ++k) x[k] = (o.R[k] * X[0] + o.R[3 + k] * X[1] + o.R[6 + k] * X[2]) * o.s + o.b[k];
+                if ((pmin[0] < x[0] || pmin[1] < x[1] || pmin[2] < x[2]) && (x[0] < pmax[0] || x[1] < pmax[1] || x[2] < pmax[2])) corners.push_back(x);
+            }
+            for (const auto& x : corners) {
+                const double xb[3] = { x[0] - o.b[0], x[1] - o.b[1], x[2] - o.b[2] }, ss = o.dsdt / o.s;
+                const double v[3] = { o.omega[1] * xb[2] - o.omega[2] * xb[1] + ss * xb[0] + o.dbdt[0], o.omega[2] * xb[0] - o.omega[0] * xb[2] + ss * xb[1] + o.dbdt[1],
+                    o.omega[0] * xb[1] - o.omega[1] * xb[0] + ss * xb[2] + o.dbdt[2] };
+                best = std::max(best, std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]));
+            }
+        }
+        ms = std::max(ms, (T)best);
+    }
     T dtc = (T)max_dt;
     if (ms) dtc = (T)cfg.cfl * dx / ms;
     if (max_speed) *max_speed = (double)ms;

@@ -288,7 +288,57 @@ def test_analytic_collision_objects_against_oracle(hotlib, oracle, boundaryType)
         out[name] = (dv0, ctx.get_dv(), st)
     g, c_ = out["gpu"], out["cpu"]
     assert rel(g[0], c_[0]) < 1e-13  # Newton initial guess = resolved node velocities
-    assert np.abs(g[0] - np.array([0, -9.8 / 24, 0])).max(axis=1).astype(bool).sum() > 50  # many nodes did collide
+    assert 50 < (np.abs(g[0] - np.array([0, -9.8 / 24, 0])).max(axis=1) > 1e-9).sum() < g[0].shape[0]  # many nodes did collide, not all
     for k in ("iterations", "linesearch_trials", "linear_iterations", "vcycles"):
         assert g[2][k] == c_[2][k], (k, g[2], c_[2])
     assert rel(g[1], c_[1]) < 1e-9
+
+
+def _rot(axis, angle):
+    a = np.asarray(axis, np.float64) / np.linalg.norm(axis)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+
+
+def test_turning_and_scaling_collision_objects_against_oracle(hotlib, oracle):
+    """The full object transform x = R s X + b with its rates: a turning, growing slip sphere, a turned sticky box and
+    an oblique slip plane given through R — resolved node velocities (object velocity omega x r + (s'/s) r + b'),
+    the solve on top of them, and the CFL step that has to see the objects' corner speeds."""
+    from hot_amd.binding import BOX, HALFSPACE, SLIP, SPHERE, STICKY
+    R1, R2 = _rot((1, 2, 0.5), 0.7), _rot((0, 0, 1), 0.4)
+    objs = [
+        # material-space sphere of radius 0.02 at the origin, doubled, placed near the body's top corner, spinning and growing
+        dict(shape=SPHERE, type=SLIP, p0=(0, 0, 0), p1=0.02, b=(5.02, 5.085, 5.03), R=R1, s=2.0, dsdt=0.3, omega=(0.0, 3.0, 1.0), dbdt=(0.1, -0.4, 0.0), friction=0.2),
+        # unit-ish box turned about z, shrunk, sticky, turning
+        dict(shape=BOX, type=STICKY, p0=(-0.04, -0.02, -0.04), p1=(0.04, 0.02, 0.04), b=(5.07, 5.0, 5.07), R=R2, s=0.5, omega=(0, 0, 2.0), dsdt=-0.1),
+        # the plane y <= 0 in material space, tilted by R and lifted: an oblique slip floor
+        dict(shape=HALFSPACE, type=SLIP, p0=(0, 0, 0), p1=(0, 1.0, 0), b=(5.0, 5.0049, 5.0), R=_rot((1, 0, 0), 0.05)),
+    ]
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=8, bc=False, levelCnt=2, cneps=1e-7, max_iterations=4, boundaryType=1)
+        ctx.set_collision_objects(objs)
+        cd = ctx.calculate_dt(1.0)
+        pc.prepare(ctx)
+        dv0 = ctx.get_dv()
+        st = ctx.solve()
+        out[name] = (dv0, ctx.get_dv(), st, cd)
+    g, c_ = out["gpu"], out["cpu"]
+    assert rel(g[0], c_[0]) < 1e-12
+    assert 30 < (np.abs(g[0] - np.array([0, -9.8 / 24, 0])).max(axis=1) > 1e-9).sum() < g[0].shape[0]
+    for k in ("iterations", "linesearch_trials", "linear_iterations", "vcycles"):
+        assert g[2][k] == c_[2][k], (k, g[2], c_[2])
+    assert rel(g[1], c_[1]) < 1e-9
+    # the particles are at rest: the step comes from the objects alone
+    assert g[3]["max_speed"] > 0.4 and abs(g[3]["max_speed"] - c_[3]["max_speed"]) < 1e-13 and abs(g[3]["dt"] - c_[3]["dt"]) < 1e-15
+
+
+def test_collision_object_validation(hotlib):
+    from hot_amd.binding import HALFSPACE, SLIP, HotError
+    ctx, c = pc.make_ctx(hotlib, n=4, bc=False)
+    with pytest.raises(HotError):
+        ctx.set_collision_objects([dict(shape=HALFSPACE, type=SLIP, p0=(0, 0, 0), p1=(0, 1, 0), s=0.0)])
+    with pytest.raises(HotError):
+        ctx.set_collision_objects([dict(shape=HALFSPACE, type=SLIP, p0=(0, 0, 0), p1=(0, 1, 0), R=2 * np.eye(3))])
+    with pytest.raises(HotError):
+        ctx.set_collision_objects([dict(shape=HALFSPACE, type=SLIP, p0=(0, 0, 0), p1=(0, 1, 0), omega=(0, 1, 0))])
