@@ -148,6 +148,10 @@ struct Ctx : CtxBase {
         }
     }
     DBuf<T> ap; // A*P scratch (n*64*9)
+    // ---- baseline geometric multigrid (--baseline): one whole grid context per coarse level (spacing 2^l dx)
+    std::vector<Ctx<T>*> gmg;
+    DBuf<int32_t> orig2slot; // inverse of slot2orig
+    Ctx<T>* build_gmg_grid(int level); // sort / mass P2G / boundaries / re-rasterised matrix of coarse level `level`
 
     Ctx(const hot_config& c);
     ~Ctx();

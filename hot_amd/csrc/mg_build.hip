@@ -415,6 +415,75 @@ static void alloc_work(Level<T>& L)
     L.built = true;
 }
 
+// ------------------------------------------------------------------------------------------------ baseline geometric multigrid
+// MultigridSimulation::particlesToMultigrids (Projects/multigrid/MultigridSimulation.inl:345-456): coarse level l is a
+// real MPM grid of spacing 2^l dx — particles re-sorted into it (:40-124), mass rasterised (:404-428), boundaries queried at
+// its own nodes (buildMultigridBoundaries :126-161), and the system matrix re-assembled from the same per-particle
+// dP/dF (buildMultigridMatrices :163-342; the reference caches dP/dF per particle, here it is recomputed from the same
+// trial F, which gives the same numbers).  Each such grid is a whole context of this library; its level-0 matrix
+// becomes level l of the hierarchy.
+__global__ void k_invert_perm(const int32_t* __restrict__ slot2orig, int32_t* __restrict__ orig2slot, int64_t n)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) orig2slot[slot2orig[p]] = (int32_t)p;
+}
+// dst[c][i] = src[c][ orig2slot[ slot2orig_dst[i] ] ]: a per-particle SoA array of the fine context, in the coarse context's sorted order
+template <class T>
+__global__ void k_gather_via_orig(const T* __restrict__ src, T* __restrict__ dst, const int32_t* __restrict__ slot2orig_dst, const int32_t* __restrict__ orig2slot_src, int64_t n, int comps)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int64_t q = orig2slot_src[slot2orig_dst[p]];
+    for (int c = 0; c < comps; ++c) dst[(int64_t)c * n + p] = src[(int64_t)c * n + q];
+}
+__global__ void k_count_missing_parents(const int32_t* __restrict__ pcol, int64_t n, int32_t* count)
+{
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n && pcol[e] < 0) atomicAdd(count, 1);
+}
+
+template <class T>
+Ctx<T>* Ctx<T>::build_gmg_grid(int level)
+{
+    while ((int)gmg.size() < level) gmg.push_back(nullptr);
+    Ctx<T>*& g = gmg[level - 1];
+    if (!g) {
+        hot_config c = cfg;
+        c.dx = cfg.dx * (double)(1 << level);
+        c.levelCnt = 1, c.useBaselineMultigrid = 0, c.profile = 0, c.debug_store = 0;
+        g = new Ctx<T>(c);
+    }
+    g->cfg.project = cfg.project, g->cfg.systemBCProject = cfg.systemBCProject, g->cfg.Ainv = cfg.Ainv, g->cfg.boundaryType = cfg.boundaryType;
+    const int64_t n = Np;
+    // particles in this context's sorted order, carrying their original indices (the sort key's tie break, :69-71)
+    g->Np = n;
+    g->pX.reserve(3 * n), g->pV.reserve(3 * n), g->pM.reserve(n), g->pC.reserve(9 * n), g->pF.reserve(9 * n), g->pVol.reserve(n), g->pMu.reserve(n), g->pLam.reserve(n), g->pJp.reserve(n);
+    g->pFn.reserve(9 * n), g->pFt.reserve(9 * n), g->pStress.reserve(9 * n), g->pGradV.reserve(9 * n);
+    g->spare1.reserve(n), g->spare3.reserve(3 * n), g->spare9.reserve(9 * n), g->sparei.reserve(n), g->slot2orig.reserve(n);
+    auto give = [&](DBuf<T>& dst, const DBuf<T>& src, int comps) { HOT_HIP(hipMemcpyAsync(dst.p, src.p, (size_t)n * comps * sizeof(T), hipMemcpyDeviceToDevice, stream)); };
+    give(g->pX, pX, 3), give(g->pV, pV, 3), give(g->pM, pM, 1), give(g->pC, pC, 9), give(g->pF, pFn, 9), give(g->pVol, pVol, 1), give(g->pMu, pMu, 1), give(g->pLam, pLam, 1), give(g->pJp, pJp, 1);
+    HOT_HIP(hipMemcpyAsync(g->slot2orig.p, slot2orig.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+    orig2slot.reserve(n);
+    HOT_LAUNCH(this, "gmg_invert_perm", k_invert_perm, div_up(n, 256), 256, 0, slot2orig.p, orig2slot.p, n);
+    sync();
+    g->Ng = g->Nb = g->Nn = 0;
+    // boundaries: the collision objects are queried again at the coarse grid's nodes
+    if (!cobjs.empty())
+        g->set_collision_objects((int32_t)cobjs.size(), cobjs.data());
+    else if (!hs_origin.empty())
+        g->set_halfspaces((int32_t)hs_origin.size() / 3, hs_origin.data(), hs_normal.data());
+    else
+        need(Nc == 0, "useBaselineMultigrid: the boundaries must be given as hot_set_collision_objects / hot_set_sticky_halfspaces (every coarse grid queries them at its own nodes; an explicit node list only describes level 0)");
+    g->sort();
+    g->p2g();
+    g->begin_step((double)dt);
+    // trial F of every particle (the linearisation point of dP/dF), in the coarse context's order
+    HOT_LAUNCH(this, "gmg_gather_F", k_gather_via_orig<T>, div_up(n, 256), 256, 0, pFt.p, g->pFt.p, g->slot2orig.p, orig2slot.p, n, 9);
+    sync();
+    g->build_hessian();
+    return g;
+}
+
 template <class T>
 void Ctx<T>::build_mg()
 {
@@ -423,13 +492,18 @@ void Ctx<T>::build_mg()
     need(cfg.levelCnt >= 1 && cfg.levelCnt <= 10, "levelCnt must be in [1,10] (MultigridPreconditioner.h:369)");
     for (int k : { cfg.smoother, cfg.coarseSolver })
         need(k == 0 || k == 1 || k == 2 || k == 5 || k == 6, "smoother/coarseSolver must be 0, 1, 2, 5 or 6 (7 = Eigen IncompleteCholesky: not built; 3/4 are not selectable in the reference either)");
+    const bool baseline = cfg.useBaselineMultigrid != 0;
+    if (baseline) {
+        need(cfg.Ainv == 1, "useBaselineMultigrid scales with the inverse diagonal blocks (MultigridSimulation.inl:446): set Ainv = 1");
+        need(!cfg.topDownMGS, "useBaselineMultigrid fixes the V-cycle schedule (MultigridSimulation.inl:447-454); topDownMGS does not apply");
+    }
     double t0 = wall_ms();
     release_levels(1);
-    bool colors = cfg.smoother == 5 || cfg.coarseSolver == 5;
+    bool colors = baseline || cfg.smoother == 5 || cfg.coarseSolver == 5; // baseline: GS smoother, PCG on top (:447-448)
     Level<T>& L0 = *levels[0];
     alloc_work(L0);
     if (colors) mark_colors(this, L0);
-    if ((cfg.coarseSolver == 6 && cfg.levelCnt == 1) || (cfg.smoother == 6 && cfg.levelCnt > 1)) estimate_2norm(L0, 1e-6); // MultigridPreconditioner.h:610-611
+    if (!baseline && ((cfg.coarseSolver == 6 && cfg.levelCnt == 1) || (cfg.smoother == 6 && cfg.levelCnt > 1))) estimate_2norm(L0, 1e-6); // MultigridPreconditioner.h:610-611
     for (int level = 0; level < cfg.levelCnt - 1; ++level) {
         Level<T>& F = *levels[level];
         int n = F.n;
@@ -437,35 +511,59 @@ void Ctx<T>::build_mg()
         Level<T>* Cp = acquire_level(level + 1);
         levels.push_back(Cp);
         Level<T>& C = *Cp;
-        // ---- coarse node set with first-touch numbering
-        uint32_t cap = 1024;
-        while (cap < 2u * (uint32_t)n + 16u) cap <<= 1;
-        C.hkeys.reserve(cap), C.hrank.reserve(cap), C.hid.reserve(cap);
-        C.map.keys = C.hkeys.p, C.map.minrank = C.hrank.p, C.map.id = C.hid.p, C.map.mask = cap - 1;
-        HOT_LAUNCH(this, "mg_hash_clear", k_hash_clear2, div_up(cap, 256), 256, 0, C.map);
-        size_t cand = 8 * (size_t)n;
-        flags.reserve(cand), scan.reserve(cand);
-        HOT_LAUNCH(this, "mg_coarse_insert", k_coarse_insert, div_up(cand, 256), 256, 0, C.map, F.coord.p, n);
-        HOT_LAUNCH(this, "mg_coarse_flag", k_coarse_flag, div_up(cand, 256), 256, 0, C.map, F.coord.p, flags.p, n);
-        C.n = exclusive_scan_i32(flags.p, scan.p, cand);
-        size_t nc = C.n;
-        C.coord.reserve(3 * nc), C.col.reserve(125 * nc), C.val.reserve(1125 * nc), C.child.reserve(27 * nc);
-        HOT_LAUNCH(this, "mg_coarse_assign", k_coarse_assign, div_up(cand, 256), 256, 0, C.map, F.coord.p, flags.p, scan.p, C.coord.p, n);
+        Ctx<T>* grid = baseline ? build_gmg_grid(level + 1) : nullptr;
+        size_t nc;
+        if (baseline) {
+            // ---- coarse node set and matrix = the coarse grid's own DOFs and re-rasterised system
+            Level<T>& G0 = *grid->levels[0];
+            C.n = G0.n;
+            nc = C.n;
+            C.coord.reserve(3 * nc), C.col.reserve(125 * nc), C.val.reserve(1125 * nc), C.child.reserve(27 * nc);
+            HOT_HIP(hipMemcpyAsync(C.coord.p, G0.coord.p, 3 * nc * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+            HOT_HIP(hipMemcpyAsync(C.col.p, G0.col.p, 125 * nc * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+            HOT_HIP(hipMemcpyAsync(C.val.p, G0.val.p, 1125 * nc * sizeof(T), hipMemcpyDeviceToDevice, stream));
+            build_coord_map(this, C);
+        }
+        else {
+            // ---- coarse node set with first-touch numbering
+            uint32_t cap = 1024;
+            while (cap < 2u * (uint32_t)n + 16u) cap <<= 1;
+            C.hkeys.reserve(cap), C.hrank.reserve(cap), C.hid.reserve(cap);
+            C.map.keys = C.hkeys.p, C.map.minrank = C.hrank.p, C.map.id = C.hid.p, C.map.mask = cap - 1;
+            HOT_LAUNCH(this, "mg_hash_clear", k_hash_clear2, div_up(cap, 256), 256, 0, C.map);
+            size_t cand = 8 * (size_t)n;
+            flags.reserve(cand), scan.reserve(cand);
+            HOT_LAUNCH(this, "mg_coarse_insert", k_coarse_insert, div_up(cand, 256), 256, 0, C.map, F.coord.p, n);
+            HOT_LAUNCH(this, "mg_coarse_flag", k_coarse_flag, div_up(cand, 256), 256, 0, C.map, F.coord.p, flags.p, n);
+            C.n = exclusive_scan_i32(flags.p, scan.p, cand);
+            nc = C.n;
+            C.coord.reserve(3 * nc), C.col.reserve(125 * nc), C.val.reserve(1125 * nc), C.child.reserve(27 * nc);
+            HOT_LAUNCH(this, "mg_coarse_assign", k_coarse_assign, div_up(cand, 256), 256, 0, C.map, F.coord.p, flags.p, scan.p, C.coord.p, n);
+        }
         // ---- transfer tables
         F.pcol.reserve(8 * (size_t)n), F.pw.reserve(8 * (size_t)n);
         HOT_LAUNCH(this, "mg_build_P", k_build_P<T>, div_up(n, 256), 256, 0, C.map, F.coord.p, F.pcol.p, F.pw.p, n);
         HOT_LAUNCH(this, "mg_build_children", k_build_children, div_up(27 * nc, 256), 256, 0, F.map, C.coord.p, C.child.p, C.n);
-        HOT_LAUNCH(this, "mg_coarse_cols", k_coarse_cols, div_up(125 * nc, 256), 256, 0, C.map, C.coord.p, C.col.p, C.n);
+        if (baseline) { // ZIRAN_ASSERT(new_coord2id->find(...)) of buildMultigridMatrices (:207)
+            HOT_HIP(hipMemsetAsync(dscal.p + 210, 0, sizeof(double), stream));
+            HOT_LAUNCH(this, "gmg_check_parents", k_count_missing_parents, div_up(8 * (size_t)n, 256), 256, 0, F.pcol.p, 8 * (int64_t)n, (int32_t*)(dscal.p + 210));
+            int32_t missing = 0;
+            HOT_HIP(hipMemcpyAsync(&missing, dscal.p + 210, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            sync();
+            need(missing == 0, "useBaselineMultigrid: a fine node has a trilinear parent that is not a DOF of the coarse grid");
+        }
+        else
+            HOT_LAUNCH(this, "mg_coarse_cols", k_coarse_cols, div_up(125 * nc, 256), 256, 0, C.map, C.coord.p, C.col.p, C.n);
         // ---- A_c = R (A P)
         F.apv.reserve(576 * (size_t)n), F.apc.reserve(64 * (size_t)n);
         HOT_LAUNCH(this, "mg_AP", k_ap<T>, div_up(n, 4), 256, 0, F.coord.p, F.val.p, F.apv.p, n);
         HOT_LAUNCH(this, "mg_AP_cols", k_ap_cols, div_up(64 * (size_t)n, 256), 256, 0, C.map, F.coord.p, F.apc.p, n);
-        HOT_LAUNCH(this, "mg_RAP", k_rap<T>, div_up(nc, 4), 256, 0, C.coord.p, C.child.p, F.apv.p, C.val.p, C.n);
+        if (!baseline) HOT_LAUNCH(this, "mg_RAP", k_rap<T>, div_up(nc, 4), 256, 0, C.coord.p, C.child.p, F.apv.p, C.val.p, C.n);
         build_diagonal(C);
         count_nnzb(C);
         alloc_work(C);
         if (colors) mark_colors(this, C);
-        if ((cfg.coarseSolver == 6 && level + 2 == cfg.levelCnt) || (cfg.smoother == 6 && level + 2 < cfg.levelCnt)) estimate_2norm(C, 1e-6); // :682-683
+        if (!baseline && ((cfg.coarseSolver == 6 && level + 2 == cfg.levelCnt) || (cfg.smoother == 6 && level + 2 < cfg.levelCnt))) estimate_2norm(C, 1e-6); // :682-683
         if (colors) split_rows(this, F); // level `level` is no longer needed in stencil-slot order
     }
     if (colors) split_rows(this, *levels.back());

@@ -938,8 +938,9 @@ void Ctx<T>::vcycle_dev(const T* in, T* out)
     int splitLevel;
     auto downIter = [&](int level) { return times + level * levelscale; };
     auto upIter = [&](int level) { return cfg.topDownMGS ? 0 : times + level * levelscale; };
+    const bool baseline = cfg.useBaselineMultigrid != 0; // GS smoother, PCG on top, 10000 top iterations (MultigridSimulation.inl:446-453)
     auto topIter = [&](int level) {
-        if (cfg.topDownMGS) return 10000;
+        if (cfg.topDownMGS || baseline) return 10000;
         if (cfg.levelCnt == 1) return times + level * levelscale;
         if (!(cfg.coarseSolver == 2 || cfg.coarseSolver == 6)) return (times + level * levelscale) * 3;
         return 10000;
@@ -948,7 +949,7 @@ void Ctx<T>::vcycle_dev(const T* in, T* out)
     T tolTop = (T)(cfg.cneps * cfg.cneps);
     auto run = [&](bool regular, int level, T* sol, int its, bool final_residual = true) {
         Level<T>& L = *levels[level];
-        smooth_dev(level, regular ? cfg.smoother : cfg.coarseSolver, its, regular ? (T)0 : tolTop, sol, L.residual.p, L.du.p, L.dAu.p, final_residual);
+        smooth_dev(level, regular ? (baseline ? 5 : cfg.smoother) : (baseline ? 2 : cfg.coarseSolver), its, regular ? (T)0 : tolTop, sol, L.residual.p, L.du.p, L.dAu.p, final_residual);
     };
     stats.vcycles++;
     Level<T>& L0 = *levels[0];

@@ -236,6 +236,7 @@ Ctx<T>::Ctx(const hot_config& c)
 template <class T>
 Ctx<T>::~Ctx()
 {
+    for (auto* g : gmg) delete g;
     for (auto* l : levels) delete l;
     for (auto& pool : level_pool)
         for (auto* l : pool) delete l;

@@ -38,6 +38,7 @@
         (cfg).matrixFree = HOTSettings::matrixFree, (cfg).boundaryType = HOTSettings::boundaryType;        \
         (cfg).useAdaptiveHessian = HOTSettings::useAdaptiveHessian;                                        \
         (cfg).topDownMGS = HOTSettings::topDownMGS;                                                        \
+        (cfg).useBaselineMultigrid = HOTSettings::useBaselineMultigrid;                                    \
     } while (0)
 
 namespace hotmi {

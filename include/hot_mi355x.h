@@ -73,7 +73,8 @@ typedef struct hot_config {
     double snow[5]; /* psi, theta_c, theta_s, min_Jp, max_Jp */
     int32_t profile; /* 1: bracket every kernel launch with HIP events on the launch stream */
     int32_t debug_store; /* 1: also keep per-particle grad v for hot_get_particle_state (extra 9 stores per particle and pass) */
-    int32_t reserved[6];
+    int32_t useBaselineMultigrid; /* --baseline: geometric multigrid, every coarse level a real MPM grid of spacing 2^l dx whose matrix is re-rasterised from the particles */
+    int32_t reserved[5];
 } hot_config;
 
 typedef struct hot_stats {

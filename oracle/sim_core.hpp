@@ -10,6 +10,7 @@
 // P2G, DOF numbering, mass vector, BCs, G2P.
 #pragma once
 #include <functional>
+#include <memory>
 #include "../include/hot_mi355x.h"
 #include "spgrid_index.hpp"
 #include "corotated.hpp"
@@ -100,6 +101,7 @@ struct Sim {
     std::vector<std::vector<std::array<int, 3>>> level_coords;
     std::vector<std::vector<TV>> mg_residuals, mg_initialResiduals, mg_sols, mg_dus, mg_dAus, mg_tmps;
     int mg_level = 0;
+    std::vector<std::unique_ptr<Sim<T>>> gmg; // --baseline: the coarse MPM grids (MultigridSimulation.h `multigrids`)
     hot_stats stats;
 
     // =============================================================== particles

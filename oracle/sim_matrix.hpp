@@ -1,6 +1,7 @@
 // ORACLE (test infrastructure only).  Hessian assembly (padded ELL-125 of 3x3 blocks), Galerkin multigrid
 // hierarchy, smoothers and the V-cycle.
 #pragma once
+#include <stdexcept>
 #include "sim_force.hpp"
 #include <map>
 
@@ -303,15 +304,40 @@ void Sim<T>::build_mg()
     sysmats.resize(1);
     promats.clear(), resmats.clear();
     level_coords.resize(1);
-    bool colors = (cfg.coarseSolver == 5 || cfg.smoother == 5);
+    const bool baseline = cfg.useBaselineMultigrid != 0;
+    bool colors = baseline || (cfg.coarseSolver == 5 || cfg.smoother == 5);
     build_diagonal(sysmats[0], cfg.Ainv);
     if (colors) mark_colors(level_coords[0], sysmats[0]);
-    if ((cfg.coarseSolver == 6 && levelCnt == 1) || (cfg.smoother == 6 && levelCnt > 1)) estimate_2norm(sysmats[0], (T)1e-6); // :610-611
+    if (!baseline && ((cfg.coarseSolver == 6 && levelCnt == 1) || (cfg.smoother == 6 && levelCnt > 1))) estimate_2norm(sysmats[0], (T)1e-6); // :610-611
     const T w1d[2][3] = { { 0, 1, 0 }, { 0, (T)0.5, (T)0.5 } };
     for (int level = 0; level < levelCnt - 1; ++level) {
         const auto& coords = level_coords[level];
         std::vector<std::array<int, 3>> new_coords;
         std::unordered_map<ULL, int> new_coord2id;
+        Sim<T>* grid = nullptr;
+        if (baseline) {
+            // MultigridSimulation::particlesToMultigrids (Projects/multigrid/MultigridSimulation.inl:345-456): the coarse level is
+            // an MPM grid of spacing 2^(level+1) dx — sortParticlesAndPolluteMultigrid (:40-124), mass P2G (:404-428),
+            // buildMultigridBoundaries (:126-161), buildMultigridMatrices (:163-342) with the particles' dP/dF at the current F
+            while ((int)gmg.size() <= level) gmg.emplace_back(new Sim<T>());
+            grid = gmg[level].get();
+            grid->cfg = cfg;
+            grid->cfg.levelCnt = 1, grid->cfg.useBaselineMultigrid = 0;
+            grid->cfg.dx = cfg.dx * (double)(1 << (level + 1));
+            grid->dx = (T)grid->cfg.dx; // (curdx *= 2)
+            grid->gravity = gravity;
+            grid->Np = Np, grid->X = X, grid->Vel = Vel, grid->mass = mass, grid->vol = vol, grid->mu = mu, grid->lambda = lambda, grid->Jp = Jp, grid->C = C;
+            grid->F = Fn;
+            grid->cobjs = cobjs, grid->hs_origin = hs_origin, grid->hs_normal = hs_normal;
+            grid->collision_nodes.clear();
+            grid->sort_particles();
+            grid->particles_to_grid();
+            grid->begin_step(dt);
+            grid->F = F;
+            grid->build_matrix();
+            new_coords = grid->id2coord;
+            for (int j = 0; j < (int)new_coords.size(); ++j) new_coord2id[(ULL)new_coords[j][0] * hash_seed * hash_seed + (ULL)new_coords[j][1] * hash_seed + (ULL)new_coords[j][2]] = j;
+        }
         EllMat<T> P;
         P.colsize = 8;
         P.nrows = (int)coords.size();
@@ -333,6 +359,7 @@ void Sim<T>::build_mg()
                         auto it = new_coord2id.find(key);
                         int j;
                         if (it == new_coord2id.end()) {
+                            if (baseline) throw std::runtime_error("baseline multigrid: a fine node's parent is not a coarse-grid DOF (MultigridSimulation.inl:207)");
                             new_coords.push_back({ new_x, new_y, new_z });
                             j = (int)new_coords.size() - 1;
                             new_coord2id[key] = j;
@@ -346,11 +373,15 @@ void Sim<T>::build_mg()
         EllMat<T> R;
         build_transpose(R, P, (int)new_coords.size());
         EllMat<T> AP, RAP;
-        build_product(AP, sysmats[level], P);
-        build_product(RAP, R, AP);
+        if (baseline)
+            RAP = std::move(grid->sysmats[0]);
+        else {
+            build_product(AP, sysmats[level], P);
+            build_product(RAP, R, AP);
+        }
         build_diagonal(RAP, cfg.Ainv);
         if (colors) mark_colors(new_coords, RAP);
-        if ((cfg.coarseSolver == 6 && level + 2 == levelCnt) || (cfg.smoother == 6 && level + 2 < levelCnt)) estimate_2norm(RAP, (T)1e-6); // :682-683
+        if (!baseline && ((cfg.coarseSolver == 6 && level + 2 == levelCnt) || (cfg.smoother == 6 && level + 2 < levelCnt))) estimate_2norm(RAP, (T)1e-6); // :682-683
         promats.push_back(std::move(P));
         resmats.push_back(std::move(R));
         sysmats.push_back(std::move(RAP));
@@ -526,7 +557,13 @@ void Sim<T>::vcycle(const std::vector<TV>& in, std::vector<TV>& out)
     int splitLevel;
     auto downIter = [&](int level) { return times + level * levelscale; };
     std::function<int(int)> upIter, topIter;
-    if (cfg.topDownMGS) {
+    const bool baseline = cfg.useBaselineMultigrid != 0; // gs_smooth / cg_smooth / 10000 (MultigridSimulation.inl:446-453)
+    if (baseline) {
+        splitLevel = cfg.levelCnt - 1;
+        upIter = downIter;
+        topIter = [](int) { return 10000; };
+    }
+    else if (cfg.topDownMGS) {
         splitLevel = 1;
         upIter = [](int) { return 0; };
         topIter = [](int) { return 10000; };
@@ -543,11 +580,11 @@ void Sim<T>::vcycle(const std::vector<TV>& in, std::vector<TV>& out)
     }
     auto tolTop = [&](int) { return (T)(cfg.cneps * cfg.cneps); };
     auto run = [&](bool regular, int level, std::vector<TV>& sol, int its) {
-        smooth(regular ? cfg.smoother : cfg.coarseSolver, level, sol, mg_residuals[level], mg_dus[level], mg_dAus[level], its, regular ? (T)0 : tolTop(level));
+        smooth(regular ? (baseline ? 5 : cfg.smoother) : (baseline ? 2 : cfg.coarseSolver), level, sol, mg_residuals[level], mg_dus[level], mg_dAus[level], its, regular ? (T)0 : tolTop(level));
     };
     stats.vcycles++;
     mg_residuals[0] = in;
-    if (cfg.systemBCProject)
+    if (cfg.systemBCProject && !baseline) // correctResidualProjection (MultigridPreconditioner.h:695 ; the baseline installs a no-op, .inl:455)
         for (int i = 0; i < (int)in.size(); ++i) mg_residuals[0][i] += dRhs[i];
     out.assign(in.size(), TV::zero());
     if (levelCnt > 1)

@@ -342,3 +342,55 @@ def test_collision_object_validation(hotlib):
         ctx.set_collision_objects([dict(shape=HALFSPACE, type=SLIP, p0=(0, 0, 0), p1=(0, 1, 0), R=2 * np.eye(3))])
     with pytest.raises(HotError):
         ctx.set_collision_objects([dict(shape=HALFSPACE, type=SLIP, p0=(0, 0, 0), p1=(0, 1, 0), omega=(0, 1, 0))])
+
+
+@pytest.mark.parametrize("dtype,tol", [(1, 1e-10), (0, 5e-4)])
+def test_baseline_geometric_multigrid_against_oracle(hotlib, oracle, dtype, tol):
+    """--baseline: every coarse level is an MPM grid of doubled spacing (own sort, mass P2G, DOF numbering, boundaries from
+    the collision objects at its own nodes, matrix re-rasterised from the particles); trilinear transfers in between."""
+    from hot_amd.binding import HALFSPACE, SLIP, STICKY
+    objs = [
+        dict(shape=HALFSPACE, type=STICKY, p0=(0, 5.0 + 0.0049, 0), p1=(0, 1.0, 0)),
+        dict(shape=HALFSPACE, type=SLIP, p0=(5.0 + 0.0151, 0, 0), p1=(0.8, 0, 0.6)),
+    ]
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=12, dtype=dtype, bc=False, levelCnt=3, cneps=1e-7, useBaselineMultigrid=1, boundaryType=1, max_iterations=60)
+        ctx.set_collision_objects(objs)
+        pc.prepare(ctx)
+        ctx.update_state(ctx.get_dv())
+        ctx.build_hessian()
+        ctx.build_mg()
+        out[name] = ctx
+    g, c = out["gpu"], out["cpu"]
+    mg, mc = level_matrices(g, 3), level_matrices(c, 3)
+    for l in range(3):
+        assert np.array_equal(g.level(l)["id2coord"], c.level(l)["id2coord"])  # the coarse grids' DOF numbering is bit-exact
+        assert abs(mg[l] - mc[l]).max() < tol * abs(mc[l]).max(), l
+    assert g.level(1, coords=False)["nrows"] < g.level(0, coords=False)["nrows"] // 4
+    for l in range(2):
+        gp, cp = g.prolongation(l), c.prolongation(l)
+        assert np.array_equal(gp[0], cp[0]) and np.array_equal(gp[1], cp[1])
+    if dtype == 0:
+        return
+    rng = np.random.default_rng(11)
+    b = c.project(rng.standard_normal((g.Nn, 3)))
+    assert rel(g.vcycle(b), c.vcycle(b)) < 1e-8
+    sg, sc = g.solve(), c.solve()
+    for k in ("iterations", "converged", "linesearch_trials", "vcycles"):
+        assert sg[k] == sc[k], (k, sg, sc)
+    assert sc["converged"] == 1
+    assert rel(g.get_dv(), c.get_dv()) < 1e-7
+
+
+def test_baseline_multigrid_needs_analytic_boundaries(hotlib):
+    from hot_amd.binding import HotError
+    ctx, c = pc.make_ctx(hotlib, n=6, levelCnt=2, useBaselineMultigrid=1, bc=False)
+    pc.prepare(ctx)
+    nn = ctx.Nn
+    ctx.set_bc(np.array([0], np.int32), np.zeros((1, 3, 3)))  # explicit node list: only describes level 0
+    ctx.begin_step(1.0 / 24)
+    ctx.update_state(ctx.get_dv())
+    ctx.build_hessian()
+    with pytest.raises(HotError):
+        ctx.build_mg()
