@@ -56,3 +56,31 @@ def test_solvers_converge_and_agree(oracle):
         assert np.sqrt((m * (a - b) ** 2).sum()) < 2e-2 * np.sqrt((m * a ** 2).sum())  # kinetic-energy norm
         ea, eb = res["lbfgs"][1]["energy"], res[other][1]["energy"]
         assert abs(ea - eb) < 1e-6 * max(abs(ea), 1e-3)
+
+
+def test_baseline_geometric_hierarchy(oracle):
+    """--baseline: the coarse matrices are re-rasterised on grids of doubled spacing.  They are symmetric, act like the
+    fine operator on a smooth field restricted to them (same physics, coarser discretisation: rigid translations see
+    only the mass term, sum of the entries of a row = node mass), and the solver reaches the same minimiser."""
+    ctx, c = pc.make_ctx(oracle, n=6, bc=False, levelCnt=3, useBaselineMultigrid=1, cneps=1e-8)
+    pc.prepare(ctx)
+    ctx.update_state(ctx.get_dv())
+    ctx.build_hessian()
+    ctx.build_mg()
+    mass_total = ctx.grid()["mass"].sum()
+    for l in range(3):
+        col, val = ctx.matrix(l)
+        A = pc.ell_to_scipy(col, val, col.shape[0])
+        assert abs(A - A.T).max() < 1e-12 * abs(A).max()
+        t = np.tile(np.array([1.0, 0.0, 0.0]), col.shape[0])  # a rigid translation has no elastic energy
+        assert abs(t @ (A @ t) - mass_total) < 1e-9 * mass_total
+    dv = {}
+    for base in (0, 1):
+        ctx, c = pc.make_ctx(oracle, n=6, levelCnt=2, useBaselineMultigrid=base, cneps=1e-8)
+        pc.prepare(ctx)
+        st = ctx.solve()
+        assert st["converged"] == 1
+        dv[base] = (ctx.get_dv(), st["energy"], ctx.grid()["mass"][:, None])
+    a, b, m = dv[0][0], dv[1][0], dv[0][2]
+    assert np.sqrt((m * (a - b) ** 2).sum()) < 2e-2 * np.sqrt((m * a ** 2).sum())
+    assert abs(dv[0][1] - dv[1][1]) < 1e-6 * max(abs(dv[0][1]), 1e-3)
