@@ -322,6 +322,243 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles(const T* __restric
     }
 }
 
+// ---- second version of pass 2.  The first one evaluates block(i,j) = sum_{v,q} dP[(a,v),(b,q)] g_i[v] g_j[q] from scratch
+// for every (particle, row, column): 81 multiply-adds and 51 LDS reads each, and its work-item phase is bound by the
+// fp64 FMA rate of the CU (measured with clock64: 68 % of a tile's 124 us).  Here the contraction is split:
+//   K phase      K_i[a][b][q] = sum_v dP[(a,v),(b,q)] g_i[v]        once per (particle, tile row in its support), kept in LDS
+//   pair phase   block(i,j)[a][b] = sum_q K_i[a][b][q] g_j[q]        a lane owns (cell segment, row, a, the 3 columns j = (jx,jy,0..2)):
+//                                                                     9 K reads + 9 g reads feed 27 multiply-adds for 3 block rows
+// i.e. 27 instead of 81 multiply-adds per block.  Chunks are packed by LDS budget (particles and K entries); particles of
+// cells that touch no active row of the tile are skipped altogether.
+__constant__ uint8_t kSymRow[45] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 7, 7, 8 };
+__constant__ uint8_t kSymCol[45] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4, 5, 6, 7, 8, 2, 3, 4, 5, 6, 7, 8, 3, 4, 5, 6, 7, 8, 4, 5, 6, 7, 8, 5, 6, 7, 8, 6, 7, 8, 7, 8, 8 };
+
+// inclusive prefix sum over the 64 lanes (DPP row shifts + row broadcasts)
+__device__ __forceinline__ int wave_scan_incl(int x)
+{
+    const int t = x;
+    x += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xf, 0xf, true); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xf, 0xf, true); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, t, 0x113, 0xf, 0xf, true); // row_shr:3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xe, true); // row_shr:4, banks 1-3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xc, true); // row_shr:8, banks 2-3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true); // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true); // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+template <class T>
+struct TileLds2 {
+    static constexpr int CH = sizeof(T) == 8 ? 40 : 64; // particles per chunk
+    static constexpr int KMAX = sizeof(T) == 8 ? 136 : 224; // (particle, row) entries per chunk
+    static constexpr int NINT = 64 * 3 + 8 + 64 * 3 + 2 * CH + KMAX + 512 + 8; // cstart, ccnt, cmask, rdof, segs, soff, sbase, pidx, pseg, entinfo, items, ctl
+    static constexpr size_t bytes = ((size_t)8 * 1125 + (size_t)CH * (81 + 81 + 12) + (size_t)KMAX * 27) * sizeof(T) + (size_t)NINT * sizeof(int32_t);
+};
+
+template <class T>
+__global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ dp, int64_t Np, const uint64_t* __restrict__ blocks,
+    const int32_t* __restrict__ gIdx, const int32_t* __restrict__ cell_first, HashMap cmap, const T* __restrict__ mass, T* __restrict__ val, T one_over_dx, int ntiles)
+{
+    using G = Geo<T>;
+    constexpr int CH = TileLds2<T>::CH, KMAX = TileLds2<T>::KMAX;
+    constexpr int TPBY = G::BY / 2, TPBZ = G::BZ / 2, TPB = (G::BX / 2) * TPBY * TPBZ;
+    extern __shared__ __attribute__((aligned(16))) char ht_smem[];
+    T* tile = (T*)ht_smem; // [8][1125]
+    T* sdp = tile + 8 * 1125; // [CH][9][9] full symmetric dP
+    T* sg = sdp + CH * 81; // [CH][27][3]
+    T* sxf = sg + CH * 81; // [CH][12]
+    T* sk = sxf + CH * 12; // [KMAX][27]: K[a + 3 b][q]; before the K phase its head holds the per-axis spline weights [CH][3][6]
+    int32_t* cstart = (int32_t*)(sk + KMAX * 27); // [64] first particle of each contributing cell
+    int32_t* ccnt = cstart + 64; // [64] its particle count
+    int32_t* cmask = ccnt + 64; // [64] tile rows inside its 3x3x3 support (and active)
+    int32_t* rdof = cmask + 64; // [8]
+    int32_t* segs = rdof + 8; // [64] cell | first << 8 | end << 16 (chunk-relative)
+    int32_t* soff = segs + 64; // [64] offset of the segment inside its cell
+    int32_t* sbase = soff + 64; // [64] first K entry of the segment
+    int32_t* pidx = sbase + 64; // [CH] global particle index
+    int32_t* pseg = pidx + CH; // [CH] segment of the chunk member
+    int32_t* entinfo = pseg + CH; // [KMAX] chunk member | node index of the row inside the member's kernel << 8
+    int32_t* items = entinfo + KMAX; // [512] segment << 3 | row
+    int32_t* ctl = items + 512; // nitems, nseg, cnt, nent, next cell, next offset
+    const int tid = threadIdx.x;
+    const int id = blockIdx.x, run = (id & 7) + 8 * (id >> 8), tile_id = run * 32 + ((id >> 3) & 31); // runs of 32 tiles per XCD, as above
+    if (tile_id >= ntiles) return;
+    const int b = tile_id / TPB, tt = tile_id % TPB;
+    int bx, by, bz;
+    G::linear_to_coord(blocks[b], bx, by, bz);
+    const int tx0 = bx + 2 * (tt / (TPBY * TPBZ)), ty0 = by + 2 * ((tt / TPBZ) % TPBY), tz0 = bz + 2 * (tt % TPBZ);
+    if (tid < 8) {
+        int ex = (tx0 - bx) + (tid >> 2), ey = (ty0 - by) + ((tid >> 1) & 1), ez = (tz0 - bz) + (tid & 1);
+        rdof[tid] = gIdx[(int64_t)b * G::EPB + ((ex << (G::yb + G::zb)) | (ey << G::zb) | ez)];
+    }
+    for (int e = tid; e < 8 * 1125; e += HT_THREADS) tile[e] = (T)0;
+    __syncthreads();
+    bool any = false;
+    for (int r = 0; r < 8; ++r) any = any || rdof[r] >= 0;
+    if (!any) return;
+    int my_first = 0, my_n = 0, my_w = 0; // lanes of wavefront 0: first particle, particle count (0 if no row is touched), rows touched of cell `tid`
+    if (tid < 64) {
+        const int ox = (tid >> 4) - 2, oy = ((tid >> 2) & 3) - 2, oz = (tid & 3) - 2; // base cell = tile origin + (-2..1)^3
+        const int cx = tx0 + ox, cy = ty0 + oy, cz = tz0 + oz;
+        int first = 0, cnt = 0, mask = 0;
+        if ((cx | cy | cz) >= 0) {
+            int32_t c = hash_find_id(cmap, G::linear_offset(cx, cy, cz) >> G::data_bits);
+            if (c >= 0) first = cell_first[c], cnt = cell_first[c + 1] - first;
+        }
+        for (int r = 0; r < 8; ++r) {
+            const int ax = (r >> 2) - ox, ay = ((r >> 1) & 1) - oy, az = (r & 1) - oz; // row node inside the cell's kernel
+            if ((unsigned)ax < 3u && (unsigned)ay < 3u && (unsigned)az < 3u && rdof[r] >= 0) mask |= 1 << r;
+        }
+        cstart[tid] = first, ccnt[tid] = cnt, cmask[tid] = mask;
+        my_first = first, my_w = __popc(mask), my_n = my_w ? cnt : 0;
+    }
+    int pk_c = 0, pk_off = 0; // packing cursor (wavefront 0): cell, offset inside it
+    __syncthreads();
+    for (;;) {
+        // ---- pack the next chunk: whole or partial cells until CH particles or KMAX entries.  Wavefront 0, lane = cell:
+        // the particles (and K entries) from the chunk start to the end of each cell by two prefix sums, the first cell
+        // that does not fit whole is split.
+        if (tid < 64) {
+            const int rem = tid < pk_c ? 0 : (tid == pk_c ? my_n - pk_off : my_n);
+            const int pin = wave_scan_incl(rem), ein = wave_scan_incl(rem * my_w);
+            const unsigned long long notfull = __ballot(pin > CH || ein > KMAX);
+            const int f = notfull ? __ffsll((long long)notfull) - 1 : 64;
+            const int pbef = pin - rem, ebef = ein - rem * my_w;
+            int take = tid < f ? rem : 0;
+            if (tid == f) take = min(min(rem, CH - pbef), (KMAX - ebef) / my_w); // my_w > 0 here: rem > 0
+            const unsigned long long inc = __ballot(take > 0);
+            const int k = __popcll(inc & ((1ull << tid) - 1ull));
+            if (take > 0) {
+                const int off = tid == pk_c ? pk_off : 0;
+                segs[k] = tid | (pbef << 8) | ((pbef + take) << 16), soff[k] = off, sbase[k] = ebef;
+                for (int t = 0; t < take; ++t) pseg[pbef + t] = k, pidx[pbef + t] = my_first + off + t;
+            }
+            const int last = f < 64 ? f : 63;
+            const int cnt_all = __shfl(pbef + take, last), ent_all = __shfl(ebef + take * my_w, last);
+            const int take_f = __shfl(take, last);
+            if (tid == 0) ctl[0] = 0, ctl[1] = __popcll(inc), ctl[2] = cnt_all, ctl[3] = ent_all;
+            if (f < 64) {
+                pk_off = (f == pk_c ? pk_off : 0) + take_f;
+                pk_c = f;
+            }
+            else
+                pk_c = 64, pk_off = 0;
+        }
+        __syncthreads();
+        const int nseg = ctl[1], cnt = ctl[2], nent = ctl[3];
+        if (cnt == 0) break;
+        // ---- stage dP (45 -> full 9x9), X and Fn: the loads are issued first and land in LDS after the entry / item tables
+        // below are built.  Lanes run over the chunk members first (neighbours in every SoA component).
+        constexpr int NS = (CH * 45 + HT_THREADS - 1) / HT_THREADS;
+        static_assert(CH * 12 <= HT_THREADS, "one X / Fn slot per thread");
+        T ld[NS], ldx = (T)0;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int e = tid + k * HT_THREADS;
+            ld[k] = e < cnt * 45 ? dp[(int64_t)(e / cnt) * Np + pidx[e % cnt]] : (T)0;
+        }
+        if (tid < cnt * 12) {
+            const int q = tid / cnt, p = pidx[tid % cnt];
+            ldx = q < 3 ? X[(int64_t)q * Np + p] : Fn[(int64_t)(q - 3) * Np + p];
+        }
+        for (int e = tid; e < cnt * 8; e += HT_THREADS) {
+            const int l = e >> 3, r = e & 7, sp = pseg[l], sd = segs[sp], cell = sd & 255, mask = cmask[cell];
+            if ((mask >> r) & 1) {
+                const int ax = (r >> 2) - ((cell >> 4) - 2), ay = ((r >> 1) & 1) - (((cell >> 2) & 3) - 2), az = (r & 1) - ((cell & 3) - 2);
+                entinfo[sbase[sp] + (l - ((sd >> 8) & 255)) * __popc(mask) + __popc(mask & ((1 << r) - 1))] = l | ((ax * 9 + ay * 3 + az) << 8);
+            }
+        }
+        for (int e = tid; e < nseg * 8; e += HT_THREADS)
+            if ((cmask[segs[e >> 3] & 255] >> (e & 7)) & 1) items[atomicAdd(ctl, 1)] = e;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int e = tid + k * HT_THREADS;
+            if (e < cnt * 45) {
+                const int q = e / cnt, l = e - q * cnt, ra = kSymRow[q], cb = kSymCol[q];
+                sdp[l * 81 + ra * 9 + cb] = ld[k], sdp[l * 81 + cb * 9 + ra] = ld[k];
+            }
+        }
+        if (tid < cnt * 12) sxf[(tid % cnt) * 12 + tid / cnt] = ldx;
+        __syncthreads();
+        // ---- spline weights once per (particle, axis), then g = Fn^T grad w for the 27 nodes
+        T* sw = sk; // [CH][3][6]: w[3], dw[3] / dx
+        for (int e = tid; e < cnt * 3; e += HT_THREADS) {
+            int base;
+            T w[3], dw[3];
+            bspline<T>(one_over_dx * sxf[(e / 3) * 12 + e % 3], base, w, dw);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sw[e * 6 + k] = w[k], sw[e * 6 + 3 + k] = one_over_dx * dw[k];
+        }
+        __syncthreads();
+        for (int e = tid; e < cnt * 27; e += HT_THREADS) {
+            const int l = e / 27, nd = e - l * 27;
+            const int i = nd / 9, j = (nd / 3) % 3, k = nd % 3;
+            const T* wl = sw + l * 18;
+            const T wi = wl[i], dwi = wl[3 + i], wj = wl[6 + j], dwj = wl[9 + j], wk = wl[12 + k], dwk = wl[15 + k];
+            const T g0 = dwi * wj * wk, g1 = wi * dwj * wk, g2 = wi * wj * dwk;
+            const T* xf = sxf + l * 12;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) sg[e * 3 + cc] = xf[3 + cc * 3] * g0 + xf[3 + cc * 3 + 1] * g1 + xf[3 + cc * 3 + 2] * g2;
+        }
+        __syncthreads();
+        // ---- K phase: lane = (entry, (a, b)) -> the 3 values over q
+        for (int e = tid; e < nent * 9; e += HT_THREADS) {
+            const int entry = e / 9, ab = e - entry * 9, a = ab % 3, bb = ab / 3;
+            const int info = entinfo[entry], l = info & 255;
+            const T* D = sdp + l * 81 + bb;
+            const T* gi = sg + (l * 27 + (info >> 8)) * 3;
+            const T g0 = gi[0], g1 = gi[1], g2 = gi[2];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) sk[e * 3 + q] = D[a * 9 + 3 * q] * g0 + D[(a + 3) * 9 + 3 * q] * g1 + D[(a + 6) * 9 + 3 * q] * g2;
+        }
+        __syncthreads();
+        // ---- pair phase
+        const int ni = ctl[0] * 27;
+        for (int it = tid; it < ni; it += HT_THREADS) {
+            const int e = items[it / 27], rem = it % 27, jg = rem / 3, a = rem % 3, s = e >> 3, r = e & 7;
+            const int sd = segs[s], cell = sd & 255, l0 = (sd >> 8) & 255, l1 = sd >> 16, mask = cmask[cell];
+            const int nrows = __popc(mask), rowpos = __popc(mask & ((1 << r) - 1));
+            const int ax = (r >> 2) - ((cell >> 4) - 2), ay = ((r >> 1) & 1) - (((cell >> 2) & 3) - 2), az = (r & 1) - ((cell & 3) - 2);
+            const int jx = jg / 3, jy = jg % 3;
+            T acc[3][3]; // [column z][b]
+#pragma unroll
+            for (int z = 0; z < 3; ++z)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc[z][q] = (T)0;
+            const T* Kp = sk + (sbase[s] + rowpos) * 27 + a * 3;
+            const T* gp = sg + (l0 * 27 + jg * 3) * 3;
+#pragma unroll 2
+            for (int l = l0; l < l1; ++l, Kp += nrows * 27, gp += 81) {
+                T g[9]; // g_j[q] of the columns j = (jx, jy, z): g[3 z + q]
+#pragma unroll
+                for (int q = 0; q < 9; ++q) g[q] = gp[q];
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const T k = Kp[bb * 9 + q];
+#pragma unroll
+                        for (int z = 0; z < 3; ++z) acc[z][bb] += k * g[3 * z + q];
+                    }
+            }
+            T* o = tile + r * 1125 + ((ax - jx + 2) * 25 + (ay - jy + 2) * 5 + (az + 2)) * 9 + a;
+#pragma unroll
+            for (int z = 0; z < 3; ++z)
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) lds_atomic_add(o - z * 9 + 3 * bb, acc[z][bb]);
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < 8 * 1125; e += HT_THREADS) {
+        int r = e / 1125, q = e - r * 1125;
+        int dof = rdof[r];
+        if (dof < 0) continue;
+        T v = tile[e];
+        if (q >= 62 * 9 && q < 63 * 9 && ((q - 62 * 9) % 4 == 0)) v += mass[dof];
+        val[(int64_t)dof * 1125 + q] = v;
+    }
+}
+
 template <class T>
 void Ctx<T>::assemble_tiles(Level<T>& L)
 {
@@ -330,9 +567,15 @@ void Ctx<T>::assemble_tiles(Level<T>& L)
     static bool attr_set = false;
     if (!attr_set) {
         HOT_HIP(hipFuncSetAttribute((const void*)k_hessian_tiles<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileLds<T>::bytes));
+        HOT_HIP(hipFuncSetAttribute((const void*)k_hessian_tiles2<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileLds2<T>::bytes));
         attr_set = true;
     }
     constexpr int TPB = (G::BX / 2) * (G::BY / 2) * (G::BZ / 2);
+    static const bool tiles_v1 = getenv("HOT_HESSIAN_TILES_V1") != nullptr; // A/B switch: 81 multiply-adds per (particle, row, column)
+    if (!tiles_v1) {
+        HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles2<T>, 256 * div_up(Nb * TPB, 256), HT_THREADS, TileLds2<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx, Nb * TPB);
+        return;
+    }
     HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles<T>, 256 * div_up(Nb * TPB, 256), HT_THREADS, TileLds<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx, Nb * TPB);
 }
 

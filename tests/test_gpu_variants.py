@@ -23,6 +23,7 @@ CASES = [
     ({"HOT_MG_FULL_SPMV": "1"}, SOLVER, "vcycle or iterates"),
     ({"HOT_LBFGS_UNFUSED": "1"}, SOLVER, "iterates"),
     ({"HOT_HESSIAN_V1": "1"}, SOLVER, "hessian_and_hierarchy"),
+    ({"HOT_HESSIAN_TILES_V1": "1"}, SOLVER, "hessian_and_hierarchy"),
     ({"HOT_P2G_V1": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),
     ({"HOT_FORCE_V1": "1"}, "tests/test_gpu_force.py", "objective_pieces"),
 ]
