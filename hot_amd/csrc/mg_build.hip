@@ -332,7 +332,11 @@ __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col
     const uint32_t keyi = ckey[i];
     int32_t* c = col + (int64_t)i * 125;
     T* v = val + (int64_t)i * 1125;
-    constexpr int NCLS = 6; // 0 pre-off, 1 pre-in, 2 diagonal, 3 follow-in, 4 follow-off, 5 structural zero ; 6 = lane has no slot
+    // 0 pre-off of the previous colour, 1 other pre-off, 2 pre-in, 3 diagonal, 4 follow-in, 5 follow-off, 6 follow-off of the
+    // next colour, 7 structural zero ; 8 = lane has no slot.  The columns a chained sweep (k_gs_sweep) has to wait for — those
+    // of the colour just before the row's own in sweep order — sit at the outer ends of the two halves, in the 64 slots the
+    // sweep keeps in registers.
+    constexpr int NCLS = 8;
     int cls[2], jj[2];
     T bv[2][9];
 #pragma unroll
@@ -346,13 +350,14 @@ __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col
 #pragma unroll
             for (int e = 0; e < 9; ++e) bv[r][e] = v[k * 9 + e], nz = nz || bv[r][e] != (T)0;
             if (!nz)
-                cls[r] = 5;
+                cls[r] = 7;
             else if (jj[r] == i)
-                cls[r] = 2;
+                cls[r] = 3;
             else {
                 const uint32_t keyj = ckey[jj[r]];
                 const bool in = (keyj >> 7) == (keyi >> 7);
-                cls[r] = keyj < keyi ? (in ? 1 : 0) : (in ? 3 : 4);
+                const int cj = (int)(keyj >> 28), ci = (int)(keyi >> 28);
+                cls[r] = keyj < keyi ? (in ? 2 : (cj == ci - 1 ? 0 : 1)) : (in ? 4 : (cj == ci + 1 ? 6 : 5));
             }
         }
     }
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col
     if (!valid) return;
     for (int e = lane; e < 1125; e += 64) v[e] = sval[w][e];
     for (int k = lane; k < 125; k += 64) c[k] = scol[w][k];
-    if (lane == 0) rowcnt[4 * i] = cnt[0], rowcnt[4 * i + 1] = cnt[1], rowcnt[4 * i + 2] = cnt[3], rowcnt[4 * i + 3] = cnt[4];
+    if (lane == 0) rowcnt[4 * i] = cnt[0] + cnt[1], rowcnt[4 * i + 1] = cnt[2], rowcnt[4 * i + 2] = cnt[4], rowcnt[4 * i + 3] = cnt[5] + cnt[6];
 }
 
 // per (colour block, position in block) record {node or -1, the node's four row-class counts}: one 32-byte load gives a GS

@@ -535,6 +535,7 @@ struct GsPasses {
     int wg_begin[34]; // first workgroup of pass p ; wg_begin[npass] = grid size
     int block0[33]; // first colour block of the pass
     int sub[33]; // sub-block index of the pass
+    int color[33]; // colour of the pass
 };
 
 template <class T, bool FWD, int SB>
@@ -556,6 +557,7 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     const int start = block_start[b] + lo, cnt = max(0, min(SB, block_start[b + 1] - start));
     T* sDinv = (T*)(nodes + 5 * SB); // [SB][9] D_i^-1 and (forward) [SB][9] D_i of the rows: fetched before the wait, so that
     T* sD = sDinv + 9 * SB; // nothing after it has to go to global memory for them
+    T* srhs = sD + 9 * SB; // [SB][3] right-hand sides of the rows, likewise
     for (int e = tid; e < 9 * TRI; e += 64 * NW) tri[e] = (T)0;
     if (tid < SB) nodes[tid] = tid < cnt ? gs_order[start + tid] : -1;
     __syncthreads();
@@ -564,13 +566,16 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
         sDinv[e] = diagBlockInv[9 * i + e % 9];
         if (FWD) sD[e] = diagVal[9 * i + e % 9];
     }
+    for (int e = tid; e < 3 * cnt; e += 64 * NW) srhs[e] = rhs[3 * (int64_t)nodes[e / 3] + e % 3];
     // ---- 1. stream the half rows (lane = slot), keep what couples to nodes outside the sub-block
     T bv[RQ][9];
     int jj[RQ], node[RQ], kb2[RQ], ke[RQ];
+    bool late[RQ]; // the column is published by pass p-1: its x is gathered after the wait, every other one before
+    const uint32_t prevkey = p > 0 ? ((uint32_t)P.color[p - 1] << 8) | (uint32_t)P.sub[p - 1] : 0xffffffffu;
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
         const int ii = w + NW * q;
-        jj[q] = -1, node[q] = -1, kb2[q] = 0, ke[q] = 0;
+        jj[q] = -1, node[q] = -1, kb2[q] = 0, ke[q] = 0, late[q] = false;
 #pragma unroll
         for (int e = 0; e < 9; ++e) bv[q][e] = (T)0;
         if (ii < cnt) {
@@ -579,16 +584,20 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
             const int po = rowcnt[4 * i], pi = rowcnt[4 * i + 1], fi = rowcnt[4 * i + 2], fo = rowcnt[4 * i + 3];
             const int kbeg = FWD ? 0 : po + pi + 1, kend = FWD ? po + pi : po + pi + 1 + fi + fo;
             const int ibeg = FWD ? po : kbeg, iend = FWD ? po + pi : kbeg + fi;
-            kb2[q] = kbeg + 64, ke[q] = kend;
-            const int k = kbeg + lane;
-            if (k < kend) {
+            // the 64 slots kept in registers: the first ones of a preceding half, the last ones of a following half (that is
+            // where k_gs_split_rows puts the columns of pass p-1); the rest of a longer half row is the "tail"
+            kb2[q] = FWD ? kbeg + 64 : kbeg, ke[q] = FWD ? kend : kend - 64;
+            const int k = FWD ? kbeg + lane : kend - 64 + lane;
+            if (k >= kbeg && k < kend) {
                 const int j = col[(int64_t)i * 125 + k];
                 const T* bb = val + ((int64_t)i * 125 + k) * 9;
 #pragma unroll
                 for (int e = 0; e < 9; ++e) bv[q][e] = bb[e];
                 jj[q] = j;
+                const uint32_t keyj = ckey[j];
+                late[q] = (((keyj >> 28) << 8) | (((keyj & 127u) - 1u) / (uint32_t)SB)) == prevkey;
                 if (k >= ibeg && k < iend) {
-                    const int l = (int)(ckey[j] & 127u) - 1 - lo;
+                    const int l = (int)(keyj & 127u) - 1 - lo;
                     if (l >= 0 && l < SB) {
                         const int idx = FWD ? gs_tri_fwd<SB>(ii, l) : gs_tri_bwd(ii, l);
                         gs_store_tri<T>(tri, TRI, idx, diagBlockInv + 9 * (int64_t)i, bv[q]);
@@ -598,7 +607,67 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
             }
         }
     }
-    // ---- 2. wait for the previous pass
+    // ---- 2a. every column except those of pass p-1 was published two or more passes ago: make sure pass p-2 is complete (it
+    //          nearly always is) and fold those columns into the staged right-hand side now, off the critical path
+    if (p > 1 && tid == 0) {
+        const int need2 = P.wg_begin[p - 1] - P.wg_begin[p - 2];
+        int spins = 0;
+        while (__hip_atomic_load(done + p - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need2) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1 << 22) || ((spins & 1023) == 0 && *(volatile int*)err)) {
+                *(volatile int*)err = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads(); // also orders the staging of D^-1 / D / rhs (and the zeroed triangle) before their users
+    auto is_late = [&](uint32_t keyj) { return (((keyj >> 28) << 8) | (((keyj & 127u) - 1u) / (uint32_t)SB)) == prevkey; };
+    bool tail_late[RQ]; // the tail of the half row (slots past the first 64) holds columns of pass p-1 (rows are sorted to avoid it)
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+        const int ii = w + NW * q;
+        tail_late[q] = false;
+        if (ii >= cnt) continue; // wave-uniform
+        const int i = node[q];
+        T e0 = 0, e1 = 0, e2 = 0;
+        if (jj[q] >= 0 && !late[q]) {
+            const int64_t j = jj[q];
+            const T x0 = __hip_atomic_load(x + 3 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(x + 3 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                    x2 = __hip_atomic_load(x + 3 * j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            e0 = bv[q][0] * x0 + bv[q][3] * x1 + bv[q][6] * x2;
+            e1 = bv[q][1] * x0 + bv[q][4] * x1 + bv[q][7] * x2;
+            e2 = bv[q][2] * x0 + bv[q][5] * x1 + bv[q][8] * x2;
+        }
+        // half rows longer than one wave: plain strided tail; the in-block slots come first (FWD: last) in the range, so
+        // the tail may still hold sub-block couplings
+        bool tl = false;
+        for (int k = kb2[q] + lane; k < ke[q]; k += 64) {
+            const int j = col[(int64_t)i * 125 + k];
+            const T* bb = val + ((int64_t)i * 125 + k) * 9;
+            const uint32_t keyj = ckey[j], keyi = ckey[i];
+            const int l = (int)(keyj & 127u) - 1 - lo;
+            if ((keyj >> 7) == (keyi >> 7) && l >= 0 && l < SB) {
+                const int idx = FWD ? gs_tri_fwd<SB>(ii, l) : gs_tri_bwd(ii, l);
+                T bt[9];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) bt[e] = bb[e];
+                gs_store_tri<T>(tri, TRI, idx, diagBlockInv + 9 * (int64_t)i, bt);
+            }
+            else if (is_late(keyj))
+                tl = true;
+            else {
+                const T x0 = __hip_atomic_load(x + 3 * (int64_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(x + 3 * (int64_t)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                        x2 = __hip_atomic_load(x + 3 * (int64_t)j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                e0 += bb[0] * x0 + bb[3] * x1 + bb[6] * x2;
+                e1 += bb[1] * x0 + bb[4] * x1 + bb[7] * x2;
+                e2 += bb[2] * x0 + bb[5] * x1 + bb[8] * x2;
+            }
+        }
+        tail_late[q] = __ballot(tl) != 0ull;
+        e0 = wave_sum(e0), e1 = wave_sum(e1), e2 = wave_sum(e2);
+        if (lane == 0) srhs[3 * ii] -= e0, srhs[3 * ii + 1] -= e1, srhs[3 * ii + 2] -= e2;
+    }
+    // ---- 2b. wait for the previous pass
     {
         if (p > 0 && tid == 0) {
             const int need = P.wg_begin[p] - P.wg_begin[p - 1];
@@ -613,18 +682,18 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
                 }
             }
         }
-        __syncthreads(); // also for pass 0: orders the staging of D^-1 / D (and the triangle) before their readers
+        __syncthreads();
     }
     // x of other workgroups was published with write-through stores and is read with sc1 loads below: no cache
     // maintenance (buffer_wbl2 / buffer_inv) on either side
-    // ---- 3. row sums against the now final unknowns
+    // ---- 3. the columns of pass p-1 against the now final unknowns
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
         const int ii = w + NW * q;
         if (ii >= cnt) continue; // wave-uniform
         const int i = node[q];
         T s0 = 0, s1 = 0, s2 = 0;
-        if (jj[q] >= 0) {
+        if (jj[q] >= 0 && late[q]) {
             const int64_t j = jj[q];
             const T x0 = __hip_atomic_load(x + 3 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(x + 3 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                     x2 = __hip_atomic_load(x + 3 * j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -632,30 +701,23 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
             s1 = bv[q][1] * x0 + bv[q][4] * x1 + bv[q][7] * x2;
             s2 = bv[q][2] * x0 + bv[q][5] * x1 + bv[q][8] * x2;
         }
-        // half rows longer than one wave (boundary-free interior rows never are): plain strided tail; the in-block
-        // slots come first (FWD: last) in the range, so the tail may still hold sub-block couplings
-        for (int k = kb2[q] + lane; k < ke[q]; k += 64) {
-            const int j = col[(int64_t)i * 125 + k];
-            const T* bb = val + ((int64_t)i * 125 + k) * 9;
-            const uint32_t keyj = ckey[j], keyi = ckey[i];
-            const int l = (int)(keyj & 127u) - 1 - lo;
-            if ((keyj >> 7) == (keyi >> 7) && l >= 0 && l < SB) {
-                const int idx = FWD ? gs_tri_fwd<SB>(ii, l) : gs_tri_bwd(ii, l);
-                T bt[9];
-#pragma unroll
-                for (int e = 0; e < 9; ++e) bt[e] = bb[e];
-                gs_store_tri<T>(tri, TRI, idx, diagBlockInv + 9 * (int64_t)i, bt);
-            }
-            else {
-                const T x0 = __hip_atomic_load(x + 3 * (int64_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(x + 3 * (int64_t)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                        x2 = __hip_atomic_load(x + 3 * (int64_t)j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s0 += bb[0] * x0 + bb[3] * x1 + bb[6] * x2;
-                s1 += bb[1] * x0 + bb[4] * x1 + bb[7] * x2;
-                s2 += bb[2] * x0 + bb[5] * x1 + bb[8] * x2;
+        if (tail_late[q]) { // wave-uniform, rare
+            for (int k = kb2[q] + lane; k < ke[q]; k += 64) {
+                const int j = col[(int64_t)i * 125 + k];
+                const T* bb = val + ((int64_t)i * 125 + k) * 9;
+                const uint32_t keyj = ckey[j], keyi = ckey[i];
+                const int l = (int)(keyj & 127u) - 1 - lo;
+                if (!((keyj >> 7) == (keyi >> 7) && l >= 0 && l < SB) && is_late(keyj)) {
+                    const T x0 = __hip_atomic_load(x + 3 * (int64_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(x + 3 * (int64_t)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                            x2 = __hip_atomic_load(x + 3 * (int64_t)j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s0 += bb[0] * x0 + bb[3] * x1 + bb[6] * x2;
+                    s1 += bb[1] * x0 + bb[4] * x1 + bb[7] * x2;
+                    s2 += bb[2] * x0 + bb[5] * x1 + bb[8] * x2;
+                }
             }
         }
         s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
-        if (lane == 0) gs_store_rhs<T>(sv, ii, sDinv + 9 * ii, rhs[3 * (int64_t)i] - s0, rhs[3 * (int64_t)i + 1] - s1, rhs[3 * (int64_t)i + 2] - s2);
+        if (lane == 0) gs_store_rhs<T>(sv, ii, sDinv + 9 * ii, srhs[3 * ii] - s0, srhs[3 * ii + 1] - s1, srhs[3 * ii + 2] - s2);
     }
     __syncthreads();
     if (w != 0) return;
@@ -808,8 +870,8 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         if (!attr_set) {
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
-            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 18 * 64 * sizeof(T))));
-            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 18 * 64 * sizeof(T))));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T))));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T))));
             attr_set = true;
         }
         // sub-block size: levels whose colours hold more blocks than the chip has CUs run half blocks (36 KB LDS, 4
@@ -864,7 +926,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             auto add = [&](GsPasses& P, int c, int h) {
                 int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
                 if (nb <= 0) return;
-                P.block0[P.npass] = b0, P.sub[P.npass] = h, P.wg_begin[P.npass + 1] = P.wg_begin[P.npass] + nb;
+                P.block0[P.npass] = b0, P.sub[P.npass] = h, P.color[P.npass] = c, P.wg_begin[P.npass + 1] = P.wg_begin[P.npass] + nb;
                 ++P.npass;
             };
             for (int c = 0; c < 8; ++c)
@@ -883,7 +945,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             HOT_HIP(hipMemsetAsync(gs_done.p, 0, 40 * sizeof(int), stream));
             const int grid = P.wg_begin[P.npass];
 #define HOT_GS_CASE(F, S)                                                                                                                                              \
-    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_sweep<T, F, S>), grid, 16 * S, (GsLds<T, S>::bytes + 18 * S * sizeof(T)), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
+    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_sweep<T, F, S>), grid, 16 * S, (GsLds<T, S>::bytes + 21 * S * sizeof(T)), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
         L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, P, rc, gs_done.p, (int*)(hscal + 250))
             if (fwd) {
                 if (sb == 64) HOT_GS_CASE(true, 64);
