@@ -264,14 +264,16 @@ __global__ void k_bc_project_matrix(const int32_t* __restrict__ col, T* val, con
 
 // buildDiagonal (SquareMatrix.h:301-324): D_i = sum of entries whose column is i; scaler by Ainv; block inverse
 template <class T>
-__global__ void k_diag(const int32_t* __restrict__ col, const T* __restrict__ val, T* diagVal, T* diagInv, T* diagBlockInv, int n, int Ainv)
+__global__ void k_diag(const int32_t* __restrict__ col, const T* __restrict__ val, T* diagVal, T* diagInv, T* diagBlockInv, int n, int Ainv, int stencil_order)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Mat3<T> D;
 #pragma unroll
     for (int c = 0; c < 9; ++c) D.a[c] = (T)0;
-    for (int k = 0; k < 125; ++k) {
+    // rows still in stencil-slot order: the only slot whose column is i is the centre one (62); padded slots name column 0
+    // (or 1 in row 0) and hold zeros (SquareMatrix.h:563-566, ImplicitSolver.h:594-602)
+    for (int k = stencil_order ? 62 : 0; k < (stencil_order ? 63 : 125); ++k) {
         if (col[(int64_t)i * 125 + k] == i) {
             const T* v = val + ((int64_t)i * 125 + k) * 9;
 #pragma unroll
@@ -303,7 +305,7 @@ template <class T>
 void Ctx<T>::build_diagonal(Level<T>& L)
 {
     L.diagVal.reserve(9 * (size_t)L.n), L.diagInv.reserve(9 * (size_t)L.n), L.diagBlockInv.reserve(9 * (size_t)L.n);
-    HOT_LAUNCH(this, "build_diagonal", k_diag<T>, div_up(L.n, 256), 256, 0, L.col.p, L.val.p, L.diagVal.p, L.diagInv.p, L.diagBlockInv.p, L.n, cfg.Ainv);
+    HOT_LAUNCH(this, "build_diagonal", k_diag<T>, div_up(L.n, 256), 256, 0, L.col.p, L.val.p, L.diagVal.p, L.diagInv.p, L.diagBlockInv.p, L.n, cfg.Ainv, L.split ? 0 : 1);
 }
 
 template <class T>
@@ -355,7 +357,7 @@ void Ctx<T>::build_hessian()
     if (cfg.systemBCProject && Nc > 0)
         HOT_LAUNCH(this, "hessian_bc_project", k_bc_project_matrix<T>, div_up(ne, 256), 256, 0, L->col.p, L->val.p, bcIdx.p, bcR.p, bcRinv.p, bcSlip.p, Nn);
     build_diagonal(*L);
-    count_nnzb(*L);
+    L->nnzb = -1; // counted on request (hot_get_level_nnzb)
     sync();
     stats.ms_hessian += wall_ms() - t0;
 }

@@ -198,7 +198,12 @@ struct Ctx : CtxBase {
     void build_mg() override;
     void get_level(int32_t level, int32_t* nrows, int32_t* colsize, int32_t* id2coord) override;
     void get_matrix(int32_t level, int32_t* entryCol, void* entryVal) override;
-    long long get_level_nnzb(int32_t level) override { need(level >= 0 && level < (int)levels.size(), "level out of range"); return levels[level]->nnzb; }
+    long long get_level_nnzb(int32_t level) override
+    {
+        need(level >= 0 && level < (int)levels.size(), "level out of range");
+        if (levels[level]->nnzb < 0) count_nnzb(*levels[level]); // one pass over the values, only when somebody asks
+        return levels[level]->nnzb;
+    }
     void get_prolongation(int32_t level, int32_t* entryCol, void* weight) override;
     void spmv(int32_t level, const void* x, void* y) override;
     void restrict_(int32_t level, const void* fine, void* coarse) override;

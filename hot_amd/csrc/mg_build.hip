@@ -565,7 +565,7 @@ void Ctx<T>::build_mg()
         HOT_LAUNCH(this, "mg_AP_cols", k_ap_cols, div_up(64 * (size_t)n, 256), 256, 0, C.map, F.coord.p, F.apc.p, n);
         if (!baseline) HOT_LAUNCH(this, "mg_RAP", k_rap<T>, div_up(nc, 4), 256, 0, C.coord.p, C.child.p, F.apv.p, C.val.p, C.n);
         build_diagonal(C);
-        count_nnzb(C);
+        C.nnzb = -1; // counted on request (hot_get_level_nnzb)
         alloc_work(C);
         if (colors) mark_colors(this, C);
         if (!baseline && ((cfg.coarseSolver == 6 && level + 2 == cfg.levelCnt) || (cfg.smoother == 6 && level + 2 < cfg.levelCnt))) estimate_2norm(C, 1e-6); // :682-683
