@@ -365,8 +365,9 @@ template <class T, bool FWD, int SB, bool WT = false>
 __device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int32_t* nodes, int cnt, int lane, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, T* x, T* hD,
     const T* ldsD = nullptr);
 
+// six waves per SIMD (three 512-thread workgroups per CU: a colour of the finest level is resident in one round) = at most 80 VGPRs
 template <class T, bool FWD, int SB>
-__global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_gs_block(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
     const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, int block0, int sub,
     const int32_t* __restrict__ rowcnt, const int32_t* __restrict__ gs_pad)
 {
@@ -378,12 +379,18 @@ __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ c
     int32_t* rcl = nodes + SB; // [SB][4] row class counts (from gs_pad)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = block0 + blockIdx.x;
-    const int dbg = sub >> 8; // timing experiments only (wrong results): 1 skip phase B, 2 skip phase A
-    sub &= 255;
+    const int dbg = (sub >> 8) & 255; // timing experiments only (wrong results): 1 skip phase B, 2 skip phase A
+    // sub-blocks [sub & 255, +nmerge) of the colour block are processed back to back by this workgroup, in sweep order: the
+    // launch boundary between them (gap, dispatch ramp, header round trip: ~7 us of a ~30 us pass) is replaced by a barrier;
+    // what the later sub-block reads of the earlier one was stored before the barrier by the same workgroup
+    const int nmerge = max(sub >> 16, 1), sub_first = sub & 255;
+    const int nthreads = blockDim.x, nwaves = blockDim.x >> 6;
+    for (int m = 0; m < nmerge; ++m) {
+    sub = FWD ? sub_first + m : sub_first + nmerge - 1 - m;
     const int lo = sub * SB; // first local index of this sub-block
     const int start = block_start[b] + lo, cnt = min(SB, block_start[b + 1] - start);
-    if (cnt <= 0) return; // workgroup-uniform
-    const int nthreads = blockDim.x, nwaves = blockDim.x >> 6;
+    if (cnt <= 0) continue; // workgroup-uniform
+    if (m > 0) __syncthreads(); // the previous sub-block's substitution wave is done with the triangle / rhs / node tables
     for (int e = tid; e < 9 * TRI; e += nthreads) tri[e] = (T)0;
     if (tid < SB) {
         // one 32-byte record per position: node id + its row class counts (no block_start -> gs_order -> rowcnt chain)
@@ -459,8 +466,8 @@ __global__ __launch_bounds__(1024) void k_gs_block(const int32_t* __restrict__ c
         }
     }
     __syncthreads();
-    if (w != 0 || (dbg & 1)) return;
-    gs_phase_b<T, FWD, SB>(tri, sv, nodes, cnt, lane, diagVal, diagBlockInv, x, hD);
+    if (w == 0 && !(dbg & 1)) gs_phase_b<T, FWD, SB>(tri, sv, nodes, cnt, lane, diagVal, diagBlockInv, x, hD);
+    }
 }
 
 // ---------------- phase B of the block GS kernels: lane = row, executed by one wavefront.  WT: publish x with
@@ -883,9 +890,13 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         const int nsub = 64 / sb;
         HOT_CHECK(L.split || simple_gs, HOT_ERR_INVALID, "block GS kernels need the regrouped rows (k_gs_split_rows)");
         const int32_t* rc = L.rowcnt.p;
+        // one launch per colour: its sub-blocks are walked inside the kernel (A/B switch: one launch per sub-block)
+        static const bool split_launches = getenv("HOT_GS_SPLIT_LAUNCHES") != nullptr;
+        const int nmerge = (split_launches || simple_gs) ? 1 : nsub;
         auto pass = [&](bool fwd, int c, int h) {
             int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
             if (nb <= 0) return;
+            if (nmerge > 1 && h != 0) return; // sub-blocks 1.. ride along with sub-block 0's launch
             const char* nm = fwd ? "gs_forward" : "gs_backward";
             const T* rhs = fwd ? r : dAu;
             T* xx = fwd ? hdu : du;
@@ -900,7 +911,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             }
 #define HOT_GS_CASE(F, S)                                                                                                                                      \
     HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_block<T, F, S>), nb, gs_threads, (GsLds<T, S>::bytes), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
-        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, b0, h | (gs_dbg << 8), rc, L.gs_pad.p)
+        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, b0, h | (gs_dbg << 8) | (nmerge << 16), rc, L.gs_pad.p)
             if (fwd) {
                 if (sb == 64) HOT_GS_CASE(true, 64);
                 else if (sb == 32) HOT_GS_CASE(true, 32);
