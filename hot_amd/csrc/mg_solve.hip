@@ -891,7 +891,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         HOT_CHECK(L.split || simple_gs, HOT_ERR_INVALID, "block GS kernels need the regrouped rows (k_gs_split_rows)");
         const int32_t* rc = L.rowcnt.p;
         // one launch per colour: its sub-blocks are walked inside the kernel (A/B switch: one launch per sub-block)
-        static const bool split_launches = getenv("HOT_GS_SPLIT_LAUNCHES") != nullptr;
+        const bool split_launches = getenv("HOT_GS_SPLIT_LAUNCHES") != nullptr; // read per call: tools/gs_merge_check.py flips it on one matrix
         const int nmerge = (split_launches || simple_gs) ? 1 : nsub;
         auto pass = [&](bool fwd, int c, int h) {
             int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;

@@ -123,3 +123,25 @@ def test_fullsize_invariants(hotlib, name):
     ctx.g2p(cfg["dt"])
     p = ctx.get_particles()
     assert np.isfinite(p["X"]).all() and np.isfinite(p["F"]).all()
+
+
+@pytest.mark.parametrize("cname,n", [("C2", 63), ("C3", 100)])
+def test_gs_colour_launch_equals_sub_block_launches(hotlib, cname, n):
+    """The finest-level GS walks both 32-node sub-blocks of a colour block inside one launch; the later sub-block must see what
+    the earlier one stored.  With a launch per sub-block (HOT_GS_SPLIT_LAUNCHES, read per call) the arithmetic is the same,
+    so on one and the same matrix the V-cycle is bitwise identical."""
+    import os
+    cfg = synth.CONFIGS[cname]
+    ctx, cloud = make(hotlib, cfg, n)
+    ctx.sort(), ctx.p2g(), ctx.begin_step(cfg["dt"])
+    ctx.update_state(ctx.get_dv())
+    ctx.build_hessian(), ctx.build_mg()
+    x = ctx.project(np.random.default_rng(1).standard_normal((ctx.Nn, 3)))
+    os.environ.pop("HOT_GS_SPLIT_LAUNCHES", None)
+    a = [ctx.vcycle(x) for _ in range(3)]
+    os.environ["HOT_GS_SPLIT_LAUNCHES"] = "1"
+    try:
+        b = [ctx.vcycle(x) for _ in range(3)]
+    finally:
+        os.environ.pop("HOT_GS_SPLIT_LAUNCHES", None)
+    assert all(np.array_equal(a[0], y) for y in a[1:] + b)
