@@ -268,6 +268,29 @@ __global__ void k_color_ckey(const uint64_t* __restrict__ keys, const int32_t* _
     ckey[node] = (color << 28) | (bid << 7) | (uint32_t)(p - start + 1);
 }
 
+// the 26 colour blocks around block b (block coordinates +-1): global block id | colour << 28, or -1.  A row of b only
+// couples to nodes of b and of these blocks (stencil reach 2 < block edge 4).
+__global__ void k_block_neighbours(HashMap h, const int32_t* __restrict__ coord, const int32_t* __restrict__ gs_order, const int32_t* __restrict__ block_start,
+    const int32_t* __restrict__ color_begin, int32_t* __restrict__ nbr, int nblocks)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nblocks * 26) return;
+    const int b = e / 26;
+    int q = e - b * 26;
+    if (q >= 13) ++q; // skip the centre
+    const int node = gs_order[block_start[b]];
+    const int x = (coord[3 * node] >> 2) + q / 9 - 1, y = (coord[3 * node + 1] >> 2) + (q / 3) % 3 - 1, z = (coord[3 * node + 2] >> 2) + q % 3 - 1;
+    int32_t out = -1;
+    if ((x | y | z) >= 0) {
+        const int32_t bid = hash_find_id(h, coord_key(x, y, z));
+        if (bid >= 0) {
+            const int c = ((x & 1) << 2) | ((y & 1) << 1) | (z & 1);
+            out = (color_begin[c] + bid) | (c << 28);
+        }
+    }
+    nbr[e] = out;
+}
+
 template <class T>
 static void build_coord_map(Ctx<T>* ctx, Level<T>& L)
 {
@@ -313,6 +336,9 @@ static void mark_colors(Ctx<T>* ctx, Level<T>& L)
     cb.reserve(16);
     HOT_LAUNCH(ctx, "color_finish", k_color_finish, div_up(n, 256), 256, 0, ctx->keys2.p, ctx->flags.p, ctx->scan.p, L.gs_order.p, L.gs_block_start.p, cb.p, n, L.nblocks);
     HOT_LAUNCH(ctx, "color_ckey", k_color_ckey, div_up(n, 256), 256, 0, ctx->keys2.p, ctx->scan.p, L.gs_block_start.p, L.ckey.p, n);
+    L.gs_nbr.reserve(26 * (size_t)L.nblocks), L.gs_flag.reserve(L.nblocks);
+    HOT_LAUNCH(ctx, "color_block_neighbours", k_block_neighbours, div_up(26 * (size_t)L.nblocks, 256), 256, 0, h, L.coord.p, L.gs_order.p, L.gs_block_start.p, cb.p, L.gs_nbr.p, L.nblocks);
+    HOT_HIP(hipMemsetAsync(L.gs_flag.p, 0, (size_t)L.nblocks * sizeof(int), ctx->stream)); // sweep numbers start at 1
     HOT_HIP(hipMemcpyAsync(L.color_block_begin, cb.p, 9 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
 }

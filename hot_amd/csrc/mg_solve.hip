@@ -548,7 +548,7 @@ struct GsPasses {
 template <class T, bool FWD, int SB>
 __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
     const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, GsPasses P,
-    const int32_t* __restrict__ rowcnt, int* done, int* err)
+    const int32_t* __restrict__ rowcnt, int* done, int* err, const int32_t* __restrict__ nbr, int* flag, int epoch)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     constexpr int TRI = GsLds<T, SB>::TRI;
@@ -616,7 +616,33 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     }
     // ---- 2a. every column except those of pass p-1 was published two or more passes ago: make sure pass p-2 is complete (it
     //          nearly always is) and fold those columns into the staged right-hand side now, off the critical path
-    if (p > 1 && tid == 0) {
+    // point-to-point mode (nbr != null, one sub-block per block): a block only waits for the adjacent blocks whose colours run
+    // earlier in the sweep, each of which stamps flag[block] with the sweep number when its nodes are published — no pass-wide
+    // counter, so a slow block holds up its neighbours only
+    int mynb = -1, mynb_pass = 1 << 30; // lanes 0..25 of wavefront 0: one adjacent block each, and the pass it belongs to
+    if (nbr && tid < 26) {
+        mynb = nbr[(int64_t)b * 26 + tid];
+        if (mynb >= 0) {
+            const int cn = mynb >> 28;
+            for (int q = 0; q < P.npass; ++q)
+                if (P.color[q] == cn) mynb_pass = q;
+            mynb &= 0x0fffffff;
+        }
+    }
+    auto wait_blocks = [&](bool want) { // spin until the block of this lane carries the current sweep number
+        if (!want) return;
+        int spins = 0;
+        while (__hip_atomic_load(flag + mynb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1 << 22) || ((spins & 1023) == 0 && *(volatile int*)err)) {
+                *(volatile int*)err = 1;
+                break;
+            }
+        }
+    };
+    if (nbr)
+        wait_blocks(mynb >= 0 && mynb_pass < p - 1);
+    else if (p > 1 && tid == 0) {
         const int need2 = P.wg_begin[p - 1] - P.wg_begin[p - 2];
         int spins = 0;
         while (__hip_atomic_load(done + p - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need2) {
@@ -676,7 +702,9 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     }
     // ---- 2b. wait for the previous pass
     {
-        if (p > 0 && tid == 0) {
+        if (nbr)
+            wait_blocks(mynb >= 0 && mynb_pass == p - 1);
+        else if (p > 0 && tid == 0) {
             const int need = P.wg_begin[p] - P.wg_begin[p - 1];
             int spins = 0;
             while (__hip_atomic_load(done + p - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
@@ -731,7 +759,12 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     if (cnt > 0) gs_phase_b<T, FWD, SB, true>(tri, sv, nodes, cnt, lane, diagVal, diagBlockInv, x, hD, sD);
     // ---- publish: the write-through stores of every lane have left the CU before lane 0 bumps the pass counter
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(done + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) {
+        if (nbr)
+            __hip_atomic_store(flag + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            __hip_atomic_fetch_add(done + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // r_i = sum over the nl slots preceding row i of A_ik (h - du)_k   (rows regrouped by k_gs_split_rows)
@@ -953,11 +986,17 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             const T* rhs = fwd ? r : dAu;
             T* xx = fwd ? hdu : du;
             T* hD = fwd ? dAu : (T*)nullptr;
-            HOT_HIP(hipMemsetAsync(gs_done.p, 0, 40 * sizeof(int), stream));
+            // hand-off between passes: point-to-point block flags when a block is one sub-block (A/B switch: pass counters)
+            static const bool pass_counters = getenv("HOT_GS_PASS_COUNTERS") != nullptr;
+            const bool p2p = nsub == 1 && !pass_counters;
+            if (p2p)
+                ++gs_epoch;
+            else
+                HOT_HIP(hipMemsetAsync(gs_done.p, 0, 40 * sizeof(int), stream));
             const int grid = P.wg_begin[P.npass];
 #define HOT_GS_CASE(F, S)                                                                                                                                              \
     HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_sweep<T, F, S>), grid, 16 * S, (GsLds<T, S>::bytes + 21 * S * sizeof(T)), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
-        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, P, rc, gs_done.p, (int*)(hscal + 250))
+        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, P, rc, gs_done.p, (int*)(hscal + 250), p2p ? L.gs_nbr.p : (const int32_t*)nullptr, L.gs_flag.p, gs_epoch)
             if (fwd) {
                 if (sb == 64) HOT_GS_CASE(true, 64);
                 else if (sb == 32) HOT_GS_CASE(true, 32);
