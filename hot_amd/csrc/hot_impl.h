@@ -28,7 +28,7 @@ struct Level {
     DBuf<T> apv; // n*64*9: A*P of this level (4^3 coarse window per row), kept for the coarse-correction residual update
     DBuf<int32_t> apc; // n*64: coarse column of every window slot (0 where the coarse node does not exist; its block is 0)
     DBuf<int32_t> gs_nbr; // nblocks*26: the adjacent colour blocks (global block id | colour << 28, or -1): whose unknowns a block's rows read
-    DBuf<int> gs_flag; // nblocks: sweep number in which the block was last finished (k_gs_sweep's point-to-point hand-off)
+    DBuf<int> gs_flag; // 4*nblocks: sweep number in which the (block, sub-block) was last finished (k_gs_sweep's point-to-point hand-off)
     DBuf<int32_t> gs_pad; // nblocks*64*8: per (colour block, position) {node or -1, the row's four class counts, pad}: the GS kernels' header in one load
     DBuf<int32_t> rowcnt; // 4n: (precede-off, precede-in, follow-in, follow-off) slot counts of the regrouped rows
     bool split = false;

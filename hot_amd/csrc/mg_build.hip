@@ -336,9 +336,9 @@ static void mark_colors(Ctx<T>* ctx, Level<T>& L)
     cb.reserve(16);
     HOT_LAUNCH(ctx, "color_finish", k_color_finish, div_up(n, 256), 256, 0, ctx->keys2.p, ctx->flags.p, ctx->scan.p, L.gs_order.p, L.gs_block_start.p, cb.p, n, L.nblocks);
     HOT_LAUNCH(ctx, "color_ckey", k_color_ckey, div_up(n, 256), 256, 0, ctx->keys2.p, ctx->scan.p, L.gs_block_start.p, L.ckey.p, n);
-    L.gs_nbr.reserve(26 * (size_t)L.nblocks), L.gs_flag.reserve(L.nblocks);
+    L.gs_nbr.reserve(26 * (size_t)L.nblocks), L.gs_flag.reserve(4 * (size_t)L.nblocks);
     HOT_LAUNCH(ctx, "color_block_neighbours", k_block_neighbours, div_up(26 * (size_t)L.nblocks, 256), 256, 0, h, L.coord.p, L.gs_order.p, L.gs_block_start.p, cb.p, L.gs_nbr.p, L.nblocks);
-    HOT_HIP(hipMemsetAsync(L.gs_flag.p, 0, (size_t)L.nblocks * sizeof(int), ctx->stream)); // sweep numbers start at 1
+    HOT_HIP(hipMemsetAsync(L.gs_flag.p, 0, 4 * (size_t)L.nblocks * sizeof(int), ctx->stream)); // sweep numbers start at 1
     HOT_HIP(hipMemcpyAsync(L.color_block_begin, cb.p, 9 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
 }

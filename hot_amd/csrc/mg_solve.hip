@@ -577,6 +577,11 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     // ---- 1. stream the half rows (lane = slot), keep what couples to nodes outside the sub-block
     T bv[RQ][9];
     int jj[RQ], node[RQ], kb2[RQ], ke[RQ];
+    // which 64 slots of a half row stay in registers: the end of the half where the columns of pass p-1 sit.  First sub-block of
+    // its colour in sweep order: the previous colour's columns (sorted to the outer end of the half by k_gs_split_rows); a later
+    // sub-block: the own block's previous sub-block, i.e. the in-block slots at the inner end.
+    const bool first_sub = p == 0 || P.color[p - 1] != P.color[p];
+    const bool head = FWD ? first_sub : !first_sub;
     bool late[RQ]; // the column is published by pass p-1: its x is gathered after the wait, every other one before
     const uint32_t prevkey = p > 0 ? ((uint32_t)P.color[p - 1] << 8) | (uint32_t)P.sub[p - 1] : 0xffffffffu;
 #pragma unroll
@@ -591,10 +596,9 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
             const int po = rowcnt[4 * i], pi = rowcnt[4 * i + 1], fi = rowcnt[4 * i + 2], fo = rowcnt[4 * i + 3];
             const int kbeg = FWD ? 0 : po + pi + 1, kend = FWD ? po + pi : po + pi + 1 + fi + fo;
             const int ibeg = FWD ? po : kbeg, iend = FWD ? po + pi : kbeg + fi;
-            // the 64 slots kept in registers: the first ones of a preceding half, the last ones of a following half (that is
-            // where k_gs_split_rows puts the columns of pass p-1); the rest of a longer half row is the "tail"
-            kb2[q] = FWD ? kbeg + 64 : kbeg, ke[q] = FWD ? kend : kend - 64;
-            const int k = FWD ? kbeg + lane : kend - 64 + lane;
+            // the 64 slots kept in registers (see `head`); the rest of a longer half row is the "tail"
+            kb2[q] = head ? kbeg + 64 : kbeg, ke[q] = head ? kend : kend - 64;
+            const int k = head ? kbeg + lane : kend - 64 + lane;
             if (k >= kbeg && k < kend) {
                 const int j = col[(int64_t)i * 125 + k];
                 const T* bb = val + ((int64_t)i * 125 + k) * 9;
@@ -616,23 +620,35 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     }
     // ---- 2a. every column except those of pass p-1 was published two or more passes ago: make sure pass p-2 is complete (it
     //          nearly always is) and fold those columns into the staged right-hand side now, off the critical path
-    // point-to-point mode (nbr != null, one sub-block per block): a block only waits for the adjacent blocks whose colours run
+    // point-to-point mode (nbr != null): a sub-block only waits for the adjacent blocks whose colours run
     // earlier in the sweep, each of which stamps flag[block] with the sweep number when its nodes are published — no pass-wide
     // counter, so a slow block holds up its neighbours only
-    int mynb = -1, mynb_pass = 1 << 30; // lanes 0..25 of wavefront 0: one adjacent block each, and the pass it belongs to
+    // flag index = 4 * block + sub-block.  A sub-block waits for the sub-block before it in its own block, which has waited
+    // for the one before that, so a block's last sub-block in sweep order vouches for the whole block.
+    int early_idx = -1, late_idx = -1; // lanes 0..27 of wavefront 0: what to see stamped before the early / the late gather
     if (nbr && tid < 26) {
-        mynb = nbr[(int64_t)b * 26 + tid];
-        if (mynb >= 0) {
-            const int cn = mynb >> 28;
+        const int nb = nbr[(int64_t)b * 26 + tid];
+        if (nb >= 0) {
+            const int cn = nb >> 28, gid = nb & 0x0fffffff;
+            int qlast = -1;
             for (int q = 0; q < P.npass; ++q)
-                if (P.color[q] == cn) mynb_pass = q;
-            mynb &= 0x0fffffff;
+                if (P.color[q] == cn) qlast = q;
+            if (qlast >= 0 && qlast < p) { // that colour runs before this one
+                if (qlast < p - 1)
+                    early_idx = 4 * gid + P.sub[qlast];
+                else {
+                    late_idx = 4 * gid + P.sub[qlast];
+                    if (qlast > 0 && P.color[qlast - 1] == cn) early_idx = 4 * gid + P.sub[qlast - 1];
+                }
+            }
         }
     }
-    auto wait_blocks = [&](bool want) { // spin until the block of this lane carries the current sweep number
-        if (!want) return;
+    if (nbr && tid == 26 && p > 0 && P.color[p - 1] == P.color[p]) late_idx = 4 * b + P.sub[p - 1];
+    if (nbr && tid == 27 && p > 1 && P.color[p - 2] == P.color[p]) early_idx = 4 * b + P.sub[p - 2];
+    auto wait_blocks = [&](int idx) { // spin until that sub-block carries the current sweep number
+        if (idx < 0) return;
         int spins = 0;
-        while (__hip_atomic_load(flag + mynb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        while (__hip_atomic_load(flag + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
             __builtin_amdgcn_s_sleep(4);
             if (++spins > (1 << 22) || ((spins & 1023) == 0 && *(volatile int*)err)) {
                 *(volatile int*)err = 1;
@@ -641,7 +657,7 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
         }
     };
     if (nbr)
-        wait_blocks(mynb >= 0 && mynb_pass < p - 1);
+        wait_blocks(early_idx);
     else if (p > 1 && tid == 0) {
         const int need2 = P.wg_begin[p - 1] - P.wg_begin[p - 2];
         int spins = 0;
@@ -703,7 +719,7 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     // ---- 2b. wait for the previous pass
     {
         if (nbr)
-            wait_blocks(mynb >= 0 && mynb_pass == p - 1);
+            wait_blocks(late_idx);
         else if (p > 0 && tid == 0) {
             const int need = P.wg_begin[p] - P.wg_begin[p - 1];
             int spins = 0;
@@ -761,7 +777,7 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
         if (nbr)
-            __hip_atomic_store(flag + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flag + 4 * b + P.sub[p], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else
             __hip_atomic_fetch_add(done + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -988,7 +1004,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             T* hD = fwd ? dAu : (T*)nullptr;
             // hand-off between passes: point-to-point block flags when a block is one sub-block (A/B switch: pass counters)
             static const bool pass_counters = getenv("HOT_GS_PASS_COUNTERS") != nullptr;
-            const bool p2p = nsub == 1 && !pass_counters;
+            const bool p2p = !pass_counters;
             if (p2p)
                 ++gs_epoch;
             else
