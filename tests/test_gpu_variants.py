@@ -1,5 +1,5 @@
-"""The library picks kernel variants by problem size (block GS: one launch per (colour, sub-block) pass on large levels,
-one chained launch per half sweep on small ones; sub-block size 32 / 64) and keeps first-generation kernels behind
+"""The library picks kernel variants by problem size (block GS: one launch per colour on large levels, one chained launch
+per half sweep with point-to-point block flags on small ones; sub-block size 32 / 64) and keeps first-generation kernels behind
 A/B switches.  The parity tests use small problems, so without this file only the small-problem variants would be
 compared with the oracle.  Each case re-runs the relevant parity tests in a subprocess with the switch set (the
 switches are read once per process)."""
@@ -18,6 +18,9 @@ CASES = [
     ({"HOT_GS_MULTILAUNCH": "1", "HOT_GS_SB": "64"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_GS_DATAFLOW": "1", "HOT_GS_SB": "32"}, SOLVER, "smoothers or vcycle or iterates"),
     ({"HOT_GS_DATAFLOW": "1", "HOT_GS_SB": "16"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_GS_PASS_COUNTERS": "1"}, SOLVER, "smoothers or vcycle or iterates"),
+    ({"HOT_GS_DATAFLOW": "1", "HOT_GS_SB": "32", "HOT_GS_PASS_COUNTERS": "1"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_GS_MULTILAUNCH": "1", "HOT_GS_SB": "32", "HOT_GS_SPLIT_LAUNCHES": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_SIMPLE_GS": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_GS_FULL_RESIDUAL": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_MG_FULL_SPMV": "1"}, SOLVER, "vcycle or iterates"),
