@@ -7,8 +7,8 @@
 //   k_apmv_sub      the r -= A (P e) of the V-cycle as r -= (A P) e with the A P kept from the Galerkin build (half the bytes).
 //   k_gs_block      MultigridOperator::gs_smooth (Projects/multigrid/MultigridPreconditioner.h:266-318): symmetric coloured
 //                   block Gauss–Seidel in the reference's exact node order (colour, first-touch block, id), one launch per
-//                   (colour, sub-block) pass: streaming phase + LDS-triangle substitution (see the comment at the kernel).
-//   k_gs_sweep      the same passes chained inside one launch (coarse levels).   k_gs_color: the simple one-wavefront-
+//                   colour, its sub-blocks walked inside: streaming phase + LDS-triangle substitution (see the kernel).
+//   k_gs_sweep      the same passes chained inside one launch by per-block flags (coarse levels).   k_gs_color: the simple one-wavefront-
 //                   per-block version kept as the A/B reference (HOT_SIMPLE_GS).
 //   restrict/prolong SparseMPMMatrix::transposeMultiply / multiply on the transfer matrices (MPMMultigridMatrix.h:63-70) as
 //                   pure gathers over the child / parent tables with scalar weights (the reference stores 3x3 w*I blocks).
@@ -531,12 +531,14 @@ __device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int3
 
 // A whole half sweep (all colours, all sub-blocks) in ONE launch.  Workgroups are ordered by pass = (colour, sub-block)
 // in sweep order; a workgroup of pass p
-//   1. streams the preceding half of its rows into registers and files the in-sub-block couplings into the LDS
-//      triangle — none of this depends on the unknowns, so it overlaps with the substitution phase of pass p-1;
-//   2. waits until every workgroup of pass p-1 has published its nodes (device-scope counter, acquire);
-//   3. gathers x, reduces the row sums, runs phase B, publishes (release + counter increment).
-// Progress: workgroups are dispatched in index order (per XCD), so every workgroup of the lowest unfinished pass is
-// resident and waits on nothing; the spin is bounded anyway and reports through `err` instead of hanging.
+//   1. streams the needed half of its rows into registers and files the in-sub-block couplings into the LDS triangle —
+//      none of this depends on the unknowns, so it overlaps with the substitution phase of earlier passes;
+//   2. a) makes sure everything older than pass p-1 that it reads is published and folds those columns into the staged
+//         right-hand side;  b) waits for what pass p-1 publishes (its adjacent blocks of that colour, or its own block's
+//         previous sub-block): point-to-point through gs_flag stamps, or pass counters (HOT_GS_PASS_COUNTERS);
+//   3. gathers the remaining columns, reduces the row sums, runs phase B, publishes (write-through stores, then the stamp).
+// Progress: workgroups are dispatched in index order (per XCD), so every workgroup a resident one waits for has been
+// dispatched before it and waits on nothing itself that is not; the spin is bounded anyway and reports through `err`.
 struct GsPasses {
     int npass;
     int wg_begin[34]; // first workgroup of pass p ; wg_begin[npass] = grid size
