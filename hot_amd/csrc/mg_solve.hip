@@ -130,6 +130,79 @@ __global__ __launch_bounds__(256) void k_apmv_sub(const int32_t* __restrict__ ap
     s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
     if (lane == 0) r[3 * (int64_t)row] -= s0, r[3 * (int64_t)row + 1] -= s1, r[3 * (int64_t)row + 2] -= s2;
 }
+// ---- cg_smooth (MultigridPreconditioner.h:190-226) in three launches per iteration instead of nine.  Device scalars:
+// s[0] z'r of the current iterate, s[1] du'A du, s[4] z'r of the next one, s[6] "s[4] is to become s[0]".
+template <class T>
+__global__ __launch_bounds__(256) void k_cg_spmv_dot(const int32_t* __restrict__ col, const T* __restrict__ val, const T* __restrict__ du, T* __restrict__ dAu, int n, double* s)
+{
+    __shared__ double red[4];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { // nobody reads s[0] / s[4] in this launch
+        if (s[6] != 0.0) s[0] = s[4];
+        s[4] = 0.0;
+    }
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    double part = 0;
+    if (row < n) {
+        const int32_t* c = col + (int64_t)row * 125;
+        const T* v = val + (int64_t)row * 1125;
+        T s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int k = lane + 64 * r;
+            if (k < 125) {
+                int j = c[k];
+                const T* b = v + k * 9;
+                T x0 = du[3 * (int64_t)j], x1 = du[3 * (int64_t)j + 1], x2 = du[3 * (int64_t)j + 2];
+                s0 += b[0] * x0 + b[3] * x1 + b[6] * x2;
+                s1 += b[1] * x0 + b[4] * x1 + b[7] * x2;
+                s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
+            }
+        }
+        s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
+        if (lane == 0) {
+            dAu[3 * (int64_t)row] = s0, dAu[3 * (int64_t)row + 1] = s1, dAu[3 * (int64_t)row + 2] = s2;
+            part = (double)(s0 * du[3 * (int64_t)row]) + (double)(s1 * du[3 * (int64_t)row + 1]) + (double)(s2 * du[3 * (int64_t)row + 2]);
+        }
+    }
+    if (lane == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_add(s + 1, red[0] + red[1] + red[2] + red[3]);
+}
+// u += w du ; r -= w A du ; z = Dinv r ; s[4] += z'r      (w = s[0] / s[1])
+template <class T>
+__global__ __launch_bounds__(256) void k_cg_update(const T* __restrict__ Dinv, const T* __restrict__ du, const T* __restrict__ dAu, T* __restrict__ u, T* __restrict__ r, T* __restrict__ z, int n, double* s)
+{
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const double omega = s[0] / s[1];
+    const T wp = (T)omega, wm = (T)(-omega);
+    double part = 0;
+    if (i < n) {
+        T rr[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            u[3 * (int64_t)i + c] += wp * du[3 * (int64_t)i + c];
+            rr[c] = r[3 * (int64_t)i + c] + wm * dAu[3 * (int64_t)i + c];
+            r[3 * (int64_t)i + c] = rr[c];
+        }
+        const T* d = Dinv + 9 * (int64_t)i;
+        const T z0 = d[0] * rr[0] + d[3] * rr[1] + d[6] * rr[2], z1 = d[1] * rr[0] + d[4] * rr[1] + d[7] * rr[2], z2 = d[2] * rr[0] + d[5] * rr[1] + d[8] * rr[2];
+        z[3 * (int64_t)i] = z0, z[3 * (int64_t)i + 1] = z1, z[3 * (int64_t)i + 2] = z2;
+        part = (double)(z0 * rr[0]) + (double)(z1 * rr[1]) + (double)(z2 * rr[2]);
+    }
+    const double t = block_sum_256<double>(part, red);
+    if (threadIdx.x == 0) atomic_add(s + 4, t);
+}
+// du = z + b du      (b = s[4] / s[0])
+template <class T>
+__global__ void k_cg_direction(size_t n3, const T* __restrict__ z, T* __restrict__ du, double* s)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const T b = (T)(s[4] / s[0]);
+    if (i < n3) du[i] = z[i] + b * du[i];
+    if (i == 0) s[1] = 0.0, s[6] = 1.0; // nobody reads them in this launch
+}
 template <class T>
 __global__ void k_scal_v(size_t n, T a, T* x)
 {
@@ -870,7 +943,22 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         double tol = (double)(T)(zTrk0 * 0.25); // cgratio = 0.5 hard-wired (:203-209)
         HOT_HIP(hipMemcpyAsync(s, &zTrk, sizeof(double), hipMemcpyHostToDevice, stream));
         int cnt = 0;
-        for (; iterations--;) {
+        static const bool cg_unfused = getenv("HOT_CG_UNFUSED") != nullptr; // A/B switch: one launch per vector operation
+        if (!cg_unfused && !(level == 0 && !cfg.systemBCProject)) {
+            HOT_HIP(hipMemsetAsync(s + 1, 0, 6 * sizeof(double), stream));
+            for (; iterations--;) {
+                if (zTrk < tol) break;
+                HOT_LAUNCH(this, lname("spmv", L.id).c_str(), k_cg_spmv_dot<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, du, dAu, L.n, s);
+                HOT_LAUNCH(this, "cg_update", k_cg_update<T>, div_up(L.n, 256), 256, 0, L.diagInv.p, du, dAu, u, r, z, L.n, s);
+                HOT_LAUNCH(this, "cg_direction", k_cg_direction<T>, div_up(n3, 256), 256, 0, n3, z, du, s);
+                HOT_HIP(hipMemcpyAsync(hscal + 40, s + 4, sizeof(double), hipMemcpyDeviceToHost, stream));
+                sync();
+                zTrk = hscal[40];
+                ++cnt;
+            }
+            iterations = 0;
+        }
+        for (; iterations-- > 0;) {
             if (zTrk < tol) break;
             spmv_dev(L, du, dAu);
             Aproject(dAu);

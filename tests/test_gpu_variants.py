@@ -25,6 +25,7 @@ CASES = [
     ({"HOT_GS_FULL_RESIDUAL": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_MG_FULL_SPMV": "1"}, SOLVER, "vcycle or iterates"),
     ({"HOT_LBFGS_UNFUSED": "1"}, SOLVER, "iterates"),
+    ({"HOT_CG_UNFUSED": "1"}, SOLVER, "smoothers or vcycle or iterates"),
     ({"HOT_HESSIAN_V1": "1"}, SOLVER, "hessian_and_hierarchy"),
     ({"HOT_HESSIAN_TILES_V1": "1"}, SOLVER, "hessian_and_hierarchy"),
     ({"HOT_P2G_V1": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),
