@@ -599,6 +599,9 @@ __device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int3
             hD[3 * (int64_t)i + 1] = dd[1] * h0 + dd[4] * h1 + dd[7] * h2;
             hD[3 * (int64_t)i + 2] = dd[2] * h0 + dd[5] * h1 + dd[8] * h2;
         }
+        else if (hD) { // backward: hD is the iterate u, which takes the correction here (u += du of gs_smooth) instead of in an axpy launch
+            hD[3 * (int64_t)i] += h0, hD[3 * (int64_t)i + 1] += h1, hD[3 * (int64_t)i + 2] += h2;
+        }
     }
 }
 
@@ -1039,7 +1042,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             const char* nm = fwd ? "gs_forward" : "gs_backward";
             const T* rhs = fwd ? r : dAu;
             T* xx = fwd ? hdu : du;
-            T* hD = fwd ? dAu : (T*)nullptr;
+            T* hD = fwd ? dAu : (simple_gs ? (T*)nullptr : u); // backward block kernels add du to u themselves
             if (simple_gs) {
                 if (h != 0) return;
                 if (fwd)
@@ -1091,7 +1094,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             const char* nm = fwd ? "gs_forward" : "gs_backward";
             const T* rhs = fwd ? r : dAu;
             T* xx = fwd ? hdu : du;
-            T* hD = fwd ? dAu : (T*)nullptr;
+            T* hD = fwd ? dAu : (simple_gs ? (T*)nullptr : u); // backward block kernels add du to u themselves
             // hand-off between passes: point-to-point block flags when a block is one sub-block (A/B switch: pass counters)
             static const bool pass_counters = getenv("HOT_GS_PASS_COUNTERS") != nullptr;
             const bool p2p = !pass_counters;
@@ -1130,7 +1133,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             else
                 for (int c = 7; c >= 0; --c)
                     for (int h = nsub - 1; h >= 0; --h) pass(false, c, h);
-            axpy(n3, (T)1, du, u);
+            if (simple_gs) axpy(n3, (T)1, du, u);
             if (!final_residual && iterations == 0) break;
             if (L.split && !simple_gs && !(level == 0 && !cfg.systemBCProject) && !no_lres) {
                 // r - A du = L (h - du): with (D+L) h = r and (D+U) du = D h the full product A du collapses to the
