@@ -31,11 +31,11 @@ class hot_config(C.Structure):
 
 class hot_collision_object(C.Structure):
     _fields_ = [("shape", C.c_int32), ("type", C.c_int32), ("p0", C.c_double * 3), ("p1", C.c_double * 3), ("friction", C.c_double),
-                ("b", C.c_double * 3), ("dbdt", C.c_double * 3), ("R", C.c_double * 9), ("omega", C.c_double * 3), ("s", C.c_double), ("dsdt", C.c_double)]
+                ("b", C.c_double * 3), ("dbdt", C.c_double * 3), ("R", C.c_double * 9), ("omega", C.c_double * 3), ("s", C.c_double), ("dsdt", C.c_double), ("lsq", C.c_double * 4)]
 
 
 STICKY, SLIP, SEPARATE = 1, 2, 3
-HALFSPACE, SPHERE, BOX = 0, 1, 2
+HALFSPACE, SPHERE, BOX, CAPPED_CYLINDER, TORUS = 0, 1, 2, 3, 4
 
 
 class hot_stats(C.Structure):
@@ -257,7 +257,7 @@ class Context:
         self._call("set_sticky_halfspaces", C.c_int32(len(o)), _ptr(o), _ptr(n))
 
     def set_collision_objects(self, objects):
-        """objects: list of dicts(shape, type, p0, p1, friction=0, b=(0,0,0), dbdt=(0,0,0), R=I (3x3), omega=(0,0,0), s=1, dsdt=0)
+        """objects: list of dicts(shape, type, p0, p1, friction=0, b=(0,0,0), dbdt=(0,0,0), R=I (3x3), omega=(0,0,0), s=1, dsdt=0, lsq=(1,0,0,0))
         evaluated per node at begin_step; p0 / p1 are in the object's material space (world x = R s X + b)."""
         arr = (hot_collision_object * max(len(objects), 1))()
         for o, d in zip(arr, objects):
@@ -270,6 +270,8 @@ class Context:
             for k in range(9):
                 o.R[k] = R[k % 3, k // 3]  # column-major
             o.s, o.dsdt = d.get("s", 1.0), d.get("dsdt", 0.0)
+            for k in range(4):
+                o.lsq[k] = d.get("lsq", (1.0, 0.0, 0.0, 0.0))[k]
         self._call("set_collision_objects", C.c_int32(len(objects)), C.cast(arr, C.c_void_p))
 
     def begin_step(self, dt):

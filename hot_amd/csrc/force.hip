@@ -171,9 +171,12 @@ void Ctx<T>::set_collision_objects(int32_t n, const hot_collision_object* objs)
 {
     need(n >= 0 && n <= 64, "hot_set_collision_objects: 0 <= n <= 64");
     for (int i = 0; i < n; ++i) {
-        need(objs[i].shape >= HOT_SHAPE_HALFSPACE && objs[i].shape <= HOT_SHAPE_BOX, "unknown collision shape");
+        need(objs[i].shape >= HOT_SHAPE_HALFSPACE && objs[i].shape <= HOT_SHAPE_TORUS, "unknown collision shape");
         need(objs[i].type >= HOT_COLLISION_STICKY && objs[i].type <= HOT_COLLISION_SEPARATE, "collision type must be STICKY (1), SLIP (2) or SEPARATE (3)");
-        need(!(objs[i].shape == HOT_SHAPE_BOX && objs[i].type != HOT_COLLISION_STICKY), "boxes must be STICKY (the reference's box normal is undefined inside the box)");
+        need(!((objs[i].shape == HOT_SHAPE_BOX || objs[i].shape == HOT_SHAPE_CAPPED_CYLINDER) && objs[i].type != HOT_COLLISION_STICKY),
+            "boxes and capped cylinders must be STICKY (the reference's automatic-differentiation normal is undefined inside them)");
+        if (objs[i].shape == HOT_SHAPE_CAPPED_CYLINDER || objs[i].shape == HOT_SHAPE_TORUS)
+            need(objs[i].lsq[0] != 0 || objs[i].lsq[1] != 0 || objs[i].lsq[2] != 0 || objs[i].lsq[3] != 0, "lsq must be a rotation quaternion ((1,0,0,0) = none)");
         need(objs[i].s > 0, "collision object scaling s must be > 0 (1 = none)");
         need(!(objs[i].shape == HOT_SHAPE_HALFSPACE && (objs[i].dsdt != 0 || objs[i].omega[0] != 0 || objs[i].omega[1] != 0 || objs[i].omega[2] != 0)),
             "a half space cannot turn or scale (no bounds available for its speed: AnalyticLevelSet.cpp:122-125)");
@@ -202,6 +205,9 @@ void Ctx<T>::eval_collision_objects()
         for (int d = 0; d < 3; ++d) h[i].p0[d] = (T)cobjs[i].p0[d], h[i].p1[d] = (T)cobjs[i].p1[d], h[i].b[d] = (T)cobjs[i].b[d], h[i].dbdt[d] = (T)cobjs[i].dbdt[d], h[i].omega[d] = (T)cobjs[i].omega[d];
         for (int d = 0; d < 9; ++d) h[i].R[d] = (T)cobjs[i].R[d];
         h[i].inv_s = (T)1 / (T)cobjs[i].s, h[i].dsdt = (T)cobjs[i].dsdt;
+        double Rls[9];
+        co_quat_to_matrix(cobjs[i].lsq, Rls);
+        for (int d = 0; d < 9; ++d) h[i].Rls[d] = (T)Rls[d];
     }
     d_cobjs.reserve(nobj * sizeof(CollObj<T>));
     HOT_HIP(hipMemcpyAsync(d_cobjs.p, h.data(), nobj * sizeof(CollObj<T>), hipMemcpyHostToDevice, stream));

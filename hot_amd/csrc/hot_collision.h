@@ -4,6 +4,8 @@
 //   AnalyticCollisionObject::detectAndResolveCollision   Lib/Ziran/Math/Geometry/CollisionObject.cpp:384-447
 //   AnalyticCollisionObject::multiObjectCollision (wn)    :107-148
 //   HalfSpace / Sphere / AxisAlignedAnalyticBox queries   Lib/Ziran/Math/Geometry/AnalyticLevelSet.cpp:111-118,264-288,353-363,435-452,504-529
+//   CappedCylinder (AnalyticLevelSet.h:221-297), Torus (AnalyticLevelSet.cpp:565-608): distance of the y-axis primitive after the
+//   level set's own rotation / translation; the torus normal is the gradient the reference gets by automatic differentiation
 //   RotationExtractor<T,3>::rotate (Eigen::Quaternion::setFromTwoVectors + toRotationMatrix)   Lib/MPM/MpmSimulationBase.h:271-281
 // The box's normal comes from automatic differentiation of a distance that is not differentiable inside the box in the
 // reference; only STICKY boxes (no normal needed) are accepted.
@@ -20,6 +22,7 @@ struct CollObj { // device copy of hot_collision_object in the simulation's scal
     int32_t shape, type;
     T p0[3], p1[3], friction, b[3], dbdt[3];
     T R[9], omega[3], inv_s, dsdt; // R column-major; inv_s = 1 / s
+    T Rls[9]; // capped cylinder / torus: rotation of the level set itself (column-major)
 };
 
 // returns whether node position x collides with o; v is replaced by the resolved velocity, n by the world normal (SLIP / SEPARATE)
@@ -48,6 +51,26 @@ __device__ __forceinline__ bool co_detect_resolve(const CollObj<T>& o, const T (
                 const T inv = (T)1 / dist;
                 N[0] = inv * t0, N[1] = inv * t1, N[2] = inv * t2;
             }
+        }
+    }
+    else if (o.shape == HOT_SHAPE_CAPPED_CYLINDER || o.shape == HOT_SHAPE_TORUS) {
+        const T t[3] = { X[0] - o.p0[0], X[1] - o.p0[1], X[2] - o.p0[2] };
+        T P[3]; // primitive space: R_ls^-1 (X - b_ls)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) P[k] = o.Rls[3 * k] * t[0] + o.Rls[3 * k + 1] * t[1] + o.Rls[3 * k + 2] * t[2];
+        const T rho = hsqrt(P[0] * P[0] + P[2] * P[2]);
+        if (o.shape == HOT_SHAPE_TORUS) {
+            const T q0 = rho - o.p1[0], L = hsqrt(q0 * q0 + P[1] * P[1]);
+            colliding = L - o.p1[1] <= (T)0;
+            // gradient of sqrt((sqrt(x^2 + z^2) - r0)^2 + y^2) - r1 in primitive space, then R_ls
+            const T gr = q0 / L, G[3] = { gr * P[0] / rho, P[1] / L, gr * P[2] / rho };
+#pragma unroll
+            for (int k = 0; k < 3; ++k) N[k] = o.Rls[k] * G[0] + o.Rls[3 + k] * G[1] + o.Rls[6 + k] * G[2];
+        }
+        else { // STICKY only: no normal needed
+            const T d0 = rho - o.p1[0], d1 = habs(P[1]) - (T)0.5 * o.p1[1];
+            const T m0 = d0 > (T)0 ? d0 : (T)0, m1 = d1 > (T)0 ? d1 : (T)0, mx = d0 > d1 ? d0 : d1;
+            colliding = (mx < (T)0 ? mx : (T)0) + hsqrt(m0 * m0 + m1 * m1) <= (T)0;
         }
     }
     else { // axis-aligned box (STICKY only): signedDistancePrimitive of the centred box
@@ -95,6 +118,18 @@ __device__ __forceinline__ bool co_detect_resolve(const CollObj<T>& o, const T (
     return true;
 }
 
+// Eigen::Quaternion(w, x, y, z).normalized().toRotationMatrix(), column-major
+inline void co_quat_to_matrix(const double (&q)[4], double (&R)[9])
+{
+    double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (!(n > 0)) n = 1;
+    const double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz), R[3] = txy - twz, R[6] = txz + twy;
+    R[1] = txy + twz, R[4] = 1 - (txx + tzz), R[7] = tyz - twx;
+    R[2] = txz - twy, R[5] = tyz + twx, R[8] = 1 - (txx + tyy);
+}
+
 // AnalyticCollisionObject::evalMaxSpeed (CollisionObject.cpp:200-238): the object's largest speed over the corners of
 // the particle box (expanded by the caller) and of the level set's bounds that pass the reference's overlap test
 // (kept as written there: "any component above the min" and "any component below the max").
@@ -106,6 +141,12 @@ inline double co_max_speed(const hot_collision_object& o, const double (&pmin)[3
     for (int d = 0; d < 3; ++d) {
         if (o.shape == HOT_SHAPE_SPHERE)
             lo[d] = o.p0[d] - o.p1[0], hi[d] = o.p0[d] + o.p1[0];
+        else if (o.shape == HOT_SHAPE_TORUS) // bounding sphere r0 + r1 (AnalyticLevelSet.cpp:610-617)
+            lo[d] = o.p0[d] - (o.p1[0] + o.p1[1]), hi[d] = o.p0[d] + (o.p1[0] + o.p1[1]);
+        else if (o.shape == HOT_SHAPE_CAPPED_CYLINDER) { // AnalyticLevelSet.h:289-295
+            const double rr = std::sqrt(o.p1[0] * o.p1[0] + 0.25 * o.p1[1] * o.p1[1]);
+            lo[d] = o.p0[d] - rr, hi[d] = o.p0[d] + rr;
+        }
         else
             lo[d] = o.p0[d], hi[d] = o.p1[d];
     }

@@ -96,7 +96,7 @@ public:
     {
         check(ctx, hot_set_bc(ctx, Nc, node_id, P, R, Rinv, shouldRotate, dv), "hot_set_bc");
     }
-    // AnalyticCollisionObject list (half spaces, spheres, sticky boxes; STICKY / SLIP / SEPARATE) evaluated per node on the device
+    // AnalyticCollisionObject list (half spaces, spheres, tori, sticky boxes / capped cylinders; STICKY / SLIP / SEPARATE) evaluated per node on the device
     void setCollisionObjects(int n, const hot_collision_object* objects) { check(ctx, hot_set_collision_objects(ctx, n, objects), "hot_set_collision_objects"); }
     void startBackwardEuler(double dt) { check(ctx, hot_begin_step(ctx, dt), "hot_begin_step"); }
     void backwardEulerStep() { check(ctx, hot_solve(ctx, &stats), "hot_solve"); }

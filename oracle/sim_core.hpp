@@ -483,6 +483,31 @@ struct Sim {
                     N = to_center * ((T)1 / dist);
             }
         }
+        else if (o.shape == HOT_SHAPE_CAPPED_CYLINDER || o.shape == HOT_SHAPE_TORUS) {
+            // CappedCylinder (AnalyticLevelSet.h:221-297) / Torus (AnalyticLevelSet.cpp:565-608): y-axis primitive behind the level
+            // set's own rotation (Eigen quaternion w,x,y,z, normalised) and translation; the torus normal is the gradient the
+            // reference obtains by automatic differentiation
+            double qn = std::sqrt(o.lsq[0] * o.lsq[0] + o.lsq[1] * o.lsq[1] + o.lsq[2] * o.lsq[2] + o.lsq[3] * o.lsq[3]);
+            if (!(qn > 0)) qn = 1;
+            const double w = o.lsq[0] / qn, qx = o.lsq[1] / qn, qy = o.lsq[2] / qn, qz = o.lsq[3] / qn;
+            TM Rl;
+            Rl(0, 0) = (T)(1 - 2 * (qy * qy + qz * qz)), Rl(0, 1) = (T)(2 * (qx * qy - w * qz)), Rl(0, 2) = (T)(2 * (qx * qz + w * qy));
+            Rl(1, 0) = (T)(2 * (qx * qy + w * qz)), Rl(1, 1) = (T)(1 - 2 * (qx * qx + qz * qz)), Rl(1, 2) = (T)(2 * (qy * qz - w * qx));
+            Rl(2, 0) = (T)(2 * (qx * qz - w * qy)), Rl(2, 1) = (T)(2 * (qy * qz + w * qx)), Rl(2, 2) = (T)(1 - 2 * (qx * qx + qy * qy));
+            TV P = Rl.transpose() * (X - p0);
+            T rho = std::sqrt(P(0) * P(0) + P(2) * P(2));
+            if (o.shape == HOT_SHAPE_TORUS) {
+                T q0 = rho - p1(0), L = std::sqrt(q0 * q0 + P(1) * P(1));
+                colliding = L - p1(1) <= (T)0;
+                T gr = q0 / L;
+                N = Rl * TV{ { gr * P(0) / rho, P(1) / L, gr * P(2) / rho } };
+            }
+            else {
+                T d0 = rho - p1(0), d1 = std::abs(P(1)) - (T)0.5 * p1(1);
+                T m0 = std::max(d0, (T)0), m1 = std::max(d1, (T)0);
+                colliding = std::min(std::max(d0, d1), (T)0) + std::sqrt(m0 * m0 + m1 * m1) <= (T)0;
+            }
+        }
         else {
             T dd = -(T)3.4e38, q2 = 0;
             for (int k = 0; k < 3; ++k) {

@@ -409,8 +409,11 @@ double Sim<T>::calculate_dt(double max_dt, double* max_speed, double* min_corner
             double pmin[3], pmax[3], blo[3], bhi[3];
             for (int d = 0; d < 3; ++d) {
                 pmin[d] = (double)(-nlo[d] - (T)4 * dx), pmax[d] = (double)(hi[d] + (T)4 * dx); // particle box expanded by (degree + 2) dx
-                blo[d] = o.shape == HOT_SHAPE_SPHERE ? o.p0[d] - o.p1[0] : o.p0[d];
-                bhi[d] = o.shape == HOT_SHAPE_SPHERE ? o.p0[d] + o.p1[0] : o.p1[d];
+                // ls->getBounds: Sphere, Torus (r0 + r1), CappedCylinder (sqrt(r^2 + (h/2)^2)), AxisAlignedAnalyticBox
+                const double rad = o.shape == HOT_SHAPE_SPHERE ? o.p1[0] : o.shape == HOT_SHAPE_TORUS ? o.p1[0] + o.p1[1] : std::sqrt(o.p1[0] * o.p1[0] + 0.25 * o.p1[1] * o.p1[1]);
+                const bool round_ = o.shape == HOT_SHAPE_SPHERE || o.shape == HOT_SHAPE_TORUS || o.shape == HOT_SHAPE_CAPPED_CYLINDER;
+                blo[d] = round_ ? o.p0[d] - rad : o.p0[d];
+                bhi[d] = round_ ? o.p0[d] + rad : o.p1[d];
             }
             std::vector<std::array<double, 3>> corners;
             for (int i = 0; i < 8; ++i) {

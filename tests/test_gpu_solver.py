@@ -396,3 +396,39 @@ def test_baseline_multigrid_needs_analytic_boundaries(hotlib):
     ctx.build_hessian()
     with pytest.raises(HotError):
         ctx.build_mg()
+
+
+def test_torus_and_capped_cylinder_against_oracle(hotlib, oracle):
+    """The two remaining analytic level sets of the reference scenes: a slip torus (normal = gradient of its distance) and
+    a sticky capped cylinder, both behind their own rotation / translation and an object transform on top."""
+    from hot_amd.binding import CAPPED_CYLINDER, SLIP, STICKY, TORUS
+    c30, s30 = np.cos(0.3), np.sin(0.3)
+    objs = [
+        # ring around the top corner of the body, tube radius 0.012, tilted about z, the object itself drifting and turning
+        dict(shape=TORUS, type=SLIP, p0=(5.04, 5.07, 5.04), p1=(0.03, 0.012, 0.0), lsq=(c30, 0.0, 0.0, s30), friction=0.1, dbdt=(0.0, -0.2, 0.0), omega=(0.0, 1.0, 0.0), b=(0.0, 0.0, 0.0)),
+        # a peg standing in the body, axis tilted about x
+        dict(shape=CAPPED_CYLINDER, type=STICKY, p0=(5.02, 5.03, 5.06), p1=(0.015, 0.05, 0.0), lsq=(np.cos(0.2), np.sin(0.2), 0.0, 0.0)),
+    ]
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=8, bc=False, levelCnt=2, cneps=1e-7, max_iterations=4, boundaryType=1)
+        ctx.set_collision_objects(objs)
+        cd = ctx.calculate_dt(1.0)
+        pc.prepare(ctx)
+        dv0 = ctx.get_dv()
+        st = ctx.solve()
+        out[name] = (dv0, ctx.get_dv(), st, cd)
+    g, c_ = out["gpu"], out["cpu"]
+    assert rel(g[0], c_[0]) < 1e-12
+    assert 20 < (np.abs(g[0] - np.array([0, -9.8 / 24, 0])).max(axis=1) > 1e-9).sum() < g[0].shape[0]
+    for k in ("iterations", "linesearch_trials", "linear_iterations", "vcycles"):
+        assert g[2][k] == c_[2][k], (k, g[2], c_[2])
+    assert rel(g[1], c_[1]) < 1e-9
+    assert g[3]["max_speed"] > 0.2 and abs(g[3]["max_speed"] - c_[3]["max_speed"]) < 1e-13
+
+
+def test_capped_cylinder_must_be_sticky(hotlib):
+    from hot_amd.binding import CAPPED_CYLINDER, SLIP, HotError
+    ctx, c = pc.make_ctx(hotlib, n=4, bc=False)
+    with pytest.raises(HotError):
+        ctx.set_collision_objects([dict(shape=CAPPED_CYLINDER, type=SLIP, p0=(5, 5, 5), p1=(0.1, 0.1, 0))])
