@@ -564,11 +564,10 @@ void Ctx<T>::assemble_tiles(Level<T>& L)
 {
     pDP.reserve(45 * (size_t)Np);
     HOT_LAUNCH(this, "hessian_dpdf", k_dpdf45<T>, div_up(Np, 256), 256, 0, pFt.p, pVol.p, pMu.p, pLam.p, pDP.p, Np, dt, cfg.project);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!attr_tiles_set) {
         HOT_HIP(hipFuncSetAttribute((const void*)k_hessian_tiles<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileLds<T>::bytes));
         HOT_HIP(hipFuncSetAttribute((const void*)k_hessian_tiles2<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileLds2<T>::bytes));
-        attr_set = true;
+        attr_tiles_set = true;
     }
     constexpr int TPB = (G::BX / 2) * (G::BY / 2) * (G::BZ / 2);
     static const bool tiles_v1 = getenv("HOT_HESSIAN_TILES_V1") != nullptr; // A/B switch: 81 multiply-adds per (particle, row, column)

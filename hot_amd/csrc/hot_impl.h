@@ -121,6 +121,7 @@ struct Ctx : CtxBase {
     DBuf<T> rhs, work0, work1, work2, work3;
     DBuf<double> dscal; // device scalars
     int gs_epoch = 0; // sweep number, never reused inside a context
+    bool attr_tiles_set = false, attr_gs_set = false; // dynamic-LDS limits raised on this context's device (hipFuncSetAttribute is per device)
     DBuf<int> gs_done; // [0,40) pass counters of k_gs_sweep (the sticky wait-timeout flag lives in pinned host memory, hscal[250])
     double* hscal = nullptr; // pinned host mirror
     // ---- L-BFGS history

@@ -1015,13 +1015,12 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         static const int env_sb = getenv("HOT_GS_SB") ? atoi(getenv("HOT_GS_SB")) : 0; // sub-block size 16 / 32 / 64
         static const bool no_lres = getenv("HOT_GS_FULL_RESIDUAL") != nullptr; // A/B switch: r -= A du by a full SpMV
         static const int gs_dbg = getenv("HOT_GS_DBG") ? atoi(getenv("HOT_GS_DBG")) : 0; // timing experiments only (wrong results)
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!attr_gs_set) {
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T))));
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T))));
-            attr_set = true;
+            attr_gs_set = true;
         }
         // sub-block size: levels whose colours hold more blocks than the chip has CUs run half blocks (36 KB LDS, 4
         // workgroups per CU, one round per launch); small levels are latency-bound per launch and keep whole blocks
