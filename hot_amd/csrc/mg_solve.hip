@@ -395,10 +395,10 @@ __global__ __launch_bounds__(64) void k_gs_color(const int32_t* __restrict__ col
 
 // Two-phase block GS (the production path; k_gs_color above is the simple reference kernel kept for A/B checks).
 // The reference sweeps the nodes of one 4^3 colour block sequentially (MultigridPreconditioner.h:266-318).  Here a
-// colour block is cut into 64/SB consecutive sub-blocks of SB nodes; sub-block h of every block of a colour is one
-// launch (one workgroup per block), launches ordered (colour, h).  Nodes of the same block that belong to an earlier
-// sub-block are final in global memory by then and are treated like any other preceding node, so the sequence of
-// updates each node sees is the reference's.  SB = 32 keeps the LDS footprint at 36 KB (fp64), several workgroups
+// colour block is cut into 64/SB consecutive sub-blocks of SB nodes; one launch per colour, one workgroup per block, which
+// walks the block's sub-blocks in sweep order (a launch per (colour, sub-block) behind HOT_GS_SPLIT_LAUNCHES).  Nodes of the
+// same block that belong to an earlier sub-block are final in global memory by then (stored before a workgroup barrier) and
+// are treated like any other preceding node, so the sequence of updates each node sees is the reference's.  SB = 32 keeps the LDS footprint at 36 KB (fp64), several workgroups
 // per CU overlap their phases, and one launch fits the chip in a single round.
 //   phase A (all waves, bandwidth-bound): every wave streams the preceding half of whole matrix rows (rows are
 //           regrouped by k_gs_split_rows, lane = slot).  Couplings to nodes outside the sub-block are folded into
