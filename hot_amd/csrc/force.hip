@@ -520,22 +520,27 @@ __global__ __launch_bounds__(256) void k_inertia_energy(const T* __restrict__ dv
     }
 }
 
+// rasterizeForceToTVStack from the stresses the last k_state left behind (the line search needs it once, at the accepted
+// point: lineSearch evaluates only the energy per trial, ImplicitSolver.h:312-333)
+template <class T>
+void Ctx<T>::force_pass()
+{
+    int64_t slots = (int64_t)Nb * EPB;
+    static const bool force_v1 = getenv("HOT_FORCE_V1") != nullptr; // A/B switch: one LDS atomic per particle, node and component
+    if (force_v1)
+        HOT_LAUNCH(this, "force_scatter", k_force_scatter<T>, Ng, 256, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, (T)1 / dx, dt);
+    else
+        HOT_LAUNCH(this, "force_scatter", k_force_cells<T>, Ng, FORCE_THREADS, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, (T)1 / dx, dt);
+    reduce_tiles(3, gF.p, gF.p + slots, gF.p + 2 * slots, nullptr, nullptr, "force_reduce");
+}
+
 template <class T>
 double Ctx<T>::state_pass(const T* dv_in, bool want_force)
 {
-    int64_t slots = (int64_t)Nb * EPB;
     HOT_HIP(hipMemsetAsync(dscal.p, 0, 4 * sizeof(double), stream));
     HOT_LAUNCH(this, "state_update", k_state<T>, Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, pFt.p, pStress.p, keep_debug ? pGradV.p : (T*)nullptr, Np, group_first.p, group_origin.p,
         group_nb.p, gIdx.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p);
-    if (want_force)
-    {
-        static const bool force_v1 = getenv("HOT_FORCE_V1") != nullptr; // A/B switch: one LDS atomic per particle, node and component
-        if (force_v1)
-            HOT_LAUNCH(this, "force_scatter", k_force_scatter<T>, Ng, 256, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, (T)1 / dx, dt);
-        else
-            HOT_LAUNCH(this, "force_scatter", k_force_cells<T>, Ng, FORCE_THREADS, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, (T)1 / dx, dt);
-        reduce_tiles(3, gF.p, gF.p + slots, gF.p + 2 * slots, nullptr, nullptr, "force_reduce");
-    }
+    if (want_force) force_pass();
     HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, std::min(div_up(Nn, 256), 1024), 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1);
     HOT_HIP(hipMemcpyAsync(hscal, dscal.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();

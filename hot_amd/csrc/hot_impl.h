@@ -224,7 +224,8 @@ struct Ctx : CtxBase {
     void eval_halfspaces();
     void eval_collision_objects();
     double state_pass(const T* dv_in, bool want_force); // G2P(vn+dv) -> F, energy, force scatter; returns total energy (syncs)
-    void residual_dev(T* r); // from the force tiles of the last state_pass
+    void force_pass(); // force scatter from the stresses of the last state_pass
+    void residual_dev(T* r); // from the force tiles of the last state_pass / force_pass
     void project_dev(T* v);
     void transform_dev(T* v, bool inverse); // transformResidual / recoverSolution
     void cn_tolerance_dev();

@@ -130,7 +130,7 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
     do {
         HOT_LAUNCH(this, "linesearch_combine", k_combine<T>, div_up(n3, 256), 256, 0, n3, dv0.p, alpha, ddv, dvnew);
         copy(n3, dvnew, dv.p); // moveNodes
-        Ek = state_pass(dv.p, true);
+        Ek = state_pass(dv.p, false); // a trial needs the energy only; the force is rasterised once, at the accepted point
         if (!(Ek == Ek)) {
             // diagnostics for the error message: is the search direction itself already non-finite?
             double dd = dot_host(n3, ddv, ddv), d0 = dot_host(n3, dv0.p, dv0.p);
@@ -145,6 +145,7 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
     alpha *= 2;
     HOT_LAUNCH(this, "scal", k_scal<T>, div_up(n3, 256), 256, 0, n3, alpha, ddv);
     transform_dev(ddv, false); // transformResidual
+    force_pass(); // the stresses of the last (accepted) trial are still in place
     residual_dev(residual_out);
     updated = true;
     copy(n3, dvnew, dv0.p);
