@@ -432,14 +432,17 @@ __global__ __launch_bounds__(FORCE_THREADS) void k_force_cells(const T* __restri
 {
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
-    constexpr int CH = FORCE_CHUNK;
-    __shared__ T acc[3][TILE];
+    constexpr int CH = sizeof(T) == 4 ? 2 * FORCE_CHUNK : FORCE_CHUNK; // fp32 groups (4x4x4 cells) hold twice the particles: same LDS bytes, one staging round
+    // LDS float atomics (ds_add_f32) retire ~40x slower than the double ones on this chip (measured: 34 k of 43 k clocks of a
+    // workgroup's item phase; with a double tile 0.4 k): the fp32 build accumulates its tile in double as well
+    using AT = AccT<T>;
+    __shared__ AT acc[3][TILE];
     __shared__ T sp[27][CH]; // S(9) w(3x3) dw(3x3)
     __shared__ int32_t sbase[3][CH];
     __shared__ int32_t segs[G::EPB + 2];
     __shared__ int32_t nseg;
     const int g = blockIdx.x, tid = threadIdx.x;
-    for (int t = tid; t < 3 * TILE; t += FORCE_THREADS) (&acc[0][0])[t] = (T)0;
+    for (int t = tid; t < 3 * TILE; t += FORCE_THREADS) (&acc[0][0])[t] = (AT)0;
     const int first = group_first[g], last = group_first[g + 1];
     const int c0 = group_cell0[g], c1 = group_cell0[g + 1];
     const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
@@ -493,13 +496,13 @@ __global__ __launch_bounds__(FORCE_THREADS) void k_force_cells(const T* __restri
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int t = ((b0 - ox + i) * TY + (b1 - oy + j)) * TZ + (b2 - oz + k);
-                lds_atomic_add(&acc[0][t], a[i][0]), lds_atomic_add(&acc[1][t], a[i][1]), lds_atomic_add(&acc[2][t], a[i][2]);
+                lds_atomic_add(&acc[0][t], (AT)a[i][0]), lds_atomic_add(&acc[1][t], (AT)a[i][1]), lds_atomic_add(&acc[2][t], (AT)a[i][2]);
             }
         }
     }
     __syncthreads();
     T* out = part + (int64_t)g * 3 * TILE; // partial tile, summed per node by k_tile_reduce
-    for (int t = tid; t < 3 * TILE; t += FORCE_THREADS) out[t] = (&acc[0][0])[t];
+    for (int t = tid; t < 3 * TILE; t += FORCE_THREADS) out[t] = (T)(&acc[0][0])[t];
 }
 
 template <class T>
@@ -746,7 +749,8 @@ __global__ __launch_bounds__(256) void k_matfree(const T* __restrict__ X, const 
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
     __shared__ T nv[3][TILE];
-    __shared__ T acc[3][TILE];
+    using AT = AccT<T>; // double tile also in fp32 (LDS float atomics are slow, see k_force_cells)
+    __shared__ AT acc[3][TILE];
     __shared__ int32_t nb8[8];
     const int g = blockIdx.x;
     if (threadIdx.x < 8) nb8[threadIdx.x] = group_nb[g * 8 + threadIdx.x];
@@ -756,7 +760,7 @@ __global__ __launch_bounds__(256) void k_matfree(const T* __restrict__ X, const 
         T a = 0, b = 0, c = 0;
         if (idx >= 0) a = x[3 * idx], b = x[3 * idx + 1], c = x[3 * idx + 2];
         nv[0][t] = a, nv[1][t] = b, nv[2][t] = c;
-        acc[0][t] = acc[1][t] = acc[2][t] = (T)0;
+        acc[0][t] = acc[1][t] = acc[2][t] = (AT)0;
     }
     __syncthreads();
     const int first = group_first[g], last = group_first[g + 1];
@@ -801,14 +805,14 @@ __global__ __launch_bounds__(256) void k_matfree(const T* __restrict__ X, const 
             int i = n / 9, j = (n / 3) % 3, k = n % 3;
             T g0 = one_over_dx * dw[0][i] * w[1][j] * w[2][k], g1 = w[0][i] * one_over_dx * dw[1][j] * w[2][k], g2 = w[0][i] * w[1][j] * one_over_dx * dw[2][k];
             int t = ((cx + i) * TY + (cy + j)) * TZ + (cz + k);
-            lds_atomic_add(&acc[0][t], sc * (S(0, 0) * g0 + S(0, 1) * g1 + S(0, 2) * g2));
-            lds_atomic_add(&acc[1][t], sc * (S(1, 0) * g0 + S(1, 1) * g1 + S(1, 2) * g2));
-            lds_atomic_add(&acc[2][t], sc * (S(2, 0) * g0 + S(2, 1) * g1 + S(2, 2) * g2));
+            lds_atomic_add(&acc[0][t], (AT)(sc * (S(0, 0) * g0 + S(0, 1) * g1 + S(0, 2) * g2)));
+            lds_atomic_add(&acc[1][t], (AT)(sc * (S(1, 0) * g0 + S(1, 1) * g1 + S(1, 2) * g2)));
+            lds_atomic_add(&acc[2][t], (AT)(sc * (S(2, 0) * g0 + S(2, 1) * g1 + S(2, 2) * g2)));
         }
     }
     __syncthreads();
     T* out = part + (int64_t)g * 3 * TILE;
-    for (int t = threadIdx.x; t < 3 * TILE; t += 256) out[t] = (&acc[0][0])[t];
+    for (int t = threadIdx.x; t < 3 * TILE; t += 256) out[t] = (T)(&acc[0][0])[t];
 }
 template <class T>
 __global__ void k_matfree_finish(const T* __restrict__ gOut, const int32_t* __restrict__ dofSlot, const T* __restrict__ mass, const T* __restrict__ x, T* y, int nn, int64_t slots)

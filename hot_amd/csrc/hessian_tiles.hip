@@ -352,7 +352,7 @@ struct TileLds2 {
     static constexpr int CH = sizeof(T) == 8 ? 40 : 64; // particles per chunk
     static constexpr int KMAX = sizeof(T) == 8 ? 136 : 224; // (particle, row) entries per chunk
     static constexpr int NINT = 64 * 3 + 8 + 64 * 3 + 2 * CH + KMAX + 512 + 8; // cstart, ccnt, cmask, rdof, segs, soff, sbase, pidx, pseg, entinfo, items, ctl
-    static constexpr size_t bytes = ((size_t)8 * 1125 + (size_t)CH * (81 + 81 + 12) + (size_t)KMAX * 27) * sizeof(T) + (size_t)NINT * sizeof(int32_t);
+    static constexpr size_t bytes = (size_t)8 * 1125 * sizeof(AccT<T>) + ((size_t)CH * (81 + 81 + 12) + (size_t)KMAX * 27) * sizeof(T) + (size_t)NINT * sizeof(int32_t);
 };
 
 template <class T>
@@ -363,8 +363,9 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
     constexpr int CH = TileLds2<T>::CH, KMAX = TileLds2<T>::KMAX;
     constexpr int TPBY = G::BY / 2, TPBZ = G::BZ / 2, TPB = (G::BX / 2) * TPBY * TPBZ;
     extern __shared__ __attribute__((aligned(16))) char ht_smem[];
-    T* tile = (T*)ht_smem; // [8][1125]
-    T* sdp = tile + 8 * 1125; // [CH][9][9] full symmetric dP
+    using AT = AccT<T>; // the tile is double also in the fp32 build: LDS float atomics are ~40x slower (see k_force_cells)
+    AT* tile = (AT*)ht_smem; // [8][1125]
+    T* sdp = (T*)(tile + 8 * 1125); // [CH][9][9] full symmetric dP
     T* sg = sdp + CH * 81; // [CH][27][3]
     T* sxf = sg + CH * 81; // [CH][12]
     T* sk = sxf + CH * 12; // [KMAX][27]: K[a + 3 b][q]; before the K phase its head holds the per-axis spline weights [CH][3][6]
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
         int ex = (tx0 - bx) + (tid >> 2), ey = (ty0 - by) + ((tid >> 1) & 1), ez = (tz0 - bz) + (tid & 1);
         rdof[tid] = gIdx[(int64_t)b * G::EPB + ((ex << (G::yb + G::zb)) | (ey << G::zb) | ez)];
     }
-    for (int e = tid; e < 8 * 1125; e += HT_THREADS) tile[e] = (T)0;
+    for (int e = tid; e < 8 * 1125; e += HT_THREADS) tile[e] = (AT)0;
     __syncthreads();
     bool any = false;
     for (int r = 0; r < 8; ++r) any = any || rdof[r] >= 0;
@@ -541,11 +542,11 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
                         for (int z = 0; z < 3; ++z) acc[z][bb] += k * g[3 * z + q];
                     }
             }
-            T* o = tile + r * 1125 + ((ax - jx + 2) * 25 + (ay - jy + 2) * 5 + (az + 2)) * 9 + a;
+            AT* o = tile + r * 1125 + ((ax - jx + 2) * 25 + (ay - jy + 2) * 5 + (az + 2)) * 9 + a;
 #pragma unroll
             for (int z = 0; z < 3; ++z)
 #pragma unroll
-                for (int bb = 0; bb < 3; ++bb) lds_atomic_add(o - z * 9 + 3 * bb, acc[z][bb]);
+                for (int bb = 0; bb < 3; ++bb) lds_atomic_add(o - z * 9 + 3 * bb, (AT)acc[z][bb]);
         }
         __syncthreads();
     }
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
         int r = e / 1125, q = e - r * 1125;
         int dof = rdof[r];
         if (dof < 0) continue;
-        T v = tile[e];
+        T v = (T)tile[e];
         if (q >= 62 * 9 && q < 63 * 9 && ((q - 62 * 9) % 4 == 0)) v += mass[dof];
         val[(int64_t)dof * 1125 + q] = v;
     }
@@ -588,9 +589,10 @@ __global__ __launch_bounds__(256) void k_mf_diag_col(const T* __restrict__ X, co
 {
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
-    __shared__ T acc[3][TILE];
+    using AT = AccT<T>; // double tile also in fp32 (LDS float atomics are slow, see k_force_cells)
+    __shared__ AT acc[3][TILE];
     const int g = blockIdx.x;
-    for (int t = threadIdx.x; t < 3 * TILE; t += 256) (&acc[0][0])[t] = (T)0;
+    for (int t = threadIdx.x; t < 3 * TILE; t += 256) (&acc[0][0])[t] = (AT)0;
     __syncthreads();
     const int first = group_first[g], last = group_first[g + 1];
     const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
@@ -622,13 +624,13 @@ __global__ __launch_bounds__(256) void k_mf_diag_col(const T* __restrict__ X, co
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
                     for (int vv = 0; vv < 3; ++vv) v += D[sym45(a + 3 * vv, cc + 3 * q)] * gi[vv] * gi[q];
-                lds_atomic_add(&acc[a][t], v);
+                lds_atomic_add(&acc[a][t], (AT)v);
             }
         }
     }
     __syncthreads();
     T* out = part + (int64_t)g * 3 * TILE;
-    for (int t = threadIdx.x; t < 3 * TILE; t += 256) out[t] = (&acc[0][0])[t];
+    for (int t = threadIdx.x; t < 3 * TILE; t += 256) out[t] = (T)(&acc[0][0])[t];
 }
 template <class T>
 __global__ void k_mf_diag_finish(const T* __restrict__ tile /*[9][slots]: column-major blocks*/, const int32_t* __restrict__ dofSlot, const T* __restrict__ mass, T* __restrict__ dinv, int nn,

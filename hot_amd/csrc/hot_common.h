@@ -217,6 +217,10 @@ __device__ inline void atomic_add(T* p, T v)
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// accumulator type of the LDS tiles: double also for the fp32 build (see k_force_cells)
+template <class T>
+using AccT = double;
+
 template <class T>
 __device__ inline void lds_atomic_add(T* p, T v)
 {

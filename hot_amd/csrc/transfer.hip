@@ -105,14 +105,15 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
 {
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
-    constexpr int NQ = WITH_CN ? 5 : 4, NS = 25 + (WITH_CN ? 1 : 0), CH = P2G_CHUNK;
-    __shared__ T acc[NQ][TILE];
+    constexpr int NQ = WITH_CN ? 5 : 4, NS = 25 + (WITH_CN ? 1 : 0), CH = sizeof(T) == 4 ? 2 * P2G_CHUNK : P2G_CHUNK; // fp32 groups hold twice the particles: same LDS bytes, one staging round
+    using AT = AccT<T>; // double also in the fp32 build: LDS float atomics are ~40x slower (see k_force_cells)
+    __shared__ AT acc[NQ][TILE];
     __shared__ T sp[NS][CH]; // x(3) m(1) m*v(3) m*C(9) w(3x3) [cn]
     __shared__ int32_t sbase[3][CH];
     __shared__ int32_t segs[G::EPB + 2];
     __shared__ int32_t nseg;
     const int g = blockIdx.x, tid = threadIdx.x;
-    for (int t = tid; t < NQ * TILE; t += P2G_THREADS) (&acc[0][0])[t] = (T)0;
+    for (int t = tid; t < NQ * TILE; t += P2G_THREADS) (&acc[0][0])[t] = (AT)0;
     const int first = group_first[g], last = group_first[g + 1];
     const int c0 = group_cell0[g], c1 = group_cell0[g + 1];
     const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
@@ -182,14 +183,14 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
             for (int i = 0; i < 3; ++i) {
                 const int t = ((b0 - ox + i) * TY + (b1 - oy + j)) * TZ + (b2 - oz + k);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) lds_atomic_add(&acc[q][t], a[i][q]);
+                for (int q = 0; q < NQ; ++q) lds_atomic_add(&acc[q][t], (AT)a[i][q]);
             }
         }
     }
     __syncthreads();
     // partial tile of this group, coalesced; summed per node by k_tile_reduce (no global atomics)
     T* out = part + (int64_t)g * NQ * TILE;
-    for (int t = tid; t < NQ * TILE; t += P2G_THREADS) out[t] = (&acc[0][0])[t];
+    for (int t = tid; t < NQ * TILE; t += P2G_THREADS) out[t] = (T)(&acc[0][0])[t];
 }
 
 template <class T>
