@@ -290,13 +290,10 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
     __shared__ T nv[3][TILE];
-    __shared__ int32_t nb8[8];
     __shared__ double red[4];
     const int g = blockIdx.x;
-    if (threadIdx.x < 8) nb8[threadIdx.x] = group_nb[g * 8 + threadIdx.x];
-    __syncthreads();
     for (int t = threadIdx.x; t < TILE; t += 256) {
-        int idx = gIdx[tile_slot2<T>(t, nb8)];
+        int idx = gIdx[(int64_t)g * TILE + t]; // gIdx here = tileDof: the tile's DOF ids, one load ahead of the values
         T a = 0, b = 0, c = 0;
         if (idx >= 0) a = vn[3 * idx] + dv[3 * idx], b = vn[3 * idx + 1] + dv[3 * idx + 1], c = vn[3 * idx + 2] + dv[3 * idx + 2];
         nv[0][t] = a, nv[1][t] = b, nv[2][t] = c;
@@ -542,7 +539,7 @@ double Ctx<T>::state_pass(const T* dv_in, bool want_force)
 {
     HOT_HIP(hipMemsetAsync(dscal.p, 0, 4 * sizeof(double), stream));
     HOT_LAUNCH(this, "state_update", k_state<T>, Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, pFt.p, pStress.p, keep_debug ? pGradV.p : (T*)nullptr, Np, group_first.p, group_origin.p,
-        group_nb.p, gIdx.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p);
+        group_nb.p, tileDof.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p);
     if (want_force) force_pass();
     HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, std::min(div_up(Nn, 256), 1024), 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1);
     HOT_HIP(hipMemcpyAsync(hscal, dscal.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));

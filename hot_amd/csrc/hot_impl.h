@@ -101,6 +101,8 @@ struct Ctx : CtxBase {
     // ---- node tiles (Nb*EPB)
     DBuf<T> gM, gMV, gF, gCN; // gMV/gF: 3 components, component-major over slots
     DBuf<int32_t> gIdx;
+    DBuf<int32_t> tileDof; // Ng * (BX+2)(BY+2)(BZ+2): DOF id (or -1) of every node of a particle group's tile, so that the per-trial
+                           // state pass gathers vn + dv after one index load instead of the nb8 -> gIdx -> value chain
     DBuf<int32_t> block_count; // Nb+1
     // ---- DOFs (Nn)
     DBuf<int32_t> dofSlot, id2coord, bcIdx;

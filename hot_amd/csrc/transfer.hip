@@ -237,6 +237,18 @@ __global__ __launch_bounds__(256) void k_number_nodes(const T* __restrict__ gM, 
     gMV[s] = v0, gMV[slots + s] = v1, gMV[2 * slots + s] = v2;
 }
 
+// DOF id (or -1) of every node of every particle group's tile (gathers of nodal fields then need one index load)
+template <class T>
+__global__ void k_tile_dof(const int32_t* __restrict__ group_nb, const int32_t* __restrict__ gIdx, int32_t* __restrict__ tileDof, int ng)
+{
+    using G = Geo<T>;
+    constexpr int TILE = (G::BX + 2) * (G::BY + 2) * (G::BZ + 2);
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)ng * TILE) return;
+    const int g = (int)(e / TILE), t = (int)(e - (int64_t)g * TILE);
+    tileDof[e] = gIdx[tile_slot<T>(t, group_nb + 8 * g)];
+}
+
 template <class T>
 void Ctx<T>::p2g()
 {
@@ -268,6 +280,11 @@ void Ctx<T>::p2g()
     vn.reserve(3 * n, 1.25), dv.reserve(3 * n, 1.25), dv0.reserve(3 * n, 1.25), cnTol.reserve(n, 1.25), rhs.reserve(3 * n, 1.25);
     work0.reserve(3 * n, 1.25), work1.reserve(3 * n, 1.25), work2.reserve(3 * n, 1.25), work3.reserve(3 * n, 1.25);
     HOT_LAUNCH(this, "number_nodes", k_number_nodes<T>, div_up(Nb, 4), 256, 0, gM.p, gMV.p, gIdx.p, scan.p, blocks.p, dofSlot.p, id2coord.p, mass.p, nodeV.p, Nb, slots);
+    {
+        constexpr int TILE = (G::BX + 2) * (G::BY + 2) * (G::BZ + 2);
+        tileDof.reserve((size_t)Ng * TILE, 1.25);
+        HOT_LAUNCH(this, "tile_dof", k_tile_dof<T>, div_up((size_t)Ng * TILE, 256), 256, 0, group_nb.p, gIdx.p, tileDof.p, Ng);
+    }
     stats.ms_p2g = wall_ms() - t0;
 }
 
