@@ -292,6 +292,19 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
     __shared__ T nv[3][TILE];
     __shared__ double red[4];
     const int g = blockIdx.x;
+    const int first = group_first[g], last = group_first[g + 1];
+    // position and Fn of this thread's first particle are requested before the tile gather: two of the workgroup's dependent
+    // round trips (tile indices -> nodal values, particle data) then run side by side
+    const int p0 = first + threadIdx.x;
+    T xpre[3] = { 0, 0, 0 }, fpre[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) fpre[c] = (T)0;
+    if (p0 < last) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xpre[d] = X[(int64_t)d * Np + p0];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) fpre[c] = Fn[(int64_t)c * Np + p0];
+    }
     for (int t = threadIdx.x; t < TILE; t += 256) {
         int idx = gIdx[(int64_t)g * TILE + t]; // gIdx here = tileDof: the tile's DOF ids, one load ahead of the values
         T a = 0, b = 0, c = 0;
@@ -299,13 +312,14 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
         nv[0][t] = a, nv[1][t] = b, nv[2][t] = c;
     }
     __syncthreads();
-    const int first = group_first[g], last = group_first[g + 1];
     const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
     double e = 0;
     for (int p = first + threadIdx.x; p < last; p += 256) {
         Mat3<T> Fnew;
         {
-            T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
+            T xp[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xp[d] = p == p0 ? xpre[d] : X[(int64_t)d * Np + p];
             int base[3];
             T w[3][3], dw[3][3];
 #pragma unroll
@@ -338,7 +352,7 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
             }
             Mat3<T> A, Fo;
 #pragma unroll
-            for (int c = 0; c < 9; ++c) A.a[c] = dt * gv[c] + ((c % 4 == 0) ? (T)1 : (T)0), Fo.a[c] = Fn[(int64_t)c * Np + p];
+            for (int c = 0; c < 9; ++c) A.a[c] = dt * gv[c] + ((c % 4 == 0) ? (T)1 : (T)0), Fo.a[c] = p == p0 ? fpre[c] : Fn[(int64_t)c * Np + p];
             Fnew = m3_mul(A, Fo);
         }
 #pragma unroll
