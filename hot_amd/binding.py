@@ -35,7 +35,7 @@ class hot_collision_object(C.Structure):
 
 
 STICKY, SLIP, SEPARATE = 1, 2, 3
-HALFSPACE, SPHERE, BOX, CAPPED_CYLINDER, TORUS = 0, 1, 2, 3, 4
+HALFSPACE, SPHERE, BOX, CAPPED_CYLINDER, TORUS, ROTATED_BOX = 0, 1, 2, 3, 4, 5
 
 
 class hot_stats(C.Structure):

@@ -171,11 +171,11 @@ void Ctx<T>::set_collision_objects(int32_t n, const hot_collision_object* objs)
 {
     need(n >= 0 && n <= 64, "hot_set_collision_objects: 0 <= n <= 64");
     for (int i = 0; i < n; ++i) {
-        need(objs[i].shape >= HOT_SHAPE_HALFSPACE && objs[i].shape <= HOT_SHAPE_TORUS, "unknown collision shape");
+        need(objs[i].shape >= HOT_SHAPE_HALFSPACE && objs[i].shape <= HOT_SHAPE_ROTATED_BOX, "unknown collision shape");
         need(objs[i].type >= HOT_COLLISION_STICKY && objs[i].type <= HOT_COLLISION_SEPARATE, "collision type must be STICKY (1), SLIP (2) or SEPARATE (3)");
-        need(!((objs[i].shape == HOT_SHAPE_BOX || objs[i].shape == HOT_SHAPE_CAPPED_CYLINDER) && objs[i].type != HOT_COLLISION_STICKY),
+        need(!((objs[i].shape == HOT_SHAPE_BOX || objs[i].shape == HOT_SHAPE_CAPPED_CYLINDER || objs[i].shape == HOT_SHAPE_ROTATED_BOX) && objs[i].type != HOT_COLLISION_STICKY),
             "boxes and capped cylinders must be STICKY (the reference's automatic-differentiation normal is undefined inside them)");
-        if (objs[i].shape == HOT_SHAPE_CAPPED_CYLINDER || objs[i].shape == HOT_SHAPE_TORUS)
+        if (objs[i].shape == HOT_SHAPE_CAPPED_CYLINDER || objs[i].shape == HOT_SHAPE_TORUS || objs[i].shape == HOT_SHAPE_ROTATED_BOX)
             need(objs[i].lsq[0] != 0 || objs[i].lsq[1] != 0 || objs[i].lsq[2] != 0 || objs[i].lsq[3] != 0, "lsq must be a rotation quaternion ((1,0,0,0) = none)");
         need(objs[i].s > 0, "collision object scaling s must be > 0 (1 = none)");
         need(!(objs[i].shape == HOT_SHAPE_HALFSPACE && (objs[i].dsdt != 0 || objs[i].omega[0] != 0 || objs[i].omega[1] != 0 || objs[i].omega[2] != 0)),

@@ -73,6 +73,18 @@ __device__ __forceinline__ bool co_detect_resolve(const CollObj<T>& o, const T (
             colliding = (mx < (T)0 ? mx : (T)0) + hsqrt(m0 * m0 + m1 * m1) <= (T)0;
         }
     }
+    else if (o.shape == HOT_SHAPE_ROTATED_BOX) { // AnalyticBox (AnalyticLevelSet.cpp:486-529), STICKY only
+        const T t[3] = { X[0] - o.p0[0], X[1] - o.p0[1], X[2] - o.p0[2] };
+        T dd = -(T)3.4e38, q2 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T d = habs(o.Rls[3 * k] * t[0] + o.Rls[3 * k + 1] * t[1] + o.Rls[3 * k + 2] * t[2]) - o.p1[k];
+            dd = d > dd ? d : dd;
+            const T q = d < (T)0 ? (T)0 : d;
+            q2 += q * q;
+        }
+        colliding = (dd < (T)0 ? dd : (T)0) + hsqrt(q2) <= (T)0;
+    }
     else { // axis-aligned box (STICKY only): signedDistancePrimitive of the centred box
         T dd = -(T)3.4e38, q2 = 0;
 #pragma unroll
@@ -143,6 +155,10 @@ inline double co_max_speed(const hot_collision_object& o, const double (&pmin)[3
             lo[d] = o.p0[d] - o.p1[0], hi[d] = o.p0[d] + o.p1[0];
         else if (o.shape == HOT_SHAPE_TORUS) // bounding sphere r0 + r1 (AnalyticLevelSet.cpp:610-617)
             lo[d] = o.p0[d] - (o.p1[0] + o.p1[1]), hi[d] = o.p0[d] + (o.p1[0] + o.p1[1]);
+        else if (o.shape == HOT_SHAPE_ROTATED_BOX) { // bounding sphere |half edges| (AnalyticLevelSet.cpp:542-548)
+            const double rr = std::sqrt(o.p1[0] * o.p1[0] + o.p1[1] * o.p1[1] + o.p1[2] * o.p1[2]);
+            lo[d] = o.p0[d] - rr, hi[d] = o.p0[d] + rr;
+        }
         else if (o.shape == HOT_SHAPE_CAPPED_CYLINDER) { // AnalyticLevelSet.h:289-295
             const double rr = std::sqrt(o.p1[0] * o.p1[0] + 0.25 * o.p1[1] * o.p1[1]);
             lo[d] = o.p0[d] - rr, hi[d] = o.p0[d] + rr;

@@ -130,16 +130,16 @@ int hot_set_sticky_halfspaces(hot_ctx*, int32_t n, const double* origin /*3n*/, 
  *      Sphere / AxisAlignedAnalyticBox level sets (AnalyticLevelSet.cpp), RotationExtractor for slip nodes
  *      (MpmSimulationBase.h:271-281).  Objects carry the reference's full transform x = R s X + b with rates (omega, ds/dt, db/dt);
  *      the caller's updateState callback refreshes them with another hot_set_collision_objects call.  type uses the reference's
- *      enum values (CollisionObject.h:52-57).  Boxes and capped cylinders must be STICKY (their automatic-differentiation normal is not defined inside them).
+ *      enum values (CollisionObject.h:52-57).  Boxes (both kinds) and capped cylinders must be STICKY (their automatic-differentiation normal is not defined inside them).
  *      Replaces any half spaces / explicit collision nodes set before; n = 0 clears. */
 enum hot_collision_type { HOT_COLLISION_STICKY = 1, HOT_COLLISION_SLIP = 2, HOT_COLLISION_SEPARATE = 3 };
-enum hot_collision_shape { HOT_SHAPE_HALFSPACE = 0, HOT_SHAPE_SPHERE = 1, HOT_SHAPE_BOX = 2, HOT_SHAPE_CAPPED_CYLINDER = 3, HOT_SHAPE_TORUS = 4 };
+enum hot_collision_shape { HOT_SHAPE_HALFSPACE = 0, HOT_SHAPE_SPHERE = 1, HOT_SHAPE_BOX = 2, HOT_SHAPE_CAPPED_CYLINDER = 3, HOT_SHAPE_TORUS = 4, HOT_SHAPE_ROTATED_BOX = 5 };
 typedef struct hot_collision_object {
     int32_t shape; /* hot_collision_shape */
     int32_t type; /* hot_collision_type */
-    double p0[3]; /* half space: origin ; sphere: centre ; box: min corner ; capped cylinder / torus: centre b of the level set */
+    double p0[3]; /* half space: origin ; sphere: centre ; box: min corner ; capped cylinder / torus / rotated box: centre b of the level set */
     double p1[3]; /* half space: outward normal ; sphere: (radius, -, -) ; box: max corner ; capped cylinder: (radius, height, -) ;
-                     torus: (r0, r1, -) */
+                     torus: (r0, r1, -) ; rotated box (AnalyticBox): half edges */
     double friction;
     double b[3]; /* translation of the object */
     double dbdt[3]; /* its velocity */
@@ -147,7 +147,7 @@ typedef struct hot_collision_object {
     double omega[3]; /* angular velocity (world frame) */
     double s; /* uniform scaling, > 0 (1 = none) */
     double dsdt; /* its rate */
-    double lsq[4]; /* capped cylinder / torus: the level set's own rotation, quaternion (w, x, y, z) as in their constructors
+    double lsq[4]; /* capped cylinder / torus / rotated box: the level set's own rotation, quaternion (w, x, y, z) as in their constructors
                       (AnalyticLevelSet.h:241-254, AnalyticLevelSet.cpp:568-576); the primitive's axis is y.  (1,0,0,0) = none */
 } hot_collision_object; /* world x = R s X + b  (CollisionObject.h:63-69); p0 / p1 are given in material space X */
 int hot_set_collision_objects(hot_ctx*, int32_t n, const hot_collision_object* objects);

@@ -483,7 +483,7 @@ struct Sim {
                     N = to_center * ((T)1 / dist);
             }
         }
-        else if (o.shape == HOT_SHAPE_CAPPED_CYLINDER || o.shape == HOT_SHAPE_TORUS) {
+        else if (o.shape == HOT_SHAPE_CAPPED_CYLINDER || o.shape == HOT_SHAPE_TORUS || o.shape == HOT_SHAPE_ROTATED_BOX) {
             // CappedCylinder (AnalyticLevelSet.h:221-297) / Torus (AnalyticLevelSet.cpp:565-608): y-axis primitive behind the level
             // set's own rotation (Eigen quaternion w,x,y,z, normalised) and translation; the torus normal is the gradient the
             // reference obtains by automatic differentiation
@@ -496,7 +496,17 @@ struct Sim {
             Rl(2, 0) = (T)(2 * (qx * qz - w * qy)), Rl(2, 1) = (T)(2 * (qy * qz + w * qx)), Rl(2, 2) = (T)(1 - 2 * (qx * qx + qy * qy));
             TV P = Rl.transpose() * (X - p0);
             T rho = std::sqrt(P(0) * P(0) + P(2) * P(2));
-            if (o.shape == HOT_SHAPE_TORUS) {
+            if (o.shape == HOT_SHAPE_ROTATED_BOX) { // AnalyticBox::signedDistancePrimitive (AnalyticLevelSet.cpp:502-522)
+                T dd = -(T)3.4e38, q2 = 0;
+                for (int k = 0; k < 3; ++k) {
+                    T d = std::abs(P(k)) - p1(k);
+                    dd = std::max(dd, d);
+                    T q = d < (T)0 ? (T)0 : d;
+                    q2 += q * q;
+                }
+                colliding = std::min(dd, (T)0) + std::sqrt(q2) <= (T)0;
+            }
+            else if (o.shape == HOT_SHAPE_TORUS) {
                 T q0 = rho - p1(0), L = std::sqrt(q0 * q0 + P(1) * P(1));
                 colliding = L - p1(1) <= (T)0;
                 T gr = q0 / L;

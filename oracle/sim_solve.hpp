@@ -410,8 +410,8 @@ double Sim<T>::calculate_dt(double max_dt, double* max_speed, double* min_corner
             for (int d = 0; d < 3; ++d) {
                 pmin[d] = (double)(-nlo[d] - (T)4 * dx), pmax[d] = (double)(hi[d] + (T)4 * dx); // particle box expanded by (degree + 2) dx
                 // ls->getBounds: Sphere, Torus (r0 + r1), CappedCylinder (sqrt(r^2 + (h/2)^2)), AxisAlignedAnalyticBox
-                const double rad = o.shape == HOT_SHAPE_SPHERE ? o.p1[0] : o.shape == HOT_SHAPE_TORUS ? o.p1[0] + o.p1[1] : std::sqrt(o.p1[0] * o.p1[0] + 0.25 * o.p1[1] * o.p1[1]);
-                const bool round_ = o.shape == HOT_SHAPE_SPHERE || o.shape == HOT_SHAPE_TORUS || o.shape == HOT_SHAPE_CAPPED_CYLINDER;
+                const double rad = o.shape == HOT_SHAPE_SPHERE ? o.p1[0] : o.shape == HOT_SHAPE_TORUS ? o.p1[0] + o.p1[1] : o.shape == HOT_SHAPE_ROTATED_BOX ? std::sqrt(o.p1[0] * o.p1[0] + o.p1[1] * o.p1[1] + o.p1[2] * o.p1[2]) : std::sqrt(o.p1[0] * o.p1[0] + 0.25 * o.p1[1] * o.p1[1]);
+                const bool round_ = o.shape == HOT_SHAPE_SPHERE || o.shape == HOT_SHAPE_TORUS || o.shape == HOT_SHAPE_CAPPED_CYLINDER || o.shape == HOT_SHAPE_ROTATED_BOX;
                 blo[d] = round_ ? o.p0[d] - rad : o.p0[d];
                 bhi[d] = round_ ? o.p0[d] + rad : o.p1[d];
             }

@@ -401,13 +401,15 @@ def test_baseline_multigrid_needs_analytic_boundaries(hotlib):
 def test_torus_and_capped_cylinder_against_oracle(hotlib, oracle):
     """The two remaining analytic level sets of the reference scenes: a slip torus (normal = gradient of its distance) and
     a sticky capped cylinder, both behind their own rotation / translation and an object transform on top."""
-    from hot_amd.binding import CAPPED_CYLINDER, SLIP, STICKY, TORUS
+    from hot_amd.binding import CAPPED_CYLINDER, ROTATED_BOX, SLIP, STICKY, TORUS
     c30, s30 = np.cos(0.3), np.sin(0.3)
     objs = [
         # ring around the top corner of the body, tube radius 0.012, tilted about z, the object itself drifting and turning
         dict(shape=TORUS, type=SLIP, p0=(5.04, 5.07, 5.04), p1=(0.03, 0.012, 0.0), lsq=(c30, 0.0, 0.0, s30), friction=0.1, dbdt=(0.0, -0.2, 0.0), omega=(0.0, 1.0, 0.0), b=(0.0, 0.0, 0.0)),
         # a peg standing in the body, axis tilted about x
         dict(shape=CAPPED_CYLINDER, type=STICKY, p0=(5.02, 5.03, 5.06), p1=(0.015, 0.05, 0.0), lsq=(np.cos(0.2), np.sin(0.2), 0.0, 0.0)),
+        # a slab (AnalyticBox: half edges + own rotation) cutting through the far corner
+        dict(shape=ROTATED_BOX, type=STICKY, p0=(5.07, 5.01, 5.01), p1=(0.02, 0.006, 0.03), lsq=(np.cos(0.25), 0.0, np.sin(0.25), 0.0)),
     ]
     out = {}
     for name, lib in (("gpu", hotlib), ("cpu", oracle)):
