@@ -84,3 +84,60 @@ def test_baseline_geometric_hierarchy(oracle):
     a, b, m = dv[0][0], dv[1][0], dv[0][2]
     assert np.sqrt((m * (a - b) ** 2).sum()) < 2e-2 * np.sqrt((m * a ** 2).sum())
     assert abs(dv[0][1] - dv[1][1]) < 1e-6 * max(abs(dv[0][1]), 1e-3)
+
+
+def _quat_matrix(q):
+    w, x, y, z = np.asarray(q, np.float64) / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def test_level_sets_against_closed_forms(oracle):
+    """The oracle's analytic level sets (half space, sphere, torus, capped cylinder, axis-aligned and rotated box) behind the
+    object transform x = R s X + b: the set of grid nodes it flags as colliding equals the set where an independent numpy
+    evaluation of the signed distance (AnalyticLevelSet.cpp / .h formulas) is <= 0."""
+    from hot_amd.binding import BOX, CAPPED_CYLINDER, HALFSPACE, ROTATED_BOX, SPHERE, STICKY, TORUS
+
+    def phi(o, x):
+        R = np.asarray(o.get("R", np.eye(3)), np.float64)
+        X = (x - np.asarray(o.get("b", (0, 0, 0)))) @ R / o.get("s", 1.0)  # R^T (x - b) / s, row-wise
+        p0, p1 = np.asarray(o["p0"], np.float64), np.atleast_1d(np.asarray(o["p1"], np.float64))
+        if o["shape"] == HALFSPACE:
+            return (X - p0) @ p1
+        if o["shape"] == SPHERE:
+            return np.linalg.norm(X - p0, axis=1) - p1[0]
+        if o["shape"] == BOX:
+            c, h = (p0 + p1) / 2, (p1 - p0) / 2
+            d = np.abs(X - c) - h
+            return np.minimum(d.max(1), 0) + np.linalg.norm(np.maximum(d, 0), axis=1)
+        P = (X - p0) @ _quat_matrix(o.get("lsq", (1, 0, 0, 0)))  # R_ls^T (X - b_ls)
+        rho = np.hypot(P[:, 0], P[:, 2])
+        if o["shape"] == TORUS:
+            return np.hypot(rho - p1[0], P[:, 1]) - p1[1]
+        if o["shape"] == CAPPED_CYLINDER:
+            d = np.stack([rho - p1[0], np.abs(P[:, 1]) - 0.5 * p1[1]], 1)
+        else:
+            d = np.abs(P) - p1
+        return np.minimum(d.max(1), 0) + np.linalg.norm(np.maximum(d, 0), axis=1)
+
+    a = 0.35
+    Robj = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    cases = [
+        dict(shape=HALFSPACE, type=STICKY, p0=(0, 0, 0), p1=(0.0, 1.0, 0.0), b=(5.0, 5.02, 5.0), R=Robj),
+        dict(shape=SPHERE, type=STICKY, p0=(0.01, 0, 0), p1=0.03, b=(5.03, 5.04, 5.03), R=Robj, s=1.3),
+        dict(shape=BOX, type=STICKY, p0=(-0.03, -0.01, -0.02), p1=(0.02, 0.02, 0.03), b=(5.04, 5.03, 5.04), R=Robj, s=0.9),
+        dict(shape=TORUS, type=STICKY, p0=(5.04, 5.05, 5.04), p1=(0.03, 0.012, 0.0), lsq=(0.9, 0.1, 0.0, 0.4)),
+        dict(shape=CAPPED_CYLINDER, type=STICKY, p0=(5.03, 5.03, 5.05), p1=(0.018, 0.05, 0.0), lsq=(0.95, 0.3, 0.1, 0.0)),
+        dict(shape=ROTATED_BOX, type=STICKY, p0=(0.002, 0.0, -0.001), p1=(0.025, 0.008, 0.03), lsq=(0.9, 0.0, 0.42, 0.1), b=(5.05, 5.03, 5.03), R=Robj.T),
+    ]
+    for o in cases:
+        ctx, c = pc.make_ctx(oracle, n=8, bc=False, noise=0.3)
+        ctx.set_collision_objects([o])
+        pc.prepare(ctx)
+        g = ctx.grid()
+        x = g["id2coord"].astype(np.float64) * c["dx"]
+        hit = np.abs(ctx.get_dv() + g["v"]).max(1) < 1e-14  # sticky nodes start from dv = -v
+        want = phi(o, x) <= 0
+        edge = np.abs(phi(o, x)) < 1e-12  # nodes exactly on the surface may fall either way
+        assert want.sum() > 10 and np.array_equal(hit | edge, want | edge), (o["shape"], hit.sum(), want.sum())
