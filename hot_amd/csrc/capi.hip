@@ -21,6 +21,10 @@ struct hot_ctx {
     catch (const std::exception& e) {                   \
         ctx->err = e.what();                            \
         return HOT_ERR_INVALID;                         \
+    }                                                   \
+    catch (...) {                                       \
+        ctx->err = "unknown exception";                 \
+        return HOT_ERR_INVALID;                         \
     }
 
 extern "C" {
@@ -69,6 +73,15 @@ int hot_create(const hot_config* cfg, hot_ctx** out)
         fprintf(stderr, "libhotmi355x: hot_create failed: %s\n", e.msg.c_str());
         delete c;
         return e.code;
+    }
+    catch (const std::exception& e) { // std::bad_alloc and friends must not cross the extern "C" boundary either
+        fprintf(stderr, "libhotmi355x: hot_create failed: %s\n", e.what());
+        delete c;
+        return HOT_ERR_INVALID;
+    }
+    catch (...) {
+        delete c;
+        return HOT_ERR_INVALID;
     }
     *out = c;
     return HOT_OK;

@@ -16,7 +16,6 @@
 //   k_matfree       matrix-free Hessian product (ImplicitSolver.h:741-758, MpmForceBase.cpp:262-306,
 //                   FBasedMpmForceHelper.cpp:137-160).
 #include "hot_impl.h"
-#include <cstdlib>
 #include "hot_constitutive.h"
 #include "hot_collision.h"
 #include <cmath>
@@ -162,8 +161,9 @@ template <class T>
 void Ctx<T>::set_halfspaces(int32_t n, const double* origin, const double* normal)
 {
     cobjs.clear();
-    hs_origin.assign(origin, origin + 3 * n);
-    hs_normal.assign(normal, normal + 3 * n);
+    hs_origin.clear(), hs_normal.clear();
+    if (n > 0) hs_origin.assign(origin, origin + 3 * n), hs_normal.assign(normal, normal + 3 * n);
+    if (n == 0) Nc = 0;
 }
 
 template <class T>
@@ -178,6 +178,7 @@ void Ctx<T>::set_collision_objects(int32_t n, const hot_collision_object* objs)
         if (objs[i].shape == HOT_SHAPE_CAPPED_CYLINDER || objs[i].shape == HOT_SHAPE_TORUS || objs[i].shape == HOT_SHAPE_ROTATED_BOX)
             need(objs[i].lsq[0] != 0 || objs[i].lsq[1] != 0 || objs[i].lsq[2] != 0 || objs[i].lsq[3] != 0, "lsq must be a rotation quaternion ((1,0,0,0) = none)");
         need(objs[i].s > 0, "collision object scaling s must be > 0 (1 = none)");
+        need(!(objs[i].shape == HOT_SHAPE_HALFSPACE && objs[i].p1[0] == 0 && objs[i].p1[1] == 0 && objs[i].p1[2] == 0), "half space: the outward normal p1 must be non-zero (it is normalised here, as HalfSpace's constructor does)");
         need(!(objs[i].shape == HOT_SHAPE_HALFSPACE && (objs[i].dsdt != 0 || objs[i].omega[0] != 0 || objs[i].omega[1] != 0 || objs[i].omega[2] != 0)),
             "a half space cannot turn or scale (no bounds available for its speed: AnalyticLevelSet.cpp:122-125)");
         double dev = 0; // R^T R = I
@@ -204,6 +205,10 @@ void Ctx<T>::eval_collision_objects()
         h[i].shape = cobjs[i].shape, h[i].type = cobjs[i].type, h[i].friction = (T)cobjs[i].friction;
         for (int d = 0; d < 3; ++d) h[i].p0[d] = (T)cobjs[i].p0[d], h[i].p1[d] = (T)cobjs[i].p1[d], h[i].b[d] = (T)cobjs[i].b[d], h[i].dbdt[d] = (T)cobjs[i].dbdt[d], h[i].omega[d] = (T)cobjs[i].omega[d];
         for (int d = 0; d < 9; ++d) h[i].R[d] = (T)cobjs[i].R[d];
+        if (cobjs[i].shape == HOT_SHAPE_HALFSPACE) { // HalfSpace stores outward_normal.normalized() (AnalyticLevelSet.cpp:111-115)
+            const T nn = std::sqrt(h[i].p1[0] * h[i].p1[0] + h[i].p1[1] * h[i].p1[1] + h[i].p1[2] * h[i].p1[2]);
+            for (int d = 0; d < 3; ++d) h[i].p1[d] = h[i].p1[d] / nn;
+        }
         h[i].inv_s = (T)1 / (T)cobjs[i].s, h[i].dsdt = (T)cobjs[i].dsdt;
         double Rls[9];
         co_quat_to_matrix(cobjs[i].lsq, Rls);
@@ -285,7 +290,7 @@ __device__ __forceinline__ void rot3(const T (&in)[3], int r, T (&out)[3])
 template <class T>
 __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ Vol, const T* __restrict__ Mu, const T* __restrict__ Lam,
     T* __restrict__ Ft, T* __restrict__ stress_out, T* __restrict__ gradV_out, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
-    const int32_t* __restrict__ group_nb, const int32_t* __restrict__ gIdx, const T* __restrict__ vn, const T* __restrict__ dv, T dx, T one_over_dx, T dt, double* energy)
+    const int32_t* __restrict__ group_nb, const int32_t* __restrict__ gIdx, const T* __restrict__ vn, const T* __restrict__ dv, T dx, T one_over_dx, T dt, double* energy, GridRed gr)
 {
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
@@ -373,9 +378,10 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
         }
     }
     double tot = block_sum_256<double>(e, red);
-    if (threadIdx.x == 0 && tot != 0.0) atomic_add(energy, tot);
+    grid_sum_store(tot, 0.0, 1, gr, energy, nullptr, red);
 }
 
+#ifdef HOT_AB_KERNELS
 // pass B: rasterizeForceToTVStack — f_i -= dt * stress grad w_i, LDS accumulators, one global atomic per touched node
 template <class T>
 __global__ __launch_bounds__(256) void k_force_scatter(const T* __restrict__ X, const T* __restrict__ stress, int64_t Np, const int32_t* __restrict__ group_first,
@@ -430,6 +436,8 @@ __global__ __launch_bounds__(256) void k_force_scatter(const T* __restrict__ X, 
     T* out = part + (int64_t)g * 3 * TILE; // partial tile, summed per node by k_tile_reduce
     for (int t = threadIdx.x; t < 3 * TILE; t += 256) out[t] = (&acc[0][0])[t];
 }
+
+#endif
 
 // Production force scatter: same (cell, node column) work items as k_p2g_cells (transfer.hip) — the particles of a
 // base cell share their 27 nodes, so the three nodes of a column are summed in registers over the cell and added to the
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(FORCE_THREADS) void k_force_cells(const T* __restri
 }
 
 template <class T>
-__global__ __launch_bounds__(256) void k_inertia_energy(const T* __restrict__ dv, const T* __restrict__ mass, int nn, T g0, T g1, T g2, double* out)
+__global__ __launch_bounds__(256) void k_inertia_energy(const T* __restrict__ dv, const T* __restrict__ mass, int nn, T g0, T g1, T g2, double* out, GridRed gr)
 {
     __shared__ double red[4];
     double ke = 0, ge = 0;
@@ -528,10 +536,7 @@ __global__ __launch_bounds__(256) void k_inertia_energy(const T* __restrict__ dv
     }
     double k = block_sum_256<double>(ke, red);
     double gg = block_sum_256<double>(ge, red);
-    if (threadIdx.x == 0) {
-        atomic_add(out, k);
-        atomic_add(out + 1, gg);
-    }
+    grid_sum_store(k, gg, 2, gr, out, out + 1, red);
 }
 
 // rasterizeForceToTVStack from the stresses the last k_state left behind (the line search needs it once, at the accepted
@@ -540,10 +545,11 @@ template <class T>
 void Ctx<T>::force_pass()
 {
     int64_t slots = (int64_t)Nb * EPB;
-    static const bool force_v1 = getenv("HOT_FORCE_V1") != nullptr; // A/B switch: one LDS atomic per particle, node and component
-    if (force_v1)
+#ifdef HOT_AB_KERNELS
+    if (ab_flag("HOT_FORCE_V1")) // one LDS atomic per particle, node and component
         HOT_LAUNCH(this, "force_scatter", k_force_scatter<T>, Ng, 256, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, (T)1 / dx, dt);
     else
+#endif
         HOT_LAUNCH(this, "force_scatter", k_force_cells<T>, Ng, FORCE_THREADS, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, (T)1 / dx, dt);
     reduce_tiles(3, gF.p, gF.p + slots, gF.p + 2 * slots, nullptr, nullptr, "force_reduce");
 }
@@ -551,11 +557,13 @@ void Ctx<T>::force_pass()
 template <class T>
 double Ctx<T>::state_pass(const T* dv_in, bool want_force)
 {
-    HOT_HIP(hipMemsetAsync(dscal.p, 0, 4 * sizeof(double), stream));
     HOT_LAUNCH(this, "state_update", k_state<T>, Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, pFt.p, pStress.p, keep_debug ? pGradV.p : (T*)nullptr, Np, group_first.p, group_origin.p,
-        group_nb.p, tileDof.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p);
+        group_nb.p, tileDof.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p, gred(Ng));
     if (want_force) force_pass();
-    HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, std::min(div_up(Nn, 256), 1024), 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1);
+    {
+        const int grid = std::min(div_up(Nn, 256), 1024);
+        HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, grid, 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1, gred(grid));
+    }
     HOT_HIP(hipMemcpyAsync(hscal, dscal.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
     double result = (double)(T)hscal[0];

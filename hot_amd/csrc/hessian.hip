@@ -17,7 +17,6 @@
 //   k_bc_project    the per-row BC projection (:554-593); k_diag buildDiagonal (Projects/multigrid/SquareMatrix.h:301-324).
 #include "hot_impl.h"
 #include "hot_constitutive.h"
-#include <cstdlib>
 
 namespace hot {
 
@@ -49,6 +48,7 @@ __global__ void k_fill_cols(HashMap bm, const int32_t* __restrict__ gIdx, const 
     for (int c = 0; c < 9; ++c) v[c] = (c % 4 == 0) ? m : (T)0;
 }
 
+#ifdef HOT_AB_KERNELS
 // pair index q in [0,378) -> (i <= j) over 27 nodes
 __device__ __forceinline__ void pair_ij(int q, int& i, int& j)
 {
@@ -217,6 +217,8 @@ __global__ __launch_bounds__(256) void k_hessian(const T* __restrict__ X, const 
     if (have_cell) flush();
 }
 
+#endif
+
 // BC projection of the assembled system (ImplicitSolver.h:554-593)
 template <class T>
 __global__ void k_bc_project_matrix(const int32_t* __restrict__ col, T* val, const int32_t* __restrict__ bcIdx, const T* __restrict__ bcR, const T* __restrict__ bcRinv,
@@ -347,12 +349,14 @@ void Ctx<T>::build_hessian()
     size_t ne = (size_t)Nn * 125;
     L->col.reserve(ne), L->val.reserve(ne * 9), L->coord.reserve(3 * (size_t)Nn);
     HOT_HIP(hipMemcpyAsync(L->coord.p, id2coord.p, 3 * (size_t)Nn * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
-    static const bool v1 = getenv("HOT_HESSIAN_V1") != nullptr; // A/B switch: per-cell global-atomic scatter kernel
+    const bool v1 = ab_flag("HOT_HESSIAN_V1"); // A/B build only: per-cell global-atomic scatter kernel
     HOT_LAUNCH(this, "hessian_fill_cols", k_fill_cols<T>, div_up(ne, 256), 256, 0, block_map, gIdx.p, id2coord.p, mass.p, L->col.p, L->val.p, Nn, v1 ? 1 : 0);
+#ifdef HOT_AB_KERNELS
     if (v1)
         HOT_LAUNCH(this, "hessian_assemble_v1", k_hessian<T>, Ng, 256, 0, pX.p, pFn.p, pFt.p, pVol.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gIdx.p, L->val.p, dx, (T)1 / dx,
             dt, cfg.project);
     else
+#endif
         assemble_tiles(*L);
     if (cfg.systemBCProject && Nc > 0)
         HOT_LAUNCH(this, "hessian_bc_project", k_bc_project_matrix<T>, div_up(ne, 256), 256, 0, L->col.p, L->val.p, bcIdx.p, bcR.p, bcRinv.p, bcSlip.p, Nn);

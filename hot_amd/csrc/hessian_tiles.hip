@@ -149,6 +149,7 @@ void Ctx<T>::build_cell_table()
 
 constexpr int HT_THREADS = 1024; // one workgroup per CU (the LDS tile), so the workgroup itself must supply the waves
 
+#ifdef HOT_AB_KERNELS
 template <class T>
 struct TileLds {
     static constexpr int CH = 64; // particles per chunk
@@ -321,6 +322,8 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles(const T* __restric
         val[(int64_t)dof * 1125 + q] = v;
     }
 }
+
+#endif
 
 // ---- second version of pass 2.  The first one evaluates block(i,j) = sum_{v,q} dP[(a,v),(b,q)] g_i[v] g_j[q] from scratch
 // for every (particle, row, column): 81 multiply-adds and 51 LDS reads each, and its work-item phase is bound by the
@@ -566,17 +569,20 @@ void Ctx<T>::assemble_tiles(Level<T>& L)
     pDP.reserve(45 * (size_t)Np);
     HOT_LAUNCH(this, "hessian_dpdf", k_dpdf45<T>, div_up(Np, 256), 256, 0, pFt.p, pVol.p, pMu.p, pLam.p, pDP.p, Np, dt, cfg.project);
     if (!attr_tiles_set) {
+#ifdef HOT_AB_KERNELS
         HOT_HIP(hipFuncSetAttribute((const void*)k_hessian_tiles<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileLds<T>::bytes));
+#endif
         HOT_HIP(hipFuncSetAttribute((const void*)k_hessian_tiles2<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileLds2<T>::bytes));
         attr_tiles_set = true;
     }
     constexpr int TPB = (G::BX / 2) * (G::BY / 2) * (G::BZ / 2);
-    static const bool tiles_v1 = getenv("HOT_HESSIAN_TILES_V1") != nullptr; // A/B switch: 81 multiply-adds per (particle, row, column)
-    if (!tiles_v1) {
-        HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles2<T>, 256 * div_up(Nb * TPB, 256), HT_THREADS, TileLds2<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx, Nb * TPB);
+#ifdef HOT_AB_KERNELS
+    if (ab_flag("HOT_HESSIAN_TILES_V1")) { // 81 multiply-adds per (particle, row, column)
+        HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles<T>, 256 * div_up(Nb * TPB, 256), HT_THREADS, TileLds<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx, Nb * TPB);
         return;
     }
-    HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles<T>, 256 * div_up(Nb * TPB, 256), HT_THREADS, TileLds<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx, Nb * TPB);
+#endif
+    HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles2<T>, 256 * div_up(Nb * TPB, 256), HT_THREADS, TileLds2<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx, Nb * TPB);
 }
 
 // ------------------------------------------------------------------------------------------------ matrix-free diagonal

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include <map>
@@ -203,6 +204,41 @@ __device__ inline T block_sum_256(T v, T* sm4)
     return r;
 }
 
+// Order-deterministic grid-wide sum (blockDim.x == 256), one launch: every workgroup deposits its total, the one that
+// arrives last adds the deposits in index order and STORES the result (no same-address floating-point atomics, whose
+// arrival order changes the rounding from run to run and, between ranks of a sharded solve, from rank to rank).
+// Deposits and the arrival counter are agent-scope atomics, so they are coherent across the 8 XCD L2s; the counter is
+// left at 0 for the next launch on the stream.  t0 / t1: block totals, valid in thread 0 (block_sum_256).
+struct GridRed {
+    double* part; // >= 2 * gridDim.x
+    unsigned* count;
+};
+__device__ inline void grid_sum_store(double t0, double t1, int nv, GridRed gr, double* o0, double* o1, double* sm4)
+{
+    __shared__ int s_last;
+    const unsigned nb = gridDim.x;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(gr.part + blockIdx.x, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nv > 1) __hip_atomic_store(gr.part + nb + blockIdx.x, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned prev = __hip_atomic_fetch_add(gr.count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == nb - 1u;
+    }
+    __syncthreads();
+    if (!s_last) return; // workgroup-uniform
+    double a = 0, b = 0;
+    for (unsigned i = threadIdx.x; i < nb; i += 256) {
+        a += __hip_atomic_load(gr.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nv > 1) b += __hip_atomic_load(gr.part + nb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    a = block_sum_256<double>(a, sm4);
+    if (nv > 1) b = block_sum_256<double>(b, sm4);
+    if (threadIdx.x == 0) {
+        *o0 = a;
+        if (nv > 1) *o1 = b;
+        __hip_atomic_store(gr.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // broadcast lane `src` (wave-uniform) of v to every lane through SGPRs (v_readlane_b32), no LDS round trip
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 __device__ __forceinline__ double lane_bcast(double v, int src)
@@ -272,6 +308,15 @@ __device__ inline int32_t hash_find_id(const HashMap& h, uint64_t key)
 }
 // pack non-negative 3-D integer coordinates (< 2^21) into a map key
 __host__ __device__ inline uint64_t coord_key(int x, int y, int z) { return ((uint64_t)(uint32_t)x << 42) | ((uint64_t)(uint32_t)y << 21) | (uint64_t)(uint32_t)z; }
+
+// First-generation kernels and launch-structure alternatives are compiled only into the A/B build (-DHOT_AB_KERNELS,
+// libhotmi355x_ab.so), where environment variables select them for tests/test_gpu_variants.py.  The product library has
+// neither the kernels nor any getenv.
+#ifdef HOT_AB_KERNELS
+inline bool ab_flag(const char* name) { return getenv(name) != nullptr; }
+#else
+constexpr bool ab_flag(const char*) { return false; }
+#endif
 
 inline double wall_ms()
 {

@@ -120,8 +120,19 @@ struct Ctx : CtxBase {
     double Ek = 0;
     bool updated = false;
     T max_cn_tolerance = 0;
-    DBuf<T> rhs, work0, work1, work2, work3;
+    DBuf<T> rhs, work0, work1, work2, work3, solve_keep;
     DBuf<double> dscal; // device scalars
+    DBuf<T> speed_part; // block maxima of calculate_dt
+    DBuf<double> red_part; // grid_sum_store deposits (2 per workgroup)
+    DBuf<unsigned> red_count; // its arrival counter (always 0 between launches)
+    GridRed gred(size_t grid)
+    {
+        if (2 * grid > red_part.cap) {
+            HOT_HIP(hipStreamSynchronize(stream)); // a launch still summing the old deposits must be done before they are freed
+            red_part.reserve(2 * grid, 1.5);
+        }
+        return GridRed{ red_part.p, red_count.p };
+    }
     int gs_epoch = 0; // sweep number, never reused inside a context
     bool attr_tiles_set = false, attr_gs_set = false; // dynamic-LDS limits raised on this context's device (hipFuncSetAttribute is per device)
     DBuf<int> gs_done; // [0,40) pass counters of k_gs_sweep (the sticky wait-timeout flag lives in pinned host memory, hscal[250])
@@ -172,10 +183,31 @@ struct Ctx : CtxBase {
     {
         if (dst && n) HOT_HIP(hipMemcpyAsync(dst, src, n * sizeof(U), hipMemcpyDefault, stream));
     }
+    // A chained coarse-level sweep (k_gs_sweep) bounds its spin on the neighbour flags; if it ever gives up it raises the
+    // flag in pinned host memory and leaves a half-updated iterate behind.  The next sync() then switches this context to the
+    // launch-per-pass path for good and throws ERR_RETRY, which the operations that can contain such a sweep (solve, vcycle,
+    // smooth) catch to redo themselves from their saved inputs — the context is never left poisoned.
+    static constexpr int ERR_RETRY = -100; // internal, never crosses the C ABI
+    bool gs_no_chain = false;
     void sync()
     {
         HOT_HIP(hipStreamSynchronize(stream));
-        HOT_CHECK(*(volatile int*)(hscal + 250) == 0, HOT_ERR_DEVICE, "k_gs_sweep: wait on the previous pass timed out (workgroup dispatch order assumption violated)");
+        if (*(volatile int*)(hscal + 250) != 0) {
+            *(volatile int*)(hscal + 250) = 0;
+            gs_no_chain = true;
+            throw Error{ ERR_RETRY, "k_gs_sweep: wait on a neighbouring block timed out; redoing the operation with one launch per pass" };
+        }
+    }
+    template <class Fn>
+    void with_gs_retry(Fn&& fn)
+    {
+        try {
+            fn();
+        }
+        catch (const Error& e) {
+            if (e.code != ERR_RETRY) throw;
+            fn(); // gs_no_chain is set now: no chained sweep can occur, so this cannot throw ERR_RETRY again
+        }
     }
     int32_t exclusive_scan_i32(const int32_t* in, int32_t* out, size_t n); // returns total (syncs)
     void need(bool cond, const char* what) { HOT_CHECK(cond, HOT_ERR_INVALID, what); }

@@ -503,8 +503,11 @@ Ctx<T>* Ctx<T>::build_gmg_grid(int level)
         g->set_collision_objects((int32_t)cobjs.size(), cobjs.data());
     else if (!hs_origin.empty())
         g->set_halfspaces((int32_t)hs_origin.size() / 3, hs_origin.data(), hs_normal.data());
-    else
+    else {
         need(Nc == 0, "useBaselineMultigrid: the boundaries must be given as hot_set_collision_objects / hot_set_sticky_halfspaces (every coarse grid queries them at its own nodes; an explicit node list only describes level 0)");
+        g->set_collision_objects(0, nullptr); // the cached coarse context must not keep boundaries the caller has cleared since
+        g->set_halfspaces(0, nullptr, nullptr);
+    }
     g->sort();
     g->p2g();
     g->begin_step((double)dt);

@@ -17,7 +17,6 @@
 //   vcycle_dev      MultigridOperator::operator() :362-421 with setup_parameters :525-551
 #include "hot_impl.h"
 #include "hot_svd.h"
-#include <cstdlib>
 
 namespace hot {
 
@@ -44,13 +43,13 @@ __global__ void k_xpay_dev(size_t n, const double* a, const T* __restrict__ x, T
     if (i < n) y[i] = x[i] + s * y[i];
 }
 template <class T>
-__global__ __launch_bounds__(256) void k_dot(size_t n, const T* __restrict__ x, const T* __restrict__ y, double* out)
+__global__ __launch_bounds__(256) void k_dot(size_t n, const T* __restrict__ x, const T* __restrict__ y, double* out, GridRed gr)
 {
     __shared__ double red[4];
     double s = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += (double)(x[i] * y[i]);
     double t = block_sum_256<double>(s, red);
-    if (threadIdx.x == 0) atomic_add(out, t);
+    grid_sum_store(t, 0.0, 1, gr, out, nullptr, red);
 }
 template <class T>
 void Ctx<T>::axpy(size_t n, T a, const T* x, T* y)
@@ -75,8 +74,8 @@ void Ctx<T>::zero(size_t n, T* y)
 template <class T>
 void Ctx<T>::dot_to(size_t n, const T* x, const T* y, double* out)
 {
-    HOT_HIP(hipMemsetAsync(out, 0, sizeof(double), stream));
-    HOT_LAUNCH(this, "dot", k_dot<T>, std::min(div_up(n, 1024), 256), 256, 0, n, x, y, out); // <= 256 same-address atomics
+    const int grid = std::min(div_up(n, 1024), 256);
+    HOT_LAUNCH(this, "dot", k_dot<T>, grid, 256, 0, n, x, y, out, gred(grid)); // <= 256 deposits, summed in index order
 }
 template <class T>
 double Ctx<T>::dot_host(size_t n, const T* x, const T* y)
@@ -133,12 +132,11 @@ __global__ __launch_bounds__(256) void k_apmv_sub(const int32_t* __restrict__ ap
 // ---- cg_smooth (MultigridPreconditioner.h:190-226) in three launches per iteration instead of nine.  Device scalars:
 // s[0] z'r of the current iterate, s[1] du'A du, s[4] z'r of the next one, s[6] "s[4] is to become s[0]".
 template <class T>
-__global__ __launch_bounds__(256) void k_cg_spmv_dot(const int32_t* __restrict__ col, const T* __restrict__ val, const T* __restrict__ du, T* __restrict__ dAu, int n, double* s)
+__global__ __launch_bounds__(256) void k_cg_spmv_dot(const int32_t* __restrict__ col, const T* __restrict__ val, const T* __restrict__ du, T* __restrict__ dAu, int n, double* s, GridRed gr)
 {
     __shared__ double red[4];
     if (blockIdx.x == 0 && threadIdx.x == 0) { // nobody reads s[0] / s[4] in this launch
         if (s[6] != 0.0) s[0] = s[4];
-        s[4] = 0.0;
     }
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -167,11 +165,13 @@ __global__ __launch_bounds__(256) void k_cg_spmv_dot(const int32_t* __restrict__
     }
     if (lane == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
-    if (threadIdx.x == 0) atomic_add(s + 1, red[0] + red[1] + red[2] + red[3]);
+    const double t = threadIdx.x == 0 ? red[0] + red[1] + red[2] + red[3] : 0.0;
+    __syncthreads();
+    grid_sum_store(t, 0.0, 1, gr, s + 1, nullptr, red);
 }
 // u += w du ; r -= w A du ; z = Dinv r ; s[4] += z'r      (w = s[0] / s[1])
 template <class T>
-__global__ __launch_bounds__(256) void k_cg_update(const T* __restrict__ Dinv, const T* __restrict__ du, const T* __restrict__ dAu, T* __restrict__ u, T* __restrict__ r, T* __restrict__ z, int n, double* s)
+__global__ __launch_bounds__(256) void k_cg_update(const T* __restrict__ Dinv, const T* __restrict__ du, const T* __restrict__ dAu, T* __restrict__ u, T* __restrict__ r, T* __restrict__ z, int n, double* s, GridRed gr)
 {
     __shared__ double red[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_cg_update(const T* __restrict__ Dinv, c
         part = (double)(z0 * rr[0]) + (double)(z1 * rr[1]) + (double)(z2 * rr[2]);
     }
     const double t = block_sum_256<double>(part, red);
-    if (threadIdx.x == 0) atomic_add(s + 4, t);
+    grid_sum_store(t, 0.0, 1, gr, s + 4, nullptr, red);
 }
 // du = z + b du      (b = s[4] / s[0])
 template <class T>
@@ -201,7 +201,7 @@ __global__ void k_cg_direction(size_t n3, const T* __restrict__ z, T* __restrict
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const T b = (T)(s[4] / s[0]);
     if (i < n3) du[i] = z[i] + b * du[i];
-    if (i == 0) s[1] = 0.0, s[6] = 1.0; // nobody reads them in this launch
+    if (i == 0) s[6] = 1.0; // nobody reads it in this launch
 }
 template <class T>
 __global__ void k_scal_v(size_t n, T a, T* x)
@@ -334,6 +334,7 @@ void Ctx<T>::scale_dev(Level<T>& L, const T* in, T* out)
     HOT_LAUNCH(this, "diag_scale", k_scale<T>, div_up(L.n, 256), 256, 0, L.diagInv.p, in, out, L.n);
 }
 
+#ifdef HOT_AB_KERNELS
 // One colour of one half-sweep of symmetric block GS.  FWD: h_i = Dinv (rhs_i - sum_{j<i} A_ij h_j), also writes
 // hD_i = D_i h_i ; BWD: du_i = Dinv (rhs_i - sum_{j>i} A_ij du_j).  "<" is the packed (colour, block, index) key.
 template <class T, bool FWD>
@@ -392,6 +393,8 @@ __global__ __launch_bounds__(64) void k_gs_color(const int32_t* __restrict__ col
         __syncthreads(); // single-wave workgroup: orders the LDS write before the next node's reads
     }
 }
+
+#endif
 
 // Two-phase block GS (the production path; k_gs_color above is the simple reference kernel kept for A/B checks).
 // The reference sweeps the nodes of one 4^3 colour block sequentially (MultigridPreconditioner.h:266-318).  Here a
@@ -452,7 +455,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
     int32_t* rcl = nodes + SB; // [SB][4] row class counts (from gs_pad)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = block0 + blockIdx.x;
-    const int dbg = (sub >> 8) & 255; // timing experiments only (wrong results): 1 skip phase B, 2 skip phase A
     // sub-blocks [sub & 255, +nmerge) of the colour block are processed back to back by this workgroup, in sweep order: the
     // launch boundary between them (gap, dispatch ramp, header round trip: ~7 us of a ~30 us pass) is replaced by a barrier;
     // what the later sub-block reads of the earlier one was stored before the barrier by the same workgroup
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
     __syncthreads();
     // ---------------- phase A: RQ rows of this wave are in flight at once (lane = slot of the needed half row)
     constexpr int RQ = 2;
-    for (int t0 = 0; w + nwaves * t0 < cnt && !(dbg & 2); t0 += RQ) {
+    for (int t0 = 0; w + nwaves * t0 < cnt; t0 += RQ) {
         T bv[RQ][9];
         int jj[RQ], rowi[RQ], kb[RQ], ke[RQ], ib[RQ], ie[RQ];
 #pragma unroll
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
         }
     }
     __syncthreads();
-    if (w == 0 && !(dbg & 1)) gs_phase_b<T, FWD, SB>(tri, sv, nodes, cnt, lane, diagVal, diagBlockInv, x, hD);
+    if (w == 0) gs_phase_b<T, FWD, SB>(tri, sv, nodes, cnt, lane, diagVal, diagBlockInv, x, hD);
     }
 }
 
@@ -946,13 +948,13 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         double tol = (double)(T)(zTrk0 * 0.25); // cgratio = 0.5 hard-wired (:203-209)
         HOT_HIP(hipMemcpyAsync(s, &zTrk, sizeof(double), hipMemcpyHostToDevice, stream));
         int cnt = 0;
-        static const bool cg_unfused = getenv("HOT_CG_UNFUSED") != nullptr; // A/B switch: one launch per vector operation
+        const bool cg_unfused = ab_flag("HOT_CG_UNFUSED"); // A/B build only: one launch per vector operation
         if (!cg_unfused && !(level == 0 && !cfg.systemBCProject)) {
             HOT_HIP(hipMemsetAsync(s + 1, 0, 6 * sizeof(double), stream));
             for (; iterations--;) {
                 if (zTrk < tol) break;
-                HOT_LAUNCH(this, lname("spmv", L.id).c_str(), k_cg_spmv_dot<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, du, dAu, L.n, s);
-                HOT_LAUNCH(this, "cg_update", k_cg_update<T>, div_up(L.n, 256), 256, 0, L.diagInv.p, du, dAu, u, r, z, L.n, s);
+                HOT_LAUNCH(this, lname("spmv", L.id).c_str(), k_cg_spmv_dot<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, du, dAu, L.n, s, gred(div_up(L.n, 4)));
+                HOT_LAUNCH(this, "cg_update", k_cg_update<T>, div_up(L.n, 256), 256, 0, L.diagInv.p, du, dAu, u, r, z, L.n, s, gred(div_up(L.n, 256)));
                 HOT_LAUNCH(this, "cg_direction", k_cg_direction<T>, div_up(n3, 256), 256, 0, n3, z, du, s);
                 HOT_HIP(hipMemcpyAsync(hscal + 40, s + 4, sizeof(double), hipMemcpyDeviceToHost, stream));
                 sync();
@@ -1010,11 +1012,9 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
     else if (kind == 5) {
         HOT_CHECK(L.nblocks > 0, HOT_ERR_INVALID, "GS smoother requested but the level was built without colouring");
         T* hdu = L.tmp.p;
-        static const bool simple_gs = getenv("HOT_SIMPLE_GS") != nullptr; // A/B switch: one-wave-per-block reference kernel
-        static const int env_threads = getenv("HOT_GS_THREADS") ? atoi(getenv("HOT_GS_THREADS")) : 0;
-        static const int env_sb = getenv("HOT_GS_SB") ? atoi(getenv("HOT_GS_SB")) : 0; // sub-block size 16 / 32 / 64
-        static const bool no_lres = getenv("HOT_GS_FULL_RESIDUAL") != nullptr; // A/B switch: r -= A du by a full SpMV
-        static const int gs_dbg = getenv("HOT_GS_DBG") ? atoi(getenv("HOT_GS_DBG")) : 0; // timing experiments only (wrong results)
+        const bool simple_gs = ab_flag("HOT_SIMPLE_GS"); // A/B build only: one-wave-per-block reference kernel
+        const int env_sb = cfg.gs_sub_block; // tuning override: sub-block size 16 / 32 / 64 (0 = by level size)
+        const bool no_lres = ab_flag("HOT_GS_FULL_RESIDUAL"); // A/B build only: r -= A du by a full SpMV
         if (!attr_gs_set) {
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
@@ -1027,12 +1027,12 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         int max_nb = 0;
         for (int c = 0; c < 8; ++c) max_nb = std::max(max_nb, L.color_block_begin[c + 1] - L.color_block_begin[c]);
         const int sb = env_sb ? env_sb : (max_nb > 256 ? 32 : 64);
-        const int gs_threads = env_threads ? env_threads : (sb == 64 ? 1024 : 512);
+        const int gs_threads = sb == 64 ? 1024 : 512;
         const int nsub = 64 / sb;
         HOT_CHECK(L.split || simple_gs, HOT_ERR_INVALID, "block GS kernels need the regrouped rows (k_gs_split_rows)");
         const int32_t* rc = L.rowcnt.p;
         // one launch per colour: its sub-blocks are walked inside the kernel (A/B switch: one launch per sub-block)
-        const bool split_launches = getenv("HOT_GS_SPLIT_LAUNCHES") != nullptr; // read per call: tools/gs_merge_check.py flips it on one matrix
+        const bool split_launches = ab_flag("HOT_GS_SPLIT_LAUNCHES"); // A/B build only, read per call: the tests flip it on one matrix
         const int nmerge = (split_launches || simple_gs) ? 1 : nsub;
         auto pass = [&](bool fwd, int c, int h) {
             int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
@@ -1042,6 +1042,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             const T* rhs = fwd ? r : dAu;
             T* xx = fwd ? hdu : du;
             T* hD = fwd ? dAu : (simple_gs ? (T*)nullptr : u); // backward block kernels add du to u themselves
+#ifdef HOT_AB_KERNELS
             if (simple_gs) {
                 if (h != 0) return;
                 if (fwd)
@@ -1050,9 +1051,10 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                     HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_color<T, false>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, b0, nb);
                 return;
             }
+#endif
 #define HOT_GS_CASE(F, S)                                                                                                                                      \
     HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_block<T, F, S>), nb, gs_threads, (GsLds<T, S>::bytes), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
-        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, b0, h | (gs_dbg << 8) | (nmerge << 16), rc, L.gs_pad.p)
+        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, b0, h | (nmerge << 16), rc, L.gs_pad.p)
             if (fwd) {
                 if (sb == 64) HOT_GS_CASE(true, 64);
                 else if (sb == 32) HOT_GS_CASE(true, 32);
@@ -1065,14 +1067,14 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             }
 #undef HOT_GS_CASE
         };
-        HOT_CHECK(sb == 16 || sb == 32 || sb == 64, HOT_ERR_INVALID, "HOT_GS_SB must be 16, 32 or 64");
+        HOT_CHECK(sb == 16 || sb == 32 || sb == 64, HOT_ERR_INVALID, "hot_config.gs_sub_block must be 0 (auto), 16, 32 or 64");
+        HOT_CHECK(cfg.gs_chain >= 0 && cfg.gs_chain <= 2, HOT_ERR_INVALID, "hot_config.gs_chain must be 0 (auto), 1 (one launch per colour) or 2 (one chained launch per half sweep)");
         // one launch per half sweep (k_gs_sweep, passes chained by device-scope counters) unless the A/B switches ask
         // for one launch per pass
-        static const bool multilaunch = getenv("HOT_GS_MULTILAUNCH") != nullptr;
-        static const bool force_dataflow = getenv("HOT_GS_DATAFLOW") != nullptr;
+        const bool multilaunch = cfg.gs_chain == 1, force_dataflow = cfg.gs_chain == 2; // tuning overrides (0 = by level size)
         // measured (C2, fp64): the chained launch wins on levels whose colours fit the chip in one round (latency-bound
         // passes, no launch gaps); on the finest level the waiting workgroups cost more than the kernel boundaries
-        const bool dataflow = !multilaunch && !simple_gs && L.split && !gs_dbg && (force_dataflow || max_nb <= 256);
+        const bool dataflow = !gs_no_chain && !multilaunch && !simple_gs && L.split && (force_dataflow || max_nb <= 256);
         GsPasses PF{}, PB{};
         if (dataflow) {
             auto add = [&](GsPasses& P, int c, int h) {
@@ -1095,7 +1097,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             T* xx = fwd ? hdu : du;
             T* hD = fwd ? dAu : (simple_gs ? (T*)nullptr : u); // backward block kernels add du to u themselves
             // hand-off between passes: point-to-point block flags when a block is one sub-block (A/B switch: pass counters)
-            static const bool pass_counters = getenv("HOT_GS_PASS_COUNTERS") != nullptr;
+            const bool pass_counters = ab_flag("HOT_GS_PASS_COUNTERS");
             const bool p2p = !pass_counters;
             if (p2p)
                 ++gs_epoch;
@@ -1195,7 +1197,7 @@ void Ctx<T>::vcycle_dev(const T* in, T* out)
         size_t n3 = 3 * (size_t)L.n;
         prolong_dev(level, levels[level + 1]->sol.p, L.du.p);
         axpy(n3, (T)1, L.du.p, sol);
-        static const bool full_spmv = getenv("HOT_MG_FULL_SPMV") != nullptr; // A/B switch: r -= A (P e) like the reference
+        const bool full_spmv = ab_flag("HOT_MG_FULL_SPMV"); // A/B build only: r -= A (P e) like the reference
         if (full_spmv) {
             spmv_dev(L, L.du.p, L.dAu.p);
             axpy(n3, (T)-1, L.dAu.p, L.residual.p);
@@ -1257,12 +1259,16 @@ void Ctx<T>::smooth(int32_t level, int32_t kind, int32_t iterations, double tol,
     need(level >= 0 && level < (int)levels.size() && levels[level]->built, "hot_smooth: level not built (hot_build_mg)");
     Level<T>& L = *levels[level];
     size_t n3 = 3 * (size_t)L.n;
-    DBuf<T> du_, dr_;
-    du_.reserve(n3), dr_.reserve(n3);
-    HOT_HIP(hipMemcpyAsync(du_.p, u, n3 * sizeof(T), hipMemcpyDefault, stream));
-    HOT_HIP(hipMemcpyAsync(dr_.p, r, n3 * sizeof(T), hipMemcpyDefault, stream));
-    HOT_HIP(hipMemcpyAsync(L.initialResidual.p, r0 ? r0 : r, n3 * sizeof(T), hipMemcpyDefault, stream));
-    smooth_dev(level, kind, iterations, (T)tol, du_.p, dr_.p, L.du.p, L.dAu.p);
+    DBuf<T> du_, dr_, r0_;
+    du_.reserve(n3), dr_.reserve(n3), r0_.reserve(n3);
+    HOT_HIP(hipMemcpyAsync(r0_.p, r0 ? r0 : r, n3 * sizeof(T), hipMemcpyDefault, stream)); // r may be overwritten below
+    with_gs_retry([&] {
+        HOT_HIP(hipMemcpyAsync(du_.p, u, n3 * sizeof(T), hipMemcpyDefault, stream));
+        HOT_HIP(hipMemcpyAsync(dr_.p, r, n3 * sizeof(T), hipMemcpyDefault, stream));
+        HOT_HIP(hipMemcpyAsync(L.initialResidual.p, r0_.p, n3 * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        smooth_dev(level, kind, iterations, (T)tol, du_.p, dr_.p, L.du.p, L.dAu.p);
+        sync();
+    });
     download(u, du_.p, n3);
     download(r, dr_.p, n3);
     sync();
@@ -1273,7 +1279,10 @@ void Ctx<T>::vcycle(const void* in, void* out)
     need(!levels.empty() && levels[0]->built, "hot_vcycle before hot_build_mg");
     size_t n3 = 3 * (size_t)Nn;
     HOT_HIP(hipMemcpyAsync(work0.p, in, n3 * sizeof(T), hipMemcpyDefault, stream));
-    vcycle_dev(work0.p, work1.p);
+    with_gs_retry([&] {
+        vcycle_dev(work0.p, work1.p);
+        sync();
+    });
     download(out, work1.p, n3);
     sync();
 }

@@ -18,12 +18,11 @@
 #include "hot_svd.h"
 #include "hot_collision.h"
 #include <cmath>
-#include <cstdlib>
 
 namespace hot {
 
 template <class T>
-__global__ __launch_bounds__(256) void k_scaled_norm(const T* __restrict__ r, const T* __restrict__ tol, int nn, int useCN, double* out)
+__global__ __launch_bounds__(256) void k_scaled_norm(const T* __restrict__ r, const T* __restrict__ tol, int nn, int useCN, double* out, GridRed gr)
 {
     __shared__ double red[4];
     double s = 0;
@@ -34,7 +33,7 @@ __global__ __launch_bounds__(256) void k_scaled_norm(const T* __restrict__ r, co
         s += (double)q;
     }
     double t = block_sum_256<double>(s, red);
-    if (threadIdx.x == 0) atomic_add(out, t);
+    grid_sum_store(t, 0.0, 1, gr, out, nullptr, red);
 }
 // out = dv0 + alpha * ddv
 template <class T>
@@ -65,7 +64,7 @@ __global__ void k_lbfgs_scalar(double* s, int i, int what)
 // step needs, taken on the freshly updated y (z == nullptr on the last step).  Same arithmetic as the unfused
 // dot / k_lbfgs_scalar / axpy sequence, one third of the launches and two thirds of the bytes.
 template <class T>
-__global__ __launch_bounds__(256) void k_lbfgs_fused(size_t n, double* s, int in_slot, int out_slot, int ph, int what, const T* __restrict__ v, T* __restrict__ y, const T* __restrict__ z)
+__global__ __launch_bounds__(256) void k_lbfgs_fused(size_t n, double* s, int in_slot, int out_slot, int ph, int what, const T* __restrict__ v, T* __restrict__ y, const T* __restrict__ z, GridRed gr)
 {
     __shared__ double red[4];
     const double tmp = s[in_slot];
@@ -80,12 +79,12 @@ __global__ __launch_bounds__(256) void k_lbfgs_fused(size_t n, double* s, int in
     }
     if (z) { // kernel-uniform
         double t = block_sum_256<double>(acc, red);
-        if (threadIdx.x == 0) atomic_add(s + out_slot, t);
+        grid_sum_store(t, 0.0, 1, gr, s + out_slot, nullptr, red);
     }
 }
 // dst = src (optional) and dot_out += z . src in the same pass
 template <class T>
-__global__ __launch_bounds__(256) void k_copy_dot(size_t n, double* s, int out_slot, const T* __restrict__ src, T* __restrict__ dst, const T* __restrict__ z)
+__global__ __launch_bounds__(256) void k_copy_dot(size_t n, double* s, int out_slot, const T* __restrict__ src, T* __restrict__ dst, const T* __restrict__ z, GridRed gr)
 {
     __shared__ double red[4];
     double acc = 0;
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(256) void k_copy_dot(size_t n, double* s, int out_s
     }
     if (z) {
         double t = block_sum_256<double>(acc, red);
-        if (threadIdx.x == 0) atomic_add(s + out_slot, t);
+        grid_sum_store(t, 0.0, 1, gr, s + out_slot, nullptr, red);
     }
 }
 
@@ -104,8 +103,10 @@ template <class T>
 bool Ctx<T>::should_exit(const T* r)
 {
     if (Nn == 0) return true;
-    HOT_HIP(hipMemsetAsync(dscal.p + 90, 0, sizeof(double), stream));
-    HOT_LAUNCH(this, "exit_norm", k_scaled_norm<T>, std::min(div_up(Nn, 256), 1024), 256, 0, r, cnTol.p, Nn, cfg.useCN, dscal.p + 90);
+    {
+        const int grid = std::min(div_up(Nn, 256), 1024);
+        HOT_LAUNCH(this, "exit_norm", k_scaled_norm<T>, grid, 256, 0, r, cnTol.p, Nn, cfg.useCN, dscal.p + 90, gred(grid));
+    }
     HOT_HIP(hipMemcpyAsync(hscal + 90, dscal.p + 90, sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
     double v = hscal[90];
@@ -140,7 +141,7 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
         }
         stats.linesearch_trials++;
         alpha *= (T)0.5;
-        if (getenv("HOT_DEBUG")) fprintf(stderr, "[hot]   linesearch alpha=%g Ek=%.12e Ek0=%.12e\n", (double)alpha * 2, Ek, Ek0);
+        if (ab_flag("HOT_DEBUG")) fprintf(stderr, "[hot]   linesearch alpha=%g Ek=%.12e Ek0=%.12e\n", (double)alpha * 2, Ek, Ek0);
     } while (Ek > Ek0 && ++guard < 60);
     alpha *= 2;
     HOT_LAUNCH(this, "scal", k_scal<T>, div_up(n3, 256), 256, 0, n3, alpha, ddv);
@@ -184,7 +185,7 @@ bool Ctx<T>::lbfgs_solve()
     for (int it = 0; it < cfg.max_iterations; ++it) {
         stats.iterations = it;
         bool ex = should_exit(residual);
-        if (getenv("HOT_DEBUG")) fprintf(stderr, "[hot] lbfgs it=%d scaled_res=%.6e Ek=%.12e hist=%d\n", it, stats.final_scaled_residual, Ek, (int)order.size() - 1);
+        if (ab_flag("HOT_DEBUG")) fprintf(stderr, "[hot] lbfgs it=%d scaled_res=%.6e Ek=%.12e hist=%d\n", it, stats.final_scaled_residual, Ek, (int)order.size() - 1);
         if (ex) {
             stats.converged = 1;
             return true;
@@ -198,9 +199,8 @@ bool Ctx<T>::lbfgs_solve()
         }
         int wk = order.back();
         const int m = (int)order.size() - 1; // stored curvature pairs
-        static const bool unfused = getenv("HOT_LBFGS_UNFUSED") != nullptr; // A/B switch: dot / scalar / axpy as separate launches
-        static const int vgrid_max = getenv("HOT_LBFGS_GRID") ? atoi(getenv("HOT_LBFGS_GRID")) : 512;
-        const int vgrid = (int)std::min<size_t>(div_up(n3, 1024), vgrid_max);
+        const bool unfused = ab_flag("HOT_LBFGS_UNFUSED"); // A/B build only: dot / scalar / axpy as separate launches
+        const int vgrid = (int)std::min<size_t>(div_up(n3, 1024), 512);
         if (unfused) {
             copy(n3, residual, hist_dg[wk].p);
             for (int i = m - 1; i >= 0; --i) {
@@ -211,13 +211,12 @@ bool Ctx<T>::lbfgs_solve()
             }
         }
         else {
-            // dot slots: 140 + k for step k of the first loop, 160 + k for the second
-            HOT_HIP(hipMemsetAsync(s + 140, 0, 40 * sizeof(double), stream));
-            HOT_LAUNCH(this, "lbfgs_copy_dot", k_copy_dot<T>, vgrid, 256, 0, n3, s, 140, residual, hist_dg[wk].p, m > 0 ? hist_dx[order[m - 1]].p : (const T*)nullptr);
+            // dot slots: 140 + k for step k of the first loop, 160 + k for the second (each written by exactly one launch)
+            HOT_LAUNCH(this, "lbfgs_copy_dot", k_copy_dot<T>, vgrid, 256, 0, n3, s, 140, residual, hist_dg[wk].p, m > 0 ? hist_dx[order[m - 1]].p : (const T*)nullptr, gred(vgrid));
             for (int k = 0; k < m; ++k) {
                 int ph = order[m - 1 - k];
                 const T* znext = k + 1 < m ? hist_dx[order[m - 2 - k]].p : (const T*)nullptr;
-                HOT_LAUNCH(this, "lbfgs_fused", k_lbfgs_fused<T>, vgrid, 256, 0, n3, s, 140 + k, 141 + k, ph, 0, hist_dg[ph].p, residual, znext);
+                HOT_LAUNCH(this, "lbfgs_fused", k_lbfgs_fused<T>, vgrid, 256, 0, n3, s, 140 + k, 141 + k, ph, 0, hist_dg[ph].p, residual, znext, gred(vgrid));
             }
         }
         precondition_dev(residual, hist_dx[wk].p);
@@ -231,11 +230,11 @@ bool Ctx<T>::lbfgs_solve()
             }
         }
         else if (m > 0) {
-            HOT_LAUNCH(this, "lbfgs_copy_dot", k_copy_dot<T>, vgrid, 256, 0, n3, s, 160, hist_dx[wk].p, (T*)nullptr, hist_dg[order[0]].p);
+            HOT_LAUNCH(this, "lbfgs_copy_dot", k_copy_dot<T>, vgrid, 256, 0, n3, s, 160, hist_dx[wk].p, (T*)nullptr, hist_dg[order[0]].p, gred(vgrid));
             for (int k = 0; k < m; ++k) {
                 int ph = order[k];
                 const T* znext = k + 1 < m ? hist_dg[order[k + 1]].p : (const T*)nullptr;
-                HOT_LAUNCH(this, "lbfgs_fused", k_lbfgs_fused<T>, vgrid, 256, 0, n3, s, 160 + k, 161 + k, ph, 1, hist_dx[ph].p, hist_dx[wk].p, znext);
+                HOT_LAUNCH(this, "lbfgs_fused", k_lbfgs_fused<T>, vgrid, 256, 0, n3, s, 160 + k, 161 + k, ph, 1, hist_dx[ph].p, hist_dx[wk].p, znext, gred(vgrid));
             }
         }
         if (cfg.linesearch) line_search(hist_dx[wk].p, residual, (T)1);
@@ -480,12 +479,26 @@ void Ctx<T>::solve(hot_stats* st)
     stats.ms_sort = keep_sort, stats.ms_p2g = keep_p2g, stats.ms_begin = keep_begin;
     double t0 = wall_ms();
     if (cfg.useCN) cn_tolerance_dev();
-    release_levels();
-    if (cfg.lsolver == 3)
-        lbfgs_solve();
-    else
-        newton_solve();
-    sync();
+    // what the solve overwrites of its own inputs, kept for the (never yet observed) redo after a timed-out chained sweep
+    const size_t n3 = 3 * (size_t)Nn;
+    solve_keep.reserve(2 * n3, 1.25);
+    copy(n3, dv.p, solve_keep.p), copy(n3, dv0.p, solve_keep.p + n3);
+    const double Ek_in = Ek;
+    const hot_stats stats_in = stats;
+    bool first_try = true;
+    with_gs_retry([&] {
+        if (!first_try) {
+            copy(n3, solve_keep.p, dv.p), copy(n3, solve_keep.p + n3, dv0.p);
+            updated = false, Ek = Ek_in, stats = stats_in; // the state pass is redone from dv (the failed attempt overwrote the force tiles)
+        }
+        first_try = false;
+        release_levels();
+        if (cfg.lsolver == 3)
+            lbfgs_solve();
+        else
+            newton_solve();
+        sync();
+    });
     prof.collect();
     stats.num_nodes = Nn;
     stats.num_levels = (int)levels.size();
@@ -552,10 +565,9 @@ void Ctx<T>::calculate_dt(double max_dt, double* dt_out, double* max_speed, doub
 {
     need(Np > 0, "hot_calculate_dt before hot_set_particles");
     const int nb = (int)std::min<int64_t>(div_up(Np, 1024), 256);
-    DBuf<T> part;
-    part.reserve(8 * (size_t)nb);
-    HOT_LAUNCH(this, "max_speed", k_max_speed<T>, nb, 256, 0, pX.p, pV.p, Np, part.p);
-    HOT_LAUNCH(this, "max_speed_fold", k_max_fold<T>, 1, 64, 0, part.p, nb, dscal.p + 200);
+    speed_part.reserve(8 * 256); // kept across calls: once per substep in advance_frame
+    HOT_LAUNCH(this, "max_speed", k_max_speed<T>, nb, 256, 0, pX.p, pV.p, Np, speed_part.p);
+    HOT_LAUNCH(this, "max_speed_fold", k_max_fold<T>, 1, 64, 0, speed_part.p, nb, dscal.p + 200);
     HOT_HIP(hipMemcpyAsync(hscal + 200, dscal.p + 200, 7 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
     T ms = (T)hscal[200];

@@ -229,6 +229,8 @@ Ctx<T>::Ctx(const hot_config& c)
     prof.on = c.profile != 0;
     keep_debug = c.debug_store != 0;
     dscal.reserve(256);
+    red_part.reserve(4096), red_count.reserve(4);
+    HOT_HIP(hipMemset(red_count.p, 0, 4 * sizeof(unsigned)));
     HOT_HIP(hipHostMalloc((void**)&hscal, 256 * sizeof(double)));
     std::memset(hscal, 0, 256 * sizeof(double)); // hscal[250] doubles as the device-written k_gs_sweep wait-timeout flag
     std::memset(&stats, 0, sizeof(stats));

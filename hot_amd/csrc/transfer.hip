@@ -16,7 +16,6 @@
 //                  fused: node tile staged in LDS, particle streams fully coalesced.
 #include "hot_impl.h"
 #include "hot_constitutive.h"
-#include <cstdlib>
 
 namespace hot {
 
@@ -32,6 +31,7 @@ __device__ __forceinline__ int tile_slot(int t, const int32_t* __restrict__ nb8)
     return nb8[ox * 4 + oy * 2 + oz] * G::EPB + elem;
 }
 
+#ifdef HOT_AB_KERNELS
 template <class T, bool WITH_CN>
 __global__ __launch_bounds__(256) void k_p2g(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C,
     const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
@@ -89,6 +89,8 @@ __global__ __launch_bounds__(256) void k_p2g(const T* __restrict__ X, const T* _
     T* out = part + (int64_t)g * NQ * TILE;
     for (int t = threadIdx.x; t < NQ * TILE; t += 256) out[t] = (&acc[0][0])[t];
 }
+
+#endif
 
 // Production P2G.  The particles of one base cell share their 27 support nodes, so a (cell, node column) work item sums
 // the contributions of the whole cell to its 3 nodes in registers and touches the LDS accumulator once per node and
@@ -256,21 +258,21 @@ void Ctx<T>::p2g()
     double t0 = wall_ms();
     int64_t slots = (int64_t)Nb * EPB;
     T one_over_dx = (T)1 / dx;
-    static const bool p2g_v1 = getenv("HOT_P2G_V1") != nullptr; // A/B switch: one LDS atomic per particle, node and quantity
-    if (cfg.useCN) {
-        if (p2g_v1)
+    const int nq = cfg.useCN ? 5 : 4;
+#ifdef HOT_AB_KERNELS
+    if (ab_flag("HOT_P2G_V1")) { // one LDS atomic per particle, node and quantity
+        if (cfg.useCN)
             HOT_LAUNCH(this, "p2g", (k_p2g<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, dx, one_over_dx);
         else
-            HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, true>), Ng, P2G_THREADS, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
-        reduce_tiles(5, gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p, "p2g_reduce");
-    }
-    else {
-        if (p2g_v1)
             HOT_LAUNCH(this, "p2g", (k_p2g<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, dx, one_over_dx);
-        else
-            HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, false>), Ng, P2G_THREADS, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
-        reduce_tiles(4, gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p, "p2g_reduce");
     }
+    else
+#endif
+    if (cfg.useCN)
+        HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, true>), Ng, P2G_THREADS, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
+    else
+        HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, false>), Ng, P2G_THREADS, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
+    reduce_tiles(nq, gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p, "p2g_reduce");
     HOT_LAUNCH(this, "block_count", k_block_count<T>, div_up(Nb, 4), 256, 0, gM.p, block_count.p, Nb);
     scan.reserve(Nb + 1);
     Nn = exclusive_scan_i32(block_count.p, scan.p, Nb);

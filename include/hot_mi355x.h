@@ -74,7 +74,9 @@ typedef struct hot_config {
     int32_t profile; /* 1: bracket every kernel launch with HIP events on the launch stream */
     int32_t debug_store; /* 1: also keep per-particle grad v for hot_get_particle_state (extra 9 stores per particle and pass) */
     int32_t useBaselineMultigrid; /* --baseline: geometric multigrid, every coarse level a real MPM grid of spacing 2^l dx whose matrix is re-rasterised from the particles */
-    int32_t reserved[5];
+    int32_t gs_chain; /* tuning override of the coloured-GS launch structure: 0 = by level size (default), 1 = one launch per colour, 2 = one chained launch per half sweep */
+    int32_t gs_sub_block; /* tuning override: nodes of a 4^3 colour block one workgroup substitutes at a time, 0 = by level size, or 16 / 32 / 64 */
+    int32_t reserved[3];
 } hot_config;
 
 typedef struct hot_stats {

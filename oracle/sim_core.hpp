@@ -467,6 +467,10 @@ struct Sim {
         for (int k = 0; k < 3; ++k) X.a[k] = ((T)o.R[3 * k] * xb(0) + (T)o.R[3 * k + 1] * xb(1) + (T)o.R[3 * k + 2] * xb(2)) * one_over_s; // R^T (x - b) / s
         bool colliding = false;
         if (o.shape == HOT_SHAPE_HALFSPACE) {
+            {
+                const T nn = std::sqrt(p1.squaredNorm()); // HalfSpace stores outward_normal.normalized() (AnalyticLevelSet.cpp:111-115)
+                p1 = TV{ { p1(0) / nn, p1(1) / nn, p1(2) / nn } };
+            }
             T phi = p1.dot(X - p0);
             colliding = phi <= (T)0;
             N = p1;

@@ -3,6 +3,8 @@ library on the GPU).  They re-create the reference's opt-in runtime self-checks 
 runDiffTest (Lib/Ziran/Sim/DiffTest.h:19-138), matrixSanityCheck (Projects/multigrid/ImplicitSolver.h:698-739),
 symmetricSanityCheck / PDSanityCheck (Projects/multigrid/SquareMatrix.h:84-194), checkPreconditioningMatrix
 (Lib/Ziran/Math/Nonlinear/LBFGS.h:95-175), plus analytic known answers."""
+import os
+
 import numpy as np
 
 from hot_amd import synth
@@ -10,6 +12,10 @@ from hot_amd import synth
 
 def make_ctx(lib, n=6, dtype=1, bc=True, seed=123, noise=0.1, E=5e4, ppc=8, cells=None, **kw):
     T = np.float64 if dtype == 1 else np.float32
+    for item in os.environ.get("HOT_TEST_CFG", "").split(","):  # hot_config overrides from tests/test_gpu_variants.py
+        if item:
+            k, v = item.split("=")
+            kw.setdefault(k, int(v))
     c = synth.cube_cloud(n, ppc=ppc, dtype=T, seed=seed, noise=noise, E=E, cells=cells)
     kw.setdefault("debug_store", 1)  # tests read back per-particle grad v
     ctx = lib.context(dtype=dtype, dx=c["dx"], gravity=(0, -9.8, 0), **kw)

@@ -131,8 +131,10 @@ def test_gs_colour_launch_equals_sub_block_launches(hotlib, cname, n):
     the earlier one stored.  With a launch per sub-block (HOT_GS_SPLIT_LAUNCHES, read per call) the arithmetic is the same,
     so on one and the same matrix the V-cycle is bitwise identical."""
     import os
+    import hot_amd
+    ablib = hot_amd.HotLib(hot_amd.AB_LIB_PATH)  # the launch-structure switch exists only in the A/B build of the library
     cfg = synth.CONFIGS[cname]
-    ctx, cloud = make(hotlib, cfg, n)
+    ctx, cloud = make(ablib, cfg, n)
     ctx.sort(), ctx.p2g(), ctx.begin_step(cfg["dt"])
     ctx.update_state(ctx.get_dv())
     ctx.build_hessian(), ctx.build_mg()

@@ -1,8 +1,10 @@
 """The library picks kernel variants by problem size (block GS: one launch per colour on large levels, one chained launch
-per half sweep with point-to-point block flags on small ones; sub-block size 32 / 64) and keeps first-generation kernels behind
-A/B switches.  The parity tests use small problems, so without this file only the small-problem variants would be
-compared with the oracle.  Each case re-runs the relevant parity tests in a subprocess with the switch set (the
-switches are read once per process)."""
+per half sweep with point-to-point block flags on small ones; sub-block size 32 / 64); hot_config.gs_chain / gs_sub_block
+override the choice.  The parity tests use small problems, so without this file only the small-problem variants would be
+compared with the oracle.  First-generation kernels and launch-structure alternatives live only in the A/B build of the
+library (libhotmi355x_ab.so, -DHOT_AB_KERNELS), where environment variables select them.  Each case re-runs the relevant
+parity tests in a subprocess: HOT_TEST_CFG carries hot_config overrides that tests/pipeline_checks.make_ctx applies,
+HOT_AMD_AB=1 makes hot_amd.load() pick the A/B build."""
 import os
 import subprocess
 import sys
@@ -13,14 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SOLVER = "tests/test_gpu_solver.py"
 CASES = [
-    ({"HOT_GS_MULTILAUNCH": "1", "HOT_GS_SB": "32"}, SOLVER, "smoothers or vcycle or iterates"),
-    ({"HOT_GS_MULTILAUNCH": "1", "HOT_GS_SB": "16"}, SOLVER, "smoothers or vcycle"),
-    ({"HOT_GS_MULTILAUNCH": "1", "HOT_GS_SB": "64"}, SOLVER, "smoothers or vcycle"),
-    ({"HOT_GS_DATAFLOW": "1", "HOT_GS_SB": "32"}, SOLVER, "smoothers or vcycle or iterates"),
-    ({"HOT_GS_DATAFLOW": "1", "HOT_GS_SB": "16"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32"}, SOLVER, "smoothers or vcycle or iterates"),
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=16"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=64"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_TEST_CFG": "gs_chain=2,gs_sub_block=32"}, SOLVER, "smoothers or vcycle or iterates"),
+    ({"HOT_TEST_CFG": "gs_chain=2,gs_sub_block=16"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_GS_PASS_COUNTERS": "1"}, SOLVER, "smoothers or vcycle or iterates"),
-    ({"HOT_GS_DATAFLOW": "1", "HOT_GS_SB": "32", "HOT_GS_PASS_COUNTERS": "1"}, SOLVER, "smoothers or vcycle"),
-    ({"HOT_GS_MULTILAUNCH": "1", "HOT_GS_SB": "32", "HOT_GS_SPLIT_LAUNCHES": "1"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_TEST_CFG": "gs_chain=2,gs_sub_block=32", "HOT_GS_PASS_COUNTERS": "1"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_SPLIT_LAUNCHES": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_SIMPLE_GS": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_GS_FULL_RESIDUAL": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_MG_FULL_SPMV": "1"}, SOLVER, "vcycle or iterates"),
@@ -38,6 +40,8 @@ CASES = [
 def test_kernel_variant_parity(env, path, expr):
     e = dict(os.environ)
     e.update(env)
+    if any(k != "HOT_TEST_CFG" for k in env):
+        e["HOT_AMD_AB"] = "1"  # environment switches exist only in the A/B build
     r = subprocess.run([sys.executable, "-m", "pytest", path, "-x", "-q", "-m", "gpu", "-k", expr, "-p", "no:cacheprovider"], cwd=ROOT, env=e,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
