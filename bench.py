@@ -68,6 +68,7 @@ def host_cores():
 def make_ctx(lib, cloud, cfg, device=0, profile=0, **over):
     from hot_amd import synth
     kw = dict(dtype=1 if cloud["X"].dtype == np.float64 else 0, dx=cloud["dx"], gravity=(0, -9.8, 0), levelCnt=cfg["levelCnt"], device=device, profile=profile)
+    kw.update(synth.plasticity_kwargs(cfg))
     kw.update(over)
     ctx = lib.context(**kw)
     ctx.set_particles(cloud["X"], cloud["V"], cloud["mass"], cloud["vol"], cloud["mu"], cloud["lam"])

@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "get_counts", "get_indexing", "p2g", "get_grid", "set_bc", "set_sticky_halfspaces", "set_collision_objects", "begin_step", "get_dv",
     "set_dv", "update_state", "get_particle_state", "residual", "project", "cn_tolerance", "build_hessian",
     "matfree_multiply", "build_mg", "get_level", "get_matrix", "get_level_nnzb", "get_prolongation", "spmv", "restrict", "prolong",
-    "smooth", "vcycle", "solve", "g2p", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
+    "smooth", "vcycle", "solve", "g2p", "constitutive_eval", "plasticity_eval", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
 ]
 
 
@@ -119,6 +119,8 @@ class HotLib:
             "vcycle": (C.c_int, [vp, vp, vp]),
             "solve": (C.c_int, [vp, P(hot_stats)]),
             "g2p": (C.c_int, [vp, dbl, P(i32)]),
+            "constitutive_eval": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp, vp]),
+            "plasticity_eval": (C.c_int, [vp, i32, i32, vp, vp, vp, vp]),
             "advance": (C.c_int, [vp, dbl, P(hot_stats)]),
             "calculate_dt": (C.c_int, [vp, dbl, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_double)]),
             "advance_frame": (C.c_int, [vp, dbl, dbl, dbl, P(C.c_int32), P(C.c_int32), P(hot_stats)]),
@@ -398,6 +400,27 @@ class Context:
         f = C.c_int32()
         self._call("g2p", C.c_double(dt), C.byref(f))
         return f.value
+
+    def constitutive_eval(self, F, mu, lam, project=True, derivative=True):
+        """psi (n), P (n,9), dPdF (n,81 or None) of the fixed-corotated model for deformation gradients F (n,9 column-major)."""
+        F = np.ascontiguousarray(F, self.T).reshape(-1, 9)
+        n = F.shape[0]
+        mu = np.ascontiguousarray(np.broadcast_to(mu, (n,)), self.T)
+        lam = np.ascontiguousarray(np.broadcast_to(lam, (n,)), self.T)
+        psi, P = np.empty(n, self.T), np.empty((n, 9), self.T)
+        D = np.empty((n, 81), self.T) if derivative else None
+        self._call("constitutive_eval", C.c_int32(n), _ptr(F), _ptr(mu), _ptr(lam), C.c_int32(int(project)), _ptr(psi), _ptr(P), _ptr(D))
+        return psi, P, D
+
+    def plasticity_eval(self, kind, F, mu, lam, Jp=None):
+        """In-place return mapping (1 von Mises with cfg.yield_stress, 2 snow with cfg.snow) on copies: (F, mu, lam, Jp)."""
+        F = np.array(F, self.T, order="C").reshape(-1, 9)
+        n = F.shape[0]
+        mu = np.array(np.broadcast_to(mu, (n,)), self.T)
+        lam = np.array(np.broadcast_to(lam, (n,)), self.T)
+        Jp = np.ones(n, self.T) if Jp is None else np.array(Jp, self.T)
+        self._call("plasticity_eval", C.c_int32(kind), C.c_int32(n), _ptr(F), _ptr(mu), _ptr(lam), _ptr(Jp))
+        return F, mu, lam, Jp
 
     def advance(self, dt):
         st = hot_stats()

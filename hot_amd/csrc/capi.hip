@@ -292,6 +292,18 @@ int hot_g2p(hot_ctx* ctx, double dt, int32_t* flags)
     ctx->impl->g2p(dt, flags);
     HOT_API_END
 }
+int hot_constitutive_eval(hot_ctx* ctx, int32_t n, const void* F, const void* mu, const void* lambda, int32_t project, void* psi, void* P, void* dPdF)
+{
+    HOT_API_BEGIN
+    ctx->impl->constitutive_eval(n, F, mu, lambda, project, psi, P, dPdF);
+    HOT_API_END
+}
+int hot_plasticity_eval(hot_ctx* ctx, int32_t kind, int32_t n, void* F, void* mu, void* lambda, void* Jp)
+{
+    HOT_API_BEGIN
+    ctx->impl->plasticity_eval(kind, n, F, mu, lambda, Jp);
+    HOT_API_END
+}
 int hot_advance(hot_ctx* ctx, double dt, hot_stats* stats)
 {
     HOT_API_BEGIN

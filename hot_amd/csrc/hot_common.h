@@ -207,8 +207,13 @@ __device__ inline T block_sum_256(T v, T* sm4)
 // Order-deterministic grid-wide sum (blockDim.x == 256), one launch: every workgroup deposits its total, the one that
 // arrives last adds the deposits in index order and STORES the result (no same-address floating-point atomics, whose
 // arrival order changes the rounding from run to run and, between ranks of a sharded solve, from rank to rank).
-// Deposits and the arrival counter are agent-scope atomics, so they are coherent across the 8 XCD L2s; the counter is
-// left at 0 for the next launch on the stream.  t0 / t1: block totals, valid in thread 0 (block_sum_256).
+// Deposits and the arrival counter are RELAXED agent-scope atomics: on gfx950 those are performed at the device-coherent level
+// (sc1 write-through stores / L2-bypassing loads), past the per-XCD L2s, so no cache write-back or invalidate is needed; the
+// deposit is ordered before the counter increment by s_waitcnt vmcnt(0) (the store has been acknowledged by then).  A
+// release / acquire pair would be the portable spelling, but at agent scope it compiles to buffer_wbl2 + buffer_inv, which
+// flush and invalidate the XCD's whole L2 once per workgroup (measured: k_state 0.25 -> 0.65 ms at 37 k workgroups).
+// The same hardware-level hand-off is used by k_gs_sweep (mg_solve.hip).  The counter is left at 0 for the next launch on
+// the stream.  t0 / t1: block totals, valid in thread 0 (block_sum_256).
 struct GridRed {
     double* part; // >= 2 * gridDim.x
     unsigned* count;
@@ -220,7 +225,8 @@ __device__ inline void grid_sum_store(double t0, double t1, int nv, GridRed gr, 
     if (threadIdx.x == 0) {
         __hip_atomic_store(gr.part + blockIdx.x, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (nv > 1) __hip_atomic_store(gr.part + nb + blockIdx.x, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned prev = __hip_atomic_fetch_add(gr.count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(gr.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = prev == nb - 1u;
     }
     __syncthreads();

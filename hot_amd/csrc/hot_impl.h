@@ -250,6 +250,8 @@ struct Ctx : CtxBase {
     void vcycle(const void* in, void* out) override;
     void solve(hot_stats* st) override;
     void g2p(double dt, int32_t* flags) override;
+    void constitutive_eval(int32_t n, const void* F, const void* mu, const void* lambda, int32_t project, void* psi, void* P, void* dPdF) override;
+    void plasticity_eval(int32_t kind, int32_t n, void* F, void* mu, void* lambda, void* Jp) override;
     void advance(double dt, hot_stats* st) override;
     void calculate_dt(double max_dt, double* dt, double* max_speed, double* min_corner, double* max_corner) override;
     void advance_frame(double frame_dt, double min_dt, double max_dt, int32_t* substeps, int32_t* iterations_total, hot_stats* st) override;

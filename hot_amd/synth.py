@@ -55,6 +55,13 @@ CONFIGS = {
     "C1": dict(n=22, ppc=20, E=5e4, nu=0.3, rho=2000.0, dtype=np.float64, levelCnt=1, dt=1.0 / 24),
     "C2": dict(n=63, ppc=8, E=5e4, nu=0.3, rho=2000.0, dtype=np.float64, levelCnt=3, dt=1.0 / 24),
     "C3": dict(n=100, ppc=8, E=1e9, nu=0.3, rho=2000.0, dtype=np.float32, levelCnt=3, dt=1.0 / 24),
-    "C4": dict(n=126, ppc=8, E=69e9, nu=0.33, rho=2700.0, dtype=np.float64, levelCnt=4, dt=1.0 / 24),
-    "C5": dict(n=200, ppc=8, E=1e5, nu=0.35, rho=2000.0, dtype=np.float32, levelCnt=3, dt=1.0 / 24),
+    # wheel 777019: VonMisesFixedCorotated(240e6) (Projects/multigrid/MultigridInit3D.h:3313-3331)
+    "C4": dict(n=126, ppc=8, E=69e9, nu=0.33, rho=2700.0, dtype=np.float64, levelCnt=4, dt=1.0 / 24, plasticity=1, yield_stress=240e6),
+    # "flow / goo": SnowPlasticity(psi 0, theta_c 0.01, theta_s 0.001, min_Jp -2, max_Jp 5) (MultigridInit3D.h:3056-3061)
+    "C5": dict(n=200, ppc=8, E=1e5, nu=0.35, rho=2000.0, dtype=np.float32, levelCnt=3, dt=1.0 / 24, plasticity=2, snow=(0.0, 0.01, 0.001, -2.0, 5.0)),
 }
+
+
+def plasticity_kwargs(cfg):
+    """hot_config fields of a CONFIGS entry's plastic return mapping (empty for the elastic configurations)."""
+    return {k: cfg[k] for k in ("plasticity", "yield_stress", "snow") if k in cfg}

@@ -210,6 +210,17 @@ int hot_calculate_dt(hot_ctx*, double max_dt, double* dt, double* max_speed, dou
  *      consumed.  stats = the last substep's; iterations_total sums the nonlinear iterations of all substeps. */
 int hot_advance_frame(hot_ctx*, double frame_dt, double min_dt, double max_dt, int32_t* substeps, int32_t* iterations_total, hot_stats* stats);
 
+/* ---- the constitutive model and the plastic return mappings for caller-supplied deformation gradients (arrays of `real`,
+ *      3x3 column-major, per-sample mu / lambda): CorotatedIsotropic<T,3>::updateScratch + psi + firstPiola +
+ *      firstPiolaDerivative (Lib/Ziran/Physics/ConstitutiveModel/CorotatedIsotropic.h:110-230; dPdF is the 9x9 derivative, column-major
+ *      over the column-major vectorisations of P and F, PSD-projected when project != 0), and
+ *      VonMisesFixedCorotated / SnowPlasticity::projectStrain (Lib/Ziran/Physics/PlasticityApplier.cpp:96-131, :18-50) with
+ *      cfg.yield_stress / cfg.snow, in place.  NULL outputs are skipped. */
+int hot_constitutive_eval(hot_ctx*, int32_t n, const void* F /*9n*/, const void* mu /*n*/, const void* lambda /*n*/, int32_t project,
+    void* psi /*n*/, void* P /*9n*/, void* dPdF /*81n*/);
+int hot_plasticity_eval(hot_ctx*, int32_t kind /*1 von Mises, 2 snow*/, int32_t n, void* F /*9n in/out*/, void* mu /*n in/out*/, void* lambda /*n in/out*/,
+    void* Jp /*n in/out, snow only*/);
+
 /* ---- per-kernel timings gathered with HIP events on the launch stream when cfg.profile = 1 */
 int hot_profile_reset(hot_ctx*);
 int hot_profile_count(hot_ctx*, int32_t* n);

@@ -398,6 +398,34 @@ int hoto_g2p(hoto_ctx* c, double dt, int32_t* flags)
     });
     return 0;
 }
+// CorotatedIsotropic::updateScratch + psi + firstPiola + firstPiolaDerivative for caller-supplied F (typed by the context)
+int hoto_constitutive_eval(hoto_ctx* c, int32_t n, const void* F, const void* mu, const void* lambda, int32_t project, void* psi, void* P, void* dPdF)
+{
+    DISPATCH(c, {
+        (void)S;
+        for (int k = 0; k < n; ++k) {
+            CorotatedScratch<T> s;
+            const T m = ((const T*)mu)[k], l = ((const T*)lambda)[k];
+            corotated_update_scratch(((const M3<T>*)F)[k], m, l, project != 0, s);
+            if (psi) ((T*)psi)[k] = corotated_psi(s, m, l);
+            if (P) ((M3<T>*)P)[k] = corotated_first_piola(s, m, l);
+            if (dPdF) corotated_first_piola_derivative(s, (T*)dPdF + 81 * (size_t)k);
+        }
+    });
+    return 0;
+}
+int hoto_plasticity_eval(hoto_ctx* c, int32_t kind, int32_t n, void* F, void* mu, void* lambda, void* Jp)
+{
+    DISPATCH(c, {
+        for (int k = 0; k < n; ++k) {
+            if (kind == 1)
+                von_mises_project(((M3<T>*)F)[k], ((T*)mu)[k], ((T*)lambda)[k], (T)S.cfg.yield_stress);
+            else
+                snow_project(((M3<T>*)F)[k], ((T*)mu)[k], ((T*)lambda)[k], ((T*)Jp)[k], (T)S.cfg.snow[0], (T)S.cfg.snow[1], (T)S.cfg.snow[2], (T)S.cfg.snow[3], (T)S.cfg.snow[4]);
+        }
+    });
+    return 0;
+}
 int hoto_advance(hoto_ctx* c, double dt, hot_stats* stats)
 {
     int rc = 0;

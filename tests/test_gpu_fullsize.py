@@ -22,6 +22,7 @@ def rel(a, b):
 def make(lib, cfg, n, floor=True, **kw):
     cloud = parallel.shard_cloud(cfg, 0, 1, n=n)
     args = dict(dtype=1 if cfg["dtype"] == np.float64 else 0, dx=cloud["dx"], gravity=(0, -9.8, 0), levelCnt=cfg["levelCnt"])
+    args.update(synth.plasticity_kwargs(cfg))  # C4: von Mises, C5: snow (the return mapping runs at the end of G2P)
     args.update(kw)
     ctx = lib.context(**args)
     ctx.set_particles(cloud["X"], cloud["V"], cloud["mass"], cloud["vol"], cloud["mu"], cloud["lam"])
@@ -147,3 +148,59 @@ def test_gs_colour_launch_equals_sub_block_launches(hotlib, cname, n):
     finally:
         os.environ.pop("HOT_GS_SPLIT_LAUNCHES", None)
     assert all(np.array_equal(a[0], y) for y in a[1:] + b)
+
+
+@pytest.mark.parametrize("name", ["C4_per_gpu", "C5_per_gpu"])
+def test_fullsize_plastic_return_mapping(hotlib, name):
+    """C4 / C5 with their return mapping (MultigridInit3D.h:3313-3331 von Mises, :3056-3061 snow) at the per-GPU size: G2P with
+    the mapping switched on equals G2P without it followed by the oracle's element-wise projectStrain (PlasticityApplier.cpp:18-50,
+    96-131) on the same trial F, and a sizeable share of the particles actually yields."""
+    from tests.oracle_lib import plasticity
+    cname, n = FULL[name]
+    cfg = synth.CONFIGS[cname]
+    f64 = cfg["dtype"] == np.float64
+    dt = 2e-3  # strains of ~1 %: well past both yield criteria, far from inversion
+    res = {}
+    for plastic in (True, False):
+        ctx, cloud = make(hotlib, cfg, n, **({} if plastic else dict(plasticity=0)))
+        ctx.sort(), ctx.p2g(), ctx.begin_step(dt)  # dv = g dt on free nodes: the step a zero-iteration solve would take
+        ctx.g2p(dt)
+        res[plastic] = ctx.get_particles()
+        del ctx
+    sel = np.random.default_rng(7).choice(cloud["X"].shape[0], 400_000, replace=False)
+    Fe = res[False]["F"][sel].astype(np.float64)
+    mu0, lam0 = cloud["mu"][sel].astype(np.float64), cloud["lam"][sel].astype(np.float64)
+    Fp, mu, lam, Jp = plasticity(cfg["plasticity"], Fe, mu0, lam0, np.ones(len(sel)), cfg.get("yield_stress", 0.0), cfg.get("snow", (10, 2e-2, 7.5e-3, 0.6, 20)))
+    yielded = np.abs(Fp - Fe).max(1) > 1e-7
+    assert yielded.mean() > 0.05, yielded.mean()
+    tol = 1e-9 if f64 else 2e-5  # fp32: the device projects in float (SVD + exp / sqrt), the oracle's helper in double
+    got = res[True]
+    assert np.abs(got["F"][sel] - Fp).max() < tol * np.abs(Fp).max(), np.abs(got["F"][sel] - Fp).max()
+    assert np.array_equal(got["X"], res[False]["X"]) and np.array_equal(got["V"], res[False]["V"])  # the mapping touches the strain only
+    if cfg["plasticity"] == 2:  # snow hardening rescales the Lame parameters and tracks Jp
+        assert rel(got["mu"][sel], mu) < tol * 10 and rel(got["lam"][sel], lam) < tol * 10 and rel(got["Jp"][sel], Jp) < tol * 10
+
+
+@pytest.mark.parametrize("cname,n,tol", [("C2", 63, 1e-9), ("C3", 100, 2e-2)])
+def test_fullsize_fixed_iterations_against_oracle(hotlib, oracle, cname, n, tol):
+    """C2 and C3 at full size against the oracle itself: three L-BFGS iterations of one time step (Hessian + 3-level Galerkin
+    hierarchy + three V-cycles + line searches), same control flow, dv compared.  fp64: round-off.  fp32 (C3, E = 1e9): both
+    sides run in float on a level-0 system of cond ~ 1 / eps_float, the HIP path additionally sums its node tiles in double
+    (hot_common.h AccT) where the oracle, like the reference, sums in float — the stated bound is 2 % of max|dv| after three
+    iterations, with the energies agreeing to 1e-4."""
+    cfg = synth.CONFIGS[cname]
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, cloud = make(lib, cfg, n, max_iterations=3)
+        ctx.sort(), ctx.p2g(), ctx.begin_step(cfg["dt"])
+        st = ctx.solve()
+        out[name] = (ctx.get_dv(), st)
+        del ctx
+    (dg, sg), (dc, sc) = out["gpu"], out["cpu"]
+    for k in ("iterations", "num_nodes", "num_levels", "vcycles"):
+        assert sg[k] == sc[k], (k, sg, sc)
+    print(cname, "rel dv", rel(dg, dc), "energy", sg["energy"], sc["energy"], "trials", sg["linesearch_trials"], sc["linesearch_trials"])
+    assert rel(dg, dc) < tol, rel(dg, dc)
+    assert abs(sg["energy"] - sc["energy"]) < (1e-10 if tol < 1e-6 else 1e-4) * abs(sc["energy"])
+    if tol < 1e-6:
+        assert sg["linesearch_trials"] == sc["linesearch_trials"] and sg["linear_iterations"] == sc["linear_iterations"]

@@ -150,35 +150,94 @@ def test_solve_to_convergence_against_oracle(hotlib, oracle, kw):
     assert abs(sg["energy"] - sc["energy"]) < 1e-4 * max(abs(sc["energy"]), 1e-6)
 
 
-@pytest.mark.parametrize("dtype,cneps,tolX,tolV", [(1, 1e-6, 1e-8, 1e-4), (0, 1e-4, 2e-6, 5e-2)])
-def test_three_time_steps_against_oracle(hotlib, oracle, dtype, cneps, tolX, tolV):
-    """Whole steps (sort -> P2G -> solve -> G2P) chained three times.  Each step ends at the solver's termination
+def test_three_time_steps_against_oracle(hotlib, oracle):
+    """Whole steps (sort -> P2G -> solve -> G2P) chained three times, fp64.  Each step ends at the solver's termination
     tolerance, so velocities agree to that level (relative to the initial velocity scale), positions much tighter."""
     out = {}
     v0 = None
     for name, lib in (("gpu", hotlib), ("cpu", oracle)):
-        # fp32: the comparison partner is the fp64 oracle.  A float solve of this cond ~ 1/eps_float system is chaotic, and the
-        # CPU oracle's own float run (OpenMP reductions in varying order) can occasionally fail to converge for minutes;
-        # the bounded iteration count keeps the worst case short on either side.
-        ctx, c = pc.make_ctx(lib, n=8, dtype=dtype if name == "gpu" else 1, levelCnt=2, cneps=cneps, max_iterations=300)
+        ctx, c = pc.make_ctx(lib, n=8, dtype=1, levelCnt=2, cneps=1e-6, max_iterations=300)
         v0 = np.abs(c["V"]).max()
         its = []
         for _ in range(3):
             its.append(ctx.advance(1.0 / 24)["iterations"])
         out[name] = (ctx.get_particles(), its)
     pg, pcpu = out["gpu"][0], out["cpu"][0]
-    if dtype == 1:
-        assert rel(pg["X"], pcpu["X"]) < tolX, (rel(pg["X"], pcpu["X"]), out["gpu"][1], out["cpu"][1])
-        assert np.abs(pg["V"].astype(np.float64) - pcpu["V"]).max() < tolV * v0
-        assert np.abs(pg["F"].astype(np.float64) - pcpu["F"]).max() < tolV
-    else:
-        # fp32: the level-0 system has cond ~1e8 (low-mass boundary nodes), i.e. about 1/eps_float: both the reference
-        # float instantiation and this one solve those modes with O(1) relative error, so float trajectories are only
-        # comparable statistically (the reference executable is double-only, Projects/multigrid/main.cpp:12-13).
-        dX = (pg["X"].astype(np.float64) - pcpu["X"]) / 0.01
-        print("fp32 3-step |dX|/dx: max %.3g rms %.3g, its gpu %s cpu %s" % (np.abs(dX).max(), np.sqrt((dX ** 2).mean()), out["gpu"][1], out["cpu"][1]))
-        assert np.sqrt((dX ** 2).mean()) < 0.5
-        assert np.isfinite(pg["F"]).all() and np.isfinite(pg["V"]).all()
+    assert rel(pg["X"], pcpu["X"]) < 1e-8, (rel(pg["X"], pcpu["X"]), out["gpu"][1], out["cpu"][1])
+    assert np.abs(pg["V"].astype(np.float64) - pcpu["V"]).max() < 1e-4 * v0
+    assert np.abs(pg["F"].astype(np.float64) - pcpu["F"]).max() < 1e-4
+
+
+def test_three_time_steps_fp32_against_fp32_oracle(hotlib, oracle):
+    """fp32 whole steps against the oracle's own float arithmetic.  The level-0 system has cond ~ 1e8 ~ 1 / eps_float (low-mass
+    boundary nodes), so CONVERGED float trajectories of two correct implementations drift apart chaotically through the
+    line-search decisions and cannot be compared point-wise.  What is comparable is a bounded number of iterations from one
+    and the same state: at the start of each of three consecutive time steps (the trajectory itself is advanced by the HIP
+    library's converged fp32 solve) both sides take 4 L-BFGS iterations from identical particle data.  Stated bounds: dv within
+    1 % of max|dv| (the HIP path sums node tiles in double and rounds once, the oracle sums in float like the reference —
+    hot_common.h AccT), energies within 1e-4; and along the trajectory the converged step lowers the incremental potential
+    below the 4-iteration value."""
+    T = np.float32
+    from hot_amd import synth
+    c = synth.cube_cloud(8, ppc=8, dtype=T)
+    state = dict(X=c["X"], V=c["V"], C_=None, F=None)
+    o, nrm = synth.sticky_floor(5.0, c["dx"])
+
+    def ctx_for(lib, **kw):
+        ctx = lib.context(dtype=0, dx=c["dx"], gravity=(0, -9.8, 0), levelCnt=2, cneps=1e-4, **kw)
+        ctx.set_particles(state["X"], state["V"], c["mass"], c["vol"], c["mu"], c["lam"], C_=state["C_"], F=state["F"])
+        ctx.set_sticky_halfspaces(o, nrm)
+        return ctx
+
+    for step in range(3):
+        res = {}
+        for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+            ctx = ctx_for(lib, max_iterations=4)
+            pc.prepare(ctx)
+            st = ctx.solve()
+            res[name] = (ctx.get_dv().astype(np.float64), st)
+        (dg, sg), (dc, sc) = res["gpu"], res["cpu"]
+        assert sg["iterations"] == sc["iterations"] == 4 and sg["num_nodes"] == sc["num_nodes"]
+        err = np.abs(dg - dc).max() / np.abs(dc).max()
+        print("fp32 step %d: 4 iterations, |ddv| / max|dv| = %.3g, energies %.8g %.8g" % (step, err, sg["energy"], sc["energy"]))
+        assert err < 1e-2, err
+        assert abs(sg["energy"] - sc["energy"]) < 1e-4 * max(abs(sc["energy"]), 1e-6)
+        full = ctx_for(hotlib, max_iterations=300)
+        stf = full.advance(1.0 / 24)
+        assert stf["converged"] == 1 and stf["energy"] <= sg["energy"] + 1e-6 * abs(sg["energy"]), (stf, sg["energy"])
+        p = full.get_particles()
+        assert np.isfinite(p["X"]).all() and np.isfinite(p["F"]).all()
+        state = dict(X=p["X"], V=p["V"], C_=p["C"], F=p["F"])
+
+
+KNOB_CFGS = [
+    # (hot_config overrides, max_iterations, dv tolerance)
+    (dict(levelCnt=3, topDownMGS=1), 5, 1e-9),  # splitLevel 1, no pre-smoothing, PCG on every coarse level (MultigridPreconditioner.h:534-538)
+    (dict(levelCnt=3, levelscale=1), 5, 1e-9),  # smoothing iterations grow with the level (:525-551)
+    (dict(levelCnt=2, times=2), 5, 1e-9),
+    (dict(levelCnt=3, times=3, levelscale=1, smoother=0, coarseSolver=0), 5, 1e-9),  # damped Jacobi with 3 x (times + level) top iterations
+    (dict(levelCnt=2, useCN=0, cneps=1e-9), 5, 1e-9),  # plain l2 termination (ImplicitSolver.h:185-209)
+    (dict(levelCnt=2, useAdaptiveHessian=1, cneps=1e-13), 19, 1e-6),  # Hessian + hierarchy rebuilt at iteration 16 (LBFGS.h:331-336)
+]
+
+
+@pytest.mark.parametrize("kw,its,tol", KNOB_CFGS, ids=[",".join(f"{k}={v}" for k, v in c[0].items()) for c in KNOB_CFGS])
+def test_solver_knobs_against_oracle(hotlib, oracle, kw, its, tol):
+    """HOTSettings knobs no other test reaches (Configurations.h:18-42): fixed iteration counts, same control flow, dv to round-off."""
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=8, max_iterations=its, **{"cneps": 1e-7, **kw})
+        pc.prepare(ctx)
+        st = ctx.solve()
+        out[name] = (ctx.get_dv(), st)
+    sg, sc = out["gpu"][1], out["cpu"][1]
+    for k in ("iterations", "vcycles", "num_levels", "dropped_pairs"):
+        assert sg[k] == sc[k], (k, sg, sc)
+    if tol < 1e-8:
+        assert sg["linesearch_trials"] == sc["linesearch_trials"] and sg["linear_iterations"] == sc["linear_iterations"], (sg, sc)
+    assert sg["iterations"] == its, sg  # the knob really ran for the whole budget (adaptiveH: past the rebuild at 16)
+    assert rel(out["gpu"][0], out["cpu"][0]) < tol, rel(out["gpu"][0], out["cpu"][0])
+    assert abs(sg["energy"] - sc["energy"]) < max(tol, 1e-10) * max(abs(sc["energy"]), 1e-6)
 
 
 @pytest.mark.parametrize("ppc", [343, 80, 1])
