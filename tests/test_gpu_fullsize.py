@@ -176,7 +176,8 @@ def test_fullsize_plastic_return_mapping(hotlib, name):
     tol = 1e-9 if f64 else 2e-5  # fp32: the device projects in float (SVD + exp / sqrt), the oracle's helper in double
     got = res[True]
     assert np.abs(got["F"][sel] - Fp).max() < tol * np.abs(Fp).max(), np.abs(got["F"][sel] - Fp).max()
-    assert np.array_equal(got["X"], res[False]["X"]) and np.array_equal(got["V"], res[False]["V"])  # the mapping touches the strain only
+    # the mapping touches the strain only (the two runs differ by the rounding of their LDS-atomic node sums, nothing else)
+    assert rel(got["X"], res[False]["X"]) < (1e-13 if f64 else 1e-6) and rel(got["V"], res[False]["V"]) < (1e-11 if f64 else 1e-4)
     if cfg["plasticity"] == 2:  # snow hardening rescales the Lame parameters and tracks Jp
         assert rel(got["mu"][sel], mu) < tol * 10 and rel(got["lam"][sel], lam) < tol * 10 and rel(got["Jp"][sel], Jp) < tol * 10
 
