@@ -292,6 +292,12 @@ int hot_g2p(hot_ctx* ctx, double dt, int32_t* flags)
     ctx->impl->g2p(dt, flags);
     HOT_API_END
 }
+int hot_set_comm(hot_ctx* ctx, const hot_comm* comm)
+{
+    HOT_API_BEGIN
+    ctx->impl->set_comm(comm);
+    HOT_API_END
+}
 int hot_constitutive_eval(hot_ctx* ctx, int32_t n, const void* F, const void* mu, const void* lambda, int32_t project, void* psi, void* P, void* dPdF)
 {
     HOT_API_BEGIN

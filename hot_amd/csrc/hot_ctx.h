@@ -101,6 +101,7 @@ struct CtxBase {
     virtual void vcycle(const void* in, void* out) = 0;
     virtual void solve(hot_stats* st) = 0;
     virtual void g2p(double dt, int32_t* flags) = 0;
+    virtual void set_comm(const hot_comm* c) = 0;
     virtual void constitutive_eval(int32_t n, const void* F, const void* mu, const void* lambda, int32_t project, void* psi, void* P, void* dPdF) = 0;
     virtual void plasticity_eval(int32_t kind, int32_t n, void* F, void* mu, void* lambda, void* Jp) = 0;
     virtual void advance(double dt, hot_stats* st) = 0;

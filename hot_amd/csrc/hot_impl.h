@@ -45,6 +45,17 @@ struct Level {
     HashMap map;
     // V-cycle work vectors (3n each)
     DBuf<T> residual, initialResidual, sol, du, dAu, tmp;
+    // ---- sharded solve (hot_set_comm): row ownership of this level
+    bool colored = false; // mark_colors ran for this level (sharded: already while the Hessian is built)
+    bool part = false; // rows are partitioned over the ranks (else every rank computes every row: small coarse levels)
+    std::vector<int> nstart; // [ranks + 1] id prefixes: rank r's particles first touch the nodes [nstart[r], nstart[r+1])
+    DBuf<uint8_t> owner; // n: owning rank of every row = rank whose prefix holds the lowest node of the row's 4^3 colour block
+    DBuf<uint8_t> own; // n: owner == this rank (row mask of the operator kernels)
+    std::vector<int> csplit; // [8 * (ranks + 1)] colour c: blocks color_block_begin[c] + [csplit[c][r], csplit[c][r+1]) belong to rank r
+    std::vector<int> xbeg, xcnt; // [ranks * 8] position range in gs_order of the nodes rank r owns of colour c
+    DBuf<int32_t> dxtab; // the same two tables on the device (xbeg | xcnt)
+    int xmax_full = 0, xmax_col[8] = { 0 }; // largest per-rank counts (padded all-gather slots)
+    const uint8_t* mask() const { return part ? own.p : nullptr; }
 };
 
 template <class T>
@@ -121,6 +132,22 @@ struct Ctx : CtxBase {
     bool updated = false;
     T max_cn_tolerance = 0;
     DBuf<T> rhs, work0, work1, work2, work3, solve_keep;
+    // ---- sharded solve: one connected body over several ranks (include/hot_mi355x.h hot_comm)
+    hot_comm comm{};
+    bool sharded() const { return comm.size > 1; }
+    std::vector<int> block_first; // [ranks + 1] first global block first touched by each rank's particle groups
+    DBuf<char> xsend, xrecv; // staging of the collectives
+    DBuf<uint8_t> written; // level-0 rows this rank's tile kernel has written (its partial rows)
+    void set_comm(const hot_comm* c) override;
+    void c_allreduce(void* buf, int64_t n, int dtype, int op, bool on_device);
+    void c_allgather(const void* send, void* recv, int64_t bytes, bool on_device);
+    void c_alltoallv(const void* send, const int64_t* soff, const int64_t* sbytes, void* recv, const int64_t* roff, const int64_t* rbytes);
+    void merge_block_lists(); // sort(): the ranks' first-touch block lists -> the global Set_Page order
+    void level_ownership(Level<T>& L); // owner / own / colour splits / exchange tables from L.nstart and the colouring
+    void exchange(Level<T>& L, T* x, int colour); // owners' entries of x (all colours: colour < 0) to every rank
+    void exchange_rows(Level<T>& L, const uint8_t* touched); // partial matrix rows -> their owners, summed there
+    void allreduce_tiles(T* tiles, int q); // q * Nb * EPB node-tile values, summed over the ranks
+    static constexpr int REAL = sizeof(T) == 4 ? HOT_COMM_F32 : HOT_COMM_F64;
     DBuf<double> dscal; // device scalars
     DBuf<T> speed_part; // block maxima of calculate_dt
     DBuf<double> red_part; // grid_sum_store deposits (2 per workgroup)

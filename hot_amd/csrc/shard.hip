@@ -1,0 +1,339 @@
+// libhotmi355x — one connected body over several ranks (one context per rank = per GPU): the data-path side of the
+// decomposition described in include/hot_mi355x.h (hot_comm) and DESIGN.md §7.  The reference is a single process; the
+// hazards this has to respect are the reference's own: the 8-colouring of the scatters (Lib/MPM/MpmSimulationBase.h:251-264)
+// becomes "partial tiles, summed over the ranks", the colour order of gs_smooth (Projects/multigrid/MultigridPreconditioner.h:
+// 266-318) becomes "owner computes a colour, hands it to every rank, next colour", the serial Set_Page / getNumNodes /
+// first-touch numberings (MpmSimulationBase.cpp:1099-1125, MpmGrid.h:148-161, MultigridPreconditioner.h:619-664) become
+// "rank lists concatenated in rank order", which is the serial order because a rank's shard is a contiguous range of the
+// globally sorted particle groups.
+//
+// The library itself never communicates: the three collectives of hot_comm are callbacks (RCCL through torch.distributed in
+// hot_amd/dist.py).  They are called with device pointers after the context's stream has been synchronised.
+#include "hot_impl.h"
+
+namespace hot {
+
+template <class T>
+void Ctx<T>::set_comm(const hot_comm* c)
+{
+    if (c && c->size > 1) {
+        need(c->allreduce && c->allgather && c->alltoallv, "hot_set_comm: all three collectives are required");
+        need(c->rank >= 0 && c->rank < c->size && c->size <= 64, "hot_set_comm: 0 <= rank < size <= 64");
+        need(!cfg.useBaselineMultigrid, "hot_set_comm: the --baseline geometric multigrid is single-rank only");
+        comm = *c;
+    }
+    else
+        comm = hot_comm{};
+    block_first.clear();
+}
+template <class T>
+void Ctx<T>::c_allreduce(void* buf, int64_t n, int dtype, int op, bool on_device)
+{
+    if (!sharded() || n <= 0) return;
+    if (on_device) HOT_HIP(hipStreamSynchronize(stream));
+    prof.count(on_device ? "comm_allreduce" : "comm_allreduce_scalars");
+    HOT_CHECK(comm.allreduce(comm.user, buf, n, dtype, op, on_device ? 1 : 0) == 0, HOT_ERR_DEVICE, "hot_comm.allreduce failed");
+}
+template <class T>
+void Ctx<T>::c_allgather(const void* send, void* recv, int64_t bytes, bool on_device)
+{
+    if (on_device) HOT_HIP(hipStreamSynchronize(stream));
+    prof.count("comm_allgather");
+    HOT_CHECK(comm.allgather(comm.user, send, recv, bytes, on_device ? 1 : 0) == 0, HOT_ERR_DEVICE, "hot_comm.allgather failed");
+}
+template <class T>
+void Ctx<T>::c_alltoallv(const void* send, const int64_t* soff, const int64_t* sbytes, void* recv, const int64_t* roff, const int64_t* rbytes)
+{
+    HOT_HIP(hipStreamSynchronize(stream));
+    prof.count("comm_alltoallv");
+    HOT_CHECK(comm.alltoallv(comm.user, send, soff, sbytes, recv, roff, rbytes, 1) == 0, HOT_ERR_DEVICE, "hot_comm.alltoallv failed");
+}
+template <class T>
+void Ctx<T>::allreduce_tiles(T* tiles, int q)
+{
+    c_allreduce(tiles, (int64_t)q * Nb * EPB, REAL, HOT_COMM_SUM, true);
+}
+
+// ------------------------------------------------------------------------------------------------ global block list
+struct RankCounts {
+    int v[64];
+};
+__global__ void k_hash_clear4(HashMap h)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > h.mask) return;
+    h.keys[i] = ~0ULL;
+    h.minrank[i] = ~0ULL;
+    h.id[i] = -1;
+}
+// candidate s = rank * maxn + position in that rank's first-touch list
+__global__ void k_merge_insert(HashMap h, const uint64_t* __restrict__ lists, RankCounts cnt, int maxn, int total)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= total || s % maxn >= cnt.v[s / maxn]) return;
+    hash_insert_min(h, lists[s] >> 12, (unsigned long long)s);
+}
+__global__ void k_merge_flag(HashMap h, const uint64_t* __restrict__ lists, RankCounts cnt, int maxn, int total, int32_t* flags)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= total) return;
+    int f = 0;
+    if (s % maxn < cnt.v[s / maxn]) f = h.minrank[hash_find_slot(h, lists[s] >> 12)] == (unsigned long long)s;
+    flags[s] = f;
+}
+__global__ void k_merge_assign(HashMap h, const uint64_t* __restrict__ lists, const int32_t* __restrict__ flags, const int32_t* __restrict__ scan, uint64_t* blocks, int total)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= total || !flags[s]) return;
+    h.id[hash_find_slot(h, lists[s] >> 12)] = scan[s];
+    blocks[scan[s]] = lists[s];
+}
+
+// The global block list is the concatenation, in rank order, of the ranks' own first-touch lists with repeated pages
+// dropped: exactly the serial Set_Page order of the whole body (MpmSimulationBase.cpp:1099-1125), because rank r's particle
+// groups all precede rank r+1's in the global sort.  The same min-sequence-number hashing as the single-rank list.
+template <class T>
+void Ctx<T>::merge_block_lists()
+{
+    const int R = comm.size;
+    std::vector<int64_t> counts(R, 0);
+    int64_t mine = Nb;
+    c_allgather(&mine, counts.data(), sizeof(int64_t), false);
+    int64_t maxn = 0, sum = 0;
+    RankCounts rc{};
+    for (int r = 0; r < R; ++r) maxn = std::max(maxn, counts[r]), sum += counts[r], rc.v[r] = (int)counts[r];
+    const int total = (int)(maxn * R);
+    xsend.reserve((size_t)maxn * 8), xrecv.reserve((size_t)total * 8);
+    HOT_HIP(hipMemsetAsync(xsend.p, 0, (size_t)maxn * 8, stream));
+    HOT_HIP(hipMemcpyAsync(xsend.p, blocks.p, (size_t)Nb * 8, hipMemcpyDeviceToDevice, stream));
+    c_allgather(xsend.p, xrecv.p, maxn * 8, true);
+    const uint64_t* lists = (const uint64_t*)xrecv.p;
+    uint32_t capn = 1024;
+    while (capn < 2 * (uint32_t)sum + 16u) capn <<= 1;
+    bh_keys.reserve(capn), bh_rank.reserve(capn), bh_id.reserve(capn);
+    block_map.keys = bh_keys.p, block_map.minrank = bh_rank.p, block_map.id = bh_id.p, block_map.mask = capn - 1;
+    flags.reserve(total), scan.reserve(total);
+    HOT_LAUNCH(this, "hash_clear", k_hash_clear4, div_up(capn, 256), 256, 0, block_map);
+    HOT_LAUNCH(this, "block_merge_insert", k_merge_insert, div_up(total, 256), 256, 0, block_map, lists, rc, (int)maxn, total);
+    HOT_LAUNCH(this, "block_merge_flag", k_merge_flag, div_up(total, 256), 256, 0, block_map, lists, rc, (int)maxn, total, flags.p);
+    Nb = exclusive_scan_i32(flags.p, scan.p, total);
+    blocks.reserve(Nb);
+    HOT_LAUNCH(this, "block_merge_assign", k_merge_assign, div_up(total, 256), 256, 0, block_map, lists, flags.p, scan.p, blocks.p, total);
+    block_first.assign(R + 1, Nb);
+    for (int r = 0; r < R; ++r) HOT_HIP(hipMemcpyAsync(&block_first[r], scan.p + (size_t)r * maxn, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    sync();
+}
+
+// ------------------------------------------------------------------------------------------------ row ownership
+struct Int9 {
+    int v[9];
+};
+__global__ void k_block_minid(const int32_t* __restrict__ gs_order, const int32_t* __restrict__ block_start, int32_t* out, int nb)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nb) out[b] = gs_order[block_start[b]]; // nodes of a block are ordered by id
+}
+__global__ void k_node_owner(const uint32_t* __restrict__ ckey, const uint8_t* __restrict__ owner_b, Int9 cb, uint8_t* owner, uint8_t* own, int me, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = ckey[i];
+    const uint8_t o = owner_b[cb.v[k >> 28] + (int)((k >> 7) & 0x1fffffu)];
+    owner[i] = o, own[i] = o == (uint8_t)me;
+}
+
+// A 4^3 colour block is owned by the rank whose id prefix [nstart[r], nstart[r+1]) holds the block's lowest node, i.e. the rank
+// whose particles touch it first.  Blocks of a colour are ordered by that lowest node (first-touch order), so every rank owns
+// a contiguous run of each colour's block list, and its nodes of colour c are one contiguous position range of gs_order.
+template <class T>
+void Ctx<T>::level_ownership(Level<T>& L)
+{
+    const int R = comm.size, me = comm.rank, nb = L.nblocks;
+    HOT_CHECK((int)L.nstart.size() == R + 1 && L.colored && nb > 0, HOT_ERR_INVALID, "level_ownership: prefixes / colouring missing");
+    DBuf<int32_t> minid;
+    minid.reserve(nb);
+    HOT_LAUNCH(this, "shard_block_minid", k_block_minid, div_up(nb, 256), 256, 0, L.gs_order.p, L.gs_block_start.p, minid.p, nb);
+    std::vector<int32_t> hmin(nb), hstart(nb + 1);
+    HOT_HIP(hipMemcpyAsync(hmin.data(), minid.p, (size_t)nb * 4, hipMemcpyDeviceToHost, stream));
+    HOT_HIP(hipMemcpyAsync(hstart.data(), L.gs_block_start.p, (size_t)(nb + 1) * 4, hipMemcpyDeviceToHost, stream));
+    sync();
+    std::vector<uint8_t> ob(nb);
+    L.csplit.assign(8 * (R + 1), 0);
+    L.xbeg.assign(R * 8, 0), L.xcnt.assign(R * 8, 0);
+    for (int c = 0; c < 8; ++c) {
+        const int b0 = L.color_block_begin[c], b1 = L.color_block_begin[c + 1];
+        int r = 0;
+        for (int b = b0; b < b1; ++b) {
+            while (r + 1 < R && hmin[b] >= L.nstart[r + 1]) ++r;
+            HOT_CHECK(hmin[b] >= L.nstart[r], HOT_ERR_INVALID, "level_ownership: colour blocks are not in first-touch order");
+            ob[b] = (uint8_t)r;
+        }
+        // split[c][r] = first block (relative to b0) owned by a rank >= r
+        int b = b0;
+        for (int q = 0; q <= R; ++q) {
+            while (b < b1 && (int)ob[b] < q) ++b;
+            L.csplit[c * (R + 1) + q] = (q == R ? b1 : b) - b0;
+        }
+        for (int q = 0; q < R; ++q) {
+            const int lo = b0 + L.csplit[c * (R + 1) + q], hi = b0 + L.csplit[c * (R + 1) + q + 1];
+            L.xbeg[q * 8 + c] = hstart[lo], L.xcnt[q * 8 + c] = hstart[hi] - hstart[lo];
+        }
+    }
+    L.xmax_full = 0;
+    for (int c = 0; c < 8; ++c) L.xmax_col[c] = 0;
+    for (int q = 0; q < R; ++q) {
+        int tot = 0;
+        for (int c = 0; c < 8; ++c) tot += L.xcnt[q * 8 + c], L.xmax_col[c] = std::max(L.xmax_col[c], L.xcnt[q * 8 + c]);
+        L.xmax_full = std::max(L.xmax_full, tot);
+    }
+    DBuf<uint8_t> dob;
+    dob.reserve(nb);
+    L.owner.reserve(L.n), L.own.reserve(L.n), L.dxtab.reserve(2 * R * 8);
+    std::vector<int32_t> tab(2 * R * 8);
+    for (int k = 0; k < R * 8; ++k) tab[k] = L.xbeg[k], tab[R * 8 + k] = L.xcnt[k];
+    HOT_HIP(hipMemcpyAsync(dob.p, ob.data(), nb, hipMemcpyHostToDevice, stream));
+    HOT_HIP(hipMemcpyAsync(L.dxtab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, stream));
+    Int9 cb;
+    for (int c = 0; c < 9; ++c) cb.v[c] = L.color_block_begin[c];
+    HOT_LAUNCH(this, "shard_node_owner", k_node_owner, div_up(L.n, 256), 256, 0, L.ckey.p, dob.p, cb, L.owner.p, L.own.p, me, L.n);
+    sync(); // ob / tab / dob go out of scope
+    L.part = true;
+}
+
+// ------------------------------------------------------------------------------------------------ vector exchange
+// position in gs_order of the k-th exchanged node of rank r (all colours: the rank's eight colour ranges back to back), or -1
+__device__ __forceinline__ int xchg_pos(const int32_t* __restrict__ tab, int R, int r, int colour, int k)
+{
+    const int32_t* beg = tab + r * 8;
+    const int32_t* cnt = tab + R * 8 + r * 8;
+    if (colour >= 0) return k < cnt[colour] ? beg[colour] + k : -1;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (k < cnt[c]) return beg[c] + k;
+        k -= cnt[c];
+    }
+    return -1;
+}
+template <class T>
+__global__ void k_xchg_pack(const T* __restrict__ x, const int32_t* __restrict__ gs_order, const int32_t* __restrict__ tab, int R, int me, int colour, T* __restrict__ out, int maxc)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= maxc) return;
+    const int p = xchg_pos(tab, R, me, colour, k);
+    T a = 0, b = 0, c = 0;
+    if (p >= 0) {
+        const int64_t i = gs_order[p];
+        a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
+    }
+    out[3 * (int64_t)k] = a, out[3 * (int64_t)k + 1] = b, out[3 * (int64_t)k + 2] = c;
+}
+template <class T>
+__global__ void k_xchg_unpack(T* __restrict__ x, const int32_t* __restrict__ gs_order, const int32_t* __restrict__ tab, int R, int me, int colour, const T* __restrict__ in, int maxc)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R * maxc) return;
+    const int r = e / maxc, k = e - r * maxc;
+    if (r == me) return;
+    const int p = xchg_pos(tab, R, r, colour, k);
+    if (p < 0) return;
+    const int64_t i = gs_order[p];
+    x[3 * i] = in[3 * (int64_t)e], x[3 * i + 1] = in[3 * (int64_t)e + 1], x[3 * i + 2] = in[3 * (int64_t)e + 2];
+}
+
+// Every rank receives the owners' entries of x: after a row-partitioned operator (all colours) or after one colour of a
+// Gauss-Seidel sweep.  One all-gather of equally sized (padded) slots; the slot layout follows gs_order, so packing and
+// unpacking need no index lists beyond the per-(rank, colour) ranges.
+template <class T>
+void Ctx<T>::exchange(Level<T>& L, T* x, int colour)
+{
+    if (!L.part) return;
+    const int R = comm.size, me = comm.rank;
+    const int maxc = colour < 0 ? L.xmax_full : L.xmax_col[colour];
+    if (maxc == 0) return;
+    const size_t slot = (size_t)maxc * 3 * sizeof(T);
+    xsend.reserve(slot), xrecv.reserve(slot * R);
+    HOT_LAUNCH(this, "xchg_pack", k_xchg_pack<T>, div_up(maxc, 256), 256, 0, x, L.gs_order.p, L.dxtab.p, R, me, colour, (T*)xsend.p, maxc);
+    c_allgather(xsend.p, xrecv.p, (int64_t)slot, true);
+    HOT_LAUNCH(this, "xchg_unpack", k_xchg_unpack<T>, div_up((size_t)R * maxc, 256), 256, 0, x, L.gs_order.p, L.dxtab.p, R, me, colour, (const T*)xrecv.p, maxc);
+}
+
+// ------------------------------------------------------------------------------------------------ partial matrix rows
+__global__ void k_rows_flag(const uint8_t* __restrict__ touched, const uint8_t* __restrict__ owner, int q, int32_t* flags, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (touched[i] && owner[i] == (uint8_t)q) ? 1 : 0;
+}
+__global__ void k_rows_compact(const int32_t* __restrict__ flags, const int32_t* __restrict__ scan, int32_t* out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flags[i]) out[scan[i]] = i;
+}
+template <class T>
+__global__ void k_rows_pack(const T* __restrict__ val, const int32_t* __restrict__ rows, int64_t nrows, T* __restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nrows * 1125) return;
+    const int64_t k = e / 1125;
+    out[e] = val[(int64_t)rows[k] * 1125 + (e - k * 1125)];
+}
+template <class T>
+__global__ void k_rows_add(T* __restrict__ val, const int32_t* __restrict__ rows, int64_t nrows, const T* __restrict__ in)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nrows * 1125) return;
+    const int64_t k = e / 1125;
+    val[(int64_t)rows[k] * 1125 + (e - k * 1125)] += in[e];
+}
+
+// Rows of L's matrix for which this rank holds a partial sum (`touched`) but which another rank owns are sent to the owner and
+// added there, source ranks in ascending order (deterministic).  Used for the level-0 Hessian (rows near the shard boundary get
+// contributions from both sides' particles) and for the Galerkin products (a coarse row sums over fine rows of several owners).
+template <class T>
+void Ctx<T>::exchange_rows(Level<T>& L, const uint8_t* touched)
+{
+    const int R = comm.size, me = comm.rank, n = L.n;
+    flags.reserve(n), scan.reserve(n);
+    DBuf<int32_t> sendrows, recvrows;
+    sendrows.reserve(n);
+    std::vector<int64_t> scnt(R, 0), soff(R, 0);
+    int64_t off = 0;
+    for (int q = 0; q < R; ++q) {
+        soff[q] = off;
+        if (q == me) continue;
+        HOT_LAUNCH(this, "rows_flag", k_rows_flag, div_up(n, 256), 256, 0, touched, L.owner.p, q, flags.p, n);
+        const int c = exclusive_scan_i32(flags.p, scan.p, n);
+        if (c > 0) HOT_LAUNCH(this, "rows_compact", k_rows_compact, div_up(n, 256), 256, 0, flags.p, scan.p, sendrows.p + off, n);
+        scnt[q] = c, off += c;
+    }
+    std::vector<int64_t> all((size_t)R * R, 0);
+    c_allgather(scnt.data(), all.data(), (int64_t)R * sizeof(int64_t), false);
+    std::vector<int64_t> rcnt(R, 0), roff(R, 0);
+    int64_t rtot = 0;
+    for (int s = 0; s < R; ++s) roff[s] = rtot, rcnt[s] = all[(size_t)s * R + me], rtot += rcnt[s];
+    recvrows.reserve(std::max<int64_t>(rtot, 1));
+    auto scaled = [&](const std::vector<int64_t>& v, int64_t f) {
+        std::vector<int64_t> o(v);
+        for (auto& x : o) x *= f;
+        return o;
+    };
+    {
+        auto so = scaled(soff, 4), sb = scaled(scnt, 4), ro = scaled(roff, 4), rb = scaled(rcnt, 4);
+        c_alltoallv(sendrows.p, so.data(), sb.data(), recvrows.p, ro.data(), rb.data());
+    }
+    const int64_t rowbytes = 1125 * (int64_t)sizeof(T);
+    xsend.reserve((size_t)std::max<int64_t>(off, 1) * rowbytes), xrecv.reserve((size_t)std::max<int64_t>(rtot, 1) * rowbytes);
+    if (off > 0) HOT_LAUNCH(this, "rows_pack", k_rows_pack<T>, div_up((size_t)off * 1125, 256), 256, 0, L.val.p, sendrows.p, off, (T*)xsend.p);
+    {
+        auto so = scaled(soff, rowbytes), sb = scaled(scnt, rowbytes), ro = scaled(roff, rowbytes), rb = scaled(rcnt, rowbytes);
+        c_alltoallv(xsend.p, so.data(), sb.data(), xrecv.p, ro.data(), rb.data());
+    }
+    for (int s = 0; s < R; ++s)
+        if (rcnt[s] > 0)
+            HOT_LAUNCH(this, "rows_add", k_rows_add<T>, div_up((size_t)rcnt[s] * 1125, 256), 256, 0, L.val.p, recvrows.p + roff[s], rcnt[s], (const T*)xrecv.p + roff[s] * 1125);
+    sync(); // the local buffers go out of scope
+}
+
+template struct Ctx<float>;
+template struct Ctx<double>;
+
+} // namespace hot

@@ -210,6 +210,47 @@ int hot_calculate_dt(hot_ctx*, double max_dt, double* dt, double* max_speed, dou
  *      consumed.  stats = the last substep's; iterations_total sums the nonlinear iterations of all substeps. */
 int hot_advance_frame(hot_ctx*, double frame_dt, double min_dt, double max_dt, int32_t* substeps, int32_t* iterations_total, hot_stats* stats);
 
+/* ---- one connected body over several ranks (one context per rank = per GPU).  The reference is a single process (SURVEY.md
+ *      §8e); this is the MI355X-native extension of the path.  Decomposition ("particle shard, replicated grid, row-
+ *      partitioned operators"):
+ *        particles   every rank holds a contiguous range of the globally sorted particle_group list (its shard); scatters
+ *                    (P2G, force, CN tolerance, matrix-free product) are computed from the shard and summed over the ranks
+ *                    with one all-reduce of the node tiles; per-particle sums (energy, max speed) with a scalar all-reduce;
+ *        grid        block list, node numbering, DOF vectors, collision nodes and the hierarchy's index structure are
+ *                    replicated: identical on every rank by construction (bit-identical all-reduce results), so every rank
+ *                    takes the same line-search / termination decisions without further communication;
+ *        operators   matrix rows (level 0 and every coarse level above `partition_min_rows` rows) are owned by one rank
+ *                    each: a 4^3 colour block belongs to the rank whose particles first touch it.  Hessian / Galerkin rows
+ *                    that receive contributions from another rank's particles / fine rows are completed by a personalised
+ *                    exchange of partial rows; SpMV, the residual updates and each colour of the Gauss-Seidel sweeps are
+ *                    computed by the owner and handed to the other ranks right after (colour-synchronous, i.e. the update
+ *                    order is the reference's: MultigridPreconditioner.h:266-318); small coarse levels are replicated.
+ *      The library performs no communication itself: it calls the three collectives below at those points, with DEVICE
+ *      pointers (the CPU oracle: host pointers), after synchronising its stream; the callee must have completed the
+ *      operation when it returns.  hot_amd/dist.py implements them over torch.distributed (RCCL on GPUs, gloo in the CPU
+ *      tests); a C++ host would pass ncclAllReduce / ncclAllGather / grouped ncclSend+ncclRecv on its own stream + sync.
+ *      All ranks must make the same sequence of API calls.  Return 0 on success. */
+enum hot_comm_dtype { HOT_COMM_F32 = 0, HOT_COMM_F64 = 1, HOT_COMM_I32 = 2, HOT_COMM_I64 = 3 };
+enum hot_comm_op { HOT_COMM_SUM = 0, HOT_COMM_MAX = 1 };
+typedef struct hot_comm {
+    int32_t rank, size;
+    void* user;
+    /* in-place element-wise reduction over the ranks of n elements at buf; on_device: buf is device memory (else host) */
+    int32_t (*allreduce)(void* user, void* buf, int64_t n, int32_t dtype, int32_t op, int32_t on_device);
+    /* recv[r * bytes .. (r + 1) * bytes) = rank r's `bytes` bytes at send (the same count on every rank) */
+    int32_t (*allgather)(void* user, const void* send, void* recv, int64_t bytes, int32_t on_device);
+    /* personalised exchange: send_bytes[r] bytes at send + send_off[r] go to rank r, recv_bytes[r] bytes from rank r land
+     * at recv + recv_off[r]; both sides know all counts (host arrays of `size` entries); a rank sends nothing to itself */
+    int32_t (*alltoallv)(void* user, const void* send, const int64_t* send_off, const int64_t* send_bytes, void* recv, const int64_t* recv_off, const int64_t* recv_bytes,
+        int32_t on_device);
+    int32_t partition_min_rows; /* coarse levels with fewer rows are replicated instead of partitioned; 0 = default (32768) */
+    int32_t reserved[3];
+} hot_comm;
+/* Install (size > 1) or remove (NULL or size == 1) the communicator; call before hot_set_particles.  The shard given to
+ * hot_set_particles must be a contiguous range of the global particle list in sort-key order of their SPGrid pages
+ * (hot_amd/dist.py: shard_by_page_order does this split) for node numbering identical to the single-rank run. */
+int hot_set_comm(hot_ctx*, const hot_comm* comm);
+
 /* ---- the constitutive model and the plastic return mappings for caller-supplied deformation gradients (arrays of `real`,
  *      3x3 column-major, per-sample mu / lambda): CorotatedIsotropic<T,3>::updateScratch + psi + firstPiola +
  *      firstPiolaDerivative (Lib/Ziran/Physics/ConstitutiveModel/CorotatedIsotropic.h:110-230; dPdF is the 9x9 derivative, column-major

@@ -398,6 +398,16 @@ int hoto_g2p(hoto_ctx* c, double dt, int32_t* flags)
     });
     return 0;
 }
+int hoto_set_comm(hoto_ctx* c, const hot_comm* comm)
+{
+    DISPATCH(c, {
+        if (comm && comm->size > 1)
+            S.comm = *comm;
+        else
+            S.comm = hot_comm{};
+    });
+    return 0;
+}
 // CorotatedIsotropic::updateScratch + psi + firstPiola + firstPiolaDerivative for caller-supplied F (typed by the context)
 int hoto_constitutive_eval(hoto_ctx* c, int32_t n, const void* F, const void* mu, const void* lambda, int32_t project, void* psi, void* P, void* dPdF)
 {

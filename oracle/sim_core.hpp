@@ -10,6 +10,7 @@
 // P2G, DOF numbering, mass vector, BCs, G2P.
 #pragma once
 #include <functional>
+#include <stdexcept>
 #include <memory>
 #include "../include/hot_mi355x.h"
 #include "spgrid_index.hpp"
@@ -61,6 +62,32 @@ struct Sim {
     std::string err;
     T dx = 0, dt = 0;
     TV gravity;
+
+    // ---- sharded mode (hot_set_comm; include/hot_mi355x.h "one connected body over several ranks"): this rank holds a
+    // contiguous range of the globally sorted particle groups.  The oracle keeps every grid-sized array replicated — node
+    // scatters and the assembled matrix are summed over the ranks with all-reduces — and partitions only the coloured
+    // Gauss-Seidel passes (colour-synchronous exchange), which is what the product's decomposition has to reproduce.
+    hot_comm comm{};
+    bool sharded() const { return comm.size > 1 && comm.allreduce; }
+    static constexpr int REAL = sizeof(T) == 4 ? HOT_COMM_F32 : HOT_COMM_F64;
+    void allreduce(void* buf, int64_t n, int dtype, int op = HOT_COMM_SUM)
+    {
+        if (sharded() && n > 0 && comm.allreduce(comm.user, buf, n, dtype, op, 0) != 0) throw std::runtime_error("hot_comm.allreduce failed");
+    }
+    std::vector<int> block_first; // [size+1] first global block first touched by each rank's particle groups
+    std::vector<std::vector<int>> level_nstart; // per level [size+1]: rank r's id prefix = nodes first touched by ranks < r
+    bool partitioned(int level) const
+    {
+        const int minrows = comm.partition_min_rows > 0 ? comm.partition_min_rows : 32768;
+        return sharded() && level < (int)level_nstart.size() && level < (int)sysmats.size() && sysmats[level].nrows >= minrows;
+    }
+    int owner_of(int level, int node) const // rank whose id prefix holds `node`
+    {
+        const auto& ns = level_nstart[level];
+        int r = 0;
+        while (r + 1 < comm.size && node >= ns[r + 1]) ++r;
+        return r;
+    }
 
     // ---- particles
     int64_t Np = 0;
@@ -295,6 +322,26 @@ struct Sim {
                         for (int c = 0; c < 2; ++c) set_page(Mask::packed_add(offset, Mask::linear_offset(x * a, y * b, z * c)));
             }
         }
+        if (sharded()) {
+            // the global block list = the ranks' lists concatenated in rank order, first occurrence kept: with shards that are
+            // contiguous ranges of the global group order this is exactly the serial Set_Page order of the whole body
+            std::vector<int64_t> counts(comm.size, 0);
+            int64_t mine = (int64_t)blocks.size();
+            if (comm.allgather(comm.user, &mine, counts.data(), sizeof(int64_t), 0) != 0) throw std::runtime_error("hot_comm.allgather failed");
+            int64_t maxn = 0;
+            for (auto c : counts) maxn = std::max(maxn, c);
+            std::vector<uint64_t> send(maxn, 0), recv((size_t)maxn * comm.size);
+            std::copy(blocks.begin(), blocks.end(), send.begin());
+            if (comm.allgather(comm.user, send.data(), recv.data(), maxn * (int64_t)sizeof(uint64_t), 0) != 0) throw std::runtime_error("hot_comm.allgather failed");
+            blocks.clear();
+            page2block.clear();
+            block_first.assign(comm.size + 1, 0);
+            for (int r = 0; r < comm.size; ++r) {
+                block_first[r] = (int)blocks.size();
+                for (int64_t k = 0; k < counts[r]; ++k) set_page(recv[(size_t)r * maxn + k]);
+            }
+            block_first[comm.size] = (int)blocks.size();
+        }
         // neighbour table (replaces the reference's virtual-memory addressing)
         group_nb.resize(particle_group.size());
         for (size_t g = 0; g < particle_group.size(); ++g) {
@@ -358,7 +405,25 @@ struct Sim {
                 gs.v += dvel;
             });
         });
+        if (sharded()) { // sum the shards' partial node masses / momenta (every rank then numbers the same nodes)
+            std::vector<T> buf(nodes.size() * 4);
+            for (size_t s = 0; s < nodes.size(); ++s) buf[4 * s] = nodes[s].m, buf[4 * s + 1] = nodes[s].v(0), buf[4 * s + 2] = nodes[s].v(1), buf[4 * s + 3] = nodes[s].v(2);
+            allreduce(buf.data(), (int64_t)buf.size(), REAL);
+            for (size_t s = 0; s < nodes.size(); ++s) nodes[s].m = buf[4 * s], nodes[s].v = TV{ { buf[4 * s + 1], buf[4 * s + 2], buf[4 * s + 3] } };
+        }
         num_nodes = get_num_nodes();
+        if (sharded()) { // id prefix of every rank: the nodes of the blocks first touched by lower ranks
+            level_nstart.assign(1, std::vector<int>(comm.size + 1, num_nodes));
+            for (int r = 0; r <= comm.size; ++r) {
+                int first = num_nodes;
+                for (size_t s = (size_t)block_first[r] * EPB; s < nodes.size(); ++s)
+                    if (nodes[s].idx >= 0) {
+                        first = (int)nodes[s].idx;
+                        break;
+                    }
+                level_nstart[0][r] = first;
+            }
+        }
         iterate_grid([&](const int*, Node& g) {
             if (g.m != 0)
                 for (int d = 0; d < 3; ++d) g.v.a[d] = g.v.a[d] / g.m; // g.v /= g.m (:526)
@@ -742,6 +807,11 @@ struct Sim {
                 if (inc > dx2) flags |= 1;
                 if (inc > dx2 * (T)0.25 * (T)(cfg.cfl * cfg.cfl)) flags |= 2;
             }
+        if (sharded()) {
+            int32_t f[2] = { flags & 1, (flags >> 1) & 1 };
+            allreduce(f, 2, HOT_COMM_I32, HOT_COMM_MAX);
+            flags = f[0] | (f[1] << 1);
+        }
         // evolveStrain
 #pragma omp parallel for schedule(static)
         for (int64_t p = 0; p < Np; ++p) F[p] = (TM::identity() + scratch_gradV[p] * dtT) * F[p];

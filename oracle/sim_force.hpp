@@ -61,6 +61,7 @@ double Sim<T>::force_total_energy()
         corotated_update_scratch(F[p], mu[p], lambda[p], proj, s);
         e += vol[p] * corotated_psi(s, mu[p], lambda[p]);
     }
+    allreduce(&e, 1, HOT_COMM_F64); // sharded: sum of the shards' strain energies
     return e;
 }
 
@@ -104,6 +105,13 @@ void Sim<T>::rasterize_force(T scale, std::vector<TV>& force)
             gs.new_v -= delta * scale;
         });
     });
+    if (sharded()) {
+        std::vector<T> buf(nodes.size() * 3);
+        for (size_t s = 0; s < nodes.size(); ++s)
+            for (int d = 0; d < 3; ++d) buf[3 * s + d] = nodes[s].new_v(d);
+        allreduce(buf.data(), (int64_t)buf.size(), REAL);
+        for (size_t s = 0; s < nodes.size(); ++s) nodes[s].new_v = TV{ { buf[3 * s], buf[3 * s + 1], buf[3 * s + 2] } };
+    }
     iterate_grid([&](const int*, Node& g) { force[g.idx] += g.new_v; });
 }
 
@@ -142,6 +150,7 @@ void Sim<T>::evaluate_cn_tolerance()
         for (int k = 0; k < 81; ++k) nrm += dPdF[k] * dPdF[k];
         max_nrm = std::max(max_nrm, std::sqrt(nrm));
     }
+    allreduce(&max_nrm, 1, REAL, HOT_COMM_MAX);
     max_cn_tolerance = (T)cfg.cneps * dt * 24 * std::sqrt((T)num_nodes) * dx * dx * max_nrm;
     for_each_particle_colored([&](int g, int i) {
         CorotatedScratch<T> s;
@@ -158,6 +167,7 @@ void Sim<T>::evaluate_cn_tolerance()
             nodeCNTol[gs.idx] += w * mass[i] * nrm;
         });
     });
+    allreduce(nodeCNTol.data(), num_nodes, REAL);
     T eps = (T)cfg.cneps;
 #pragma omp parallel for schedule(static)
     for (int n = 0; n < num_nodes; ++n) nodeCNTol[n] *= (eps * 24 * dx * dx * dt) / mass_matrix[n];

@@ -22,9 +22,10 @@ void Sim<T>::build_matrix()
     A.entryVal.assign((size_t)num_nodes * 125, TM::zero());
     dRhs.assign(num_nodes, TV::zero());
     level_coords.assign(1, id2coord);
-    // inertia term
+    // inertia term (sharded: contributed once, by rank 0, the shards' force terms are summed below)
 #pragma omp parallel for schedule(static)
     for (int n = 0; n < num_nodes; ++n) {
+        if (sharded() && comm.rank != 0) continue;
         A.entryCol[(size_t)n * 125 + linear_offset125(0, 0, 0)] = n;
         A.entryVal[(size_t)n * 125 + linear_offset125(0, 0, 0)] = TM::identity() * mass_matrix[n];
     }
@@ -77,6 +78,10 @@ void Sim<T>::build_matrix()
             }
         }
     });
+    if (sharded()) {
+        allreduce(A.entryVal.data(), (int64_t)A.entryVal.size() * 9, REAL);
+        allreduce(A.entryCol.data(), (int64_t)A.entryCol.size(), HOT_COMM_I32, HOT_COMM_MAX); // -1 where no rank's particle couples the pair
+    }
     // BC projection of the assembled system (:554-593), or only the padding rule (:594-602)
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < num_nodes; ++i) {
@@ -343,7 +348,11 @@ void Sim<T>::build_mg()
         P.nrows = (int)coords.size();
         P.entryCol.resize(coords.size() * 8);
         P.entryVal.resize(coords.size() * 8);
+        std::vector<int> cstart;
+        if (sharded() && (int)level_nstart.size() > level) cstart.assign(comm.size + 1, -1);
         for (int i = 0; i < (int)coords.size(); ++i) {
+            for (int r = 0; r < (int)cstart.size(); ++r) // a rank's coarse id prefix: the coarse nodes first touched by fine ids below its fine prefix
+                if (cstart[r] < 0 && i >= level_nstart[level][r]) cstart[r] = (int)new_coords.size();
             int x = coords[i][0], y = coords[i][1], z = coords[i][2];
             for (int new_x = x / 2; new_x <= x / 2 + 1; ++new_x)
                 for (int new_y = y / 2; new_y <= y / 2 + 1; ++new_y)
@@ -369,6 +378,12 @@ void Sim<T>::build_mg()
                         P.entryCol[(size_t)i * 8 + linear_idx] = j;
                         P.entryVal[(size_t)i * 8 + linear_idx] = TM::identity() * weight;
                     }
+        }
+        if (!cstart.empty()) {
+            for (auto& c : cstart)
+                if (c < 0) c = (int)new_coords.size();
+            level_nstart.resize(level + 1);
+            level_nstart.push_back(cstart);
         }
         EllMat<T> R;
         build_transpose(R, P, (int)new_coords.size());
@@ -484,12 +499,30 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
     else if (kind == 5) {
         std::vector<TV>& hdu = mg_tmps[level];
         iterations = ((iterations + 1) >> 1);
+        // sharded, partitioned level: a colour block is processed by the rank whose id prefix holds its lowest node (the rank whose
+        // particles first touch it); after each colour the owners' values are handed to everybody (colour-synchronous: the
+        // sequence of updates every node sees is the single-rank one).  The exchange here is the simplest possible: an all-reduce
+        // of a vector that is zero off the rank's own blocks.
+        const bool part = partitioned(level);
+        auto mine = [&](const std::vector<int>& blockNodes) { return !part || owner_of(level, blockNodes[0]) == comm.rank; };
+        auto exchange_colour = [&](std::vector<TV>& x, int c) {
+            if (!part) return;
+            std::vector<T> buf((size_t)n * 3, (T)0);
+            for (const auto& blockNodes : A.coloredBlockDofs[c])
+                if (mine(blockNodes))
+                    for (int i : blockNodes)
+                        for (int d = 0; d < 3; ++d) buf[3 * (size_t)i + d] = x[i](d);
+            allreduce(buf.data(), (int64_t)buf.size(), REAL);
+            for (const auto& blockNodes : A.coloredBlockDofs[c])
+                for (int i : blockNodes) x[i] = TV{ { buf[3 * (size_t)i], buf[3 * (size_t)i + 1], buf[3 * (size_t)i + 2] } };
+        };
         for (; iterations--;) {
             hdu.assign(n, TV::zero());
             for (int c = 0; c < 8; ++c) {
 #pragma omp parallel for schedule(dynamic, 4)
                 for (int bid = 0; bid < (int)A.coloredBlockDofs[c].size(); ++bid) {
                     const auto& blockNodes = A.coloredBlockDofs[c][bid];
+                    if (!mine(blockNodes)) continue;
                     for (int ii = 0; ii < (int)blockNodes.size(); ++ii) {
                         int i = blockNodes[ii];
                         TV sigma = TV::zero();
@@ -500,6 +533,7 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
                         hdu[i] = A.diagonalBlock[i] * (r[i] - sigma);
                     }
                 }
+                exchange_colour(hdu, c);
             }
             for (int i = 0; i < n; ++i) hdu[i] = A.diagonalVal[i] * hdu[i];
             du.assign(n, TV::zero());
@@ -507,6 +541,7 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
 #pragma omp parallel for schedule(dynamic, 4)
                 for (int bid = 0; bid < (int)A.coloredBlockDofs[c].size(); ++bid) {
                     const auto& blockNodes = A.coloredBlockDofs[c][bid];
+                    if (!mine(blockNodes)) continue;
                     for (int ii = (int)blockNodes.size() - 1; ii >= 0; --ii) {
                         int i = blockNodes[ii];
                         TV sigma = TV::zero();
@@ -517,6 +552,7 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
                         du[i] = A.diagonalBlock[i] * (hdu[i] - sigma);
                     }
                 }
+                exchange_colour(du, c);
             }
             for (int i = 0; i < n; ++i) u[i] += du[i];
             multiply(A, du, dAu);

@@ -261,7 +261,7 @@ bool Sim<T>::newton_solve()
         else {
             // buildDiagonal (ImplicitSolver.h:605-665): block diagonal of the matrix-free operator
             std::vector<TM> diag(num_nodes);
-            for (int n = 0; n < num_nodes; ++n) diag[n] = TM::identity() * mass_matrix[n];
+            for (int n = 0; n < num_nodes; ++n) diag[n] = (sharded() && comm.rank != 0) ? TM::zero() : TM::identity() * mass_matrix[n];
             bool proj = cfg.project != 0;
             for_each_particle_colored([&](int g, int i) {
                 CorotatedScratch<T> s;
@@ -282,6 +282,7 @@ bool Sim<T>::newton_solve()
                     diag[gs.idx] += dFdX * (dt * dt * vol[i]);
                 });
             });
+            allreduce(diag.data(), (int64_t)num_nodes * 9, REAL);
             std::vector<TM> dinv(num_nodes);
             for (int n = 0; n < num_nodes; ++n) {
                 if (cfg.Ainv == 0) {
@@ -399,6 +400,12 @@ double Sim<T>::calculate_dt(double max_dt, double* max_speed, double* min_corner
     for (size_t p = 0; p < X.size(); ++p) {
         ms = std::max(ms, (T)std::sqrt(Vel[p].squaredNorm()));
         for (int d = 0; d < 3; ++d) hi[d] = std::max(hi[d], X[p](d)), nlo[d] = std::max(nlo[d], -X[p](d));
+    }
+    if (sharded()) {
+        T m7[7] = { ms, hi[0], hi[1], hi[2], nlo[0], nlo[1], nlo[2] };
+        allreduce(m7, 7, REAL, HOT_COMM_MAX);
+        ms = m7[0];
+        for (int d = 0; d < 3; ++d) hi[d] = m7[1 + d], nlo[d] = m7[4 + d];
     }
     for (const auto& o : cobjs) { // MpmSimulationBase.cpp:802-806 with AnalyticCollisionObject::evalMaxSpeed (CollisionObject.cpp:200-238)
         const double wn = std::sqrt(o.omega[0] * o.omega[0] + o.omega[1] * o.omega[1] + o.omega[2] * o.omega[2]);
