@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "get_counts", "get_indexing", "p2g", "get_grid", "set_bc", "set_sticky_halfspaces", "set_collision_objects", "begin_step", "get_dv",
     "set_dv", "update_state", "get_particle_state", "residual", "project", "cn_tolerance", "build_hessian",
     "matfree_multiply", "build_mg", "get_level", "get_matrix", "get_level_nnzb", "get_prolongation", "spmv", "restrict", "prolong",
-    "smooth", "vcycle", "solve", "g2p", "constitutive_eval", "plasticity_eval", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
+    "smooth", "vcycle", "solve", "g2p", "set_comm", "constitutive_eval", "plasticity_eval", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
 ]
 
 
@@ -119,6 +119,7 @@ class HotLib:
             "vcycle": (C.c_int, [vp, vp, vp]),
             "solve": (C.c_int, [vp, P(hot_stats)]),
             "g2p": (C.c_int, [vp, dbl, P(i32)]),
+            "set_comm": (C.c_int, [vp, vp]),
             "constitutive_eval": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp, vp]),
             "plasticity_eval": (C.c_int, [vp, i32, i32, vp, vp, vp, vp]),
             "advance": (C.c_int, [vp, dbl, P(hot_stats)]),
@@ -400,6 +401,11 @@ class Context:
         f = C.c_int32()
         self._call("g2p", C.c_double(dt), C.byref(f))
         return f.value
+
+    def set_comm(self, comm):
+        """Install a hot_amd.dist.TorchComm (one connected body over several ranks) or remove it (None).  Before set_particles."""
+        self._comm = comm  # keeps the ctypes callbacks alive
+        self._call("set_comm", C.byref(comm.struct) if comm is not None else None)
 
     def constitutive_eval(self, F, mu, lam, project=True, derivative=True):
         """psi (n), P (n,9), dPdF (n,81 or None) of the fixed-corotated model for deformation gradients F (n,9 column-major)."""

@@ -552,6 +552,7 @@ void Ctx<T>::force_pass()
 #endif
         HOT_LAUNCH(this, "force_scatter", k_force_cells<T>, Ng, FORCE_THREADS, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, (T)1 / dx, dt);
     reduce_tiles(3, gF.p, gF.p + slots, gF.p + 2 * slots, nullptr, nullptr, "force_reduce");
+    if (sharded()) allreduce_tiles(gF.p, 3);
 }
 
 template <class T>
@@ -566,6 +567,7 @@ double Ctx<T>::state_pass(const T* dv_in, bool want_force)
     }
     HOT_HIP(hipMemcpyAsync(hscal, dscal.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
+    if (sharded()) c_allreduce(hscal, 1, HOT_COMM_F64, HOT_COMM_SUM, false); // the shards' strain energies; the inertia terms are computed from replicated vectors
     double result = (double)(T)hscal[0];
     result += hscal[1] / 2;
     result -= (double)dt * hscal[2];
@@ -747,6 +749,7 @@ void Ctx<T>::cn_tolerance_dev()
     HOT_LAUNCH(this, "max_dpdf_norm", k_max_dpdf<T>, std::min(div_up(Np, 256), 1024), 256, 0, pMu.p, pLam.p, Np, (unsigned long long*)(dscal.p + 8));
     HOT_HIP(hipMemcpyAsync(hscal + 8, dscal.p + 8, sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
+    if (sharded()) c_allreduce(hscal + 8, 1, HOT_COMM_F64, HOT_COMM_MAX, false);
     max_cn_tolerance = (T)cfg.cneps * dt * 24 * (T)std::sqrt((double)Nn) * dx * dx * (T)hscal[8];
 }
 template <class T>
@@ -852,6 +855,7 @@ void Ctx<T>::matfree_dev(const T* x, T* y)
     HOT_LAUNCH(this, "matfree_hessian_product", k_matfree<T>, Ng, 256, 0, pX.p, pFn.p, pFt.p, pVol.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gIdx.p, x, gPart.p, dx,
         (T)1 / dx, dt, cfg.project);
     reduce_tiles(3, tile.p, tile.p + slots, tile.p + 2 * slots, nullptr, nullptr, "matfree_reduce");
+    if (sharded()) allreduce_tiles(tile.p, 3);
     HOT_LAUNCH(this, "matfree_finish", k_matfree_finish<T>, div_up(Nn, 256), 256, 0, tile.p, dofSlot.p, mass.p, x, y, Nn, slots);
 }
 template <class T>

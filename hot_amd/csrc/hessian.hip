@@ -222,11 +222,12 @@ __global__ __launch_bounds__(256) void k_hessian(const T* __restrict__ X, const 
 // BC projection of the assembled system (ImplicitSolver.h:554-593)
 template <class T>
 __global__ void k_bc_project_matrix(const int32_t* __restrict__ col, T* val, const int32_t* __restrict__ bcIdx, const T* __restrict__ bcR, const T* __restrict__ bcRinv,
-    const uint8_t* __restrict__ bcSlip, int nn)
+    const uint8_t* __restrict__ bcSlip, int nn, const uint8_t* __restrict__ own)
 {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)nn * 125) return;
     int i = (int)(e / 125);
+    if (own && !own[i]) return; // sharded: rows of other ranks
     int j = col[e];
     int ic = bcIdx[i], jc = bcIdx[j];
     if (ic < 0 && jc < 0) return;
@@ -266,10 +267,10 @@ __global__ void k_bc_project_matrix(const int32_t* __restrict__ col, T* val, con
 
 // buildDiagonal (SquareMatrix.h:301-324): D_i = sum of entries whose column is i; scaler by Ainv; block inverse
 template <class T>
-__global__ void k_diag(const int32_t* __restrict__ col, const T* __restrict__ val, T* diagVal, T* diagInv, T* diagBlockInv, int n, int Ainv, int stencil_order)
+__global__ void k_diag(const int32_t* __restrict__ col, const T* __restrict__ val, T* diagVal, T* diagInv, T* diagBlockInv, int n, int Ainv, int stencil_order, const uint8_t* __restrict__ own)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || (own && !own[i])) return;
     Mat3<T> D;
 #pragma unroll
     for (int c = 0; c < 9; ++c) D.a[c] = (T)0;
@@ -307,15 +308,18 @@ template <class T>
 void Ctx<T>::build_diagonal(Level<T>& L)
 {
     L.diagVal.reserve(9 * (size_t)L.n), L.diagInv.reserve(9 * (size_t)L.n), L.diagBlockInv.reserve(9 * (size_t)L.n);
-    HOT_LAUNCH(this, "build_diagonal", k_diag<T>, div_up(L.n, 256), 256, 0, L.col.p, L.val.p, L.diagVal.p, L.diagInv.p, L.diagBlockInv.p, L.n, cfg.Ainv, L.split ? 0 : 1);
+    HOT_LAUNCH(this, "build_diagonal", k_diag<T>, div_up(L.n, 256), 256, 0, L.col.p, L.val.p, L.diagVal.p, L.diagInv.p, L.diagBlockInv.p, L.n, cfg.Ainv, L.split ? 0 : 1, L.mask());
+    if (L.part) // the diagonal blocks are used by the replicated vector algebra of the smoothers (scalers) as well: every rank gets all of them
+        exchange(L, L.diagVal.p, -1, 9), exchange(L, L.diagInv.p, -1, 9), exchange(L, L.diagBlockInv.p, -1, 9);
 }
 
 template <class T>
-__global__ __launch_bounds__(256) void k_count_nnzb(const T* __restrict__ val, int64_t nblocks, unsigned long long* out)
+__global__ __launch_bounds__(256) void k_count_nnzb(const T* __restrict__ val, int64_t nblocks, unsigned long long* out, const uint8_t* __restrict__ own)
 {
     __shared__ double red[4];
     double c = 0;
     for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nblocks; b += (int64_t)gridDim.x * 256) {
+        if (own && !own[b / 125]) continue;
         const T* v = val + b * 9;
         bool nz = false;
 #pragma unroll
@@ -330,11 +334,13 @@ void Ctx<T>::count_nnzb(Level<T>& L)
 {
     unsigned long long* d = (unsigned long long*)(dscal.p + 120);
     HOT_HIP(hipMemsetAsync(d, 0, 8, stream));
-    HOT_LAUNCH(this, "count_nnzb", k_count_nnzb<T>, std::min(div_up((size_t)L.n * 125, 256), 2048), 256, 0, L.val.p, (int64_t)L.n * 125, d);
+    HOT_LAUNCH(this, "count_nnzb", k_count_nnzb<T>, std::min(div_up((size_t)L.n * 125, 256), 2048), 256, 0, L.val.p, (int64_t)L.n * 125, d, L.mask());
     unsigned long long h = 0;
     HOT_HIP(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream));
     sync();
-    L.nnzb = (long long)h;
+    int64_t total = (int64_t)h;
+    if (L.part) c_allreduce(&total, 1, HOT_COMM_I64, HOT_COMM_SUM, false); // every rank counted the rows it owns
+    L.nnzb = (long long)total;
 }
 
 template <class T>
@@ -349,6 +355,12 @@ void Ctx<T>::build_hessian()
     size_t ne = (size_t)Nn * 125;
     L->col.reserve(ne), L->val.reserve(ne * 9), L->coord.reserve(3 * (size_t)Nn);
     HOT_HIP(hipMemcpyAsync(L->coord.p, id2coord.p, 3 * (size_t)Nn * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+    L->part = false, L->colored = false;
+    if (sharded()) { // row ownership of level 0 (always partitioned): needs the colouring, which only reads the coordinates
+        L->nstart = nstart0;
+        color_level(*L);
+        level_ownership(*L);
+    }
     const bool v1 = ab_flag("HOT_HESSIAN_V1"); // A/B build only: per-cell global-atomic scatter kernel
     HOT_LAUNCH(this, "hessian_fill_cols", k_fill_cols<T>, div_up(ne, 256), 256, 0, block_map, gIdx.p, id2coord.p, mass.p, L->col.p, L->val.p, Nn, v1 ? 1 : 0);
 #ifdef HOT_AB_KERNELS
@@ -358,8 +370,9 @@ void Ctx<T>::build_hessian()
     else
 #endif
         assemble_tiles(*L);
+    if (L->part) exchange_rows(*L, written.p); // rows near the shard boundary: the other side's particles contribute as well
     if (cfg.systemBCProject && Nc > 0)
-        HOT_LAUNCH(this, "hessian_bc_project", k_bc_project_matrix<T>, div_up(ne, 256), 256, 0, L->col.p, L->val.p, bcIdx.p, bcR.p, bcRinv.p, bcSlip.p, Nn);
+        HOT_LAUNCH(this, "hessian_bc_project", k_bc_project_matrix<T>, div_up(ne, 256), 256, 0, L->col.p, L->val.p, bcIdx.p, bcR.p, bcRinv.p, bcSlip.p, Nn, L->mask());
     build_diagonal(*L);
     L->nnzb = -1; // counted on request (hot_get_level_nnzb)
     sync();

@@ -360,7 +360,8 @@ struct TileLds2 {
 
 template <class T>
 __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ dp, int64_t Np, const uint64_t* __restrict__ blocks,
-    const int32_t* __restrict__ gIdx, const int32_t* __restrict__ cell_first, HashMap cmap, const T* __restrict__ mass, T* __restrict__ val, T one_over_dx, int ntiles)
+    const int32_t* __restrict__ gIdx, const int32_t* __restrict__ cell_first, HashMap cmap, const T* __restrict__ mass, T* __restrict__ val, T one_over_dx, int ntiles,
+    const uint8_t* __restrict__ own /*sharded: rows this rank owns (they get the inertia term here), else null*/, uint8_t* __restrict__ written /*sharded: rows this launch wrote*/)
 {
     using G = Geo<T>;
     constexpr int CH = TileLds2<T>::CH, KMAX = TileLds2<T>::KMAX;
@@ -418,6 +419,13 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
     }
     int pk_c = 0, pk_off = 0; // packing cursor (wavefront 0): cell, offset inside it
     __syncthreads();
+    if (own) { // sharded: a tile none of whose rows this rank owns and none of whose cells hold particles of its shard is not its business
+        bool mine = false;
+        for (int r = 0; r < 8; ++r) mine = mine || (rdof[r] >= 0 && own[rdof[r]]);
+        bool any_particles = false;
+        for (int c = 0; c < 64; ++c) any_particles = any_particles || (ccnt[c] > 0 && cmask[c] != 0);
+        if (!mine && !any_particles) return; // workgroup-uniform (LDS tables)
+    }
     for (;;) {
         // ---- pack the next chunk: whole or partial cells until CH particles or KMAX entries.  Wavefront 0, lane = cell:
         // the particles (and K entries) from the chunk start to the end of each cell by two prefix sums, the first cell
@@ -558,8 +566,9 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
         int dof = rdof[r];
         if (dof < 0) continue;
         T v = (T)tile[e];
-        if (q >= 62 * 9 && q < 63 * 9 && ((q - 62 * 9) % 4 == 0)) v += mass[dof];
+        if (q >= 62 * 9 && q < 63 * 9 && ((q - 62 * 9) % 4 == 0) && (!own || own[dof])) v += mass[dof];
         val[(int64_t)dof * 1125 + q] = v;
+        if (written && q == 0) written[dof] = 1;
     }
 }
 
@@ -582,7 +591,12 @@ void Ctx<T>::assemble_tiles(Level<T>& L)
         return;
     }
 #endif
-    HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles2<T>, 256 * div_up(Nb * TPB, 256), HT_THREADS, TileLds2<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx, Nb * TPB);
+    if (L.part) {
+        written.reserve(Nn);
+        HOT_HIP(hipMemsetAsync(written.p, 0, Nn, stream));
+    }
+    HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles2<T>, 256 * div_up(Nb * TPB, 256), HT_THREADS, TileLds2<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx, Nb * TPB,
+        L.mask(), L.part ? written.p : (uint8_t*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ matrix-free diagonal
@@ -673,6 +687,7 @@ void Ctx<T>::matfree_diagonal(T* dinv)
         HOT_LAUNCH(this, "matfree_diag_scatter", k_mf_diag_col<T>, Ng, 256, 0, pX.p, pFn.p, pDP.p, Np, group_first.p, group_origin.p, gPart.p, (T)1 / dx, cc);
         reduce_tiles(3, tile.p + (3 * cc) * slots, tile.p + (3 * cc + 1) * slots, tile.p + (3 * cc + 2) * slots, nullptr, nullptr, "matfree_diag_reduce");
     }
+    if (sharded()) allreduce_tiles(tile.p, 9);
     HOT_LAUNCH(this, "matfree_diag_finish", k_mf_diag_finish<T>, div_up(Nn, 256), 256, 0, tile.p, dofSlot.p, mass.p, dinv, Nn, slots, cfg.Ainv);
 }
 

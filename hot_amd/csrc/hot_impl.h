@@ -136,6 +136,7 @@ struct Ctx : CtxBase {
     hot_comm comm{};
     bool sharded() const { return comm.size > 1; }
     std::vector<int> block_first; // [ranks + 1] first global block first touched by each rank's particle groups
+    std::vector<int> nstart0; // [ranks + 1] level-0 id prefixes (nodes of those blocks)
     DBuf<char> xsend, xrecv; // staging of the collectives
     DBuf<uint8_t> written; // level-0 rows this rank's tile kernel has written (its partial rows)
     void set_comm(const hot_comm* c) override;
@@ -143,8 +144,9 @@ struct Ctx : CtxBase {
     void c_allgather(const void* send, void* recv, int64_t bytes, bool on_device);
     void c_alltoallv(const void* send, const int64_t* soff, const int64_t* sbytes, void* recv, const int64_t* roff, const int64_t* rbytes);
     void merge_block_lists(); // sort(): the ranks' first-touch block lists -> the global Set_Page order
+    void color_level(Level<T>& L); // markColors of one level (mg_build.hip)
     void level_ownership(Level<T>& L); // owner / own / colour splits / exchange tables from L.nstart and the colouring
-    void exchange(Level<T>& L, T* x, int colour); // owners' entries of x (all colours: colour < 0) to every rank
+    void exchange(Level<T>& L, T* x, int colour, int ncomp = 3); // owners' entries of x (ncomp values per node; all colours: colour < 0) to every rank
     void exchange_rows(Level<T>& L, const uint8_t* touched); // partial matrix rows -> their owners, summed there
     void allreduce_tiles(T* tiles, int q); // q * Nb * EPB node-tile values, summed over the ranks
     static constexpr int REAL = sizeof(T) == 4 ? HOT_COMM_F32 : HOT_COMM_F64;
@@ -180,7 +182,7 @@ struct Ctx : CtxBase {
         }
         else
             l = new Level<T>();
-        l->id = id, l->n = 0, l->nnzb = 0, l->nblocks = 0, l->built = false, l->split = false;
+        l->id = id, l->n = 0, l->nnzb = 0, l->nblocks = 0, l->built = false, l->split = false, l->part = false, l->colored = false;
         return l;
     }
     void release_levels(size_t keep = 0)

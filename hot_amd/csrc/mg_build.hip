@@ -115,11 +115,12 @@ __global__ void k_coarse_cols(HashMap cmap, const int32_t* __restrict__ ccoord, 
 // AP[i][(a,b,c) in 4^3][9]: coarse window origin cb = (coord - 2) >> 1 ;  J = cb + (a,b,c)
 // AP[i,J] = sum_{d in {-1,0,1}^3} w(d) A[i][slot(i - (2J + d))]
 template <class T>
-__global__ __launch_bounds__(256) void k_ap(const int32_t* __restrict__ coord, const T* __restrict__ val, T* ap, int n)
+__global__ __launch_bounds__(256) void k_ap(const int32_t* __restrict__ coord, const T* __restrict__ val, T* ap, int n, const uint8_t* __restrict__ own)
 {
     __shared__ T row[4][1125];
     int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int i = blockIdx.x * 4 + w;
+    if (own && i < n && !own[i]) i = n; // sharded: rows of other ranks (wave-uniform; the barrier below is still reached)
     if (i < n) {
         const T* src = val + (int64_t)i * 1125;
         for (int e = lane; e < 1125; e += 64) row[w][e] = src[e];
@@ -165,7 +166,8 @@ __global__ void k_ap_cols(HashMap cmap, const int32_t* __restrict__ coord, int32
 }
 // RAP[I][slot k][9] = sum_{d} w(d) AP[child(I,d)][J - cb(child)] ,  J = I - Delta(k)
 template <class T>
-__global__ __launch_bounds__(256) void k_rap(const int32_t* __restrict__ ccoord, const int32_t* __restrict__ child, const T* __restrict__ ap, T* cval, int nc)
+__global__ __launch_bounds__(256) void k_rap(const int32_t* __restrict__ ccoord, const int32_t* __restrict__ child, const T* __restrict__ ap, T* cval, int nc,
+    const uint8_t* __restrict__ fine_own /*sharded: only the fine rows this rank owns contribute (partial sums), else null*/)
 {
     int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int I = blockIdx.x * 4 + w;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void k_rap(const int32_t* __restrict__ ccoord,
         T sum = (T)0;
         for (int q = 0; q < 27; ++q) {
             int ci = child[I * 27 + q];
-            if (ci < 0) continue;
+            if (ci < 0 || (fine_own && !fine_own[ci])) continue;
             int da = q / 9 - 1, db = (q / 3) % 3 - 1, dc = q % 3 - 1;
             int x = 2 * X + da, y = 2 * Y + db, z = 2 * Z + dc;
             int a = Jx - ((x - 2) >> 1), b = Jy - ((y - 2) >> 1), c = Jz - ((z - 2) >> 1);
@@ -347,13 +349,14 @@ static void mark_colors(Ctx<T>* ctx, Level<T>& L)
 // w.r.t. the GS order ("in" = column inside the row's own 4^3 colour block), stable inside each class.  One wavefront
 // per row, the row is staged in LDS and rewritten in place.  rowcnt[4 i ..] = the four off-diagonal class sizes.
 template <class T>
-__global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col, T* __restrict__ val, const uint32_t* __restrict__ ckey, int32_t* __restrict__ rowcnt, int n)
+__global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col, T* __restrict__ val, const uint32_t* __restrict__ ckey, int32_t* __restrict__ rowcnt, int n,
+    const uint8_t* __restrict__ own)
 {
     __shared__ T sval[4][1125];
     __shared__ int32_t scol[4][125];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = blockIdx.x * 4 + w;
-    const bool valid = i0 < n; // no early return: the workgroup barrier below must be reached by all four waves
+    const bool valid = i0 < n && (!own || own[i0]); // sharded: only the rows this rank owns hold a matrix // no early return: the workgroup barrier below must be reached by all four waves
     const int i = valid ? i0 : n - 1;
     const uint32_t keyi = ckey[i];
     int32_t* c = col + (int64_t)i * 125;
@@ -432,7 +435,7 @@ template <class T>
 static void split_rows(Ctx<T>* ctx, Level<T>& L)
 {
     L.rowcnt.reserve(4 * (size_t)L.n);
-    HOT_LAUNCH(ctx, "gs_split_rows", k_gs_split_rows<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.ckey.p, L.rowcnt.p, L.n);
+    HOT_LAUNCH(ctx, "gs_split_rows", k_gs_split_rows<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.ckey.p, L.rowcnt.p, L.n, L.mask());
     L.gs_pad.reserve(512 * (size_t)L.nblocks);
     HOT_LAUNCH(ctx, "gs_pad", k_gs_pad, div_up((size_t)L.nblocks * 64, 256), 256, 0, L.gs_block_start.p, L.gs_order.p, L.rowcnt.p, L.gs_pad.p, L.nblocks);
     L.split = true;
@@ -444,6 +447,26 @@ static void alloc_work(Level<T>& L)
     size_t m = 3 * (size_t)L.n;
     L.residual.reserve(m), L.initialResidual.reserve(m), L.sol.reserve(m), L.du.reserve(m), L.dAu.reserve(m), L.tmp.reserve(m);
     L.built = true;
+}
+
+template <class T>
+void Ctx<T>::color_level(Level<T>& L)
+{
+    if (L.colored) return;
+    mark_colors(this, L);
+    L.colored = true;
+}
+// coarse rows for which this rank holds a partial Galerkin sum: at least one of the <= 27 fine children is a row it owns
+__global__ void k_coarse_touched(const int32_t* __restrict__ child, const uint8_t* __restrict__ fine_own, uint8_t* touched, int nc)
+{
+    int I = blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= nc) return;
+    bool t = false;
+    for (int q = 0; q < 27; ++q) {
+        const int ci = child[I * 27 + q];
+        t = t || (ci >= 0 && fine_own[ci]);
+    }
+    touched[I] = t ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ baseline geometric multigrid
@@ -533,10 +556,10 @@ void Ctx<T>::build_mg()
     }
     double t0 = wall_ms();
     release_levels(1);
-    bool colors = baseline || cfg.smoother == 5 || cfg.coarseSolver == 5; // baseline: GS smoother, PCG on top (:447-448)
+    bool colors = baseline || cfg.smoother == 5 || cfg.coarseSolver == 5 || sharded(); // baseline: GS smoother, PCG on top (:447-448); sharded: row ownership follows the colour blocks
     Level<T>& L0 = *levels[0];
     alloc_work(L0);
-    if (colors) mark_colors(this, L0);
+    if (colors) color_level(L0);
     if (!baseline && ((cfg.coarseSolver == 6 && cfg.levelCnt == 1) || (cfg.smoother == 6 && cfg.levelCnt > 1))) estimate_2norm(L0, 1e-6); // MultigridPreconditioner.h:610-611
     for (int level = 0; level < cfg.levelCnt - 1; ++level) {
         Level<T>& F = *levels[level];
@@ -573,6 +596,12 @@ void Ctx<T>::build_mg()
             nc = C.n;
             C.coord.reserve(3 * nc), C.col.reserve(125 * nc), C.val.reserve(1125 * nc), C.child.reserve(27 * nc);
             HOT_LAUNCH(this, "mg_coarse_assign", k_coarse_assign, div_up(cand, 256), 256, 0, C.map, F.coord.p, flags.p, scan.p, C.coord.p, n);
+            if (sharded()) { // a rank's coarse id prefix: the coarse nodes first touched by fine ids below its fine prefix (first-touch numbering keeps prefixes)
+                C.nstart.assign(comm.size + 1, C.n);
+                for (int r = 0; r < comm.size; ++r)
+                    if (F.nstart[r] < n) HOT_HIP(hipMemcpyAsync(&C.nstart[r], scan.p + 8 * (size_t)F.nstart[r], sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                sync();
+            }
         }
         // ---- transfer tables
         F.pcol.reserve(8 * (size_t)n), F.pw.reserve(8 * (size_t)n);
@@ -590,13 +619,28 @@ void Ctx<T>::build_mg()
             HOT_LAUNCH(this, "mg_coarse_cols", k_coarse_cols, div_up(125 * nc, 256), 256, 0, C.map, C.coord.p, C.col.p, C.n);
         // ---- A_c = R (A P)
         F.apv.reserve(576 * (size_t)n), F.apc.reserve(64 * (size_t)n);
-        HOT_LAUNCH(this, "mg_AP", k_ap<T>, div_up(n, 4), 256, 0, F.coord.p, F.val.p, F.apv.p, n);
+        HOT_LAUNCH(this, "mg_AP", k_ap<T>, div_up(n, 4), 256, 0, F.coord.p, F.val.p, F.apv.p, n, F.mask());
         HOT_LAUNCH(this, "mg_AP_cols", k_ap_cols, div_up(64 * (size_t)n, 256), 256, 0, C.map, F.coord.p, F.apc.p, n);
-        if (!baseline) HOT_LAUNCH(this, "mg_RAP", k_rap<T>, div_up(nc, 4), 256, 0, C.coord.p, C.child.p, F.apv.p, C.val.p, C.n);
+        if (!baseline) HOT_LAUNCH(this, "mg_RAP", k_rap<T>, div_up(nc, 4), 256, 0, C.coord.p, C.child.p, F.apv.p, C.val.p, C.n, F.mask());
+        if (F.part) {
+            // every rank has summed its own fine rows into ALL coarse rows (zeros where it owns no child).  Large coarse levels
+            // stay partitioned: partial rows go to their owners; small ones are replicated: one all-reduce of the whole matrix
+            const int minrows = comm.partition_min_rows > 0 ? comm.partition_min_rows : 32768;
+            if (C.n >= minrows) {
+                color_level(C);
+                level_ownership(C);
+                DBuf<uint8_t> touched;
+                touched.reserve(nc);
+                HOT_LAUNCH(this, "shard_coarse_touched", k_coarse_touched, div_up(nc, 256), 256, 0, C.child.p, F.own.p, touched.p, C.n);
+                exchange_rows(C, touched.p);
+            }
+            else
+                c_allreduce(C.val.p, (int64_t)nc * 1125, REAL, HOT_COMM_SUM, true);
+        }
         build_diagonal(C);
         C.nnzb = -1; // counted on request (hot_get_level_nnzb)
         alloc_work(C);
-        if (colors) mark_colors(this, C);
+        if (colors) color_level(C);
         if (!baseline && ((cfg.coarseSolver == 6 && level + 2 == cfg.levelCnt) || (cfg.smoother == 6 && level + 2 < cfg.levelCnt))) estimate_2norm(C, 1e-6); // :682-683
         if (colors) split_rows(this, F); // level `level` is no longer needed in stencil-slot order
     }

@@ -88,11 +88,11 @@ double Ctx<T>::dot_host(size_t n, const T* x, const T* y)
 
 // ------------------------------------------------------------------------------------------------ SpMV
 template <class T>
-__global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ col, const T* __restrict__ val, const T* __restrict__ x, T* __restrict__ y, int n)
+__global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ col, const T* __restrict__ val, const T* __restrict__ x, T* __restrict__ y, int n, const uint8_t* __restrict__ own)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
+    if (row >= n || (own && !own[row])) return; // sharded: rows of other ranks (wave-uniform)
     const int32_t* c = col + (int64_t)row * 125;
     const T* v = val + (int64_t)row * 1125;
     T s0 = 0, s1 = 0, s2 = 0;
@@ -115,11 +115,11 @@ __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ col, c
 // vector; A P is a by-product of the Galerkin build with 64 window slots per row instead of the 125 of A, i.e. half
 // the bytes of the SpMV the reference performs here (MultigridPreconditioner.h:362-421).
 template <class T>
-__global__ __launch_bounds__(256) void k_apmv_sub(const int32_t* __restrict__ apc, const T* __restrict__ apv, const T* __restrict__ e, T* __restrict__ r, int n)
+__global__ __launch_bounds__(256) void k_apmv_sub(const int32_t* __restrict__ apc, const T* __restrict__ apv, const T* __restrict__ e, T* __restrict__ r, int n, const uint8_t* __restrict__ own)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
+    if (row >= n || (own && !own[row])) return;
     const int j = apc[(int64_t)row * 64 + lane];
     const T* b = apv + ((int64_t)row * 64 + lane) * 9;
     const T x0 = e[3 * (int64_t)j], x1 = e[3 * (int64_t)j + 1], x2 = e[3 * (int64_t)j + 2];
@@ -217,7 +217,8 @@ void Ctx<T>::scal(size_t n, T a, T* x)
 template <class T>
 void Ctx<T>::spmv_dev(Level<T>& L, const T* x, T* y)
 {
-    HOT_LAUNCH(this, lname("spmv", L.id).c_str(), k_spmv<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, x, y, L.n);
+    HOT_LAUNCH(this, lname("spmv", L.id).c_str(), k_spmv<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, x, y, L.n, L.mask());
+    exchange(L, y, -1); // sharded: every rank computed the rows it owns; all of y is needed by the replicated vector algebra
 }
 
 // ------------------------------------------------------------------------------------------------ transfers
@@ -866,11 +867,11 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
 // r_i = sum over the nl slots preceding row i of A_ik (h - du)_k   (rows regrouped by k_gs_split_rows)
 template <class T>
 __global__ __launch_bounds__(256) void k_gs_residual(const int32_t* __restrict__ col, const T* __restrict__ val, const int32_t* __restrict__ rowcnt, const T* __restrict__ h,
-    const T* __restrict__ du, T* __restrict__ r, int n)
+    const T* __restrict__ du, T* __restrict__ r, int n, const uint8_t* __restrict__ own)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
+    if (row >= n || (own && !own[row])) return;
     const int nl = rowcnt[4 * row] + rowcnt[4 * row + 1];
     const int32_t* c = col + (int64_t)row * 125;
     const T* v = val + (int64_t)row * 1125;
@@ -949,7 +950,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         HOT_HIP(hipMemcpyAsync(s, &zTrk, sizeof(double), hipMemcpyHostToDevice, stream));
         int cnt = 0;
         const bool cg_unfused = ab_flag("HOT_CG_UNFUSED"); // A/B build only: one launch per vector operation
-        if (!cg_unfused && !(level == 0 && !cfg.systemBCProject)) {
+        if (!cg_unfused && !(level == 0 && !cfg.systemBCProject) && !L.part) { // (partitioned level: the generic path below, whose SpMV exchanges)
             HOT_HIP(hipMemsetAsync(s + 1, 0, 6 * sizeof(double), stream));
             for (; iterations--;) {
                 if (zTrk < tol) break;
@@ -1041,7 +1042,25 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             const char* nm = fwd ? "gs_forward" : "gs_backward";
             const T* rhs = fwd ? r : dAu;
             T* xx = fwd ? hdu : du;
-            T* hD = fwd ? dAu : (simple_gs ? (T*)nullptr : u); // backward block kernels add du to u themselves
+            // sharded: this rank substitutes the colour blocks it owns (a contiguous run of the colour's list), then every rank
+            // receives the colour's new values before the next colour starts — the reference's update order, across ranks
+            struct AfterPass {
+                Ctx<T>* ctx;
+                Level<T>& L;
+                T* x;
+                int c;
+                bool last;
+                ~AfterPass()
+                {
+                    if (L.part && last) ctx->exchange(L, x, c);
+                }
+            } after{ this, L, xx, c, nmerge > 1 || (fwd ? h == nsub - 1 : h == 0) };
+            if (L.part) {
+                const int R1 = comm.size + 1;
+                b0 += L.csplit[c * R1 + comm.rank], nb = L.csplit[c * R1 + comm.rank + 1] - L.csplit[c * R1 + comm.rank];
+                if (nb <= 0) return;
+            }
+            T* hD = fwd ? dAu : ((simple_gs || L.part) ? (T*)nullptr : u); // backward block kernels add du to u themselves (partitioned level: only the owner's rows would get it, see below)
 #ifdef HOT_AB_KERNELS
             if (simple_gs) {
                 if (h != 0) return;
@@ -1074,7 +1093,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         const bool multilaunch = cfg.gs_chain == 1, force_dataflow = cfg.gs_chain == 2; // tuning overrides (0 = by level size)
         // measured (C2, fp64): the chained launch wins on levels whose colours fit the chip in one round (latency-bound
         // passes, no launch gaps); on the finest level the waiting workgroups cost more than the kernel boundaries
-        const bool dataflow = !gs_no_chain && !multilaunch && !simple_gs && L.split && (force_dataflow || max_nb <= 256);
+        const bool dataflow = !gs_no_chain && !multilaunch && !simple_gs && L.split && !L.part && (force_dataflow || max_nb <= 256); // a chained launch cannot stop for the exchange
         GsPasses PF{}, PB{};
         if (dataflow) {
             auto add = [&](GsPasses& P, int c, int h) {
@@ -1134,12 +1153,13 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             else
                 for (int c = 7; c >= 0; --c)
                     for (int h = nsub - 1; h >= 0; --h) pass(false, c, h);
-            if (simple_gs) axpy(n3, (T)1, du, u);
+            if (simple_gs || L.part) axpy(n3, (T)1, du, u); // partitioned level: du is complete on every rank after the colour exchanges, u stays replicated
             if (!final_residual && iterations == 0) break;
             if (L.split && !simple_gs && !(level == 0 && !cfg.systemBCProject) && !no_lres) {
                 // r - A du = L (h - du): with (D+L) h = r and (D+U) du = D h the full product A du collapses to the
                 // strictly-preceding half of the matrix applied to (h - du) (same value, half the bytes of an SpMV)
-                HOT_LAUNCH(this, lname("gs_residual", L.id).c_str(), k_gs_residual<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.rowcnt.p, hdu, du, r, L.n);
+                HOT_LAUNCH(this, lname("gs_residual", L.id).c_str(), k_gs_residual<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.rowcnt.p, hdu, du, r, L.n, L.mask());
+                exchange(L, r, -1); // partitioned level: the restriction / the next smoother read all of r
             }
             else {
                 spmv_dev(L, du, dAu);
@@ -1203,7 +1223,9 @@ void Ctx<T>::vcycle_dev(const T* in, T* out)
             axpy(n3, (T)-1, L.dAu.p, L.residual.p);
         }
         else
-            HOT_LAUNCH(this, lname("apmv", L.id).c_str(), k_apmv_sub<T>, div_up(L.n, 4), 256, 0, L.apc.p, L.apv.p, levels[level + 1]->sol.p, L.residual.p, L.n);
+            HOT_LAUNCH(this, lname("apmv", L.id).c_str(), k_apmv_sub<T>, div_up(L.n, 4), 256, 0, L.apc.p, L.apv.p, levels[level + 1]->sol.p, L.residual.p, L.n, L.mask());
+        if (L.part && (level < splitLevel ? (baseline ? 5 : cfg.smoother) : (baseline ? 2 : cfg.coarseSolver)) != 5)
+            exchange(L, L.residual.p, -1); // a GS post-smoother reads only the rows it owns; every other smoother runs replicated vector algebra on all of r
         run(level < splitLevel, level, sol, level < splitLevel ? downIter(level) : topIter(level), false);
     }
 }

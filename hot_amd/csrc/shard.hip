@@ -215,20 +215,16 @@ __device__ __forceinline__ int xchg_pos(const int32_t* __restrict__ tab, int R, 
     return -1;
 }
 template <class T>
-__global__ void k_xchg_pack(const T* __restrict__ x, const int32_t* __restrict__ gs_order, const int32_t* __restrict__ tab, int R, int me, int colour, T* __restrict__ out, int maxc)
+__global__ void k_xchg_pack(const T* __restrict__ x, const int32_t* __restrict__ gs_order, const int32_t* __restrict__ tab, int R, int me, int colour, T* __restrict__ out, int maxc, int ncomp)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= maxc) return;
     const int p = xchg_pos(tab, R, me, colour, k);
-    T a = 0, b = 0, c = 0;
-    if (p >= 0) {
-        const int64_t i = gs_order[p];
-        a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
-    }
-    out[3 * (int64_t)k] = a, out[3 * (int64_t)k + 1] = b, out[3 * (int64_t)k + 2] = c;
+    const int64_t i = p >= 0 ? gs_order[p] : 0;
+    for (int d = 0; d < ncomp; ++d) out[ncomp * (int64_t)k + d] = p >= 0 ? x[ncomp * i + d] : (T)0;
 }
 template <class T>
-__global__ void k_xchg_unpack(T* __restrict__ x, const int32_t* __restrict__ gs_order, const int32_t* __restrict__ tab, int R, int me, int colour, const T* __restrict__ in, int maxc)
+__global__ void k_xchg_unpack(T* __restrict__ x, const int32_t* __restrict__ gs_order, const int32_t* __restrict__ tab, int R, int me, int colour, const T* __restrict__ in, int maxc, int ncomp)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= R * maxc) return;
@@ -237,24 +233,24 @@ __global__ void k_xchg_unpack(T* __restrict__ x, const int32_t* __restrict__ gs_
     const int p = xchg_pos(tab, R, r, colour, k);
     if (p < 0) return;
     const int64_t i = gs_order[p];
-    x[3 * i] = in[3 * (int64_t)e], x[3 * i + 1] = in[3 * (int64_t)e + 1], x[3 * i + 2] = in[3 * (int64_t)e + 2];
+    for (int d = 0; d < ncomp; ++d) x[ncomp * i + d] = in[ncomp * (int64_t)e + d];
 }
 
 // Every rank receives the owners' entries of x: after a row-partitioned operator (all colours) or after one colour of a
 // Gauss-Seidel sweep.  One all-gather of equally sized (padded) slots; the slot layout follows gs_order, so packing and
 // unpacking need no index lists beyond the per-(rank, colour) ranges.
 template <class T>
-void Ctx<T>::exchange(Level<T>& L, T* x, int colour)
+void Ctx<T>::exchange(Level<T>& L, T* x, int colour, int ncomp)
 {
     if (!L.part) return;
     const int R = comm.size, me = comm.rank;
     const int maxc = colour < 0 ? L.xmax_full : L.xmax_col[colour];
     if (maxc == 0) return;
-    const size_t slot = (size_t)maxc * 3 * sizeof(T);
+    const size_t slot = (size_t)maxc * ncomp * sizeof(T);
     xsend.reserve(slot), xrecv.reserve(slot * R);
-    HOT_LAUNCH(this, "xchg_pack", k_xchg_pack<T>, div_up(maxc, 256), 256, 0, x, L.gs_order.p, L.dxtab.p, R, me, colour, (T*)xsend.p, maxc);
+    HOT_LAUNCH(this, "xchg_pack", k_xchg_pack<T>, div_up(maxc, 256), 256, 0, x, L.gs_order.p, L.dxtab.p, R, me, colour, (T*)xsend.p, maxc, ncomp);
     c_allgather(xsend.p, xrecv.p, (int64_t)slot, true);
-    HOT_LAUNCH(this, "xchg_unpack", k_xchg_unpack<T>, div_up((size_t)R * maxc, 256), 256, 0, x, L.gs_order.p, L.dxtab.p, R, me, colour, (const T*)xrecv.p, maxc);
+    HOT_LAUNCH(this, "xchg_unpack", k_xchg_unpack<T>, div_up((size_t)R * maxc, 256), 256, 0, x, L.gs_order.p, L.dxtab.p, R, me, colour, (const T*)xrecv.p, maxc, ncomp);
 }
 
 // ------------------------------------------------------------------------------------------------ partial matrix rows

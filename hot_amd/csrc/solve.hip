@@ -570,6 +570,7 @@ void Ctx<T>::calculate_dt(double max_dt, double* dt_out, double* max_speed, doub
     HOT_LAUNCH(this, "max_speed_fold", k_max_fold<T>, 1, 64, 0, speed_part.p, nb, dscal.p + 200);
     HOT_HIP(hipMemcpyAsync(hscal + 200, dscal.p + 200, 7 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
+    if (sharded()) c_allreduce(hscal + 200, 7, HOT_COMM_F64, HOT_COMM_MAX, false); // max speed, max corner, -min corner over the shards
     T ms = (T)hscal[200];
     if (!cobjs.empty()) { // :802-806 collision objects inside the particle box expanded by (degree + 2) dx
         double lo[3], hi[3];

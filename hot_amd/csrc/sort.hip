@@ -361,6 +361,7 @@ void Ctx<T>::sort()
     Nb = exclusive_scan_i32(flags.p, scan.p, cand);
     blocks.reserve(Nb);
     HOT_LAUNCH(this, "block_assign", k_block_assign<T>, div_up(cand, 256), 256, 0, block_map, group_origin.p, flags.p, scan.p, blocks.p, Ng);
+    if (sharded()) merge_block_lists(); // the global Set_Page order: block ids, Nb and block_map are global from here on
     HOT_LAUNCH(this, "group_nb", k_group_nb<T>, div_up(cand, 256), 256, 0, block_map, group_origin.p, group_nb.p, Ng);
     // node tiles
     size_t slots = (size_t)Nb * EPB;

@@ -273,6 +273,15 @@ void Ctx<T>::p2g()
     else
         HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, false>), Ng, P2G_THREADS, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
     reduce_tiles(nq, gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p, "p2g_reduce");
+    if (sharded()) { // the shards' partial node sums -> the body's (one all-reduce of nq values per node slot)
+        DBuf<T>& st = ap; // scratch, otherwise used only while the hierarchy is built
+        st.reserve((size_t)nq * slots);
+        copy(slots, gM.p, st.p), copy(3 * (size_t)slots, gMV.p, st.p + slots);
+        if (nq == 5) copy(slots, gCN.p, st.p + 4 * slots);
+        allreduce_tiles(st.p, nq);
+        copy(slots, st.p, gM.p), copy(3 * (size_t)slots, st.p + slots, gMV.p);
+        if (nq == 5) copy(slots, st.p + 4 * slots, gCN.p);
+    }
     HOT_LAUNCH(this, "block_count", k_block_count<T>, div_up(Nb, 4), 256, 0, gM.p, block_count.p, Nb);
     scan.reserve(Nb + 1);
     Nn = exclusive_scan_i32(block_count.p, scan.p, Nb);
@@ -281,6 +290,12 @@ void Ctx<T>::p2g()
     dofSlot.reserve(n, 1.25), id2coord.reserve(3 * n, 1.25), mass.reserve(n, 1.25), nodeV.reserve(3 * n, 1.25), bcIdx.reserve(n, 1.25);
     vn.reserve(3 * n, 1.25), dv.reserve(3 * n, 1.25), dv0.reserve(3 * n, 1.25), cnTol.reserve(n, 1.25), rhs.reserve(3 * n, 1.25);
     work0.reserve(3 * n, 1.25), work1.reserve(3 * n, 1.25), work2.reserve(3 * n, 1.25), work3.reserve(3 * n, 1.25);
+    if (sharded()) { // id prefixes: the nodes of the blocks first touched by lower ranks (scan = exclusive block prefix of the node counts)
+        nstart0.assign(comm.size + 1, Nn);
+        for (int r = 0; r < comm.size; ++r)
+            if (block_first[r] < Nb) HOT_HIP(hipMemcpyAsync(&nstart0[r], scan.p + block_first[r], sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        sync();
+    }
     HOT_LAUNCH(this, "number_nodes", k_number_nodes<T>, div_up(Nb, 4), 256, 0, gM.p, gMV.p, gIdx.p, scan.p, blocks.p, dofSlot.p, id2coord.p, mass.p, nodeV.p, Nb, slots);
     {
         constexpr int TILE = (G::BX + 2) * (G::BY + 2) * (G::BZ + 2);
@@ -424,6 +439,11 @@ void Ctx<T>::g2p(double dt_, int32_t* flags)
     int32_t f = 0;
     HOT_HIP(hipMemcpyAsync(&f, dflags, 4, hipMemcpyDeviceToHost, stream));
     sync();
+    if (sharded()) {
+        int32_t bits[2] = { f & 1, (f >> 1) & 1 };
+        c_allreduce(bits, 2, HOT_COMM_I32, HOT_COMM_MAX, false);
+        f = bits[0] | (bits[1] << 1);
+    }
     if (flags) *flags = f;
     stats.ms_g2p = wall_ms() - t0;
 }
