@@ -8,11 +8,14 @@ Prints ONE JSON line on rank 0.  `value` = ms per nonlinear (L-BFGS) iteration, 
 `roofline` = the kernel (device symbol) with the largest share of the timed region, from HIP events recorded on the
 library's launch stream (hot_config.profile); its `avg_launch_ms` is what rocprofv3 --kernel-trace --stats reports
 for the same symbol (profiles/).  `cpu_baseline` = the CPU oracle (a port of the reference's TBB decomposition to
-OpenMP) on a bounded sample, with the GPU timed on that same sample next to it.
+OpenMP) timed on the GPU box's host cores on the headline configuration itself: one whole time step in each of two
+variants ("faithful": serial where the reference is serial; "fair": those sections parallelised as well), ~1 minute.
 
-N > 1: one process per GPU (torch.distributed / RCCL for the barriers and the max-over-ranks clock); the scene is N
-non-touching bodies, one per rank (hot_amd/parallel.py): bodies further apart than the kernel support share no grid
-node, so the by-body partition needs no halo exchange (weak scaling).
+N > 1: one process per GPU (launched by torch.distributed.run, or spawned here when WORLD_SIZE is unset), RCCL through
+torch.distributed.  ONE connected body is sharded over the ranks (hot_set_comm, hot_amd/dist.py): particle
+ranges of the global sort order per rank, node tiles summed with all-reduces, matrix rows owned by one rank each,
+colour-synchronous Gauss-Seidel.  Weak scaling: the body grows so that every GPU keeps C2's particle count
+(N = 8: a 126^3-cell body of 16 M particles, BASELINE config 4's size).
 """
 import argparse
 import json
@@ -65,12 +68,14 @@ def host_cores():
     return n
 
 
-def make_ctx(lib, cloud, cfg, device=0, profile=0, **over):
+def make_ctx(lib, cloud, cfg, device=0, profile=0, comm=None, **over):
     from hot_amd import synth
     kw = dict(dtype=1 if cloud["X"].dtype == np.float64 else 0, dx=cloud["dx"], gravity=(0, -9.8, 0), levelCnt=cfg["levelCnt"], device=device, profile=profile)
     kw.update(synth.plasticity_kwargs(cfg))
     kw.update(over)
     ctx = lib.context(**kw)
+    if comm is not None:
+        ctx.set_comm(comm)  # this rank's shard of ONE body (hot_amd/dist.py)
     ctx.set_particles(cloud["X"], cloud["V"], cloud["mass"], cloud["vol"], cloud["mu"], cloud["lam"])
     o, n = synth.sticky_floor(cloud["corner"][1], cloud["dx"])
     ctx.set_sticky_halfspaces(o, n)
@@ -103,20 +108,37 @@ def algorithmic_bytes(name, s, Np, levels, launches_per_half_sweep=8.0):
     return None
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C2")
-    ap.add_argument("--cells", type=int, default=0, help="override the cube edge (cells) for quick runs")
+    ap.add_argument("--cells", type=int, default=0, help="override the cube edge (cells) of the per-GPU body for quick runs")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-cells", type=int, default=32)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-cells", type=int, default=0, help="cube edge of the CPU baseline's sample; 0 = the benchmark configuration itself")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo with --share-gpu on a one-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks on device 0 (functional check of the N > 1 path on a one-GPU box, not a measurement)")
+    return ap.parse_args()
+
+
+def _spawned(rank, world, port, argv):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.argv = argv
+    main()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torch.distributed.run: start the ranks ourselves, one process per GPU
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned, args=(args.gpus, 29400 + os.getpid() % 500, sys.argv), nprocs=args.gpus, join=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     cores = host_cores()
     os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(cores, 32))))
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
@@ -128,10 +150,16 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP library has no CPU fallback)"
     torch.cuda.set_device(local)
     dist = None
+    comm = None
     if world > 1:
         import torch.distributed as dist_
+        from hot_amd import dist as hdist
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
+        comm = hdist.TorchComm(device=torch.device("cuda", local))
 
     def barrier():
         if dist is not None:
@@ -140,13 +168,14 @@ def main():
 
     lib = hot_amd.load()
     cfg = dict(synth.CONFIGS[args.config])
-    n = args.cells or cfg["n"]
+    n1 = args.cells or cfg["n"]  # per-GPU body edge
+    n = parallel.cells_for_world(n1, world)  # edge of the one body all ranks share
     cloud = parallel.shard_cloud(cfg, rank, world, n=n)
     Np = cloud["X"].shape[0]
     s = 8 if cfg["dtype"] == np.float64 else 4
     dt = cfg["dt"]
 
-    ctx = make_ctx(lib, cloud, cfg, device=local)
+    ctx = make_ctx(lib, cloud, cfg, device=local, comm=comm)
     for _ in range(args.warmup):
         ctx.advance(dt)
     barrier()
@@ -166,7 +195,7 @@ def main():
 
     # ---- profiled pass (HIP events on the launch stream) for the roofline and the transfer half of the metric
     roof, transfers, prof_top = None, None, None
-    if rank == 0:
+    if rank == 0 and world == 1:
         pctx = make_ctx(lib, cloud, cfg, device=local, profile=1)
         pctx.advance(dt)
         pctx.profile_reset()
@@ -210,28 +239,48 @@ def main():
         prof_top = sorted(((k, round(v["ms"] / nprof, 3), v["calls"] // nprof) for k, v in groups.items()), key=lambda x: -x[1])[:14]
         del pctx
 
-    # ---- CPU baseline: the oracle on a bounded sample, and the GPU on that same sample
+    # ---- CPU baseline: the oracle (the reference's TBB decomposition restated with OpenMP) on the GPU box's host cores, timed on the
+    # headline configuration itself — one whole time step per variant, same inputs, same solver knobs — in two variants
+    # (SURVEY.md §8d): "faithful" leaves serial what the reference leaves serial, "fair" parallelises those sections too.
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         from tests.oracle_lib import load_oracle
         ora = load_oracle()
-        nc = args.cpu_cells
-        sample = parallel.shard_cloud(cfg, 0, 1, n=nc)
-        res = {}
-        for nm, L in (("cpu", ora), ("gpu", lib)):
-            c = make_ctx(L, sample, cfg, device=local)
-            c.advance(dt)  # warm-up step (first touch, thread pool)
-            res[nm] = c.advance(dt)
-            del c
+        nc = args.cpu_cells or n1
+        sample = cloud if nc == n1 else parallel.shard_cloud(cfg, 0, 1, n=nc)
 
         def per_iter(st):
             return (st["ms_solve"] - st["ms_hessian"] - st["ms_mg_build"]) / max(st["iterations"], 1)
-        cpu = {"value": per_iter(res["cpu"]), "unit": "ms per L-BFGS iteration", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
-               "sample": f"{nc}^3-cell cube, {sample['X'].shape[0]} particles, {res['cpu']['num_nodes']} nodes, 1 timed step of {res['cpu']['iterations']} iterations (same solver knobs)",
-               "gpu_same_sample_ms_per_iter": per_iter(res["gpu"]), "speedup_same_sample": per_iter(res["cpu"]) / max(per_iter(res["gpu"]), 1e-9),
-               "cpu_step_ms": res["cpu"]["ms_total"], "gpu_step_ms": res["gpu"]["ms_total"], "step_speedup_same_sample": res["cpu"]["ms_total"] / res["gpu"]["ms_total"],
-               "cpu_p2g_g2p_mparticles_per_s": sample["X"].shape[0] / ((res["cpu"]["ms_p2g"] + res["cpu"]["ms_g2p"]) * 1e-3) / 1e6,
-               "cpu_build_ms": res["cpu"]["ms_hessian"] + res["cpu"]["ms_mg_build"], "gpu_build_ms": res["gpu"]["ms_hessian"] + res["gpu"]["ms_mg_build"]}
+        res = {}
+        for nm in ("faithful", "fair"):
+            if nm == "fair":
+                os.environ["HOT_ORACLE_FAIR"] = "1"  # read by the oracle when the context is created
+            try:
+                c = make_ctx(ora, sample, cfg, device=local)
+                res[nm] = c.advance(dt)  # the first step of the run (the GPU's first step is timed beside it below)
+                del c
+            finally:
+                os.environ.pop("HOT_ORACLE_FAIR", None)
+        g = make_ctx(lib, sample, cfg, device=local)
+        res["gpu"] = g.advance(dt)
+        del g
+        try:
+            model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            model = "unknown"
+        f, fa, gp = res["faithful"], res["fair"], res["gpu"]
+        cpu = {"value": per_iter(f), "unit": "ms per L-BFGS iteration", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port", "variant": "faithful",
+               "cpu_model": model, "host_cores_visible": cores,
+               "sample": f"{args.config} itself: {nc}^3-cell cube, {sample['X'].shape[0]} particles, {f['num_nodes']} nodes, the first time step of the run "
+                         f"({f['iterations']} L-BFGS iterations, same solver knobs), one step per variant, no warm-up",
+               "fair_value": per_iter(fa), "fair_iterations": fa["iterations"], "iterations": f["iterations"],
+               "gpu_same_step_ms_per_iter": per_iter(gp), "gpu_iterations": gp["iterations"],
+               "speedup_per_iteration_vs_faithful": per_iter(f) / max(per_iter(gp), 1e-9), "speedup_per_iteration_vs_fair": per_iter(fa) / max(per_iter(gp), 1e-9),
+               "cpu_step_ms": f["ms_total"], "cpu_fair_step_ms": fa["ms_total"], "gpu_step_ms": gp["ms_total"],
+               "step_speedup_vs_faithful": f["ms_total"] / gp["ms_total"], "step_speedup_vs_fair": fa["ms_total"] / gp["ms_total"],
+               "cpu_p2g_g2p_mparticles_per_s": sample["X"].shape[0] / ((f["ms_p2g"] + f["ms_g2p"]) * 1e-3) / 1e6,
+               "cpu_build_ms": f["ms_hessian"] + f["ms_mg_build"], "cpu_fair_build_ms": fa["ms_hessian"] + fa["ms_mg_build"], "gpu_build_ms": gp["ms_hessian"] + gp["ms_mg_build"],
+               "cpu_sort_ms": f["ms_sort"], "cpu_fair_sort_ms": fa["ms_sort"]}
 
     if rank == 0:
         out = {
@@ -239,14 +288,16 @@ def main():
             "value": ms_per_iter, "unit": "ms/iter", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / max(args.steps, 1), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if s == 8 else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {n}^3-cell cube x {cfg['ppc']} ppc per GPU, fixed-corotated E={cfg['E']:g} nu={cfg['nu']}, dx=0.01, dt=1/24, "
+            "config": {"workload": f"{args.config}: one {n}^3-cell cube x {cfg['ppc']} ppc ({n1}^3 cells per GPU), fixed-corotated E={cfg['E']:g} nu={cfg['nu']}, dx=0.01, dt=1/24, "
                                    f"-lsolver 3 -mg_level {cfg['levelCnt']} -smoother 5 -coarseSolver 2 --project --linesearch --bcproject --usecn -cneps 1e-7",
-                       "particles_per_gpu": Np, "particles_total": int(total_particles), "nodes_per_gpu": stats[-1]["num_nodes"], "levels": stats[-1]["num_levels"],
-                       "parallelism": "1 GPU" if world == 1 else f"{world} non-touching bodies, one per GPU (by-body partition, no halo needed)"},
+                       "particles_per_gpu": int(total_particles / world), "particles_total": int(total_particles), "nodes_total": stats[-1]["num_nodes"], "levels": stats[-1]["num_levels"],
+                       "parallelism": "1 GPU" if world == 1 else f"one connected body sharded over {world} ranks: particle ranges of the sort order, all-reduced node tiles, "
+                                                                 f"row-partitioned operators with colour-synchronous Gauss-Seidel ({args.backend})"},
             "iterations_per_step": iters / max(args.steps, 1),
             "hessian_mg_build_ms_per_step": build_ms / max(args.steps, 1),
             "ms_per_iter_build_amortised": solve_ms / max(iters, 1),
-            "p2g_g2p_mparticles_per_s": (transfers["mparticles_per_s"] * world) if transfers else None,
+            "p2g_g2p_mparticles_per_s": transfers["mparticles_per_s"] if transfers else None,
+            "comm_calls_per_step": ({k: v / max(args.steps + args.warmup, 1) for k, v in comm.calls.items()} if comm is not None else None),
             "roofline": roof, "transfers": transfers, "cpu_baseline": cpu, "kernel_ms_per_step_top": prof_top,
         }
         print(json.dumps(out))

@@ -51,7 +51,7 @@ class TorchComm:
         self.torch, self.dist, self.group = torch, dist, group
         self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
         self.backend = dist.get_backend(group)
-        self.device = device  # torch.device of this rank's GPU, or None for a host-memory library (the CPU oracle)
+        self.device = device  # torch.device of this rank's GPU, or None for a library that works on host memory (the CPU checker of the tests)
         self.calls = dict(allreduce=0, allgather=0, alltoallv=0, bytes=0)
         self._hip = None
         self._cb = (_ALLREDUCE(self._allreduce), _ALLGATHER(self._allgather), _ALLTOALLV(self._alltoallv))

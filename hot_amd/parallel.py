@@ -1,49 +1,42 @@
-"""One-process-per-GPU sharding of the hot path (host side).
+"""Workload helpers of the benchmark and the tests for one process per GPU.
 
-Round-1 decomposition: the scene is partitioned BY BODY.  Bodies whose particle clouds are separated by more than
-the kernel support (2 cells) never share a grid node, so each rank owns whole bodies and the per-rank solves are
-exactly the global solve restricted to those bodies — no halo exchange and no collective on the data path
-(SURVEY.md §8e "Does the path shard naturally?"; a single connected body split across ranks needs the block-halo
-exchange and is listed as next work in DESIGN.md §7).  torch.distributed (RCCL on GPUs, gloo in the CPU tests) is
-used only for the barrier / max-over-ranks clock and for gathering per-rank statistics.
-"""
+The multi-GPU decomposition itself lives in the library (hot_amd/csrc/shard.hip, hot_set_comm) and in hot_amd/dist.py
+(the collectives over torch.distributed, the split of a cloud into page-order shards): ONE connected body is sharded over
+the ranks — particle ranges of the global sort order per rank, node tiles summed with all-reduces, matrix rows owned by
+one rank each, colour-synchronous Gauss-Seidel.  This module only builds the synthetic
+body of a BASELINE configuration, hands a rank its shard, and provides the bench clock (max over ranks).
+
+Weak scaling: the body grows with the number of ranks so that every GPU keeps the single-GPU configuration's particle
+count (`cells_for_world`); for world == 1 it is exactly the configuration of hot_amd/synth.CONFIGS."""
 import numpy as np
 
 from . import synth
 
-GAP_CELLS = 8  # empty cells between neighbouring bodies: > kernel support (2) + motion margin
+
+def cells_for_world(n, world):
+    """Cube edge (cells) of the one body that gives `world` ranks the particle count an n^3 body gives one rank."""
+    return int(round(n * world ** (1.0 / 3.0)))
 
 
-def body_corner(body, n, dx=0.01, origin=(5.0, 5.0, 5.0)):
-    """Lower corner of body number `body` in the row of bodies along x."""
-    return (origin[0] + body * (n + GAP_CELLS) * dx, origin[1], origin[2])
-
-
-def assign_bodies(num_bodies, world):
-    """Contiguous, balanced body ranges: rank r owns bodies [lo, hi)."""
-    base, extra = divmod(num_bodies, world)
-    out, lo = [], 0
-    for r in range(world):
-        hi = lo + base + (1 if r < extra else 0)
-        out.append((lo, hi))
-        lo = hi
-    return out
-
-
-def shard_cloud(cfg, rank, world, n=None, bodies_per_rank=1, dx=0.01):
-    """Particles owned by `rank`: its bodies' clouds concatenated.  Deterministic in (body index) only, so the union
-    over ranks is independent of `world`."""
+def body_cloud(cfg, n=None, dx=0.01):
+    """The whole synthetic body of configuration `cfg` (hot_amd/synth.CONFIGS entry) with an n^3-cell cube."""
     n = n or cfg["n"]
-    lo, hi = assign_bodies(world * bodies_per_rank, world)[rank]
-    parts = []
-    for b in range(lo, hi):
-        c = synth.cube_cloud(n, ppc=cfg["ppc"], dtype=cfg["dtype"], E=cfg["E"], nu=cfg["nu"], rho=cfg["rho"], corner=body_corner(b, n, dx), seed=123 + b, dx=dx)
-        parts.append(c)
-    out = {k: np.concatenate([p[k] for p in parts]) for k in ("X", "V", "mass", "vol", "mu", "lam")}
-    out["dx"] = dx
-    out["corner"] = body_corner(lo, n, dx)
-    out["bodies"] = (lo, hi)
-    return out
+    c = synth.cube_cloud(n, ppc=cfg["ppc"], dtype=cfg["dtype"], E=cfg["E"], nu=cfg["nu"], rho=cfg["rho"], corner=(5.0, 5.0, 5.0), seed=123, dx=dx)
+    c["corner"] = (5.0, 5.0, 5.0)
+    c["cells"] = n
+    return c
+
+
+def shard_cloud(cfg, rank, world, n=None, dx=0.01):
+    """Rank `rank`'s particles of the one body `world` ranks share: the whole body for world == 1, otherwise its contiguous
+    range of the SPGrid page order (hot_amd/dist.shard_by_page_order).  `n` = cube edge of the WHOLE body."""
+    c = body_cloud(cfg, n, dx)
+    if world == 1:
+        return c
+    from . import dist as hdist
+    s = hdist.shard_by_page_order(c, rank, world)
+    s["corner"], s["cells"] = c["corner"], c["cells"]
+    return s
 
 
 def max_over_ranks(value, dist=None, device=None):

@@ -226,7 +226,7 @@ int hot_advance_frame(hot_ctx*, double frame_dt, double min_dt, double max_dt, i
  *                    computed by the owner and handed to the other ranks right after (colour-synchronous, i.e. the update
  *                    order is the reference's: MultigridPreconditioner.h:266-318); small coarse levels are replicated.
  *      The library performs no communication itself: it calls the three collectives below at those points, with DEVICE
- *      pointers (the CPU oracle: host pointers), after synchronising its stream; the callee must have completed the
+ *      pointers (a host-memory implementation of this ABI: host pointers), after synchronising its stream; the callee must have completed the
  *      operation when it returns.  hot_amd/dist.py implements them over torch.distributed (RCCL on GPUs, gloo in the CPU
  *      tests); a C++ host would pass ncclAllReduce / ncclAllGather / grouped ncclSend+ncclRecv on its own stream + sync.
  *      All ranks must make the same sequence of API calls.  Return 0 on success. */

@@ -5,6 +5,7 @@
 // the HIP library through the same Python wrapper.  All pointers are host pointers here.
 #include "sim_solve.hpp"
 #include <cstdio>
+#include <cstdlib>
 
 using namespace hot_oracle;
 
@@ -76,6 +77,7 @@ int hoto_create(const hot_config* cfg, hoto_ctx** out)
 {
     hoto_ctx* c = new hoto_ctx;
     c->dtype = cfg->dtype;
+    hot_oracle::fair_flag() = getenv("HOT_ORACLE_FAIR") != nullptr; // CPU-baseline variant (sim_core.hpp), timing only
     DISPATCH(c, {
         auto* s = new Sim<T>();
         s->cfg = *cfg;

@@ -25,6 +25,18 @@
 
 namespace hot_oracle {
 
+// CPU-baseline variants (bench.py cpu_baseline).  "faithful" (default, and what every parity test uses):
+// the sections that are serial in the reference are serial here (group scan + Set_Page loop, getNumNodes, block memset,
+// Eigen dot products / vector updates of the solvers, hierarchy build).  "fair" (HOT_ORACLE_FAIR=1 at hoto_create): the
+// ones that parallelise trivially run as OpenMP loops / reductions — a stronger CPU baseline, used for timing only
+// (summation orders change, so results differ from the faithful variant by round-off).
+inline bool& fair_flag()
+{
+    static bool f = false;
+    return f;
+}
+#define HOT_FAIR_FOR _Pragma("omp parallel for schedule(static) if (hot_oracle::fair_flag())")
+
 template <class T>
 struct EllMat { // reference Projects/multigrid/SquareMatrix.h:27-34
     int colsize = 0, nrows = 0;
@@ -310,7 +322,15 @@ struct Sim {
                 blocks.push_back(page);
             }
         };
+        if (fair_flag()) {
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < Np; ++i) {
+                particle_order[i] = (int)(particle_sorter[i] & ((1ll << index_bits) - 1));
+                particle_base_offset[particle_order[i]] = (particle_sorter[i] >> index_bits) << Mask::data_bits;
+            }
+        }
         for (int64_t i = 0; i < Np; ++i) {
+            if (fair_flag() && !(i == Np - 1 || (particle_sorter[i] >> 32) != (particle_sorter[i + 1] >> 32))) continue;
             particle_order[i] = (int)(particle_sorter[i] & ((1ll << index_bits) - 1));
             uint64_t offset = (particle_sorter[i] >> index_bits) << Mask::data_bits;
             particle_base_offset[particle_order[i]] = offset;
@@ -355,7 +375,13 @@ struct Sim {
                     }
         }
         // memset of every touched block, idx = -1 (serial in the reference, :1126-1136)
-        nodes.assign(blocks.size() * (size_t)EPB, Node{ TV::zero(), 0, TV::zero(), -1 });
+        if (fair_flag()) {
+            nodes.resize(blocks.size() * (size_t)EPB);
+#pragma omp parallel for schedule(static)
+            for (size_t k = 0; k < nodes.size(); ++k) nodes[k] = Node{ TV::zero(), 0, TV::zero(), -1 };
+        }
+        else
+            nodes.assign(blocks.size() * (size_t)EPB, Node{ TV::zero(), 0, TV::zero(), -1 });
         num_nodes = 0;
         collision_nodes.clear();
         scratch_gradV.assign(Np, TM::zero());
@@ -451,6 +477,23 @@ struct Sim {
     // reference MpmGrid::getNumNodes (MpmGrid.h:148-161) — serial, insertion-ordered blocks, memory order
     int get_num_nodes()
     {
+        if (fair_flag()) { // same numbering: per-block counts in parallel, serial prefix over the blocks, ids in parallel
+            std::vector<int> base(blocks.size() + 1, 0);
+#pragma omp parallel for schedule(static)
+            for (size_t b = 0; b < blocks.size(); ++b) {
+                int c = 0;
+                for (int e = 0; e < EPB; ++e) c += nodes[b * EPB + e].m != 0;
+                base[b + 1] = c;
+            }
+            for (size_t b = 0; b < blocks.size(); ++b) base[b + 1] += base[b];
+#pragma omp parallel for schedule(static)
+            for (size_t b = 0; b < blocks.size(); ++b) {
+                int id = base[b];
+                for (int e = 0; e < EPB; ++e)
+                    if (nodes[b * EPB + e].m != 0) nodes[b * EPB + e].idx = id++;
+            }
+            return base[blocks.size()];
+        }
         int total = 0;
         for (size_t b = 0; b < blocks.size(); ++b)
             for (int e = 0; e < EPB; ++e) {

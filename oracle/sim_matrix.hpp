@@ -426,6 +426,11 @@ static inline T dot_product(const std::vector<V3<T>>& a, const std::vector<V3<T>
 {
     // reference dotProduct is a serial Eigen reduction (MultigridPreconditioner.h:155-158)
     T s = 0;
+    if (fair_flag()) {
+#pragma omp parallel for schedule(static) reduction(+ : s)
+        for (size_t i = 0; i < a.size(); ++i) s += a[i].dot(b[i]);
+        return s;
+    }
     for (size_t i = 0; i < a.size(); ++i) s += a[i].dot(b[i]);
     return s;
 }
@@ -454,10 +459,13 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
     if (kind == 0) {
         for (; iterations--;) {
             scaler(r, du, A);
+            HOT_FAIR_FOR
             for (int i = 0; i < n; ++i) du[i] = du[i] * (T)cfg.topomega;
+            HOT_FAIR_FOR
             for (int i = 0; i < n; ++i) u[i] += du[i];
             multiply(A, du, dAu);
             Aproject(dAu);
+            HOT_FAIR_FOR
             for (int i = 0; i < n; ++i) r[i] -= dAu[i];
         }
     }
@@ -468,6 +476,7 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
             multiply(A, du, dAu);
             Aproject(dAu);
             T omega = dot_product(du, r) / dot_product(du, dAu);
+            HOT_FAIR_FOR
             for (int i = 0; i < n; ++i) u[i] += du[i] * omega, r[i] -= dAu[i] * omega;
         }
     }
@@ -486,11 +495,13 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
             multiply(A, du, dAu);
             Aproject(dAu);
             T omega = zTrk / dot_product(dAu, du);
+            HOT_FAIR_FOR
             for (int i = 0; i < n; ++i) u[i] += du[i] * omega, r[i] -= dAu[i] * omega;
             scaler(r, z, A);
             T zTrkPre = zTrk;
             zTrk = dot_product(z, r);
             T beta = zTrk / zTrkPre;
+            HOT_FAIR_FOR
             for (int i = 0; i < n; ++i) du[i] = z[i] + du[i] * beta;
             ++cnt;
         }
@@ -535,6 +546,7 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
                 }
                 exchange_colour(hdu, c);
             }
+            HOT_FAIR_FOR
             for (int i = 0; i < n; ++i) hdu[i] = A.diagonalVal[i] * hdu[i];
             du.assign(n, TV::zero());
             for (int c = 7; c >= 0; --c) {
@@ -554,9 +566,11 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
                 }
                 exchange_colour(du, c);
             }
+            HOT_FAIR_FOR
             for (int i = 0; i < n; ++i) u[i] += du[i];
             multiply(A, du, dAu);
             Aproject(dAu);
+            HOT_FAIR_FOR
             for (int i = 0; i < n; ++i) r[i] -= dAu[i];
         }
     }
@@ -570,15 +584,18 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
         du = p;
         multiply(A, du, dAu);
         Aproject(dAu);
+        HOT_FAIR_FOR
         for (int i = 0; i < n; ++i) u[i] += du[i] * alpha, r[i] -= dAu[i] * alpha;
         for (; iterations-- > 0; ++cnt) {
             scaler(r, p, A);
             beta = (T)0.5 * c * c * alpha * alpha;
             if (cnt > 1) beta *= (T)0.5;
             alpha = 1 / (d - beta / alpha);
+            HOT_FAIR_FOR
             for (int i = 0; i < n; ++i) du[i] = p[i] + du[i] * beta;
             multiply(A, du, dAu);
             Aproject(dAu);
+            HOT_FAIR_FOR
             for (int i = 0; i < n; ++i) u[i] += du[i] * alpha, r[i] -= dAu[i] * alpha;
         }
     }
@@ -642,8 +659,10 @@ void Sim<T>::vcycle(const std::vector<TV>& in, std::vector<TV>& out)
         std::vector<TV>& sol = level == 0 ? out : mg_sols[level];
         mg_level = level;
         multiply(promats[level], mg_sols[level + 1], mg_dus[level]);
+        HOT_FAIR_FOR
         for (size_t i = 0; i < sol.size(); ++i) sol[i] += mg_dus[level][i];
         multiply(sysmats[level], mg_dus[level], mg_dAus[level]);
+        HOT_FAIR_FOR
         for (size_t i = 0; i < sol.size(); ++i) mg_residuals[level][i] -= mg_dAus[level][i];
         run(level < splitLevel, level, sol, level < splitLevel ? downIter(level) : topIter(level));
     }

@@ -51,12 +51,14 @@ T Sim<T>::line_search(std::vector<TV>& ddv, std::vector<TV>& residual, T alpha)
     recover_solution(ddv);
     double Ek0 = Ek;
     do {
+        HOT_FAIR_FOR
         for (size_t i = 0; i < ddv.size(); ++i) dvnew[i] = dv0[i] + ddv[i] * alpha;
         update_state(dvnew);
         stats.linesearch_trials++;
         alpha *= (T)0.5;
     } while (Ek > Ek0);
     alpha *= 2;
+    HOT_FAIR_FOR
     for (size_t i = 0; i < ddv.size(); ++i) ddv[i] = ddv[i] * alpha;
     transform_residual(ddv);
     compute_residual(residual);
@@ -116,6 +118,7 @@ bool Sim<T>::lbfgs_solve()
         hist.back().dg = residual;
         for (int i = (int)hist.size() - 2; i >= 0; --i) {
             ksi[i] = dot_product(hist[i].dx, residual) * hist[i].dgTdx;
+            HOT_FAIR_FOR
             for (int n = 0; n < num_nodes; ++n) residual[n] -= hist[i].dg[n] * ksi[i];
         }
         hist.back().dx.resize(num_nodes);
@@ -123,14 +126,17 @@ bool Sim<T>::lbfgs_solve()
         project(hist.back().dx);
         for (int i = 0; i < (int)hist.size() - 1; ++i) {
             T c = ksi[i] - dot_product(hist[i].dg, hist.back().dx) * hist[i].dgTdx;
+            HOT_FAIR_FOR
             for (int n = 0; n < num_nodes; ++n) hist.back().dx[n] += hist[i].dx[n] * c;
         }
         if (cfg.linesearch) line_search(hist.back().dx, residual, (T)1);
         recover_solution(hist.back().dx);
+        HOT_FAIR_FOR
         for (int n = 0; n < num_nodes; ++n) x[n] += hist.back().dx[n];
         transform_residual(hist.back().dx);
         updateState();
         computeResidual();
+        HOT_FAIR_FOR
         for (int n = 0; n < num_nodes; ++n) hist.back().dg[n] -= residual[n];
         hist.back().dgTdx = (T)1 / dot_product(hist.back().dg, hist.back().dx);
         if (hist.back().dgTdx <= 0) {
@@ -162,6 +168,7 @@ int Sim<T>::minres_solve(const std::function<void(const std::vector<TV>&, std::v
         b2 = G.s * t1 + G.c * t2;
     };
     Amul(x, qkp1);
+    HOT_FAIR_FOR
     for (int i = 0; i < n; ++i) qkp1[i] = b[i] - qkp1[i];
     project(qkp1);
     prec(qkp1, z);
@@ -184,7 +191,9 @@ int Sim<T>::minres_solve(const std::function<void(const std::vector<TV>&, std::v
         Amul(mk, qkp1);
         project(qkp1);
         alpha_k = dot_product(mk, qkp1);
+        HOT_FAIR_FOR
         for (int i = 0; i < n; ++i) qkp1[i] = qkp1[i] - qk[i] * alpha_k;
+        HOT_FAIR_FOR
         for (int i = 0; i < n; ++i) qkp1[i] = qkp1[i] - qkm1[i] * beta_k;
         prec(qkp1, z);
         beta_kp1 = std::sqrt(std::max((T)0, dot_product(z, qkp1)));
@@ -213,6 +222,7 @@ int Sim<T>::minres_solve(const std::function<void(const std::vector<TV>&, std::v
             TV t = mk[i] - mkm1[i] * delta - mkm2[i] * epsilon;
             for (int d = 0; d < 3; ++d) mk[i].a[d] = t.a[d] / gamma;
         }
+        HOT_FAIR_FOR
         for (int i = 0; i < n; ++i) x[i] += mk[i] * tk;
     }
     return max_iterations;
@@ -261,6 +271,7 @@ bool Sim<T>::newton_solve()
         else {
             // buildDiagonal (ImplicitSolver.h:605-665): block diagonal of the matrix-free operator
             std::vector<TM> diag(num_nodes);
+            HOT_FAIR_FOR
             for (int n = 0; n < num_nodes; ++n) diag[n] = (sharded() && comm.rank != 0) ? TM::zero() : TM::identity() * mass_matrix[n];
             bool proj = cfg.project != 0;
             for_each_particle_colored([&](int g, int i) {
@@ -305,6 +316,7 @@ bool Sim<T>::newton_solve()
         };
         std::vector<TV> b = residual;
         if (cfg.systemBCProject)
+            HOT_FAIR_FOR
             for (int n = 0; n < num_nodes; ++n) b[n] += dRhs[n];
         if (cfg.lsolver == 1) {
             // Minres::solve (Lib/Ziran/Math/Linear/Minres.h:69-149) with relative tolerance from the Newton loop
@@ -319,6 +331,7 @@ bool Sim<T>::newton_solve()
         {
             std::vector<TV> r(num_nodes), p(num_nodes), q(num_nodes), temp(num_nodes);
             Amul(step, temp);
+            HOT_FAIR_FOR
             for (int n = 0; n < num_nodes; ++n) r[n] = b[n] - temp[n];
             project(r);
             prec(r, q);
@@ -333,11 +346,13 @@ bool Sim<T>::newton_solve()
                 Amul(p, temp);
                 project(temp);
                 T alpha = zTrk / dot_product(temp, p);
+                HOT_FAIR_FOR
                 for (int n = 0; n < num_nodes; ++n) step[n] += p[n] * alpha, r[n] -= temp[n] * alpha;
                 prec(r, q);
                 T zTrk_last = zTrk;
                 zTrk = dot_product(q, r);
                 T beta = zTrk / zTrk_last;
+                HOT_FAIR_FOR
                 for (int n = 0; n < num_nodes; ++n) p[n] = q[n] + p[n] * beta;
                 rpn = std::sqrt(zTrk);
             }
@@ -345,6 +360,7 @@ bool Sim<T>::newton_solve()
         }
         if (cfg.linesearch) line_search(step, residual, (T)1);
         recover_solution(step);
+        HOT_FAIR_FOR
         for (int n = 0; n < num_nodes; ++n) x[n] += step[n];
         transform_residual(step);
     }
