@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "get_counts", "get_indexing", "p2g", "get_grid", "set_bc", "set_sticky_halfspaces", "set_collision_objects", "begin_step", "get_dv",
     "set_dv", "update_state", "get_particle_state", "residual", "project", "cn_tolerance", "build_hessian",
     "matfree_multiply", "build_mg", "get_level", "get_matrix", "get_level_nnzb", "get_prolongation", "spmv", "restrict", "prolong",
-    "smooth", "vcycle", "solve", "g2p", "set_comm", "constitutive_eval", "plasticity_eval", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
+    "smooth", "vcycle", "solve", "g2p", "line_search", "should_exit", "recover_solution", "transform_residual", "compute_step", "set_comm", "constitutive_eval", "plasticity_eval", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
 ]
 
 
@@ -119,6 +119,11 @@ class HotLib:
             "vcycle": (C.c_int, [vp, vp, vp]),
             "solve": (C.c_int, [vp, P(hot_stats)]),
             "g2p": (C.c_int, [vp, dbl, P(i32)]),
+            "line_search": (C.c_int, [vp, vp, vp, dbl, P(dbl)]),
+            "should_exit": (C.c_int, [vp, vp, P(i32), P(dbl)]),
+            "recover_solution": (C.c_int, [vp, vp]),
+            "transform_residual": (C.c_int, [vp, vp]),
+            "compute_step": (C.c_int, [vp, vp, vp]),
             "set_comm": (C.c_int, [vp, vp]),
             "constitutive_eval": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp, vp]),
             "plasticity_eval": (C.c_int, [vp, i32, i32, vp, vp, vp, vp]),
@@ -401,6 +406,37 @@ class Context:
         f = C.c_int32()
         self._call("g2p", C.c_double(dt), C.byref(f))
         return f.value
+
+    # ---- the objective concept, member by member (what LBFGS::solve / ExtendedNewtonsMethod::solve call)
+    def line_search(self, ddv, alpha=1.0):
+        """lineSearch: returns (scaled + transformed ddv, residual at the accepted point, accepted alpha)."""
+        d = np.array(ddv, dtype=self.T, order="C")
+        r = np.empty((self.Nn, 3), self.T)
+        a = C.c_double()
+        self._call("line_search", _ptr(d), _ptr(r), C.c_double(alpha), C.byref(a))
+        return d, r, a.value
+
+    def should_exit(self, residual):
+        e, s = C.c_int32(), C.c_double()
+        r = self._real(residual)
+        self._call("should_exit", _ptr(r), C.byref(e), C.byref(s))
+        return bool(e.value), s.value
+
+    def recover_solution(self, v):
+        v = np.array(v, dtype=self.T, order="C")
+        self._call("recover_solution", _ptr(v))
+        return v
+
+    def transform_residual(self, v):
+        v = np.array(v, dtype=self.T, order="C")
+        self._call("transform_residual", _ptr(v))
+        return v
+
+    def compute_step(self, residual):
+        r = self._real(residual)
+        st = np.empty((self.Nn, 3), self.T)
+        self._call("compute_step", _ptr(r), _ptr(st))
+        return st
 
     def set_comm(self, comm):
         """Install a hot_amd.dist.TorchComm (one connected body over several ranks) or remove it (None).  Before set_particles."""

@@ -292,6 +292,36 @@ int hot_g2p(hot_ctx* ctx, double dt, int32_t* flags)
     ctx->impl->g2p(dt, flags);
     HOT_API_END
 }
+int hot_line_search(hot_ctx* ctx, void* ddv, void* residual, double alpha, double* alpha_out)
+{
+    HOT_API_BEGIN
+    ctx->impl->line_search_api(ddv, residual, alpha, alpha_out);
+    HOT_API_END
+}
+int hot_should_exit(hot_ctx* ctx, const void* residual, int32_t* exit_now, double* scaled_residual)
+{
+    HOT_API_BEGIN
+    ctx->impl->should_exit_api(residual, exit_now, scaled_residual);
+    HOT_API_END
+}
+int hot_recover_solution(hot_ctx* ctx, void* v)
+{
+    HOT_API_BEGIN
+    ctx->impl->transform_api(v, true);
+    HOT_API_END
+}
+int hot_transform_residual(hot_ctx* ctx, void* v)
+{
+    HOT_API_BEGIN
+    ctx->impl->transform_api(v, false);
+    HOT_API_END
+}
+int hot_compute_step(hot_ctx* ctx, const void* residual, void* step)
+{
+    HOT_API_BEGIN
+    ctx->impl->compute_step_api(residual, step);
+    HOT_API_END
+}
 int hot_set_comm(hot_ctx* ctx, const hot_comm* comm)
 {
     HOT_API_BEGIN

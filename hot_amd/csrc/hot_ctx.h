@@ -102,6 +102,10 @@ struct CtxBase {
     virtual void solve(hot_stats* st) = 0;
     virtual void g2p(double dt, int32_t* flags) = 0;
     virtual void set_comm(const hot_comm* c) = 0;
+    virtual void line_search_api(void* ddv, void* residual, double alpha, double* alpha_out) = 0;
+    virtual void should_exit_api(const void* residual, int32_t* exit_now, double* scaled) = 0;
+    virtual void transform_api(void* v, bool inverse) = 0;
+    virtual void compute_step_api(const void* residual, void* step) = 0;
     virtual void constitutive_eval(int32_t n, const void* F, const void* mu, const void* lambda, int32_t project, void* psi, void* P, void* dPdF) = 0;
     virtual void plasticity_eval(int32_t kind, int32_t n, void* F, void* mu, void* lambda, void* Jp) = 0;
     virtual void advance(double dt, hot_stats* st) = 0;

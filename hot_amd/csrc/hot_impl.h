@@ -320,6 +320,12 @@ struct Ctx : CtxBase {
     T line_search(T* ddv, T* residual_out, T alpha);
     bool lbfgs_solve();
     bool newton_solve();
+    void compute_step_dev(const T* residual, T* step);
+    DBuf<T> nw_step, nw_r, nw_p, nw_q, nw_t, nw_diag; // projected-Newton work vectors
+    void line_search_api(void* ddv, void* residual, double alpha, double* alpha_out) override;
+    void should_exit_api(const void* residual, int32_t* exit_now, double* scaled) override;
+    void transform_api(void* v, bool inverse) override;
+    void compute_step_api(const void* residual, void* step) override;
 };
 
 // launch helpers

@@ -370,16 +370,88 @@ int Ctx<T>::minres_dev(const std::function<void(const T*, T*)>& Amul, const std:
     return max_iterations;
 }
 
+// ImplicitSolverObjective::computeStep (ImplicitSolver.h:355-432): rebuild the matrix and the hierarchy (or the matrix-free
+// block diagonal), then InexactConjugateGradient::solve (InexactConjugateGradient.h:49-103) or Minres::solve for the step
+template <class T>
+void Ctx<T>::compute_step_dev(const T* residual, T* step)
+{
+    size_t n3 = 3 * (size_t)Nn;
+    DBuf<T>&r = nw_r, &p = nw_p, &q = nw_q, &temp = nw_t;
+    r.reserve(n3, 1.25), p.reserve(n3, 1.25), q.reserve(n3, 1.25), temp.reserve(n3, 1.25);
+    T cg_tolerance = cfg.useCN ? max_cn_tolerance : (T)1e-4; // MultigridSimulation.h:201-208 / MultigridInit3D.h:2500-2501
+    zero(n3, step);
+    const bool massPrec = !cfg.matrixFree && (cfg.lsolver == 1 || cfg.lsolver == 2) && cfg.Ainv == 2; // :365
+    if (cfg.matrixFree) {
+        nw_diag.reserve(9 * (size_t)Nn, 1.25);
+        matfree_diagonal(nw_diag.p); // buildDiagonal :605-665
+    }
+    else {
+        build_hessian();
+        if (!massPrec) build_mg();
+    }
+    bool diagPrec = (cfg.levelCnt == 1 && cfg.times == 1);
+    std::function<void(const T*, T*)> prec = [&](const T* in, T* out) {
+        if (cfg.matrixFree)
+            block_apply_dev(nw_diag.p, in, out, Nn);
+        else if (massPrec)
+            HOT_LAUNCH(this, "mass_scale", k_mass_scale<T>, div_up(n3, 256), 256, 0, mass.p, in, out, Nn);
+        else if (diagPrec)
+            scale_dev(*levels[0], in, out); // forced diagonal preconditioner (ImplicitSolver.h:376-391)
+        else
+            vcycle_dev(in, out);
+    };
+    std::function<void(const T*, T*)> Amul = [&](const T* xx, T* bb) {
+        if (cfg.matrixFree)
+            matfree_dev(xx, bb);
+        else
+            spmv_dev(*levels[0], xx, bb);
+    };
+    if (cfg.lsolver == 1) {
+        // relative tolerance from the Newton loop (ExtendedNewtonsMethod.h:57), tolerance = maxcntol
+        // (MultigridSimulation.h:204) or the scene value 1e-4 (MultigridInit3D.h:85-86)
+        T residual_norm = (T)std::sqrt(dot_host(n3, residual, residual));
+        T newton_tol = cfg.useCN ? max_cn_tolerance : (T)cfg.cneps;
+        T rel = std::min((T)0.5, (T)std::sqrt(std::max(residual_norm, newton_tol)));
+        stats.linear_iterations += minres_dev(Amul, prec, step, residual, rel, cg_tolerance, 10000);
+        return;
+    }
+    // b = residual (+ dRhs == 0)
+    Amul(step, temp.p);
+    HOT_LAUNCH(this, "sub", k_sub<T>, div_up(n3, 256), 256, 0, n3, residual, temp.p, r.p);
+    project_dev(r.p);
+    prec(r.p, q.p);
+    copy(n3, q.p, p.p);
+    double zTrk = dot_host(n3, r.p, q.p);
+    T rpn = (T)std::sqrt(zTrk);
+    T forcing = std::min((T)0.5, (T)std::sqrt(std::max(rpn, cg_tolerance)));
+    T local_tol = forcing * rpn;
+    int cnt = 0;
+    for (; cnt < 10000; ++cnt) {
+        if (rpn < local_tol) break;
+        Amul(p.p, temp.p);
+        project_dev(temp.p);
+        T alpha = (T)(zTrk / dot_host(n3, temp.p, p.p));
+        axpy(n3, alpha, p.p, step);
+        axpy(n3, -alpha, temp.p, r.p);
+        prec(r.p, q.p);
+        double zlast = zTrk;
+        zTrk = dot_host(n3, q.p, r.p);
+        T beta = (T)(zTrk / zlast);
+        HOT_LAUNCH(this, "scal", k_scal<T>, div_up(n3, 256), 256, 0, n3, beta, p.p);
+        axpy(n3, (T)1, q.p, p.p);
+        rpn = (T)std::sqrt(zTrk);
+    }
+    stats.linear_iterations += cnt;
+}
+
+// ExtendedNewtonsMethod::solve (Lib/Ziran/Math/Nonlinear/ExtendedNewtonsMethod.h:39-66)
 template <class T>
 bool Ctx<T>::newton_solve()
 {
     size_t n3 = 3 * (size_t)Nn;
     T* x = dv.p;
     T* residual = work2.p;
-    DBuf<T> step, r, p, q, temp;
-    step.reserve(n3), r.reserve(n3), p.reserve(n3), q.reserve(n3), temp.reserve(n3);
-    T cg_tolerance = cfg.useCN ? max_cn_tolerance : (T)1e-4; // MultigridSimulation.h:201-208 / MultigridInit3D.h:2500-2501
-    DBuf<T> mfdiag;
+    nw_step.reserve(n3, 1.25);
     for (int it = 0; it < cfg.max_iterations; ++it) {
         stats.iterations = it;
         if (!updated) {
@@ -390,81 +462,64 @@ bool Ctx<T>::newton_solve()
             stats.converged = 1;
             return true;
         }
-        zero(n3, step.p);
-        // computeStep (ImplicitSolver.h:355-432)
-        const bool massPrec = !cfg.matrixFree && (cfg.lsolver == 1 || cfg.lsolver == 2) && cfg.Ainv == 2; // :365
-        if (cfg.matrixFree) {
-            mfdiag.reserve(9 * (size_t)Nn);
-            matfree_diagonal(mfdiag.p); // buildDiagonal :605-665
-        }
-        else {
-            build_hessian();
-            if (!massPrec) build_mg();
-        }
-        bool diagPrec = (cfg.levelCnt == 1 && cfg.times == 1);
-        std::function<void(const T*, T*)> prec = [&](const T* in, T* out) {
-            if (cfg.matrixFree)
-                block_apply_dev(mfdiag.p, in, out, Nn);
-            else if (massPrec)
-                HOT_LAUNCH(this, "mass_scale", k_mass_scale<T>, div_up(n3, 256), 256, 0, mass.p, in, out, Nn);
-            else if (diagPrec)
-                scale_dev(*levels[0], in, out); // forced diagonal preconditioner (ImplicitSolver.h:376-391)
-            else
-                vcycle_dev(in, out);
-        };
-        std::function<void(const T*, T*)> Amul = [&](const T* xx, T* bb) {
-            if (cfg.matrixFree)
-                matfree_dev(xx, bb);
-            else
-                spmv_dev(*levels[0], xx, bb);
-        };
-        if (cfg.lsolver == 1) {
-            // relative tolerance from the Newton loop (ExtendedNewtonsMethod.h:57), tolerance = maxcntol
-            // (MultigridSimulation.h:204) or the scene value 1e-4 (MultigridInit3D.h:85-86)
-            T residual_norm = (T)std::sqrt(dot_host(n3, residual, residual));
-            T newton_tol = cfg.useCN ? max_cn_tolerance : (T)cfg.cneps;
-            T rel = std::min((T)0.5, (T)std::sqrt(std::max(residual_norm, newton_tol)));
-            stats.linear_iterations += minres_dev(Amul, prec, step.p, residual, rel, cg_tolerance, 10000);
-            if (cfg.linesearch) line_search(step.p, residual, (T)1);
-            transform_dev(step.p, true);
-            axpy(n3, (T)1, step.p, x);
-            transform_dev(step.p, false);
-            continue;
-        }
-        // b = residual (+ dRhs == 0)
-        Amul(step.p, temp.p);
-        HOT_LAUNCH(this, "sub", k_sub<T>, div_up(n3, 256), 256, 0, n3, residual, temp.p, r.p);
-        project_dev(r.p);
-        prec(r.p, q.p);
-        copy(n3, q.p, p.p);
-        double zTrk = dot_host(n3, r.p, q.p);
-        T rpn = (T)std::sqrt(zTrk);
-        T forcing = std::min((T)0.5, (T)std::sqrt(std::max(rpn, cg_tolerance)));
-        T local_tol = forcing * rpn;
-        int cnt = 0;
-        for (; cnt < 10000; ++cnt) {
-            if (rpn < local_tol) break;
-            Amul(p.p, temp.p);
-            project_dev(temp.p);
-            T alpha = (T)(zTrk / dot_host(n3, temp.p, p.p));
-            axpy(n3, alpha, p.p, step.p);
-            axpy(n3, -alpha, temp.p, r.p);
-            prec(r.p, q.p);
-            double zlast = zTrk;
-            zTrk = dot_host(n3, q.p, r.p);
-            T beta = (T)(zTrk / zlast);
-            HOT_LAUNCH(this, "scal", k_scal<T>, div_up(n3, 256), 256, 0, n3, beta, p.p);
-            axpy(n3, (T)1, q.p, p.p);
-            rpn = (T)std::sqrt(zTrk);
-        }
-        stats.linear_iterations += cnt;
-        if (cfg.linesearch) line_search(step.p, residual, (T)1);
-        transform_dev(step.p, true);
-        axpy(n3, (T)1, step.p, x);
-        transform_dev(step.p, false);
+        compute_step_dev(residual, nw_step.p);
+        if (cfg.linesearch) line_search(nw_step.p, residual, (T)1);
+        transform_dev(nw_step.p, true);
+        axpy(n3, (T)1, nw_step.p, x);
+        transform_dev(nw_step.p, false);
     }
     stats.iterations = cfg.max_iterations;
     return false;
+}
+
+// ---- the solver-facing members of the objective, one by one (C ABI: hot_line_search, hot_should_exit, hot_recover_solution,
+//      hot_transform_residual, hot_compute_step), so that a host-side LBFGS / ExtendedNewtonsMethod template can drive the device
+template <class T>
+void Ctx<T>::line_search_api(void* ddv, void* residual, double alpha, double* alpha_out)
+{
+    need(Nn > 0 && dt > 0, "hot_line_search before hot_begin_step / hot_update_state");
+    size_t n3 = 3 * (size_t)Nn;
+    HOT_HIP(hipMemcpyAsync(work0.p, ddv, n3 * sizeof(T), hipMemcpyDefault, stream));
+    T a = line_search(work0.p, work1.p, (T)alpha);
+    download(ddv, work0.p, n3), download(residual, work1.p, n3);
+    sync();
+    if (alpha_out) *alpha_out = (double)a;
+}
+template <class T>
+void Ctx<T>::should_exit_api(const void* residual, int32_t* exit_now, double* scaled)
+{
+    need(Nn > 0 && dt > 0, "hot_should_exit before hot_begin_step");
+    if (cfg.useCN) cn_tolerance_dev();
+    HOT_HIP(hipMemcpyAsync(work0.p, residual, 3 * (size_t)Nn * sizeof(T), hipMemcpyDefault, stream));
+    bool e = should_exit(work0.p);
+    if (exit_now) *exit_now = e ? 1 : 0;
+    if (scaled) *scaled = stats.final_scaled_residual;
+}
+template <class T>
+void Ctx<T>::transform_api(void* v, bool inverse)
+{
+    need(Nn > 0, "no grid");
+    HOT_HIP(hipMemcpyAsync(work0.p, v, 3 * (size_t)Nn * sizeof(T), hipMemcpyDefault, stream));
+    transform_dev(work0.p, inverse);
+    download(v, work0.p, 3 * (size_t)Nn);
+    sync();
+}
+template <class T>
+void Ctx<T>::compute_step_api(const void* residual, void* step)
+{
+    need(Nn > 0 && dt > 0, "hot_compute_step before hot_update_state");
+    need(cfg.lsolver == 1 || cfg.lsolver == 2, "hot_compute_step is the projected-Newton step (lsolver 1 / 2)");
+    size_t n3 = 3 * (size_t)Nn;
+    if (cfg.useCN) cn_tolerance_dev();
+    nw_step.reserve(n3, 1.25);
+    HOT_HIP(hipMemcpyAsync(work2.p, residual, n3 * sizeof(T), hipMemcpyDefault, stream));
+    with_gs_retry([&] {
+        release_levels();
+        compute_step_dev(work2.p, nw_step.p);
+        sync();
+    });
+    download(step, nw_step.p, n3);
+    sync();
 }
 
 template <class T>

@@ -12,7 +12,9 @@
 //        gridToParticles(dt)                    Lib/MPM/MpmSimulationBase.cpp:903-1042
 //        advanceOneTimeStep(dt)                 Projects/multigrid/MultigridSimulation.h:235-297
 //   hotmi::Objective<T>    <->  ImplicitSolverObjective<Simulation>  (Projects/multigrid/ImplicitSolver.h)
-//        updateState / totalEnergy / computeResidual / multiply / precondition / project / innerProduct
+//        updateState / totalEnergy / computeResidual / shouldExitByCN / HinvApproxInit / multiply / precondition / project /
+//        lineSearch / recoverSolution / transformResidual / computeStep / innerProduct, with raw-pointer and Vec& overloads
+//        (tests/cpp/adapter_lbfgs.cpp drives a two-loop L-BFGS written in the member-call shape of LBFGS.h:300-437 through it)
 //   hotmi::smoothFunc      <->  MultigridOperator::regular.smoothFunc (Projects/multigrid/MultigridPreconditioner.h:67-79)
 //
 // Vectors are "TVStack" (3 x N column-major == xyz interleaved) exactly like the reference's
@@ -23,6 +25,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <utility>
 
 // HOTSettings is a namespace of inline statics on the reference side (Projects/multigrid/Configurations.h:18-42),
 // so the copy into hot_config is a macro; field names are identical on both sides.
@@ -99,6 +102,7 @@ public:
     // AnalyticCollisionObject list (half spaces, spheres, tori, sticky boxes / capped cylinders; STICKY / SLIP / SEPARATE) evaluated per node on the device
     void setCollisionObjects(int n, const hot_collision_object* objects) { check(ctx, hot_set_collision_objects(ctx, n, objects), "hot_set_collision_objects"); }
     void startBackwardEuler(double dt) { check(ctx, hot_begin_step(ctx, dt), "hot_begin_step"); }
+    void getDv(T* dv) { check(ctx, hot_get_dv(ctx, dv), "hot_get_dv"); } // simulation.dv (3 x numNodes)
     void backwardEulerStep() { check(ctx, hot_solve(ctx, &stats), "hot_solve"); }
     void gridToParticles(double dt)
     {
@@ -124,25 +128,52 @@ public:
     bool faster_than_grid_cell = false, faster_than_half_grid_cell = false;
 };
 
-// The operator concept LBFGS / ExtendedNewtonsMethod / InexactConjugateGradient / Minres are templated on.
+// The objective concept LBFGS<Objective> / ExtendedNewtonsMethod<Objective> / InexactConjugateGradient / Minres are templated on
+// (Projects/multigrid/ImplicitSolver.h; calls made by Lib/Ziran/Math/Nonlinear/LBFGS.h:300-437 and ExtendedNewtonsMethod.h:39-66).
+// `Vec` is whatever the solver template uses for TVStack — any type with data() / size() over 3 x N column-major scalars
+// (Eigen::Matrix<T,3,Dynamic>, std::vector<T>, ...).  Raw-pointer overloads are kept for C-style callers.
+//
+// Two reference behaviours are reproduced on purpose, because the solver templates rely on them (DESIGN.md "reference quirks"):
+//   * `updated`: after lineSearch the objective's state IS the accepted point, so updateState / computeResidual return
+//     immediately for the rest of the step (ImplicitSolver.h:132,241, resetLSFlag at startBackwardEuler);
+//   * aliasing: the reference solves in place on simulation.dv, and lineSearch moves simulation.dv to the accepted point
+//     (moveNodes, MpmSimulationBase.cpp:736-747), i.e. the solver's x changes under it.  Here x is the caller's memory, so
+//     updateState remembers where x lives and lineSearch writes the moved dv back to it.
 template <class T>
 class Objective {
 public:
     using Scalar = T;
     Simulation<T>& simulation;
     bool matrix_free = false;
+    bool updated = false;
     T Ek = 0;
     explicit Objective(Simulation<T>& s)
         : simulation(s) {}
     hot_ctx* c() const { return simulation.ctx; }
+    int64_t numNodes() const { return simulation.numNodes(); }
+    void resetLSFlag() { updated = false; } // startBackwardEuler (MultigridSimulation.h:167-186)
+
+    // ---- raw pointers
     void updateState(const T* dv)
     {
+        x_alias = const_cast<T*>(dv);
+        if (updated) return;
         double e = 0;
         check(c(), hot_update_state(c(), dv, &e), "hot_update_state");
         Ek = (T)e;
     }
     T totalEnergy() const { return Ek; }
-    void computeResidual(T* residual) { check(c(), hot_residual(c(), residual), "hot_residual"); }
+    void computeResidual(T* residual)
+    {
+        if (updated) return;
+        check(c(), hot_residual(c(), residual), "hot_residual");
+    }
+    bool shouldExitByCN(const T* residual)
+    {
+        int32_t e = 0;
+        check(c(), hot_should_exit(c(), residual, &e, nullptr), "hot_should_exit");
+        return e != 0;
+    }
     void HinvApproxInit()
     {
         check(c(), hot_build_hessian(c()), "hot_build_hessian");
@@ -151,6 +182,18 @@ public:
     void multiply(const T* x, T* b) const { check(c(), matrix_free ? hot_matfree_multiply(c(), x, b) : hot_spmv(c(), 0, x, b), "multiply"); }
     void precondition(const T* in, T* out) const { check(c(), hot_vcycle(c(), in, out), "hot_vcycle"); }
     void project(T* v) const { check(c(), hot_project(c(), v), "hot_project"); }
+    T lineSearch(T* ddv, T* residual, T alpha)
+    {
+        double a = 0;
+        check(c(), hot_line_search(c(), ddv, residual, (double)alpha, &a), "hot_line_search");
+        updated = true;
+        if (x_alias) check(c(), hot_get_dv(c(), x_alias), "hot_get_dv"); // the solver's x is simulation.dv in the reference
+        return (T)a;
+    }
+    void recoverSolution(T* v) const { check(c(), hot_recover_solution(c(), v), "hot_recover_solution"); }
+    void transformResidual(T* v) const { check(c(), hot_transform_residual(c(), v), "hot_transform_residual"); }
+    // computeStep(step, residual, relative_tolerance): the tolerances are derived inside from the residual as in :355-432
+    void computeStep(T* step, const T* residual, T /*relative_tolerance*/ = 0) { check(c(), hot_compute_step(c(), residual, step), "hot_compute_step"); }
     // evaluatePerNodeCNTolerance (ImplicitSolver.h:667-696): per-node characteristic-norm tolerance
     void cnTolerance(T* node_tol) const { check(c(), hot_cn_tolerance(c(), node_tol), "hot_cn_tolerance"); }
     T innerProduct(const T* a, const T* b, int64_t numNodes) const
@@ -159,6 +202,33 @@ public:
         for (int64_t i = 0; i < 3 * numNodes; ++i) s += a[i] * b[i];
         return s;
     }
+
+    // ---- Vec& overloads: the member-call shape of the reference's solver templates
+    template <class Vec, class = decltype(std::declval<const Vec&>().data())>
+    void updateState(const Vec& x) { updateState(x.data()); }
+    template <class Vec, class = decltype(std::declval<Vec&>().data())>
+    void computeResidual(Vec& r) { computeResidual(r.data()); }
+    template <class Vec, class = decltype(std::declval<const Vec&>().data())>
+    bool shouldExitByCN(const Vec& r) { return shouldExitByCN(r.data()); }
+    template <class Vec, class = decltype(std::declval<Vec&>().data())>
+    void multiply(const Vec& x, Vec& b) const { multiply(x.data(), b.data()); }
+    template <class Vec, class = decltype(std::declval<Vec&>().data())>
+    void precondition(const Vec& in, Vec& out) const { precondition(in.data(), out.data()); }
+    template <class Vec, class = decltype(std::declval<Vec&>().data())>
+    void project(Vec& v) const { project(v.data()); }
+    template <class Vec, class = decltype(std::declval<Vec&>().data())>
+    T lineSearch(Vec& ddv, Vec& residual, T alpha) { return lineSearch(ddv.data(), residual.data(), alpha); }
+    template <class Vec, class = decltype(std::declval<Vec&>().data())>
+    void recoverSolution(Vec& v) const { recoverSolution(v.data()); }
+    template <class Vec, class = decltype(std::declval<Vec&>().data())>
+    void transformResidual(Vec& v) const { transformResidual(v.data()); }
+    template <class Vec, class = decltype(std::declval<Vec&>().data())>
+    void computeStep(Vec& step, const Vec& residual, T relative_tolerance = 0) { computeStep(step.data(), residual.data(), relative_tolerance); }
+    template <class Vec, class = decltype(std::declval<const Vec&>().data())>
+    T innerProduct(const Vec& a, const Vec& b) const { return innerProduct(a.data(), b.data(), (int64_t)(a.size() / 3)); }
+
+private:
+    T* x_alias = nullptr;
 };
 
 // void (*smoothFunc)(TVStack& u, TVStack& r, TVStack& du, TVStack& dAu, MPMSpMat& A, int iterations, T tolerance):

@@ -169,6 +169,18 @@ int hot_cn_tolerance(hot_ctx*, void* node_tol /*Nn*/); /* evaluatePerNodeCNToler
 int hot_build_hessian(hot_ctx*); /* buildMatrix<true> :470-603 (+ buildDiagonal of level 0) */
 int hot_matfree_multiply(hot_ctx*, const void* x, void* y); /* multiply :741-758 with matrix_free */
 
+/* ---- the remaining members the reference's solver templates call on the objective (LBFGS.h:344,410-414, ExtendedNewtonsMethod.h:48-61):
+ *      lineSearch :312-333 (energy backtracking from alpha; ddv comes back scaled by the accepted alpha and transformed, residual is the
+ *      residual at the accepted point; as in the reference the nodal dv of the context moves to the accepted point and the objective's
+ *      `updated` flag stays set for the rest of the step), shouldExitByCN :174-211 (or the l2 test without useCN), recoverSolution /
+ *      transformResidual :106-125 (slip nodes to / from their normal frame), computeStep :355-432 (projected Newton, lsolver 1 / 2:
+ *      rebuilds matrix + hierarchy, then MINRES / inexact PCG). */
+int hot_line_search(hot_ctx*, void* ddv /*3Nn in/out*/, void* residual /*3Nn out*/, double alpha, double* alpha_out);
+int hot_should_exit(hot_ctx*, const void* residual /*3Nn*/, int32_t* exit_now, double* scaled_residual /*NULL ok*/);
+int hot_recover_solution(hot_ctx*, void* v /*3Nn in/out*/);
+int hot_transform_residual(hot_ctx*, void* v /*3Nn in/out*/);
+int hot_compute_step(hot_ctx*, const void* residual /*3Nn*/, void* step /*3Nn out*/);
+
 /* ---- MultigridBuilder::build (Projects/multigrid/MultigridPreconditioner.h:554-703) */
 int hot_build_mg(hot_ctx*);
 int hot_get_level(hot_ctx*, int32_t level, int32_t* nrows, int32_t* colsize, int32_t* id2coord /*3*nrows or NULL*/);

@@ -400,6 +400,60 @@ int hoto_g2p(hoto_ctx* c, double dt, int32_t* flags)
     });
     return 0;
 }
+// the remaining members of the solver-facing objective concept (ImplicitSolver.h): lineSearch :312-333, shouldExitByCN :174-211,
+// recoverSolution / transformResidual :106-125, computeStep :355-432
+int hoto_line_search(hoto_ctx* c, void* ddv, void* residual, double alpha, double* alpha_out)
+{
+    DISPATCH(c, {
+        auto d = load_tv<T>(ddv, S.num_nodes);
+        std::vector<V3<T>> r(S.num_nodes);
+        T a = S.line_search(d, r, (T)alpha);
+        copy_tv(d, ddv);
+        copy_tv(r, residual);
+        if (alpha_out) *alpha_out = (double)a;
+    });
+    return 0;
+}
+int hoto_should_exit(hoto_ctx* c, const void* residual, int32_t* exit_now, double* scaled_residual)
+{
+    DISPATCH(c, {
+        auto r = load_tv<T>(residual, S.num_nodes);
+        if (S.cfg.useCN && S.nodeCNTol.size() != (size_t)S.num_nodes) S.evaluate_cn_tolerance();
+        bool e = S.should_exit(r);
+        if (exit_now) *exit_now = e ? 1 : 0;
+        if (scaled_residual) *scaled_residual = S.stats.final_scaled_residual;
+    });
+    return 0;
+}
+int hoto_recover_solution(hoto_ctx* c, void* v)
+{
+    DISPATCH(c, {
+        auto x = load_tv<T>(v, S.num_nodes);
+        S.recover_solution(x);
+        copy_tv(x, v);
+    });
+    return 0;
+}
+int hoto_transform_residual(hoto_ctx* c, void* v)
+{
+    DISPATCH(c, {
+        auto x = load_tv<T>(v, S.num_nodes);
+        S.transform_residual(x);
+        copy_tv(x, v);
+    });
+    return 0;
+}
+int hoto_compute_step(hoto_ctx* c, const void* residual, void* step)
+{
+    DISPATCH(c, {
+        auto r = load_tv<T>(residual, S.num_nodes);
+        std::vector<V3<T>> st(S.num_nodes, V3<T>::zero());
+        if (S.cfg.useCN && S.nodeCNTol.size() != (size_t)S.num_nodes) S.evaluate_cn_tolerance();
+        S.compute_step(r, st);
+        copy_tv(st, step);
+    });
+    return 0;
+}
 int hoto_set_comm(hoto_ctx* c, const hot_comm* comm)
 {
     DISPATCH(c, {

@@ -898,6 +898,7 @@ struct Sim {
     bool should_exit(const std::vector<TV>& residual);
     T line_search(std::vector<TV>& ddv, std::vector<TV>& residual, T alpha);
     bool lbfgs_solve();
+    void compute_step(const std::vector<TV>& residual, std::vector<TV>& step);
     bool newton_solve();
     int solve();
     int advance(double dt_);

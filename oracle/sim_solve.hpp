@@ -228,13 +228,134 @@ int Sim<T>::minres_solve(const std::function<void(const std::vector<TV>&, std::v
     return max_iterations;
 }
 
+// reference ImplicitSolverObjective::computeStep (ImplicitSolver.h:355-432): rebuild the matrix and the hierarchy (or the
+// matrix-free block diagonal), then InexactConjugateGradient::solve (InexactConjugateGradient.h:49-103) or Minres::solve
+template <class T>
+void Sim<T>::compute_step(const std::vector<TV>& residual, std::vector<TV>& step)
+{
+    // cg.tolerance: scene value 1e-4 (MultigridInit3D.h:2500-2501) unless useCN sets maxcntol (MultigridSimulation.h:201-208)
+    T cg_tolerance = cfg.useCN ? max_cn_tolerance : (T)1e-4;
+    // computeStep
+    step.assign(num_nodes, TV::zero());
+    std::function<void(const std::vector<TV>&, std::vector<TV>&)> prec;
+    if (!cfg.matrixFree) {
+        double t0 = now_ms();
+        build_matrix();
+        double t1 = now_ms();
+        // ImplicitSolver.h:365: with the mass preconditioner (Ainv 2, lsolver 1/2 only) no hierarchy is built and
+        // `precondition` stays the lumped-mass scaling installed by startBackwardEuler
+        const bool massPrec = (cfg.lsolver == 1 || cfg.lsolver == 2) && cfg.Ainv == 2;
+        if (!massPrec) build_mg();
+        double t2 = now_ms();
+        stats.ms_hessian += t1 - t0, stats.ms_mg_build += t2 - t1;
+        if (massPrec)
+            prec = [&](const std::vector<TV>& in, std::vector<TV>& out) {
+                out.resize(in.size());
+                for (int i = 0; i < num_nodes; ++i) out[i] = in[i] * ((T)1 / mass_matrix[i]);
+            };
+        else if (cfg.levelCnt == 1 && cfg.times == 1)
+            prec = [&](const std::vector<TV>& in, std::vector<TV>& out) { scaler(in, out, sysmats[0]); };
+        else
+            prec = [&](const std::vector<TV>& in, std::vector<TV>& out) { vcycle(in, out); };
+    }
+    else {
+        // buildDiagonal (ImplicitSolver.h:605-665): block diagonal of the matrix-free operator
+        std::vector<TM> diag(num_nodes);
+        HOT_FAIR_FOR
+        for (int n = 0; n < num_nodes; ++n) diag[n] = (sharded() && comm.rank != 0) ? TM::zero() : TM::identity() * mass_matrix[n];
+        bool proj = cfg.project != 0;
+        for_each_particle_colored([&](int g, int i) {
+            CorotatedScratch<T> s;
+            corotated_update_scratch(F[i], mu[i], lambda[i], proj, s);
+            T ddF[81];
+            corotated_first_piola_derivative(s, ddF);
+            TM FnT = Fn[i].transpose();
+            Spline sp;
+            compute_spline(X[i], sp);
+            iterate_kernel(sp, g, particle_base_offset[i], [&](const int*, T, const TV& dw, Node& gs) {
+                if (gs.idx < 0) return;
+                TV wi = FnT * dw;
+                TM dFdX = TM::zero();
+                for (int q = 0; q < 3; ++q)
+                    for (int v = 0; v < 3; ++v)
+                        for (int r = 0; r < 3; ++r)
+                            for (int c = 0; c < 3; ++c) dFdX(r, c) += ddF[(3 * v + r) + 9 * (3 * q + c)] * wi(v) * wi(q);
+                diag[gs.idx] += dFdX * (dt * dt * vol[i]);
+            });
+        });
+        allreduce(diag.data(), (int64_t)num_nodes * 9, REAL);
+        std::vector<TM> dinv(num_nodes);
+        for (int n = 0; n < num_nodes; ++n) {
+            if (cfg.Ainv == 0) {
+                dinv[n] = TM::zero();
+                for (int k = 0; k < 3; ++k) dinv[n](k, k) = 1 / diag[n](k, k);
+            }
+            else
+                dinv[n] = inverse(diag[n]);
+        }
+        prec = [dinv](const std::vector<TV>& in, std::vector<TV>& out) {
+            out.resize(in.size());
+            for (size_t n = 0; n < in.size(); ++n) out[n] = dinv[n] * in[n];
+        };
+    }
+    auto Amul = [&](const std::vector<TV>& xx, std::vector<TV>& bb) {
+        if (cfg.matrixFree)
+            matfree_multiply(xx, bb);
+        else
+            multiply(sysmats[0], xx, bb);
+    };
+    std::vector<TV> b = residual;
+    if (cfg.systemBCProject) {
+        HOT_FAIR_FOR
+        for (int n = 0; n < num_nodes; ++n) b[n] += dRhs[n];
+    }
+    if (cfg.lsolver == 1) {
+        // Minres::solve (Lib/Ziran/Math/Linear/Minres.h:69-149) with relative tolerance from the Newton loop
+        // (ExtendedNewtonsMethod.h:57) and tolerance = maxcntol (MultigridSimulation.h:204) or the scene's 1e-4
+        T residual_norm = std::sqrt(dot_product(residual, residual));
+        T newton_tol = cfg.useCN ? max_cn_tolerance : (T)cfg.cneps;
+        T rel = std::min((T)0.5, std::sqrt(std::max(residual_norm, newton_tol)));
+        stats.linear_iterations += minres_solve(Amul, prec, step, b, rel, cg_tolerance, 10000);
+    }
+    else
+    // inexact PCG
+    {
+        std::vector<TV> r(num_nodes), p(num_nodes), q(num_nodes), temp(num_nodes);
+        Amul(step, temp);
+        HOT_FAIR_FOR
+        for (int n = 0; n < num_nodes; ++n) r[n] = b[n] - temp[n];
+        project(r);
+        prec(r, q);
+        p = q;
+        T zTrk = dot_product(r, q);
+        T rpn = std::sqrt(zTrk);
+        T forcing = std::min((T)0.5, std::sqrt(std::max(rpn, cg_tolerance)));
+        T local_tol = forcing * rpn;
+        int cnt = 0;
+        for (; cnt < 10000; ++cnt) {
+            if (rpn < local_tol) break;
+            Amul(p, temp);
+            project(temp);
+            T alpha = zTrk / dot_product(temp, p);
+            HOT_FAIR_FOR
+            for (int n = 0; n < num_nodes; ++n) step[n] += p[n] * alpha, r[n] -= temp[n] * alpha;
+            prec(r, q);
+            T zTrk_last = zTrk;
+            zTrk = dot_product(q, r);
+            T beta = zTrk / zTrk_last;
+            HOT_FAIR_FOR
+            for (int n = 0; n < num_nodes; ++n) p[n] = q[n] + p[n] * beta;
+            rpn = std::sqrt(zTrk);
+        }
+        stats.linear_iterations += cnt;
+    }
+}
+
 template <class T>
 bool Sim<T>::newton_solve()
 {
     std::vector<TV>& x = dv;
     std::vector<TV> residual(num_nodes), step(num_nodes);
-    // cg.tolerance: scene value 1e-4 (MultigridInit3D.h:2500-2501) unless useCN sets maxcntol (MultigridSimulation.h:201-208)
-    T cg_tolerance = cfg.useCN ? max_cn_tolerance : (T)1e-4;
     for (int it = 0; it < cfg.max_iterations; ++it) {
         stats.iterations = it;
         if (!updated) {
@@ -245,119 +366,7 @@ bool Sim<T>::newton_solve()
             stats.converged = 1;
             return true;
         }
-        // computeStep
-        step.assign(num_nodes, TV::zero());
-        std::function<void(const std::vector<TV>&, std::vector<TV>&)> prec;
-        if (!cfg.matrixFree) {
-            double t0 = now_ms();
-            build_matrix();
-            double t1 = now_ms();
-            // ImplicitSolver.h:365: with the mass preconditioner (Ainv 2, lsolver 1/2 only) no hierarchy is built and
-            // `precondition` stays the lumped-mass scaling installed by startBackwardEuler
-            const bool massPrec = (cfg.lsolver == 1 || cfg.lsolver == 2) && cfg.Ainv == 2;
-            if (!massPrec) build_mg();
-            double t2 = now_ms();
-            stats.ms_hessian += t1 - t0, stats.ms_mg_build += t2 - t1;
-            if (massPrec)
-                prec = [&](const std::vector<TV>& in, std::vector<TV>& out) {
-                    out.resize(in.size());
-                    for (int i = 0; i < num_nodes; ++i) out[i] = in[i] * ((T)1 / mass_matrix[i]);
-                };
-            else if (cfg.levelCnt == 1 && cfg.times == 1)
-                prec = [&](const std::vector<TV>& in, std::vector<TV>& out) { scaler(in, out, sysmats[0]); };
-            else
-                prec = [&](const std::vector<TV>& in, std::vector<TV>& out) { vcycle(in, out); };
-        }
-        else {
-            // buildDiagonal (ImplicitSolver.h:605-665): block diagonal of the matrix-free operator
-            std::vector<TM> diag(num_nodes);
-            HOT_FAIR_FOR
-            for (int n = 0; n < num_nodes; ++n) diag[n] = (sharded() && comm.rank != 0) ? TM::zero() : TM::identity() * mass_matrix[n];
-            bool proj = cfg.project != 0;
-            for_each_particle_colored([&](int g, int i) {
-                CorotatedScratch<T> s;
-                corotated_update_scratch(F[i], mu[i], lambda[i], proj, s);
-                T ddF[81];
-                corotated_first_piola_derivative(s, ddF);
-                TM FnT = Fn[i].transpose();
-                Spline sp;
-                compute_spline(X[i], sp);
-                iterate_kernel(sp, g, particle_base_offset[i], [&](const int*, T, const TV& dw, Node& gs) {
-                    if (gs.idx < 0) return;
-                    TV wi = FnT * dw;
-                    TM dFdX = TM::zero();
-                    for (int q = 0; q < 3; ++q)
-                        for (int v = 0; v < 3; ++v)
-                            for (int r = 0; r < 3; ++r)
-                                for (int c = 0; c < 3; ++c) dFdX(r, c) += ddF[(3 * v + r) + 9 * (3 * q + c)] * wi(v) * wi(q);
-                    diag[gs.idx] += dFdX * (dt * dt * vol[i]);
-                });
-            });
-            allreduce(diag.data(), (int64_t)num_nodes * 9, REAL);
-            std::vector<TM> dinv(num_nodes);
-            for (int n = 0; n < num_nodes; ++n) {
-                if (cfg.Ainv == 0) {
-                    dinv[n] = TM::zero();
-                    for (int k = 0; k < 3; ++k) dinv[n](k, k) = 1 / diag[n](k, k);
-                }
-                else
-                    dinv[n] = inverse(diag[n]);
-            }
-            prec = [dinv](const std::vector<TV>& in, std::vector<TV>& out) {
-                out.resize(in.size());
-                for (size_t n = 0; n < in.size(); ++n) out[n] = dinv[n] * in[n];
-            };
-        }
-        auto Amul = [&](const std::vector<TV>& xx, std::vector<TV>& bb) {
-            if (cfg.matrixFree)
-                matfree_multiply(xx, bb);
-            else
-                multiply(sysmats[0], xx, bb);
-        };
-        std::vector<TV> b = residual;
-        if (cfg.systemBCProject)
-            HOT_FAIR_FOR
-            for (int n = 0; n < num_nodes; ++n) b[n] += dRhs[n];
-        if (cfg.lsolver == 1) {
-            // Minres::solve (Lib/Ziran/Math/Linear/Minres.h:69-149) with relative tolerance from the Newton loop
-            // (ExtendedNewtonsMethod.h:57) and tolerance = maxcntol (MultigridSimulation.h:204) or the scene's 1e-4
-            T residual_norm = std::sqrt(dot_product(residual, residual));
-            T newton_tol = cfg.useCN ? max_cn_tolerance : (T)cfg.cneps;
-            T rel = std::min((T)0.5, std::sqrt(std::max(residual_norm, newton_tol)));
-            stats.linear_iterations += minres_solve(Amul, prec, step, b, rel, cg_tolerance, 10000);
-        }
-        else
-        // inexact PCG
-        {
-            std::vector<TV> r(num_nodes), p(num_nodes), q(num_nodes), temp(num_nodes);
-            Amul(step, temp);
-            HOT_FAIR_FOR
-            for (int n = 0; n < num_nodes; ++n) r[n] = b[n] - temp[n];
-            project(r);
-            prec(r, q);
-            p = q;
-            T zTrk = dot_product(r, q);
-            T rpn = std::sqrt(zTrk);
-            T forcing = std::min((T)0.5, std::sqrt(std::max(rpn, cg_tolerance)));
-            T local_tol = forcing * rpn;
-            int cnt = 0;
-            for (; cnt < 10000; ++cnt) {
-                if (rpn < local_tol) break;
-                Amul(p, temp);
-                project(temp);
-                T alpha = zTrk / dot_product(temp, p);
-                HOT_FAIR_FOR
-                for (int n = 0; n < num_nodes; ++n) step[n] += p[n] * alpha, r[n] -= temp[n] * alpha;
-                prec(r, q);
-                T zTrk_last = zTrk;
-                zTrk = dot_product(q, r);
-                T beta = zTrk / zTrk_last;
-                HOT_FAIR_FOR
-                for (int n = 0; n < num_nodes; ++n) p[n] = q[n] + p[n] * beta;
-                rpn = std::sqrt(zTrk);
-            }
-            stats.linear_iterations += cnt;
-        }
+        compute_step(residual, step);
         if (cfg.linesearch) line_search(step, residual, (T)1);
         recover_solution(step);
         HOT_FAIR_FOR

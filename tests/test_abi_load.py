@@ -41,11 +41,11 @@ def test_product_never_touches_oracle():
                 assert "oracle" not in txt.lower() or f == "__init__.py" and "oracle" not in txt.replace("no CPU fallback", "").lower(), (dirpath, f)
 
 
-def _build_adapter(tmp_path):
+def _build_adapter(tmp_path, name="adapter_smoke"):
     import subprocess
-    exe = str(tmp_path / "adapter_smoke")
+    exe = str(tmp_path / name)
     libdir = os.path.join(ROOT, "hot_amd", "csrc")
-    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adapter_smoke.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
                            "-L" + libdir, "-lhotmi355x", "-Wl,-rpath," + libdir, "-o", exe])
     return exe
 
@@ -57,9 +57,10 @@ def test_cpp_adapter_compiles_and_fails_loudly_without_gpu(tmp_path):
     import torch
     if not os.path.exists(hot_amd.LIB_PATH):
         hot_amd.build()
-    exe = _build_adapter(tmp_path)
-    rc = subprocess.call([exe])
-    assert rc == (0 if torch.cuda.is_available() else 42)
+    for name in ("adapter_smoke", "adapter_lbfgs"):  # the second instantiates a host-side L-BFGS template on hotmi::Objective (the full concept)
+        exe = _build_adapter(tmp_path, name)
+        rc = subprocess.call([exe])
+        assert rc == (0 if torch.cuda.is_available() else 42), name
 
 
 import pytest  # noqa: E402
@@ -72,3 +73,15 @@ def test_cpp_adapter_runs_on_gpu(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "adapter ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_objective_concept_drives_host_lbfgs_on_gpu(tmp_path):
+    """tests/cpp/adapter_lbfgs.cpp: a two-loop L-BFGS written in the member-call shape of the reference's LBFGS::solve, instantiated
+    with hotmi::Objective<double> (updateState / computeResidual / shouldExitByCN / HinvApproxInit / precondition / project /
+    lineSearch / recoverSolution / transformResidual through the C ABI), reproduces the device-side hot_solve to 1e-9."""
+    import subprocess
+    exe = _build_adapter(tmp_path, "adapter_lbfgs")
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "adapter L-BFGS vs hot_solve" in out.stdout

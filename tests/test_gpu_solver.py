@@ -493,3 +493,40 @@ def test_capped_cylinder_must_be_sticky(hotlib):
     ctx, c = pc.make_ctx(hotlib, n=4, bc=False)
     with pytest.raises(HotError):
         ctx.set_collision_objects([dict(shape=CAPPED_CYLINDER, type=SLIP, p0=(5, 5, 5), p1=(0.1, 0.1, 0))])
+
+
+@pytest.mark.parametrize("bc", [0, 1])
+def test_objective_concept_members_against_oracle(hotlib, oracle, bc):
+    """The solver-facing members one by one (hot_should_exit, hot_line_search, hot_recover_solution / hot_transform_residual,
+    hot_compute_step): the same calls on the HIP library and on the oracle give the same numbers."""
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=8, levelCnt=2, boundaryType=bc, bc=(bc == 0))
+        if bc == 1:  # a slip floor: recoverSolution / transformResidual rotate its nodes
+            ctx.set_collision_objects([dict(shape=0, type=2, p0=(0.0, 5.015, 0.0), p1=(0.0, 1.0, 0.0), friction=0.0)])
+        pc.prepare(ctx)
+        ctx.update_state(ctx.get_dv())
+        r = ctx.residual()
+        ex, sc = ctx.should_exit(r)
+        ctx.build_hessian(), ctx.build_mg()
+        d = ctx.project(ctx.vcycle(r))
+        x = np.random.default_rng(2).standard_normal(d.shape)
+        rec, tr = ctx.recover_solution(x), ctx.transform_residual(x)
+        dd, r2, alpha = ctx.line_search(d, 1.0)
+        out[name] = (r, ex, sc, d, rec, tr, dd, r2, alpha, ctx.get_dv())
+    g, c = out["gpu"], out["cpu"]
+    assert g[1] == c[1] and abs(g[2] - c[2]) < 1e-9 * c[2] and g[8] == c[8]
+    for k in (0, 3, 4, 5, 6, 7, 9):
+        assert rel(g[k], c[k]) < 1e-9, (k, rel(g[k], c[k]))
+    if bc == 1:
+        assert rel(g[4], g[5]) > 1e-3  # the slip nodes really were rotated (recover != transform)
+
+
+def test_compute_step_against_oracle(hotlib, oracle):
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=8, levelCnt=2, lsolver=2)
+        pc.prepare(ctx)
+        ctx.update_state(ctx.get_dv())
+        out[name] = ctx.compute_step(ctx.residual())
+    assert rel(out["gpu"], out["cpu"]) < 1e-8, rel(out["gpu"], out["cpu"])
