@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "get_counts", "get_indexing", "p2g", "get_grid", "set_bc", "set_sticky_halfspaces", "set_collision_objects", "begin_step", "get_dv",
     "set_dv", "update_state", "get_particle_state", "residual", "project", "cn_tolerance", "build_hessian",
     "matfree_multiply", "build_mg", "get_level", "get_matrix", "get_level_nnzb", "get_prolongation", "spmv", "restrict", "prolong",
-    "smooth", "vcycle", "solve", "g2p", "line_search", "should_exit", "recover_solution", "transform_residual", "compute_step", "set_comm", "constitutive_eval", "plasticity_eval", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
+    "smooth", "vcycle", "solve", "g2p", "line_search", "should_exit", "recover_solution", "transform_residual", "compute_step", "write_partio", "write_restart", "read_restart", "set_comm", "constitutive_eval", "plasticity_eval", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
 ]
 
 
@@ -124,6 +124,9 @@ class HotLib:
             "recover_solution": (C.c_int, [vp, vp]),
             "transform_residual": (C.c_int, [vp, vp]),
             "compute_step": (C.c_int, [vp, vp, vp]),
+            "write_partio": (C.c_int, [vp, C.c_char_p]),
+            "write_restart": (C.c_int, [vp, C.c_char_p]),
+            "read_restart": (C.c_int, [vp, C.c_char_p]),
             "set_comm": (C.c_int, [vp, vp]),
             "constitutive_eval": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp, vp]),
             "plasticity_eval": (C.c_int, [vp, i32, i32, vp, vp, vp, vp]),
@@ -437,6 +440,17 @@ class Context:
         st = np.empty((self.Nn, 3), self.T)
         self._call("compute_step", _ptr(r), _ptr(st))
         return st
+
+    # ---- frame output
+    def write_partio(self, path):
+        self._call("write_partio", str(path).encode())
+
+    def write_restart(self, path):
+        self._call("write_restart", str(path).encode())
+
+    def read_restart(self, path):
+        self._call("read_restart", str(path).encode())
+        self.Np = self.counts()["Np"]
 
     def set_comm(self, comm):
         """Install a hot_amd.dist.TorchComm (one connected body over several ranks) or remove it (None).  Before set_particles."""

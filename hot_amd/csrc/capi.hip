@@ -322,6 +322,24 @@ int hot_compute_step(hot_ctx* ctx, const void* residual, void* step)
     ctx->impl->compute_step_api(residual, step);
     HOT_API_END
 }
+int hot_write_partio(hot_ctx* ctx, const char* path)
+{
+    HOT_API_BEGIN
+    ctx->impl->write_partio(path);
+    HOT_API_END
+}
+int hot_write_restart(hot_ctx* ctx, const char* path)
+{
+    HOT_API_BEGIN
+    ctx->impl->write_restart(path);
+    HOT_API_END
+}
+int hot_read_restart(hot_ctx* ctx, const char* path)
+{
+    HOT_API_BEGIN
+    ctx->impl->read_restart(path);
+    HOT_API_END
+}
 int hot_set_comm(hot_ctx* ctx, const hot_comm* comm)
 {
     HOT_API_BEGIN

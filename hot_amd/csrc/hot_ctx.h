@@ -102,6 +102,9 @@ struct CtxBase {
     virtual void solve(hot_stats* st) = 0;
     virtual void g2p(double dt, int32_t* flags) = 0;
     virtual void set_comm(const hot_comm* c) = 0;
+    virtual void write_partio(const char* path) = 0;
+    virtual void write_restart(const char* path) = 0;
+    virtual void read_restart(const char* path) = 0;
     virtual void line_search_api(void* ddv, void* residual, double alpha, double* alpha_out) = 0;
     virtual void should_exit_api(const void* residual, int32_t* exit_now, double* scaled) = 0;
     virtual void transform_api(void* v, bool inverse) = 0;

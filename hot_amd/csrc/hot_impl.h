@@ -140,6 +140,9 @@ struct Ctx : CtxBase {
     DBuf<char> xsend, xrecv; // staging of the collectives
     DBuf<uint8_t> written; // level-0 rows this rank's tile kernel has written (its partial rows)
     void set_comm(const hot_comm* c) override;
+    void write_partio(const char* path) override;
+    void write_restart(const char* path) override;
+    void read_restart(const char* path) override;
     void c_allreduce(void* buf, int64_t n, int dtype, int op, bool on_device);
     void c_allgather(const void* send, void* recv, int64_t bytes, bool on_device);
     void c_alltoallv(const void* send, const int64_t* soff, const int64_t* sbytes, void* recv, const int64_t* roff, const int64_t* rbytes);

@@ -274,6 +274,15 @@ int hot_constitutive_eval(hot_ctx*, int32_t n, const void* F /*9n*/, const void*
 int hot_plasticity_eval(hot_ctx*, int32_t kind /*1 von Mises, 2 snow*/, int32_t n, void* F /*9n in/out*/, void* mu /*n in/out*/, void* lambda /*n in/out*/,
     void* Jp /*n in/out, snow only*/);
 
+/* ---- frame output (SimulationBase::write -> MpmSimulationBase::writeState, Lib/Ziran/Sim/SimulationBase.h:152-190,
+ *      Lib/MPM/MpmSimulationBase.cpp:754-785): hot_write_partio = writePartio's .bgeo of the particle positions (PartioIO.h:142-180);
+ *      hot_write_restart / hot_read_restart = the particle DataManager in the container layout of DataManager::writeData
+ *      (DataManager.h:263-294) with this library's columns (see hot_amd/csrc/io.hip for what is and is not interchangeable with the
+ *      reference's restart_<frame>.dat).  Particles in the caller's order; hot_read_restart replaces the particle set. */
+int hot_write_partio(hot_ctx*, const char* path);
+int hot_write_restart(hot_ctx*, const char* path);
+int hot_read_restart(hot_ctx*, const char* path);
+
 /* ---- per-kernel timings gathered with HIP events on the launch stream when cfg.profile = 1 */
 int hot_profile_reset(hot_ctx*);
 int hot_profile_count(hot_ctx*, int32_t* n);

@@ -5,6 +5,8 @@
 // the HIP library through the same Python wrapper.  All pointers are host pointers here.
 #include "sim_solve.hpp"
 #include <cstdio>
+#include <map>
+#include <cstring>
 #include <cstdlib>
 
 using namespace hot_oracle;
@@ -43,6 +45,20 @@ static std::vector<V3<T>> load_tv(const void* in, size_t n)
     std::vector<V3<T>> v(n);
     std::memcpy(v.data(), in, n * sizeof(V3<T>));
     return v;
+}
+
+template <class U>
+static void o_put(FILE* f, U v) { fwrite(&v, sizeof(U), 1, f); }
+template <class T, class Get>
+static void o_array(FILE* f, const char* name, int64_t n, int comps, const Get& get)
+{
+    o_put<uint64_t>(f, strlen(name));
+    fwrite(name, 1, strlen(name), f);
+    o_put<int32_t>(f, 7);
+    o_put<uint64_t>(f, 1), o_put<uint64_t>(f, 8), o_put<int32_t>(f, 0), o_put<int32_t>(f, (int32_t)n);
+    o_put<uint64_t>(f, (uint64_t)n), o_put<uint64_t>(f, (uint64_t)comps * sizeof(T));
+    for (int64_t p = 0; p < n; ++p)
+        for (int k = 0; k < comps; ++k) o_put<T>(f, get(p, k));
 }
 
 extern "C" {
@@ -453,6 +469,86 @@ int hoto_compute_step(hoto_ctx* c, const void* residual, void* step)
         copy_tv(st, step);
     });
     return 0;
+}
+// frame output, restated independently of the product's io.hip from the same reference sources: writePartio's .bgeo of the positions
+// (Lib/Ziran/Math/Geometry/PartioIO.h:142-180; Bgeo v5 container, big-endian) and the particle DataManager container
+// (Lib/Ziran/CS/DataStructure/DataManager.h:263-294, DataArray.h:100-105, Lib/Ziran/CS/Util/BinaryIO.h:82-88)
+static void o_be32(FILE* f, uint32_t v)
+{
+    unsigned char b[4] = { (unsigned char)(v >> 24), (unsigned char)(v >> 16), (unsigned char)(v >> 8), (unsigned char)v };
+    fwrite(b, 1, 4, f);
+}
+int hoto_write_partio(hoto_ctx* c, const char* path)
+{
+    FILE* f = fopen(path, "wb");
+    if (!f) return HOT_ERR_INVALID;
+    DISPATCH(c, {
+        o_be32(f, 0x4267656fu); // "Bgeo"
+        fputc('V', f);
+        o_be32(f, 5), o_be32(f, (uint32_t)S.Np);
+        for (int k = 0; k < 7; ++k) o_be32(f, 0);
+        for (int64_t p = 0; p < S.Np; ++p) {
+            for (int d = 0; d < 4; ++d) {
+                float v = d < 3 ? (float)S.X[p](d) : 1.0f;
+                uint32_t u;
+                std::memcpy(&u, &v, 4);
+                o_be32(f, u);
+            }
+        }
+        fputc(0x00, f), fputc(0xff, f);
+    });
+    fclose(f);
+    return 0;
+}
+int hoto_write_restart(hoto_ctx* c, const char* path)
+{
+    FILE* f = fopen(path, "wb");
+    if (!f) return HOT_ERR_INVALID;
+    DISPATCH(c, {
+        const int64_t n = S.Np;
+        o_put<int32_t>(f, (int32_t)n), o_put<uint64_t>(f, 9);
+        o_array<T>(f, "m", n, 1, [&](int64_t p, int) { return S.mass[p]; });
+        o_array<T>(f, "P", n, 3, [&](int64_t p, int k) { return S.X[p](k); });
+        o_array<T>(f, "V", n, 3, [&](int64_t p, int k) { return S.Vel[p](k); });
+        o_array<T>(f, "C", n, 9, [&](int64_t p, int k) { return S.C[p].a[k]; });
+        o_array<T>(f, "F", n, 9, [&](int64_t p, int k) { return S.F[p].a[k]; });
+        o_array<T>(f, "element measure", n, 1, [&](int64_t p, int) { return S.vol[p]; });
+        o_array<T>(f, "mu", n, 1, [&](int64_t p, int) { return S.mu[p]; });
+        o_array<T>(f, "lambda", n, 1, [&](int64_t p, int) { return S.lambda[p]; });
+        o_array<T>(f, "Jp", n, 1, [&](int64_t p, int) { return S.Jp[p]; });
+    });
+    fclose(f);
+    return 0;
+}
+int hoto_read_restart(hoto_ctx* c, const char* path)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return HOT_ERR_INVALID;
+    int rc = 0;
+    DISPATCH(c, {
+        int32_t n = 0;
+        uint64_t narr = 0;
+        if (fread(&n, 4, 1, f) != 1 || fread(&narr, 8, 1, f) != 1 || n <= 0 || narr > 64) rc = HOT_ERR_INVALID;
+        std::map<std::string, std::vector<T>> col;
+        for (uint64_t a = 0; a < narr && rc == 0; ++a) {
+            uint64_t len = 0, nr = 0, rb = 0, cnt = 0, bytes = 0;
+            int32_t lg = 0;
+            if (fread(&len, 8, 1, f) != 1 || len > 255) { rc = HOT_ERR_INVALID; break; }
+            std::string name(len, ' ');
+            if (fread(&name[0], 1, len, f) != len || fread(&lg, 4, 1, f) != 1 || fread(&nr, 8, 1, f) != 1 || fread(&rb, 8, 1, f) != 1) { rc = HOT_ERR_INVALID; break; }
+            fseek(f, (long)(nr * rb), SEEK_CUR);
+            if (fread(&cnt, 8, 1, f) != 1 || fread(&bytes, 8, 1, f) != 1 || (int64_t)cnt != n || bytes % sizeof(T)) { rc = HOT_ERR_INVALID; break; }
+            auto& v = col[name];
+            v.resize(cnt * (bytes / sizeof(T)));
+            if (fread(v.data(), sizeof(T), v.size(), f) != v.size()) rc = HOT_ERR_INVALID;
+        }
+        if (rc == 0 && col.size() == 9)
+            S.set_particles(n, col["P"].data(), col["V"].data(), col["m"].data(), col["C"].data(), col["F"].data(), col["element measure"].data(), col["mu"].data(), col["lambda"].data(), col["Jp"].data());
+        else
+            rc = HOT_ERR_INVALID;
+    });
+    fclose(f);
+    return rc;
 }
 int hoto_set_comm(hoto_ctx* c, const hot_comm* comm)
 {

@@ -1,0 +1,73 @@
+"""Frame output (hot_write_partio / hot_write_restart / hot_read_restart) checked with an independent numpy reader of the two
+containers: Houdini .bgeo v5 (what Partio::write emits for writePartio's position-only particle set, PartioIO.h:142-180) and the
+DataManager::writeData layout (DataManager.h:263-294, DataArray.h:100-105, BinaryIO.h:82-88)."""
+import struct
+
+import numpy as np
+
+
+def read_bgeo_positions(path):
+    b = open(path, "rb").read()
+    magic, vchar, version, npoints = struct.unpack(">I c I I", b[:13])
+    assert magic == 0x4267656F and vchar == b"V" and version == 5
+    rest = struct.unpack(">7I", b[13:41])
+    assert rest == (0,) * 7  # no primitives, groups or attributes besides the position
+    body = np.frombuffer(b[41:41 + 16 * npoints], dtype=">f4").reshape(npoints, 4)
+    assert b[41 + 16 * npoints:] == b"\x00\xff"
+    assert np.all(body[:, 3] == 1.0)
+    return body[:, :3].astype(np.float32)
+
+
+def read_datamanager(path, T):
+    b = open(path, "rb").read()
+    off = 0
+
+    def take(fmt):
+        nonlocal off
+        v = struct.unpack_from("<" + fmt, b, off)
+        off += struct.calcsize("<" + fmt)
+        return v if len(v) > 1 else v[0]
+    count, narr = take("i"), take("Q")
+    out = {}
+    for _ in range(narr):
+        ln = take("Q")
+        name = b[off:off + ln].decode()
+        off += ln
+        lg = take("i")
+        nr, rb = take("Q"), take("Q")
+        ranges = [take("ii") for _ in range(nr)]
+        assert lg == 7 and rb == 8 and ranges == [(0, count)]
+        cnt, nbytes = take("Q"), take("Q")
+        comps = nbytes // np.dtype(T).itemsize
+        out[name] = np.frombuffer(b, dtype=T, count=cnt * comps, offset=off).reshape(cnt, comps).copy()
+        off += cnt * nbytes
+    assert off == len(b)
+    return count, out
+
+
+def check_io(lib, dtype, tmp_path):
+    from hot_amd import synth
+    T = np.float64 if dtype == 1 else np.float32
+    c = synth.cube_cloud(5, ppc=8, dtype=T)
+    rng = np.random.default_rng(3)
+    Cm, F = rng.standard_normal((len(c["X"]), 9)).astype(T), (np.eye(3).reshape(1, 9) + 0.1 * rng.standard_normal((len(c["X"]), 9))).astype(T)
+    ctx = lib.context(dtype=dtype, dx=c["dx"])
+    ctx.set_particles(c["X"], c["V"], c["mass"], c["vol"], c["mu"], c["lam"], C_=Cm, F=F)
+    ctx.sort()  # the library keeps the particles in sorted order internally: output must undo that
+    pb, pr = str(tmp_path / "partio_0.bgeo"), str(tmp_path / "restart_0.dat")
+    ctx.write_partio(pb), ctx.write_restart(pr)
+    assert np.array_equal(read_bgeo_positions(pb), c["X"].astype(np.float32))
+    count, cols = read_datamanager(pr, T)
+    assert count == len(c["X"]) and set(cols) == {"m", "P", "V", "C", "F", "element measure", "mu", "lambda", "Jp"}
+    for name, ref in (("P", c["X"]), ("V", c["V"]), ("C", Cm), ("F", F)):
+        assert np.array_equal(cols[name], ref), name
+    for name, ref in (("m", c["mass"]), ("element measure", c["vol"]), ("mu", c["mu"]), ("lambda", c["lam"])):
+        assert np.array_equal(cols[name][:, 0], ref), name
+    assert np.all(cols["Jp"] == 1)
+    # restart: a fresh context continues from the file exactly like the writer does
+    ctx2 = lib.context(dtype=dtype, dx=c["dx"])
+    ctx2.read_restart(pr)
+    a, b = ctx.get_particles(), ctx2.get_particles()
+    for k in ("X", "V", "C", "F", "mu", "lam", "Jp"):
+        assert np.array_equal(a[k], b[k]), k
+    return open(pb, "rb").read(), open(pr, "rb").read()

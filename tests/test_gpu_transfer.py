@@ -89,3 +89,14 @@ def test_plasticity_in_g2p(hotlib, oracle, kind, dtype):
     for k in ("F", "mu", "lam", "Jp"):
         scale = np.abs(out["cpu"][k]).max()
         assert np.abs(out["gpu"][k] - out["cpu"][k]).max() <= tol * scale, k
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_frame_output_containers(hotlib, oracle, dtype, tmp_path):
+    """hot_write_partio / hot_write_restart / hot_read_restart: parsed with an independent numpy reader, and byte-identical to what
+    the oracle's own writer emits for the same particles."""
+    from tests import io_checks
+    (tmp_path / "g").mkdir(), (tmp_path / "c").mkdir()
+    g = io_checks.check_io(hotlib, dtype, tmp_path / "g")
+    c = io_checks.check_io(oracle, dtype, tmp_path / "c")
+    assert g[0] == c[0] and g[1] == c[1]

@@ -141,3 +141,9 @@ def test_level_sets_against_closed_forms(oracle):
         want = phi(o, x) <= 0
         edge = np.abs(phi(o, x)) < 1e-12  # nodes exactly on the surface may fall either way
         assert want.sum() > 10 and np.array_equal(hit | edge, want | edge), (o["shape"], hit.sum(), want.sum())
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_frame_output_containers(oracle, dtype, tmp_path):
+    from tests import io_checks
+    io_checks.check_io(oracle, dtype, tmp_path)
