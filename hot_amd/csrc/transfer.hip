@@ -195,6 +195,109 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
     for (int t = tid; t < NQ * TILE; t += P2G_THREADS) out[t] = (T)(&acc[0][0])[t];
 }
 
+// Second production P2G: the same (cell segment, node column, half) work items as k_p2g_cells, but only the 16 (17 with the
+// CN quantity) per-particle scalars x, m, m v, m C are staged — the nine 1-D weights are recomputed per item from x (a few
+// multiply-adds against nine LDS reads) and the base cell comes from the segment's first particle.  35 KB instead of 56 KB per
+// 256-particle chunk: four 256-thread workgroups per CU instead of two 512-thread ones, i.e. twice as many independent
+// header -> staging -> items chains in flight per CU.
+template <class T, bool WITH_CN>
+__global__ __launch_bounds__(256) void k_p2g_cells2(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C,
+    const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
+    const int32_t* __restrict__ group_cell0, const int32_t* __restrict__ cell_first, T* __restrict__ part, T dx, T one_over_dx)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
+    constexpr int NQ = WITH_CN ? 5 : 4, NS = 16 + (WITH_CN ? 1 : 0), THREADS = 256, CH = sizeof(T) == 4 ? 512 : 256;
+    using AT = AccT<T>;
+    __shared__ AT acc[NQ][TILE];
+    __shared__ T sp[NS][CH]; // x(3) m(1) m*v(3) m*C(9) [cn]
+    __shared__ int32_t segs[G::EPB + 2];
+    __shared__ int32_t nseg;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    for (int t = tid; t < NQ * TILE; t += THREADS) (&acc[0][0])[t] = (AT)0;
+    const int first = group_first[g], last = group_first[g + 1];
+    const int c0 = group_cell0[g], c1 = group_cell0[g + 1];
+    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
+    for (int ch = first; ch < last; ch += CH) {
+        if (tid == 0) nseg = 0;
+        __syncthreads();
+        for (int l = tid; l < CH && ch + l < last; l += THREADS) {
+            const int p = ch + l;
+            const T m = M[p];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) sp[d][l] = X[(int64_t)d * Np + p], sp[4 + d][l] = m * V[(int64_t)d * Np + p];
+            sp[3][l] = m;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sp[7 + c][l] = m * C[(int64_t)c * Np + p];
+            if (WITH_CN) {
+                const T mu = Mu[p], la = Lam[p];
+                sp[NS - 1][l] = m * hsqrt((T)3 * ((T)2 * mu + la) * ((T)2 * mu + la) + (T)6 * la * la + (T)12 * mu * mu);
+            }
+        }
+        for (int c = c0 + tid; c < c1; c += THREADS) {
+            const int s0 = max(cell_first[c], ch), s1 = min(cell_first[c + 1], min(ch + CH, last));
+            if (s1 > s0) segs[atomicAdd(&nseg, 1)] = (s0 - ch) | ((s1 - ch) << 16);
+        }
+        __syncthreads();
+        const int ni = nseg * 18;
+        for (int it = tid; it < ni; it += THREADS) {
+            const int sd = segs[it / 18], jk = (it % 18) >> 1, hf = it & 1, s0 = sd & 0xffff, s1 = sd >> 16;
+            const int mid = (s0 + s1 + 1) >> 1, l0 = hf ? mid : s0, l1 = hf ? s1 : mid;
+            if (l0 >= l1) continue;
+            const int j = jk / 3, k = jk - 3 * j;
+            T a[3][NQ];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) a[i][q] = (T)0;
+            // the base cell is the same for every particle of the segment
+            const int b0 = base_node<T>(one_over_dx * sp[0][l0]), b1 = base_node<T>(one_over_dx * sp[1][l0]), b2 = base_node<T>(one_over_dx * sp[2][l0]);
+            const T fb0 = (T)b0, fb1 = (T)b1, fb2 = (T)b2;
+            for (int l = l0; l < l1; ++l) {
+                const T x0 = sp[0][l], x1 = sp[1][l], x2 = sp[2][l];
+                // 1-D quadratic B-spline weights, the arithmetic of bspline() (BSplines.h:55-81) for the needed components
+                auto w1 = [&](T x, T fb, int q) {
+                    const T d0 = one_over_dx * x - fb;
+                    if (q == 0) {
+                        const T z = (T)1.5 - d0;
+                        return (T)0.5 * z * z;
+                    }
+                    const T d1 = d0 - (T)1;
+                    if (q == 1) return (T)0.75 - d1 * d1;
+                    const T zz = (T)1.5 - ((T)1 - d1);
+                    return (T)0.5 * zz * zz;
+                };
+                const T wjk = w1(x1, fb1, j) * w1(x2, fb2, k);
+                const T d1 = (T)(b1 + j) * dx - x1, d2 = (T)(b2 + k) * dx - x2;
+                const T m = sp[3][l];
+                const T t0 = sp[10][l] * d1 + sp[13][l] * d2 + sp[4][l], t1 = sp[11][l] * d1 + sp[14][l] * d2 + sp[5][l], t2 = sp[12][l] * d1 + sp[15][l] * d2 + sp[6][l];
+                const T c0_ = sp[7][l], c1_ = sp[8][l], c2_ = sp[9][l];
+                T cn = (T)0;
+                if (WITH_CN) cn = sp[NS - 1][l];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const T wijk = w1(x0, fb0, i) * wjk;
+                    const T d0 = (T)(b0 + i) * dx - x0;
+                    a[i][0] += m * wijk;
+                    a[i][1] += (c0_ * d0 + t0) * wijk;
+                    a[i][2] += (c1_ * d0 + t1) * wijk;
+                    a[i][3] += (c2_ * d0 + t2) * wijk;
+                    if (WITH_CN) a[i][NQ - 1] += cn * wijk;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int t = ((b0 - ox + i) * TY + (b1 - oy + j)) * TZ + (b2 - oz + k);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) lds_atomic_add(&acc[q][t], (AT)a[i][q]);
+            }
+        }
+    }
+    __syncthreads();
+    T* out = part + (int64_t)g * NQ * TILE;
+    for (int t = tid; t < NQ * TILE; t += THREADS) out[t] = (T)(&acc[0][0])[t];
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void k_block_count(const T* __restrict__ gM, int32_t* block_count, int nb)
 {
@@ -268,10 +371,16 @@ void Ctx<T>::p2g()
     }
     else
 #endif
-    if (cfg.useCN)
-        HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, true>), Ng, P2G_THREADS, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
+    if (ab_flag("HOT_P2G_CELLS1")) { // A/B build only: the 25-scalar staging version
+        if (cfg.useCN)
+            HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, true>), Ng, P2G_THREADS, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
+        else
+            HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, false>), Ng, P2G_THREADS, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
+    }
+    else if (cfg.useCN)
+        HOT_LAUNCH(this, "p2g", (k_p2g_cells2<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
     else
-        HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, false>), Ng, P2G_THREADS, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
+        HOT_LAUNCH(this, "p2g", (k_p2g_cells2<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
     reduce_tiles(nq, gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p, "p2g_reduce");
     if (sharded()) { // the shards' partial node sums -> the body's (one all-reduce of nq values per node slot)
         DBuf<T>& st = ap; // scratch, otherwise used only while the hierarchy is built
