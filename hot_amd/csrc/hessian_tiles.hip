@@ -350,6 +350,26 @@ __device__ __forceinline__ int wave_scan_incl(int x)
     return x;
 }
 
+// ---- MFMA 16x16x4 (one A and one B scalar per lane, 4 results per lane): D[i][j] += sum_k A[i][k] B[k][j] with A in lane
+// i + 16 k, B in lane j + 16 k.  Result rows of a lane: f64 (v_mfma_f64_16x16x4_f64) row = (lane >> 4) + 4 reg, f32
+// (v_mfma_f32_16x16x4_f32) row = 4 (lane >> 4) + reg; column = lane & 15 for both.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+template <class T>
+struct Mfma16;
+template <>
+struct Mfma16<double> {
+    using Acc = v4f64;
+    __device__ static __forceinline__ Acc mac(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <>
+struct Mfma16<float> {
+    using Acc = v4f32;
+    __device__ static __forceinline__ Acc mac(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
 template <class T>
 struct TileLds2 {
     static constexpr int CH = sizeof(T) == 8 ? 40 : 64; // particles per chunk
@@ -358,7 +378,7 @@ struct TileLds2 {
     static constexpr size_t bytes = (size_t)8 * 1125 * sizeof(AccT<T>) + ((size_t)CH * (81 + 81 + 12) + (size_t)KMAX * 27) * sizeof(T) + (size_t)NINT * sizeof(int32_t);
 };
 
-template <class T>
+template <class T, bool USE_MFMA>
 __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ dp, int64_t Np, const uint64_t* __restrict__ blocks,
     const int32_t* __restrict__ gIdx, const int32_t* __restrict__ cell_first, HashMap cmap, const T* __restrict__ mass, T* __restrict__ val, T one_over_dx, int ntiles,
     const uint8_t* __restrict__ own /*sharded: rows this rank owns (they get the inertia term here), else null*/, uint8_t* __restrict__ written /*sharded: rows this launch wrote*/)
@@ -524,40 +544,100 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
             for (int q = 0; q < 3; ++q) sk[e * 3 + q] = D[a * 9 + 3 * q] * g0 + D[(a + 3) * 9 + 3 * q] * g1 + D[(a + 6) * 9 + 3 * q] * g2;
         }
         __syncthreads();
-        // ---- pair phase
-        const int ni = ctl[0] * 27;
-        for (int it = tid; it < ni; it += HT_THREADS) {
-            const int e = items[it / 27], rem = it % 27, jg = rem / 3, a = rem % 3, s = e >> 3, r = e & 7;
-            const int sd = segs[s], cell = sd & 255, l0 = (sd >> 8) & 255, l1 = sd >> 16, mask = cmask[cell];
-            const int nrows = __popc(mask), rowpos = __popc(mask & ((1 << r) - 1));
-            const int ax = (r >> 2) - ((cell >> 4) - 2), ay = ((r >> 1) & 1) - (((cell >> 2) & 3) - 2), az = (r & 1) - ((cell & 3) - 2);
-            const int jx = jg / 3, jy = jg % 3;
-            T acc[3][3]; // [column z][b]
-#pragma unroll
-            for (int z = 0; z < 3; ++z)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) acc[z][q] = (T)0;
-            const T* Kp = sk + (sbase[s] + rowpos) * 27 + a * 3;
-            const T* gp = sg + (l0 * 27 + jg * 3) * 3;
-#pragma unroll 2
-            for (int l = l0; l < l1; ++l, Kp += nrows * 27, gp += 81) {
-                T g[9]; // g_j[q] of the columns j = (jx, jy, z): g[3 z + q]
-#pragma unroll
-                for (int q = 0; q < 9; ++q) g[q] = gp[q];
-#pragma unroll
-                for (int bb = 0; bb < 3; ++bb)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const T k = Kp[bb * 9 + q];
-#pragma unroll
-                        for (int z = 0; z < 3; ++z) acc[z][bb] += k * g[3 * z + q];
+        // ---- pair phase on the matrix cores (A/B build only — measured SLOWER than the scalar version below on MI355X: C2 fp64
+        // 19.9 vs 14.4 ms, C3 fp32 64 vs 37 ms.  The chip's FP64 matrix rate equals its FP64 vector rate (78.6 TFLOP/s), and with
+        // M = 3 x rows (10 on average) padded to 16 and N = 27 padded to 32 half of every MFMA is padding; what is left is index
+        // arithmetic, predicated LDS reads and the same LDS atomics.  Kept as the documented experiment.)  For one cell segment, the blocks of its active tile rows against the 27 column nodes are
+        //   Out[(row, a)][j] (for each b) = sum over the segment's particles p and q of K_p[row][a][b][q] g_p[j][q]
+        // i.e. for every b a small GEMM with M = 3 x rows (<= 24), N = 27, contraction length 3 x particles: units of 16 x 16 x 4
+        // MFMAs (f64: v_mfma_f64_16x16x4_f64), (segment, M tile, b, N tile) dealt round-robin over the 16 waves.  A = K from `sk`,
+        // B = g from `sg`, both straight from LDS, one scalar per lane and MFMA; the 4 results per lane go to the LDS tile with
+        // the same atomics as before.  (The scalar version — 27 multiply-adds per block and particle on 27 lanes per item — kept
+        // only ~370 of the 1024 lanes busy and was bound by their dependent LDS-read / FMA chains: 86 k of a tile's 205 k clocks.)
+        if (USE_MFMA) {
+            const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+            int g0 = 0;
+            for (int s = 0; s < nseg; ++s) {
+                const int sd = segs[s], cell = sd & 255, l0 = (sd >> 8) & 255, l1 = sd >> 16, mask = cmask[cell];
+                const int nrows = __popc(mask), np = l1 - l0, m3 = nrows * 3;
+                const int cntu = ((m3 + 15) >> 4) * 6;
+                for (int sub = ((w - g0) % 16 + 16) % 16; sub < cntu; sub += 16) {
+                    const int mt = sub / 6, rem = sub - mt * 6, bb = rem >> 1, nt = rem & 1;
+                    const int mA = li + 16 * mt, rpA = mA / 3, aA = mA - rpA * 3;
+                    const bool va = mA < m3;
+                    const T* Ap = sk + (sbase[s] + (va ? rpA : 0)) * 27 + (aA + 3 * bb) * 3;
+                    const int jB = li + 16 * nt;
+                    const bool vb = jB < 27;
+                    const T* Bp = sg + (l0 * 27 + (vb ? jB : 0)) * 3;
+                    typename Mfma16<T>::Acc acc = { 0, 0, 0, 0 };
+                    int pp = lk == 3 ? 1 : 0, qq = lk == 3 ? 0 : lk; // k index 4 t + lk = 3 pp + qq
+                    const int ksteps = (3 * np + 3) >> 2;
+                    for (int t = 0; t < ksteps; ++t) {
+                        const bool vk = pp < np;
+                        const T av = (va && vk) ? Ap[pp * nrows * 27 + qq] : (T)0;
+                        const T bv = (vb && vk) ? Bp[pp * 81 + qq] : (T)0;
+                        acc = Mfma16<T>::mac(av, bv, acc);
+                        pp += 1, qq += 1; // k += 4
+                        if (qq >= 3) qq -= 3, pp += 1;
                     }
+                    if (vb) {
+                        const int jx = jB / 9, jy = (jB / 3) % 3, jz = jB % 3;
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int m = Mfma16<T>::row(lane, reg) + 16 * mt;
+                            if (m < m3) {
+                                const int rp = m / 3, a = m - rp * 3;
+                                int r = 0, seen = 0; // the rp-th active row of the cell
+                                for (int bit = 0; bit < 8; ++bit)
+                                    if ((mask >> bit) & 1) {
+                                        if (seen == rp) r = bit;
+                                        ++seen;
+                                    }
+                                const int ax = (r >> 2) - ((cell >> 4) - 2), ay = ((r >> 1) & 1) - (((cell >> 2) & 3) - 2), az = (r & 1) - ((cell & 3) - 2);
+                                lds_atomic_add(tile + r * 1125 + ((ax - jx + 2) * 25 + (ay - jy + 2) * 5 + (az - jz + 2)) * 9 + a + 3 * bb, (AT)acc[reg]);
+                            }
+                        }
+                    }
+                }
+                g0 += cntu;
             }
-            AT* o = tile + r * 1125 + ((ax - jx + 2) * 25 + (ay - jy + 2) * 5 + (az + 2)) * 9 + a;
-#pragma unroll
-            for (int z = 0; z < 3; ++z)
-#pragma unroll
-                for (int bb = 0; bb < 3; ++bb) lds_atomic_add(o - z * 9 + 3 * bb, (AT)acc[z][bb]);
+        }
+        else {
+            // ---- pair phase (production: scalar multiply-adds)
+            const int ni = ctl[0] * 27;
+            for (int it = tid; it < ni; it += HT_THREADS) {
+                const int e = items[it / 27], rem = it % 27, jg = rem / 3, a = rem % 3, s = e >> 3, r = e & 7;
+                const int sd = segs[s], cell = sd & 255, l0 = (sd >> 8) & 255, l1 = sd >> 16, mask = cmask[cell];
+                const int nrows = __popc(mask), rowpos = __popc(mask & ((1 << r) - 1));
+                const int ax = (r >> 2) - ((cell >> 4) - 2), ay = ((r >> 1) & 1) - (((cell >> 2) & 3) - 2), az = (r & 1) - ((cell & 3) - 2);
+                const int jx = jg / 3, jy = jg % 3;
+                T acc[3][3]; // [column z][b]
+    #pragma unroll
+                for (int z = 0; z < 3; ++z)
+    #pragma unroll
+                    for (int q = 0; q < 3; ++q) acc[z][q] = (T)0;
+                const T* Kp = sk + (sbase[s] + rowpos) * 27 + a * 3;
+                const T* gp = sg + (l0 * 27 + jg * 3) * 3;
+    #pragma unroll 2
+                for (int l = l0; l < l1; ++l, Kp += nrows * 27, gp += 81) {
+                    T g[9]; // g_j[q] of the columns j = (jx, jy, z): g[3 z + q]
+    #pragma unroll
+                    for (int q = 0; q < 9; ++q) g[q] = gp[q];
+    #pragma unroll
+                    for (int bb = 0; bb < 3; ++bb)
+    #pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            const T k = Kp[bb * 9 + q];
+    #pragma unroll
+                            for (int z = 0; z < 3; ++z) acc[z][bb] += k * g[3 * z + q];
+                        }
+                }
+                AT* o = tile + r * 1125 + ((ax - jx + 2) * 25 + (ay - jy + 2) * 5 + (az + 2)) * 9 + a;
+    #pragma unroll
+                for (int z = 0; z < 3; ++z)
+    #pragma unroll
+                    for (int bb = 0; bb < 3; ++bb) lds_atomic_add(o - z * 9 + 3 * bb, (AT)acc[z][bb]);
+            }
         }
         __syncthreads();
     }
@@ -581,7 +661,10 @@ void Ctx<T>::assemble_tiles(Level<T>& L)
 #ifdef HOT_AB_KERNELS
         HOT_HIP(hipFuncSetAttribute((const void*)k_hessian_tiles<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileLds<T>::bytes));
 #endif
-        HOT_HIP(hipFuncSetAttribute((const void*)k_hessian_tiles2<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileLds2<T>::bytes));
+        HOT_HIP(hipFuncSetAttribute((const void*)k_hessian_tiles2<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileLds2<T>::bytes));
+#ifdef HOT_AB_KERNELS
+        HOT_HIP(hipFuncSetAttribute((const void*)k_hessian_tiles2<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileLds2<T>::bytes));
+#endif
         attr_tiles_set = true;
     }
     constexpr int TPB = (G::BX / 2) * (G::BY / 2) * (G::BZ / 2);
@@ -595,7 +678,14 @@ void Ctx<T>::assemble_tiles(Level<T>& L)
         written.reserve(Nn);
         HOT_HIP(hipMemsetAsync(written.p, 0, Nn, stream));
     }
-    HOT_LAUNCH(this, "hessian_assemble", k_hessian_tiles2<T>, 256 * div_up(Nb * TPB, 256), HT_THREADS, TileLds2<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx, Nb * TPB,
+#ifdef HOT_AB_KERNELS
+    if (ab_flag("HOT_HESSIAN_MFMA")) {
+        HOT_LAUNCH(this, "hessian_assemble", (k_hessian_tiles2<T, true>), 256 * div_up(Nb * TPB, 256), HT_THREADS, TileLds2<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx, Nb * TPB,
+            L.mask(), L.part ? written.p : (uint8_t*)nullptr);
+        return;
+    }
+#endif
+    HOT_LAUNCH(this, "hessian_assemble", (k_hessian_tiles2<T, false>), 256 * div_up(Nb * TPB, 256), HT_THREADS, TileLds2<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx, Nb * TPB,
         L.mask(), L.part ? written.p : (uint8_t*)nullptr);
 }
 
