@@ -68,9 +68,13 @@ class TorchComm:
         """(tensor to communicate on, write-back function).  nccl communicates on the library's own device memory; gloo needs
         host tensors, so device payloads are staged through a host copy."""
         if nbytes == 0:
-            return self.torch.empty(0, dtype=self.torch.uint8), (lambda: None)
+            return self.torch.empty(0, dtype=self.torch.uint8, device=self.device if self.backend == "nccl" else "cpu"), (lambda: None)
         if not on_device:
-            return self._host(ptr, nbytes), (lambda: None)
+            h = self._host(ptr, nbytes)
+            if self.backend != "nccl" or self.device is None:
+                return h, (lambda: None)
+            d = h.to(self.device)  # RCCL communicates device memory only: small host payloads (scalars, counts) take a round trip
+            return d, (lambda: h.copy_(d))
         d = self._dev(ptr, nbytes)
         if self.backend == "nccl":
             return d, (lambda: None)

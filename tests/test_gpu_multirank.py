@@ -42,3 +42,46 @@ def test_whole_steps_over_two_ranks_hip(hotlib):
     ref = mw.single(hotlib, 8, 1, kw, steps=2)
     assert abs(ranks[0]["iterations"][0] - ref["iterations"][0]) <= 1 and abs(ranks[0]["iterations"][1] - ref["iterations"][1]) <= 2, (ranks[0]["iterations"], ref["iterations"])
     mw.compare(ranks, ref, 1e-7, tolp=1e-6, exact_counts=False)
+
+
+_RCCL_SCRIPT = r'''
+import os, sys, ctypes as C
+sys.path.insert(0, os.getcwd())
+import torch, torch.distributed as dist
+from hot_amd import dist as hdist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+comm = hdist.TorchComm(device=torch.device("cuda", 0))
+assert comm.backend == "nccl" and comm.size == 1
+# device payloads: the collectives run on the library's own memory (here: torch tensors standing in for it)
+a = torch.arange(1000, dtype=torch.float64, device="cuda")
+assert comm._allreduce(None, a.data_ptr(), 1000, 1, 0, 1) == 0 and torch.equal(a, torch.arange(1000, dtype=torch.float64, device="cuda"))
+f = torch.full((7,), 3.5, dtype=torch.float32, device="cuda")
+assert comm._allreduce(None, f.data_ptr(), 7, 0, 1, 1) == 0 and float(f.sum()) == 24.5
+s = torch.arange(256, dtype=torch.uint8, device="cuda")
+r = torch.zeros(256, dtype=torch.uint8, device="cuda")
+assert comm._allgather(None, s.data_ptr(), r.data_ptr(), 256, 1) == 0 and torch.equal(r, s)
+# host payloads (scalars, counts) under RCCL take a device round trip
+h = (C.c_double * 3)(1.0, 2.0, 3.0)
+assert comm._allreduce(None, C.addressof(h), 3, 1, 0, 0) == 0 and list(h) == [1.0, 2.0, 3.0]
+cnt = (C.c_int64 * 1)(42)
+out = (C.c_int64 * 1)(0)
+assert comm._allgather(None, C.addressof(cnt), C.addressof(out), 8, 0) == 0 and out[0] == 42
+z = (C.c_int64 * 1)(0)
+assert comm._alltoallv(None, s.data_ptr(), z, z, r.data_ptr(), z, z, 1) == 0  # nothing to exchange with oneself
+dist.destroy_process_group()
+print("rccl callbacks ok", comm.calls)
+'''
+
+
+def test_torchcomm_collectives_over_rccl_one_rank():
+    """The RCCL side of hot_amd/dist.TorchComm (backend "nccl": device tensors wrapped around raw pointers, all_gather_into_tensor,
+    host scalars staged through the device) on the one GPU this box has: a one-rank group exercises every call the multi-GPU
+    run makes except the peer-to-peer transfers themselves."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], cwd=mw.ROOT, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "rccl callbacks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
