@@ -74,7 +74,16 @@ def make_ctx(lib, cloud, cfg, device=0, profile=0, comm=None, **over):
     kw.update(synth.plasticity_kwargs(cfg))
     kw.update(over)
     ctx = lib.context(**kw)
-    if comm is not None:
+    if isinstance(comm, str):  # "rccl": the library's native communicator on the context's own stream (hot_amd/csrc/rccl_comm.hip)
+        from hot_amd import dist as hdist
+        try:
+            hdist.attach_rccl(ctx)
+        except Exception as e:  # RCCL not loadable / not attachable: torch.distributed collectives instead
+            import torch
+            print("bench: native RCCL communicator unavailable (%r), using TorchComm" % (e,), file=sys.stderr)
+            ctx._fallback_comm = hdist.TorchComm(device=torch.device("cuda", device))
+            ctx.set_comm(ctx._fallback_comm)
+    elif comm is not None:
         ctx.set_comm(comm)  # this rank's shard of ONE body (hot_amd/dist.py)
     ctx.set_particles(cloud["X"], cloud["V"], cloud["mass"], cloud["vol"], cloud["mu"], cloud["lam"])
     o, n = synth.sticky_floor(cloud["corner"][1], cloud["dx"])
@@ -118,6 +127,8 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=0, help="cube edge of the CPU baseline's sample; 0 = the benchmark configuration itself")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo with --share-gpu on a one-GPU box)")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N > 1: native stream-ordered RCCL communicator of the library (falls back to torch if RCCL "
+                    "cannot be attached) or hot_amd.dist.TorchComm (torch.distributed collectives, host-synchronous)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on device 0 (functional check of the N > 1 path on a one-GPU box, not a measurement)")
     return ap.parse_args()
 
@@ -159,7 +170,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.backend)
-        comm = hdist.TorchComm(device=torch.device("cuda", local))
+        comm = hdist.TorchComm(device=torch.device("cuda", local)) if (args.comm == "torch" or args.backend != "nccl") else "rccl"
 
     def barrier():
         if dist is not None:
@@ -297,7 +308,8 @@ def main():
             "hessian_mg_build_ms_per_step": build_ms / max(args.steps, 1),
             "ms_per_iter_build_amortised": solve_ms / max(iters, 1),
             "p2g_g2p_mparticles_per_s": transfers["mparticles_per_s"] if transfers else None,
-            "comm_calls_per_step": ({k: v / max(args.steps + args.warmup, 1) for k, v in comm.calls.items()} if comm is not None else None),
+            "communicator": (None if comm is None else ("native RCCL on the context's stream" if isinstance(comm, str) and not hasattr(ctx, "_fallback_comm") else f"torch.distributed ({args.backend})")),
+            "comm_calls_per_step": ({k: v / max(args.steps + args.warmup, 1) for k, v in comm.calls.items()} if (comm is not None and not isinstance(comm, str)) else None),
             "roofline": roof, "transfers": transfers, "cpu_baseline": cpu, "kernel_ms_per_step_top": prof_top,
         }
         print(json.dumps(out))

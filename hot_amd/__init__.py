@@ -5,7 +5,7 @@ is only its Python host-side mirror (ctypes).  There is NO CPU fallback: `load()
 extension has not been built, and hot_create() fails on a box without a GPU."""
 import os
 
-from .binding import Context, HotError, HotLib, hot_config, hot_stats, ABI_SYMBOLS  # noqa: F401
+from .binding import Context, HotError, HotLib, hot_config, hot_stats, ABI_SYMBOLS, PRODUCT_ONLY_SYMBOLS  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libhotmi355x.so")

@@ -58,8 +58,12 @@ ABI_SYMBOLS = [
     "get_counts", "get_indexing", "p2g", "get_grid", "set_bc", "set_sticky_halfspaces", "set_collision_objects", "begin_step", "get_dv",
     "set_dv", "update_state", "get_particle_state", "residual", "project", "cn_tolerance", "build_hessian",
     "matfree_multiply", "build_mg", "get_level", "get_matrix", "get_level_nnzb", "get_prolongation", "spmv", "restrict", "prolong",
-    "smooth", "vcycle", "solve", "g2p", "line_search", "should_exit", "recover_solution", "transform_residual", "compute_step", "write_partio", "write_restart", "read_restart", "set_comm", "constitutive_eval", "plasticity_eval", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
+    "smooth", "vcycle", "solve", "g2p", "line_search", "should_exit", "recover_solution", "transform_residual", "compute_step", "write_partio", "write_restart", "read_restart", "get_stream", "set_comm", "constitutive_eval", "plasticity_eval", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
 ]
+
+
+# declared by the header for the HIP product only (device-runtime services a host-memory implementation of the ABI has no use for)
+PRODUCT_ONLY_SYMBOLS = ["rccl_unique_id", "rccl_attach", "rccl_selftest"]
 
 
 class HotError(RuntimeError):
@@ -127,6 +131,7 @@ class HotLib:
             "write_partio": (C.c_int, [vp, C.c_char_p]),
             "write_restart": (C.c_int, [vp, C.c_char_p]),
             "read_restart": (C.c_int, [vp, C.c_char_p]),
+            "get_stream": (C.c_int, [vp, P(vp)]),
             "set_comm": (C.c_int, [vp, vp]),
             "constitutive_eval": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp, vp]),
             "plasticity_eval": (C.c_int, [vp, i32, i32, vp, vp, vp, vp]),
@@ -451,6 +456,31 @@ class Context:
     def read_restart(self, path):
         self._call("read_restart", str(path).encode())
         self.Np = self.counts()["Np"]
+
+    def rccl_unique_id(self):
+        """128-byte ncclUniqueId (rank 0 creates it, every rank passes it to rccl_attach).  HIP library only."""
+        buf = C.create_string_buffer(128)
+        f = getattr(self.lib.lib, self.lib.prefix + "rccl_unique_id")
+        f.restype, f.argtypes = C.c_int, [C.c_void_p]
+        rc = f(buf)
+        if rc != 0:
+            raise HotError(f"rccl_unique_id -> {rc} (RCCL not available)")
+        return buf.raw
+
+    def rccl_attach(self, unique_id, rank, size, partition_min_rows=0):
+        f = getattr(self.lib.lib, self.lib.prefix + "rccl_attach")
+        f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32]
+        rc = f(self.h, unique_id, rank, size, partition_min_rows)
+        if rc != 0:
+            msg = self.lib.fn["last_error"](self.h)
+            raise HotError(f"rccl_attach -> {rc}: {msg.decode() if msg else ''}")
+
+    def rccl_selftest(self):
+        f = getattr(self.lib.lib, self.lib.prefix + "rccl_selftest")
+        f.restype, f.argtypes = C.c_int, [C.c_void_p]
+        rc = f(self.h)
+        if rc != 0:
+            raise HotError(f"rccl_selftest -> {rc}")
 
     def set_comm(self, comm):
         """Install a hot_amd.dist.TorchComm (one connected body over several ranks) or remove it (None).  Before set_particles."""

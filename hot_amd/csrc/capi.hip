@@ -340,6 +340,12 @@ int hot_read_restart(hot_ctx* ctx, const char* path)
     ctx->impl->read_restart(path);
     HOT_API_END
 }
+int hot_get_stream(hot_ctx* ctx, void** hip_stream)
+{
+    HOT_API_BEGIN
+    if (hip_stream) *hip_stream = (void*)ctx->impl->stream;
+    HOT_API_END
+}
 int hot_set_comm(hot_ctx* ctx, const hot_comm* comm)
 {
     HOT_API_BEGIN

@@ -63,12 +63,17 @@ struct Profiler {
 };
 
 struct CtxBase {
+    void* native_comm = nullptr; // owned communicator state of hot_rccl_attach, released with the context
+    void (*native_comm_free)(void*) = nullptr;
     hot_config cfg;
     std::string err;
     hipStream_t stream = nullptr;
     Profiler prof;
     hot_stats stats;
-    virtual ~CtxBase() {}
+    virtual ~CtxBase()
+    {
+        if (native_comm && native_comm_free) native_comm_free(native_comm);
+    }
     virtual void set_particles(int64_t Np, const void* X, const void* V, const void* mass, const void* C, const void* F, const void* vol, const void* mu, const void* lambda, const void* Jp) = 0;
     virtual void get_particles(void* X, void* V, void* C, void* F, void* mu, void* lambda, void* Jp) = 0;
     virtual void sort() = 0;

@@ -30,21 +30,21 @@ template <class T>
 void Ctx<T>::c_allreduce(void* buf, int64_t n, int dtype, int op, bool on_device)
 {
     if (!sharded() || n <= 0) return;
-    if (on_device) HOT_HIP(hipStreamSynchronize(stream));
+    if (on_device && !comm.stream_ordered) HOT_HIP(hipStreamSynchronize(stream));
     prof.count(on_device ? "comm_allreduce" : "comm_allreduce_scalars");
     HOT_CHECK(comm.allreduce(comm.user, buf, n, dtype, op, on_device ? 1 : 0) == 0, HOT_ERR_DEVICE, "hot_comm.allreduce failed");
 }
 template <class T>
 void Ctx<T>::c_allgather(const void* send, void* recv, int64_t bytes, bool on_device)
 {
-    if (on_device) HOT_HIP(hipStreamSynchronize(stream));
+    if (on_device && !comm.stream_ordered) HOT_HIP(hipStreamSynchronize(stream));
     prof.count("comm_allgather");
     HOT_CHECK(comm.allgather(comm.user, send, recv, bytes, on_device ? 1 : 0) == 0, HOT_ERR_DEVICE, "hot_comm.allgather failed");
 }
 template <class T>
 void Ctx<T>::c_alltoallv(const void* send, const int64_t* soff, const int64_t* sbytes, void* recv, const int64_t* roff, const int64_t* rbytes)
 {
-    HOT_HIP(hipStreamSynchronize(stream));
+    if (!comm.stream_ordered) HOT_HIP(hipStreamSynchronize(stream));
     prof.count("comm_alltoallv");
     HOT_CHECK(comm.alltoallv(comm.user, send, soff, sbytes, recv, roff, rbytes, 1) == 0, HOT_ERR_DEVICE, "hot_comm.alltoallv failed");
 }

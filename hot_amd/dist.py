@@ -32,7 +32,7 @@ _ALLTOALLV = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)
 
 class hot_comm(C.Structure):  # include/hot_mi355x.h
     _fields_ = [("rank", C.c_int32), ("size", C.c_int32), ("user", C.c_void_p), ("allreduce", _ALLREDUCE), ("allgather", _ALLGATHER), ("alltoallv", _ALLTOALLV),
-                ("partition_min_rows", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("partition_min_rows", C.c_int32), ("stream_ordered", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class _DevMem:
@@ -55,7 +55,7 @@ class TorchComm:
         self.calls = dict(allreduce=0, allgather=0, alltoallv=0, bytes=0)
         self._hip = None
         self._cb = (_ALLREDUCE(self._allreduce), _ALLGATHER(self._allgather), _ALLTOALLV(self._alltoallv))
-        self.struct = hot_comm(self.rank, self.size, None, self._cb[0], self._cb[1], self._cb[2], int(partition_min_rows), (C.c_int32 * 3)(0, 0, 0))
+        self.struct = hot_comm(self.rank, self.size, None, self._cb[0], self._cb[1], self._cb[2], int(partition_min_rows), 0, (C.c_int32 * 2)(0, 0))
 
     # ---- raw memory <-> tensors
     def _host(self, ptr, nbytes):
@@ -141,6 +141,16 @@ class TorchComm:
         except Exception as e:
             print("hot_comm.alltoallv failed:", repr(e), flush=True)
             return 1
+
+
+def attach_rccl(ctx, group=None, partition_min_rows=0):
+    """Native, stream-ordered RCCL communicator for a HIP-library context (hot_amd/csrc/rccl_comm.hip): rank 0 creates the
+    ncclUniqueId, torch.distributed only carries its 128 bytes to the other ranks.  Raises HotError if RCCL is unavailable."""
+    import torch.distributed as dist
+    rank, size = dist.get_rank(group), dist.get_world_size(group)
+    box = [ctx.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    ctx.rccl_attach(box[0], rank, size, partition_min_rows)
 
 
 def attach(ctx, comm):

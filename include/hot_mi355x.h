@@ -256,12 +256,21 @@ typedef struct hot_comm {
     int32_t (*alltoallv)(void* user, const void* send, const int64_t* send_off, const int64_t* send_bytes, void* recv, const int64_t* recv_off, const int64_t* recv_bytes,
         int32_t on_device);
     int32_t partition_min_rows; /* coarse levels with fewer rows are replicated instead of partitioned; 0 = default (32768) */
-    int32_t reserved[3];
+    int32_t stream_ordered; /* 1: the callbacks enqueue device-payload collectives on the context's own HIP stream (hot_get_stream) and
+                               return without waiting, so the library does not synchronise its stream around them; 0: host-synchronous */
+    int32_t reserved[2];
 } hot_comm;
 /* Install (size > 1) or remove (NULL or size == 1) the communicator; call before hot_set_particles.  The shard given to
  * hot_set_particles must be a contiguous range of the global particle list in sort-key order of their SPGrid pages
  * (hot_amd/dist.py: shard_by_page_order does this split) for node numbering identical to the single-rank run. */
 int hot_set_comm(hot_ctx*, const hot_comm* comm);
+int hot_get_stream(hot_ctx*, void** hip_stream); /* the context's hipStream_t, for stream-ordered communicators */
+/* Native RCCL communicator (hot_amd/csrc/rccl_comm.hip): ncclAllReduce / ncclAllGather / grouped ncclSend + ncclRecv on the
+ * context's stream, stream-ordered.  Rank 0 calls hot_rccl_unique_id, the host hands the 128 bytes to every rank, each rank
+ * calls hot_rccl_attach before hot_set_particles.  Both fail with HOT_ERR_DEVICE when RCCL cannot be loaded. */
+int hot_rccl_unique_id(void* out128);
+int hot_rccl_attach(hot_ctx*, const void* unique_id128, int32_t rank, int32_t size, int32_t partition_min_rows);
+int hot_rccl_selftest(hot_ctx*); /* runs every collective of the attached communicator once on known data (any number of ranks) */
 
 /* ---- the constitutive model and the plastic return mappings for caller-supplied deformation gradients (arrays of `real`,
  *      3x3 column-major, per-sample mu / lambda): CorotatedIsotropic<T,3>::updateScratch + psi + firstPiola +

@@ -550,6 +550,11 @@ int hoto_read_restart(hoto_ctx* c, const char* path)
     fclose(f);
     return rc;
 }
+int hoto_get_stream(hoto_ctx*, void** s)
+{
+    if (s) *s = nullptr; // host code: no stream
+    return 0;
+}
 int hoto_set_comm(hoto_ctx* c, const hot_comm* comm)
 {
     DISPATCH(c, {

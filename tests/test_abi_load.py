@@ -13,7 +13,7 @@ def test_header_symbols_exported():
     hdr = open(os.path.join(ROOT, "include", "hot_mi355x.h")).read()
     declared = set(re.findall(r"\b(hot_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"hot_ctx"}
-    assert {"hot_" + s for s in hot_amd.ABI_SYMBOLS} == declared
+    assert {"hot_" + s for s in hot_amd.ABI_SYMBOLS + hot_amd.PRODUCT_ONLY_SYMBOLS} == declared
     if not os.path.exists(hot_amd.LIB_PATH):
         hot_amd.build()
     lib = hot_amd.load()

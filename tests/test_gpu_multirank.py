@@ -85,3 +85,41 @@ def test_torchcomm_collectives_over_rccl_one_rank():
     r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], cwd=mw.ROOT, capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0 and "rccl callbacks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+_NATIVE_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch, torch.distributed as dist
+import hot_amd
+from hot_amd import dist as hdist, synth
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+lib = hot_amd.load()
+c = synth.cube_cloud(6, ppc=8)
+ctx = lib.context(dtype=1, dx=c["dx"], levelCnt=2, gravity=(0, -9.8, 0))
+hdist.attach_rccl(ctx)                      # ncclGetUniqueId, ncclCommInitRank on the context's device, callbacks installed
+ctx.set_particles(c["X"], c["V"], c["mass"], c["vol"], c["mu"], c["lam"])
+o, n = synth.sticky_floor(5.0, c["dx"]); ctx.set_sticky_halfspaces(o, n)
+st = ctx.advance(1.0 / 24)                  # one rank: the communicator is installed but the solve is the single-rank one
+ref = lib.context(dtype=1, dx=c["dx"], levelCnt=2, gravity=(0, -9.8, 0))
+ref.set_particles(c["X"], c["V"], c["mass"], c["vol"], c["mu"], c["lam"]); ref.set_sticky_halfspaces(o, n)
+st2 = ref.advance(1.0 / 24)
+assert st["iterations"] == st2["iterations"] and st["converged"] == 1
+ctx.rccl_selftest()                         # every collective callback once, device and host payloads, on the context's stream
+print("native rccl ok", st["iterations"])
+dist.destroy_process_group()
+'''
+
+
+def test_native_rccl_communicator_attaches_on_one_rank():
+    """hot_rccl_unique_id / hot_rccl_attach (hot_amd/csrc/rccl_comm.hip): RCCL is found, a communicator is created on the context's
+    device and installed; with one rank the solve is the single-rank one.  (The collectives' multi-rank semantics are what the
+    gloo-driven tests above verify through the same hot_comm call sites.)"""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _NATIVE_SCRIPT], cwd=mw.ROOT, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "native rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
