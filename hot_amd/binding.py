@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "get_counts", "get_indexing", "p2g", "get_grid", "set_bc", "set_sticky_halfspaces", "set_collision_objects", "begin_step", "get_dv",
     "set_dv", "update_state", "get_particle_state", "residual", "project", "cn_tolerance", "build_hessian",
     "matfree_multiply", "build_mg", "get_level", "get_matrix", "get_level_nnzb", "get_prolongation", "spmv", "restrict", "prolong",
-    "smooth", "vcycle", "solve", "g2p", "line_search", "should_exit", "recover_solution", "transform_residual", "compute_step", "write_partio", "write_restart", "read_restart", "get_stream", "set_comm", "constitutive_eval", "plasticity_eval", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
+    "smooth", "vcycle", "solve", "g2p", "line_search", "should_exit", "recover_solution", "transform_residual", "compute_step", "write_partio", "write_restart", "read_restart", "set_particle_ids", "get_particle_ids", "get_stream", "set_comm", "constitutive_eval", "plasticity_eval", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
 ]
 
 
@@ -131,6 +131,8 @@ class HotLib:
             "write_partio": (C.c_int, [vp, C.c_char_p]),
             "write_restart": (C.c_int, [vp, C.c_char_p]),
             "read_restart": (C.c_int, [vp, C.c_char_p]),
+            "set_particle_ids": (C.c_int, [vp, vp]),
+            "get_particle_ids": (C.c_int, [vp, vp]),
             "get_stream": (C.c_int, [vp, P(vp)]),
             "set_comm": (C.c_int, [vp, vp]),
             "constitutive_eval": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp, vp]),
@@ -222,7 +224,20 @@ class Context:
         self._keep = arrs
         self._call("set_particles", C.c_int64(self.Np), *[_ptr(a) for a in arrs])
 
+    def set_particle_ids(self, ids):
+        """Global particle ids of a sharded run (tie break of the sort key, identity of a migrating particle)."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        assert ids.shape[0] == self.Np
+        self._call("set_particle_ids", _ptr(ids))
+
+    def particle_ids(self):
+        self.Np = self.counts()["Np"]
+        ids = np.empty(self.Np, np.int32)
+        self._call("get_particle_ids", _ptr(ids))
+        return ids
+
     def get_particles(self):
+        self.Np = self.counts()["Np"]  # a sharded context's particle set changes as particles migrate between ranks
         n, T = self.Np, self.T
         out = dict(X=np.empty((n, 3), T), V=np.empty((n, 3), T), C=np.empty((n, 9), T), F=np.empty((n, 9), T),
                    mu=np.empty(n, T), lam=np.empty(n, T), Jp=np.empty(n, T))

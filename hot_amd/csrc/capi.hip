@@ -340,6 +340,18 @@ int hot_read_restart(hot_ctx* ctx, const char* path)
     ctx->impl->read_restart(path);
     HOT_API_END
 }
+int hot_set_particle_ids(hot_ctx* ctx, const int32_t* ids)
+{
+    HOT_API_BEGIN
+    ctx->impl->set_particle_ids(ids);
+    HOT_API_END
+}
+int hot_get_particle_ids(hot_ctx* ctx, int32_t* ids)
+{
+    HOT_API_BEGIN
+    ctx->impl->get_particle_ids(ids);
+    HOT_API_END
+}
 int hot_get_stream(hot_ctx* ctx, void** hip_stream)
 {
     HOT_API_BEGIN

@@ -107,6 +107,8 @@ struct CtxBase {
     virtual void solve(hot_stats* st) = 0;
     virtual void g2p(double dt, int32_t* flags) = 0;
     virtual void set_comm(const hot_comm* c) = 0;
+    virtual void set_particle_ids(const int32_t* ids) = 0;
+    virtual void get_particle_ids(int32_t* ids) = 0;
     virtual void write_partio(const char* path) = 0;
     virtual void write_restart(const char* path) = 0;
     virtual void read_restart(const char* path) = 0;

@@ -69,6 +69,11 @@ struct Ctx : CtxBase {
     int64_t Np = 0;
     DBuf<T> pX, pV, pM, pC, pF, pVol, pMu, pLam, pJp, pFn, pFt, pStress, pGradV;
     DBuf<int32_t> slot2orig;
+    DBuf<int32_t> pGid; // global particle id (sort-key tie break of a sharded run, travels with a migrating particle)
+    void reserve_particles(int64_t n);
+    void migrate_particles(); // sharded: hand every particle to the rank of its SPGrid page range (shard.hip)
+    void set_particle_ids(const int32_t* ids) override;
+    void get_particle_ids(int32_t* ids) override;
     DBuf<T> spare1, spare3, spare9;
     DBuf<int32_t> sparei;
     bool keep_debug = true; // store stress/gradV for hot_get_particle_state

@@ -10,6 +10,8 @@
 // The library itself never communicates: the three collectives of hot_comm are callbacks (RCCL through torch.distributed in
 // hot_amd/dist.py).  They are called with device pointers after the context's stream has been synchronised.
 #include "hot_impl.h"
+#include <algorithm>
+#include <rocprim/rocprim.hpp>
 
 namespace hot {
 
@@ -327,6 +329,185 @@ void Ctx<T>::exchange_rows(Level<T>& L, const uint8_t* touched)
         if (rcnt[s] > 0)
             HOT_LAUNCH(this, "rows_add", k_rows_add<T>, div_up((size_t)rcnt[s] * 1125, 256), 256, 0, L.val.p, recvrows.p + roff[s], rcnt[s], (const T*)xrecv.p + roff[s] * 1125);
     sync(); // the local buffers go out of scope
+}
+
+// ------------------------------------------------------------------------------------------------ particle migration
+__global__ void k_idkeys(const int32_t* __restrict__ gid, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int64_t n)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) keys[p] = (uint64_t)(uint32_t)gid[p], vals[p] = (uint32_t)p;
+}
+// SPGrid page id of every particle (the high part of the sort key, MpmSimulationBase.cpp:1080-1085)
+template <class T>
+__global__ void k_page_ids(const T* __restrict__ X, uint64_t* __restrict__ page, int64_t n, T one_over_dx)
+{
+    using G = Geo<T>;
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int b0 = base_node<T>(X[p] * one_over_dx), b1 = base_node<T>(X[n + p] * one_over_dx), b2 = base_node<T>(X[2 * n + p] * one_over_dx);
+    page[p] = G::linear_offset(b0, b1, b2) >> 12;
+}
+__global__ void k_page_sample(const uint64_t* __restrict__ page, int64_t n, uint64_t* __restrict__ out, int S)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S) out[i] = page[(int64_t)(((__int128)i * n) / S)];
+}
+struct Splitters {
+    uint64_t v[63]; // rank r holds the pages [v[r-1], v[r]) ; v[-1] = 0, v[size-1] = inf
+    int n;
+};
+__global__ void k_dest_flags(const uint64_t* __restrict__ page, int64_t n, Splitters sp, int q, int32_t* __restrict__ flags)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int d = 0;
+    while (d < sp.n && page[p] >= sp.v[d]) ++d;
+    flags[p] = d == q ? 1 : 0;
+}
+// particle-major records of `comps` scalars: out[k * comps + c] = a[c * n + list[k]]
+template <class U>
+__global__ void k_pack_attr(const U* __restrict__ a, int64_t n, int comps, const int32_t* __restrict__ list, int64_t cnt, U* __restrict__ out, int stride, int off)
+{
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= cnt * comps) return;
+    const int64_t k = e / comps;
+    const int c = (int)(e - k * comps);
+    out[k * stride + off + c] = a[(int64_t)c * n + list[k]];
+}
+// new SoA array: [0, kept) gathered from the old one through `keep`, [kept, nnew) from the received records
+template <class U>
+__global__ void k_build_attr(const U* __restrict__ old, int64_t nold, int comps, const int32_t* __restrict__ keep, int64_t kept, const U* __restrict__ recv, int stride, int off, U* __restrict__ out, int64_t nnew)
+{
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnew * comps) return;
+    const int c = (int)(e / nnew);
+    const int64_t p = e - (int64_t)c * nnew;
+    out[e] = p < kept ? old[(int64_t)c * nold + keep[p]] : recv[(p - kept) * stride + off + c];
+}
+__global__ void k_rank_of(const uint32_t* __restrict__ sorted_slot, int32_t* __restrict__ slot2orig, int64_t n)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) slot2orig[sorted_slot[k]] = (int32_t)k; // hot_get_particles order = ascending global id
+}
+
+// Every hot_sort of a sharded context first re-shards the particles: rank r gets the r-th of `size` nearly equal runs of
+// the SPGrid page order (splitters = quantiles of a strided sample of all ranks' page ids, whole pages only), so a shard stays
+// spatially compact however the body moves, the ranks' group lists stay contiguous ranges of the global sort, and the rows a
+// rank's particles touch stay (mostly) the rows it owns.  Particles travel as records of their 29 scalars + their global id.
+template <class T>
+void Ctx<T>::migrate_particles()
+{
+    const int R = comm.size, me = comm.rank;
+    constexpr int S = 1024, NC = 29;
+    const int64_t n = Np;
+    keys.reserve(std::max<int64_t>(n, S)), flags.reserve(std::max<size_t>(n, 64)), scan.reserve(std::max<size_t>(n, 64));
+    uint64_t* page = keys.p;
+    HOT_LAUNCH(this, "migrate_page_ids", k_page_ids<T>, div_up(n, 256), 256, 0, pX.p, page, n, (T)1 / dx);
+    // ---- splitters from a strided sample of every rank's pages
+    xsend.reserve((size_t)S * 8), xrecv.reserve((size_t)S * 8 * R);
+    HOT_LAUNCH(this, "migrate_sample", k_page_sample, div_up(S, 256), 256, 0, page, n, (uint64_t*)xsend.p, S);
+    c_allgather(xsend.p, xrecv.p, (int64_t)S * 8, true);
+    std::vector<uint64_t> samp((size_t)S * R);
+    HOT_HIP(hipMemcpyAsync(samp.data(), xrecv.p, samp.size() * 8, hipMemcpyDeviceToHost, stream));
+    sync();
+    std::sort(samp.begin(), samp.end());
+    Splitters sp{};
+    sp.n = R - 1;
+    for (int r = 1; r < R; ++r) sp.v[r - 1] = samp[(size_t)r * samp.size() / R];
+    // ---- who goes where: one compacted list per destination (ascending slot order), the kept particles included
+    DBuf<int32_t> lists;
+    lists.reserve(n);
+    std::vector<int64_t> cnt(R, 0), off(R, 0);
+    int64_t o = 0;
+    for (int q = 0; q < R; ++q) {
+        off[q] = o;
+        HOT_LAUNCH(this, "migrate_flags", k_dest_flags, div_up(n, 256), 256, 0, page, n, sp, q, flags.p);
+        const int c = exclusive_scan_i32(flags.p, scan.p, n);
+        if (c > 0) HOT_LAUNCH(this, "rows_compact", k_rows_compact, div_up(n, 256), 256, 0, flags.p, scan.p, lists.p + o, (int)n);
+        cnt[q] = c, o += c;
+    }
+    std::vector<int64_t> all((size_t)R * R, 0);
+    c_allgather(cnt.data(), all.data(), (int64_t)R * sizeof(int64_t), false);
+    int64_t moving = 0, incoming = 0;
+    for (int a = 0; a < R; ++a)
+        for (int b = 0; b < R; ++b)
+            if (a != b) moving += all[(size_t)a * R + b];
+    if (moving == 0) return; // nobody changes rank this step
+    const int64_t kept = cnt[me];
+    std::vector<int64_t> scnt(cnt), soff(off), rcnt(R, 0), roff(R, 0);
+    scnt[me] = 0;
+    for (int src = 0; src < R; ++src) {
+        roff[src] = incoming;
+        if (src != me) rcnt[src] = all[(size_t)src * R + me], incoming += rcnt[src];
+    }
+    const int64_t nnew = kept + incoming, nout = n - kept;
+    HOT_CHECK(nnew > 0, HOT_ERR_INVALID, "particle migration left this rank without particles");
+    constexpr int index_bits = 32 - G::block_bits;
+    HOT_CHECK(nnew < (1LL << index_bits), HOT_ERR_CAPACITY, "particle count of this rank exceeds 2^(32-block_bits) after migration");
+    // ---- outgoing records: [NC scalars] per particle in list order (the kept run of the list is skipped by the offsets), ids apart
+    DBuf<T> sendT, recvT;
+    DBuf<int32_t> sendI, recvI;
+    sendT.reserve((size_t)std::max<int64_t>(n, 1) * NC), recvT.reserve((size_t)std::max<int64_t>(incoming, 1) * NC);
+    sendI.reserve(std::max<int64_t>(n, 1)), recvI.reserve(std::max<int64_t>(incoming, 1));
+    struct Attr {
+        DBuf<T>* a;
+        int comps;
+    } attrs[9] = { { &pX, 3 }, { &pV, 3 }, { &pM, 1 }, { &pVol, 1 }, { &pMu, 1 }, { &pLam, 1 }, { &pJp, 1 }, { &pC, 9 }, { &pF, 9 } };
+    {
+        int col = 0;
+        for (auto& at : attrs) {
+            HOT_LAUNCH(this, "migrate_pack", k_pack_attr<T>, div_up((size_t)n * at.comps, 256), 256, 0, at.a->p, n, at.comps, lists.p, n, sendT.p, NC, col);
+            col += at.comps;
+        }
+        HOT_LAUNCH(this, "migrate_pack", k_pack_attr<int32_t>, div_up(n, 256), 256, 0, pGid.p, n, 1, lists.p, n, sendI.p, 1, 0);
+    }
+    auto scaled = [&](const std::vector<int64_t>& v, int64_t f) {
+        std::vector<int64_t> r(v);
+        for (auto& x : r) x *= f;
+        return r;
+    };
+    {
+        auto so = scaled(soff, NC * (int64_t)sizeof(T)), sb = scaled(scnt, NC * (int64_t)sizeof(T)), ro = scaled(roff, NC * (int64_t)sizeof(T)), rb = scaled(rcnt, NC * (int64_t)sizeof(T));
+        c_alltoallv(sendT.p, so.data(), sb.data(), recvT.p, ro.data(), rb.data());
+        auto so4 = scaled(soff, 4), sb4 = scaled(scnt, 4), ro4 = scaled(roff, 4), rb4 = scaled(rcnt, 4);
+        c_alltoallv(sendI.p, so4.data(), sb4.data(), recvI.p, ro4.data(), rb4.data());
+    }
+    (void)nout;
+    // ---- the new particle set: kept particles (in their old order) followed by the arrivals (by source rank)
+    const int32_t* keep = lists.p + off[me];
+    {
+        std::vector<DBuf<T>> fresh(9);
+        int col = 0, k = 0;
+        for (auto& at : attrs) {
+            fresh[k].reserve((size_t)nnew * at.comps, 1.25);
+            HOT_LAUNCH(this, "migrate_build", k_build_attr<T>, div_up((size_t)nnew * at.comps, 256), 256, 0, at.a->p, n, at.comps, keep, kept, recvT.p, NC, col, fresh[k].p, nnew);
+            col += at.comps, ++k;
+        }
+        DBuf<int32_t> gid;
+        gid.reserve(nnew, 1.25);
+        HOT_LAUNCH(this, "migrate_build", k_build_attr<int32_t>, div_up(nnew, 256), 256, 0, pGid.p, n, 1, keep, kept, recvI.p, 1, 0, gid.p, nnew);
+        sync();
+        k = 0;
+        for (auto& at : attrs) std::swap(at.a->p, fresh[k].p), std::swap(at.a->cap, fresh[k].cap), ++k;
+        std::swap(pGid.p, gid.p), std::swap(pGid.cap, gid.cap);
+    }
+    Np = nnew;
+    reserve_particles(nnew); // the scratch / derived per-particle buffers (the nine attribute arrays above are large enough already)
+    // ---- hot_get_particles order: ascending global id
+    keys.reserve(nnew), keys2.reserve(nnew), vals.reserve(nnew), vals2.reserve(nnew);
+    {
+        // keys = id (as 64-bit), vals = slot
+        HOT_LAUNCH(this, "migrate_idkeys", k_idkeys, div_up(nnew, 256), 256, 0, pGid.p, keys.p, vals.p, nnew);
+        size_t bytes = 0;
+        HOT_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)nnew, 0, 32, stream));
+        if (bytes > sort_tmp_bytes) {
+            sort_tmp.reserve(bytes);
+            sort_tmp_bytes = sort_tmp.cap;
+        }
+        HOT_HIP(rocprim::radix_sort_pairs(sort_tmp.p, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)nnew, 0, 32, stream));
+        HOT_LAUNCH(this, "migrate_rank_of", k_rank_of, div_up(nnew, 256), 256, 0, vals2.p, slot2orig.p, nnew);
+    }
+    sync();
 }
 
 template struct Ctx<float>;

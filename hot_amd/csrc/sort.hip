@@ -271,9 +271,7 @@ void Ctx<T>::set_particles(int64_t n, const void* X, const void* V, const void* 
     HOT_CHECK(n > 0 && n < (1LL << index_bits), HOT_ERR_CAPACITY, "particle count must be in (0, 2^(32-block_bits)) (MpmSimulationBase.cpp:1071-1072)");
     need(X && V && m && vol && mu && lam, "X, V, mass, vol, mu, lambda are required");
     Np = n;
-    pX.reserve(3 * n), pV.reserve(3 * n), pM.reserve(n), pC.reserve(9 * n), pF.reserve(9 * n), pVol.reserve(n), pMu.reserve(n), pLam.reserve(n), pJp.reserve(n);
-    pFn.reserve(9 * n), pFt.reserve(9 * n), pStress.reserve(9 * n), pGradV.reserve(9 * n);
-    spare1.reserve(n), spare3.reserve(3 * n), spare9.reserve(9 * n), sparei.reserve(n), slot2orig.reserve(n);
+    reserve_particles(n);
     auto put = [&](DBuf<T>& dst, const void* src, int comps) {
         if (comps == 1) {
             HOT_HIP(hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyDefault, stream));
@@ -296,7 +294,35 @@ void Ctx<T>::set_particles(int64_t n, const void* X, const void* V, const void* 
     else
         HOT_LAUNCH(this, "fill", k_fill<T>, div_up(n, 256), 256, 0, pJp.p, n, (T)1);
     HOT_LAUNCH(this, "iota", k_iota, div_up(n, 256), 256, 0, slot2orig.p, n);
+    HOT_LAUNCH(this, "iota", k_iota, div_up(n, 256), 256, 0, pGid.p, n); // global particle ids: the caller's order unless hot_set_particle_ids says otherwise
     Ng = Nb = Nn = 0;
+    sync();
+}
+
+// every per-particle buffer for n particles (contents are not preserved on growth)
+template <class T>
+void Ctx<T>::reserve_particles(int64_t n)
+{
+    const double slack = sharded() ? 1.25 : 1.0; // shards grow and shrink as particles migrate
+    pX.reserve(3 * n, slack), pV.reserve(3 * n, slack), pM.reserve(n, slack), pC.reserve(9 * n, slack), pF.reserve(9 * n, slack), pVol.reserve(n, slack), pMu.reserve(n, slack), pLam.reserve(n, slack),
+        pJp.reserve(n, slack);
+    pFn.reserve(9 * n, slack), pFt.reserve(9 * n, slack), pStress.reserve(9 * n, slack), pGradV.reserve(9 * n, slack);
+    spare1.reserve(n, slack), spare3.reserve(3 * n, slack), spare9.reserve(9 * n, slack), sparei.reserve(n, slack), slot2orig.reserve(n, slack), pGid.reserve(n, slack);
+}
+template <class T>
+void Ctx<T>::set_particle_ids(const int32_t* ids)
+{
+    need(Np > 0 && ids, "hot_set_particle_ids after hot_set_particles");
+    HOT_HIP(hipMemcpyAsync(pGid.p, ids, (size_t)Np * sizeof(int32_t), hipMemcpyDefault, stream));
+    sync();
+}
+// ids of the particles in the order hot_get_particles returns them
+template <class T>
+void Ctx<T>::get_particle_ids(int32_t* ids)
+{
+    need(Np > 0 && ids, "no particles");
+    HOT_LAUNCH(this, "soa_to_aos", k_soa_to_aos<int32_t>, div_up(Np, 256), 256, 0, pGid.p, sparei.p, slot2orig.p, Np, 1);
+    HOT_HIP(hipMemcpyAsync(ids, sparei.p, (size_t)Np * sizeof(int32_t), hipMemcpyDefault, stream));
     sync();
 }
 
@@ -318,11 +344,14 @@ template <class T>
 void Ctx<T>::sort()
 {
     need(Np > 0, "hot_sort: no particles");
-    int64_t n = Np;
     double t0 = wall_ms();
+    if (sharded()) migrate_particles(); // every particle to the rank that holds its SPGrid page range (changes Np)
+    int64_t n = Np;
     keys.reserve(n), keys2.reserve(n), vals.reserve(n), vals2.reserve(n), flags.reserve(std::max<size_t>(n, 64)), scan.reserve(std::max<size_t>(n, 64));
     T one_over_dx = (T)1 / dx;
-    HOT_LAUNCH(this, "make_keys", k_make_keys<T>, div_up(n, 256), 256, 0, pX.p, slot2orig.p, keys.p, vals.p, n, one_over_dx);
+    // tie-break inside a cell: the caller's particle index — in a sharded run the global particle id, so that the order inside
+    // a cell is the single-rank one whatever the shard looks like
+    HOT_LAUNCH(this, "make_keys", k_make_keys<T>, div_up(n, 256), 256, 0, pX.p, sharded() ? pGid.p : slot2orig.p, keys.p, vals.p, n, one_over_dx);
     size_t bytes = 0;
     HOT_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)n, 0, 64, stream));
     if (bytes > sort_tmp_bytes) {
@@ -343,6 +372,9 @@ void Ctx<T>::sort()
     HOT_LAUNCH(this, "reorder_gather", k_gather<int32_t>, div_up(n, 256), 256, 0, slot2orig.p, sparei.p, vals2.p, n, 1);
     std::swap(slot2orig.p, sparei.p);
     std::swap(slot2orig.cap, sparei.cap);
+    HOT_LAUNCH(this, "reorder_gather", k_gather<int32_t>, div_up(n, 256), 256, 0, pGid.p, sparei.p, vals2.p, n, 1);
+    std::swap(pGid.p, sparei.p);
+    std::swap(pGid.cap, sparei.cap);
     // groups
     HOT_LAUNCH(this, "group_heads", k_group_heads, div_up(n, 256), 256, 0, keys2.p, flags.p, n);
     Ng = exclusive_scan_i32(flags.p, scan.p, n);

@@ -264,6 +264,13 @@ typedef struct hot_comm {
  * hot_set_particles must be a contiguous range of the global particle list in sort-key order of their SPGrid pages
  * (hot_amd/dist.py: shard_by_page_order does this split) for node numbering identical to the single-rank run. */
 int hot_set_comm(hot_ctx*, const hot_comm* comm);
+/* Global particle ids of a sharded run (default: 0..Np-1 in the order of hot_set_particles; pass the particles' indices in the whole body).
+ * They break ties of the sort key inside a cell (the reference uses the particle index, MpmSimulationBase.cpp:1084) and travel with a particle
+ * when hot_sort hands it to another rank: at every hot_sort of a sharded context the particles are redistributed so that rank r holds
+ * the r-th of `size` nearly equal runs of the SPGrid page order (the shard hot_set_particles was given is only the starting point), so
+ * Np changes (hot_get_counts) and hot_get_particles / hot_get_particle_ids return the rank's current particles in ascending id order. */
+int hot_set_particle_ids(hot_ctx*, const int32_t* ids /*Np*/);
+int hot_get_particle_ids(hot_ctx*, int32_t* ids /*Np*/);
 int hot_get_stream(hot_ctx*, void** hip_stream); /* the context's hipStream_t, for stream-ordered communicators */
 /* Native RCCL communicator (hot_amd/csrc/rccl_comm.hip): ncclAllReduce / ncclAllGather / grouped ncclSend + ncclRecv on the
  * context's stream, stream-ordered.  Rank 0 calls hot_rccl_unique_id, the host hands the 128 bytes to every rank, each rank

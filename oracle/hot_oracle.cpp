@@ -550,6 +550,19 @@ int hoto_read_restart(hoto_ctx* c, const char* path)
     fclose(f);
     return rc;
 }
+// global particle ids: the oracle's shards never exchange particles (its sharded mode sums grid-sized arrays), ids are kept for the caller
+int hoto_set_particle_ids(hoto_ctx* c, const int32_t* ids)
+{
+    DISPATCH(c, { S.particle_ids.assign(ids, ids + S.Np); });
+    return 0;
+}
+int hoto_get_particle_ids(hoto_ctx* c, int32_t* ids)
+{
+    DISPATCH(c, {
+        for (int64_t p = 0; p < S.Np; ++p) ids[p] = S.particle_ids.size() == (size_t)S.Np ? S.particle_ids[p] : (int32_t)p;
+    });
+    return 0;
+}
 int hoto_get_stream(hoto_ctx*, void** s)
 {
     if (s) *s = nullptr; // host code: no stream

@@ -86,6 +86,7 @@ struct Sim {
     {
         if (sharded() && n > 0 && comm.allreduce(comm.user, buf, n, dtype, op, 0) != 0) throw std::runtime_error("hot_comm.allreduce failed");
     }
+    std::vector<int32_t> particle_ids; // hot_set_particle_ids (kept for the caller; this restatement never moves particles between ranks)
     std::vector<int> block_first; // [size+1] first global block first touched by each rank's particle groups
     std::vector<std::vector<int>> level_nstart; // per level [size+1]: rank r's id prefix = nodes first touched by ranks < r
     bool partitioned(int level) const

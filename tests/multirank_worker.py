@@ -23,6 +23,8 @@ def run_case(lib, cloud, comm, cfgkw, steps, dt=1.0 / 24):
     if comm is not None:
         ctx.set_comm(comm)
     ctx.set_particles(cloud["X"], cloud["V"], cloud["mass"], cloud["vol"], cloud["mu"], cloud["lam"])
+    if comm is not None:
+        ctx.set_particle_ids(cloud["index"])  # positions in the whole body: sort-key tie break, identity of a migrating particle
     o, nrm = synth.sticky_floor(5.0, cloud["dx"])
     ctx.set_sticky_halfspaces(o, nrm)
     out = {}
@@ -49,6 +51,7 @@ def run_case(lib, cloud, comm, cfgkw, steps, dt=1.0 / 24):
         out["stats"] = sts[-1]
         out["iterations"] = [s["iterations"] for s in sts]
     out["particles"] = ctx.get_particles()
+    out["ids"] = ctx.particle_ids() if comm is not None else np.arange(len(out["particles"]["X"]), dtype=np.int32)
     return out
 
 
@@ -78,7 +81,6 @@ def worker(rank, world, port, q, libkind, n, dtype, cfgkw, steps, backend, parti
         cloud = scene(n, dtype)
         shard = hdist.shard_by_page_order(cloud, rank, world)
         out = run_case(lib, shard, comm, dict(cfgkw, dtype=dtype), steps)
-        out["index"] = shard["index"]
         out["comm_calls"] = dict(comm.calls)
         q.put((rank, out))
         dist.barrier()
@@ -114,6 +116,12 @@ def launch(world, libkind, n, dtype, cfgkw, steps=0, backend="gloo", partition_m
     return [res[r] for r in range(world)]
 
 
+def hdist_initial(n, dtype, rank, world):
+    """global ids of the shard rank `rank` starts with"""
+    from hot_amd import dist as hdist
+    return hdist.shard_by_page_order(scene(n, dtype), rank, world)["index"]
+
+
 def single(lib, n, dtype, cfgkw, steps=0):
     cloud = scene(n, dtype)
     return run_case(lib, cloud, None, dict(cfgkw, dtype=dtype), steps)
@@ -147,8 +155,10 @@ def compare(ranks, ref, tol, tolp=None, exact_counts=True):
             for k in ("iterations", "vcycles", "linesearch_trials", "linear_iterations", "dropped_pairs", "num_nodes", "num_levels"):
                 assert o["stats"][k] == ref["stats"][k], (k, o["stats"], ref["stats"])
         assert abs(o["stats"]["energy"] - ref["stats"]["energy"]) < tol * 100 * max(abs(ref["stats"]["energy"]), 1e-12)
-    idx = np.concatenate([o["index"] for o in ranks])
+    idx = np.concatenate([o["ids"] for o in ranks])  # the ranks' CURRENT particles (they migrate with the page ranges)
     assert np.array_equal(np.sort(idx), np.arange(len(ref["particles"]["X"])))  # the shards partition the body
+    for o in ranks:
+        assert np.all(np.diff(o["ids"]) > 0)  # returned in ascending id order
     for k in ("X", "V", "F", "C"):
         got = np.concatenate([o["particles"][k] for o in ranks])
         assert rel(got, ref["particles"][k][idx]) < tolp * (1 if k == "X" else 100), (k, rel(got, ref["particles"][k][idx]))

@@ -36,6 +36,21 @@ def test_one_body_over_ranks_hip(hotlib, oracle, world, n, dtype, kw, minrows, t
         assert calls["alltoallv"] > 0  # partial Hessian rows crossed the shard boundary
 
 
+def test_whole_steps_over_ranks_with_migration_hip(hotlib):
+    """Four whole time steps on three ranks: the body falls and spins, particles change SPGrid pages every step and are handed to
+    the rank of their page range at each hot_sort (hot_amd/csrc/shard.hip migrate_particles); the union of the ranks' particles,
+    matched by global id, follows the single-rank trajectory."""
+    kw = dict(lsolver=3, levelCnt=2, cneps=1e-6)
+    ranks = mw.launch(3, "hip", 10, 1, kw, steps=4, partition_min_rows=1)
+    ref = mw.single(hotlib, 10, 1, kw, steps=4)
+    sizes = [len(o["ids"]) for o in ranks]
+    assert max(sizes) - min(sizes) < 0.25 * sum(sizes) / 3, sizes  # re-balanced every step
+    moved = sum(int((np.sort(o["ids"]) != np.sort(mw.hdist_initial(10, 1, r, 3))).any()) if len(o["ids"]) == len(mw.hdist_initial(10, 1, r, 3)) else 1 for r, o in enumerate(ranks))
+    assert moved > 0  # particles really changed rank
+    assert [abs(a - b) <= 2 for a, b in zip(ranks[0]["iterations"], ref["iterations"])] == [True] * 4, (ranks[0]["iterations"], ref["iterations"])
+    mw.compare(ranks, ref, 1e-7, tolp=1e-6, exact_counts=False)
+
+
 def test_whole_steps_over_two_ranks_hip(hotlib):
     kw = dict(lsolver=3, levelCnt=3, cneps=1e-6)
     ranks = mw.launch(2, "hip", 8, 1, kw, steps=2, partition_min_rows=1)
