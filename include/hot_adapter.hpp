@@ -125,6 +125,11 @@ public:
         check(ctx, hot_advance_frame(ctx, frame_dt, min_dt, max_dt > 0 ? max_dt : frame_dt, &n, &its, &stats), "hot_advance_frame");
         return n;
     }
+    // MpmSimulationBase::writeState's particle .bgeo (Lib/MPM/MpmSimulationBase.cpp:186-224) and SimulationBase's restart write / read
+    // (Lib/Ziran/Sim/SimulationBase.h:215-263)
+    void writePartio(const std::string& path) { check(ctx, hot_write_partio(ctx, path.c_str()), "hot_write_partio"); }
+    void writeRestart(const std::string& path) { check(ctx, hot_write_restart(ctx, path.c_str()), "hot_write_restart"); }
+    void readRestart(const std::string& path) { check(ctx, hot_read_restart(ctx, path.c_str()), "hot_read_restart"); }
     bool faster_than_grid_cell = false, faster_than_half_grid_cell = false;
 };
 
