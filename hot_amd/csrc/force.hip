@@ -559,13 +559,12 @@ template <class T>
 double Ctx<T>::state_pass(const T* dv_in, bool want_force)
 {
     HOT_LAUNCH(this, "state_update", k_state<T>, Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, pFt.p, pStress.p, keep_debug ? pGradV.p : (T*)nullptr, Np, group_first.p, group_origin.p,
-        group_nb.p, tileDof.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p, gred(Ng));
+        group_nb.p, tileDof.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p, gred(Ng, hscal)); // the sums land in the pinned host slots too: one stream sync, no copy
     if (want_force) force_pass();
     {
         const int grid = std::min(div_up(Nn, 256), 1024);
-        HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, grid, 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1, gred(grid));
+        HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, grid, 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1, gred(grid, hscal + 1));
     }
-    HOT_HIP(hipMemcpyAsync(hscal, dscal.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
     if (sharded()) c_allreduce(hscal, 1, HOT_COMM_F64, HOT_COMM_SUM, false); // the shards' strain energies; the inertia terms are computed from replicated vectors
     double result = (double)(T)hscal[0];
@@ -678,7 +677,7 @@ void Ctx<T>::residual_dev(T* r)
     int slipmode = (cfg.systemBCProject && cfg.boundaryType == 1) ? 1 : 0;
     HOT_LAUNCH(this, "residual", k_residual<T>, div_up(Nn, 256), 256, 0, gF.p, dofSlot.p, mass.p, dv.p, bcIdx.p, bcP.p, bcR.p, bcSlip.p, r, Nn, (int64_t)Nb * EPB, (T)cfg.gravity[0],
         (T)cfg.gravity[1], (T)cfg.gravity[2], dt, slipmode);
-    HOT_HIP(hipMemcpyAsync(rhs.p, r, 3 * (size_t)Nn * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    copy(3 * (size_t)Nn, r, rhs.p);
 }
 template <class T>
 void Ctx<T>::project_dev(T* v)

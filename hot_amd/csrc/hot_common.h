@@ -217,6 +217,7 @@ __device__ inline T block_sum_256(T v, T* sm4)
 struct GridRed {
     double* part; // >= 2 * gridDim.x
     unsigned* count;
+    double* mirror; // optional: pinned host memory that also receives the result(s), so that the host needs a stream sync but no copy
 };
 __device__ inline void grid_sum_store(double t0, double t1, int nv, GridRed gr, double* o0, double* o1, double* sm4)
 {
@@ -241,6 +242,10 @@ __device__ inline void grid_sum_store(double t0, double t1, int nv, GridRed gr, 
     if (threadIdx.x == 0) {
         *o0 = a;
         if (nv > 1) *o1 = b;
+        if (gr.mirror) {
+            gr.mirror[0] = a;
+            if (nv > 1) gr.mirror[1] = b;
+        }
         __hip_atomic_store(gr.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

@@ -162,14 +162,15 @@ struct Ctx : CtxBase {
     DBuf<T> speed_part; // block maxima of calculate_dt
     DBuf<double> red_part; // grid_sum_store deposits (2 per workgroup)
     DBuf<unsigned> red_count; // its arrival counter (always 0 between launches)
-    GridRed gred(size_t grid)
+    GridRed gred(size_t grid, double* mirror = nullptr) // mirror: a slot of hscal (pinned, device-visible)
     {
         if (2 * grid > red_part.cap) {
             HOT_HIP(hipStreamSynchronize(stream)); // a launch still summing the old deposits must be done before they are freed
             red_part.reserve(2 * grid, 1.5);
         }
-        return GridRed{ red_part.p, red_count.p };
+        return GridRed{ red_part.p, red_count.p, mirror };
     }
+    int cg_group = 2; // iterations the last fused top-level PCG took: size of the first group of launches of the next one
     int gs_epoch = 0; // sweep number, never reused inside a context
     bool attr_tiles_set = false, attr_gs_set = false; // dynamic-LDS limits raised on this context's device (hipFuncSetAttribute is per device)
     DBuf<int> gs_done; // [0,40) pass counters of k_gs_sweep (the sticky wait-timeout flag lives in pinned host memory, hscal[250])
@@ -322,7 +323,7 @@ struct Ctx : CtxBase {
     void axpy_dev(size_t n, const double* a, double sign, const T* x, T* y); // y += sign * (*a) * x, scalar on device
     void copy(size_t n, const T* x, T* y);
     void zero(size_t n, T* y);
-    void dot_to(size_t n, const T* x, const T* y, double* out); // *out = <x,y> (device scalar)
+    void dot_to(size_t n, const T* x, const T* y, double* out, double* mirror = nullptr); // *out = <x,y> (device scalar; mirror: pinned host slot that receives it too)
     double dot_host(size_t n, const T* x, const T* y);
     bool should_exit(const T* r);
     T line_search(T* ddv, T* residual_out, T alpha);

@@ -511,9 +511,8 @@ Ctx<T>* Ctx<T>::build_gmg_grid(int level)
     const int64_t n = Np;
     // particles in this context's sorted order, carrying their original indices (the sort key's tie break, :69-71)
     g->Np = n;
-    g->pX.reserve(3 * n), g->pV.reserve(3 * n), g->pM.reserve(n), g->pC.reserve(9 * n), g->pF.reserve(9 * n), g->pVol.reserve(n), g->pMu.reserve(n), g->pLam.reserve(n), g->pJp.reserve(n);
-    g->pFn.reserve(9 * n), g->pFt.reserve(9 * n), g->pStress.reserve(9 * n), g->pGradV.reserve(9 * n);
-    g->spare1.reserve(n), g->spare3.reserve(3 * n), g->spare9.reserve(9 * n), g->sparei.reserve(n), g->slot2orig.reserve(n);
+    g->reserve_particles(n);
+    HOT_HIP(hipMemsetAsync(g->pGid.p, 0, (size_t)n * sizeof(int32_t), stream)); // ids are carried along by the sort; unused here
     auto give = [&](DBuf<T>& dst, const DBuf<T>& src, int comps) { HOT_HIP(hipMemcpyAsync(dst.p, src.p, (size_t)n * comps * sizeof(T), hipMemcpyDeviceToDevice, stream)); };
     give(g->pX, pX, 3), give(g->pV, pV, 3), give(g->pM, pM, 1), give(g->pC, pC, 9), give(g->pF, pFn, 9), give(g->pVol, pVol, 1), give(g->pMu, pMu, 1), give(g->pLam, pLam, 1), give(g->pJp, pJp, 1);
     HOT_HIP(hipMemcpyAsync(g->slot2orig.p, slot2orig.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));

@@ -61,10 +61,16 @@ void Ctx<T>::axpy_dev(size_t n, const double* a, double sign, const T* x, T* y)
 {
     HOT_LAUNCH(this, "axpy", k_axpy_dev<T>, div_up(n, 256), 256, 0, n, a, sign, x, y);
 }
+// a plain kernel: a device-to-device hipMemcpyAsync between two kernels leaves the GPU idle for ~20 us on either side of the blit
+template <class T>
+__global__ __launch_bounds__(256) void k_copy(size_t n, const T* __restrict__ x, T* __restrict__ y)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = x[i];
+}
 template <class T>
 void Ctx<T>::copy(size_t n, const T* x, T* y)
 {
-    HOT_HIP(hipMemcpyAsync(y, x, n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    if (n) HOT_LAUNCH(this, "copy", k_copy<T>, (int)std::min<size_t>(div_up(n, 256), 2048), 256, 0, n, x, y);
 }
 template <class T>
 void Ctx<T>::zero(size_t n, T* y)
@@ -72,16 +78,15 @@ void Ctx<T>::zero(size_t n, T* y)
     HOT_HIP(hipMemsetAsync(y, 0, n * sizeof(T), stream));
 }
 template <class T>
-void Ctx<T>::dot_to(size_t n, const T* x, const T* y, double* out)
+void Ctx<T>::dot_to(size_t n, const T* x, const T* y, double* out, double* mirror)
 {
     const int grid = std::min(div_up(n, 1024), 256);
-    HOT_LAUNCH(this, "dot", k_dot<T>, grid, 256, 0, n, x, y, out, gred(grid)); // <= 256 deposits, summed in index order
+    HOT_LAUNCH(this, "dot", k_dot<T>, grid, 256, 0, n, x, y, out, gred(grid, mirror)); // <= 256 deposits, summed in index order
 }
 template <class T>
 double Ctx<T>::dot_host(size_t n, const T* x, const T* y)
 {
-    dot_to(n, x, y, dscal.p + 100);
-    HOT_HIP(hipMemcpyAsync(hscal + 100, dscal.p + 100, sizeof(double), hipMemcpyDeviceToHost, stream));
+    dot_to(n, x, y, dscal.p + 100, hscal + 100); // the summing workgroup also writes the pinned host slot: no copy, one stream sync
     sync();
     return hscal[100];
 }
@@ -130,14 +135,27 @@ __global__ __launch_bounds__(256) void k_apmv_sub(const int32_t* __restrict__ ap
     if (lane == 0) r[3 * (int64_t)row] -= s0, r[3 * (int64_t)row + 1] -= s1, r[3 * (int64_t)row + 2] -= s2;
 }
 // ---- cg_smooth (MultigridPreconditioner.h:190-226) in three launches per iteration instead of nine.  Device scalars:
-// s[0] z'r of the current iterate, s[1] du'A du, s[4] z'r of the next one, s[6] "s[4] is to become s[0]".
+// s[0] z'r of the current iterate, s[1] du'A du, s[4] z'r of the next one, s[6] "s[4] is to become s[0]", s[7] z'r of the initial
+// residual, s[8] the tolerance 0.25 s[7] (cgratio 0.5 squared, :203-209), s[9] iterations done.  The loop test `z'r < tol -> stop` is
+// evaluated on the device: an iteration launched after convergence does nothing, so the host can enqueue a group of iterations and
+// look at the outcome once (k_cg_direction leaves the latest z'r and the count in the pinned host slots `hm`).
+__device__ __forceinline__ bool cg_active(double zTr, double tol) { return !(zTr < tol); }
+template <class T>
+__global__ void k_cg_setup(double* s, double* hm)
+{
+    const double tol = (double)(T)(s[7] * 0.25);
+    s[8] = tol;
+    s[1] = s[2] = s[3] = s[4] = s[5] = s[6] = s[9] = 0.0;
+    hm[0] = s[0], hm[1] = 0.0, hm[2] = tol;
+}
 template <class T>
 __global__ __launch_bounds__(256) void k_cg_spmv_dot(const int32_t* __restrict__ col, const T* __restrict__ val, const T* __restrict__ du, T* __restrict__ dAu, int n, double* s, GridRed gr)
 {
     __shared__ double red[4];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { // nobody reads s[0] / s[4] in this launch
-        if (s[6] != 0.0) s[0] = s[4];
-    }
+    const bool roll = s[6] != 0.0;
+    const double cur = roll ? s[4] : s[0]; // s[4] is not written in this launch; s[0] is read only where it is not
+    if (blockIdx.x == 0 && threadIdx.x == 0 && roll) s[0] = s[4]; // also when converged: the two kernels that follow test s[0]
+    if (!cg_active(cur, s[8])) return; // converged before this iteration
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     double part = 0;
@@ -175,6 +193,7 @@ __global__ __launch_bounds__(256) void k_cg_update(const T* __restrict__ Dinv, c
 {
     __shared__ double red[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (!cg_active(s[0], s[8])) return; // s[0] is the current z'r since k_cg_spmv_dot, and nothing writes it here
     const double omega = s[0] / s[1];
     const T wp = (T)omega, wm = (T)(-omega);
     double part = 0;
@@ -196,12 +215,18 @@ __global__ __launch_bounds__(256) void k_cg_update(const T* __restrict__ Dinv, c
 }
 // du = z + b du      (b = s[4] / s[0])
 template <class T>
-__global__ void k_cg_direction(size_t n3, const T* __restrict__ z, T* __restrict__ du, double* s)
+__global__ void k_cg_direction(size_t n3, const T* __restrict__ z, T* __restrict__ du, double* s, double* hm)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!cg_active(s[0], s[8])) return;
     const T b = (T)(s[4] / s[0]);
     if (i < n3) du[i] = z[i] + b * du[i];
-    if (i == 0) s[6] = 1.0; // nobody reads it in this launch
+    if (i == 0) { // nobody reads s[6] / s[9] in this launch
+        s[6] = 1.0;
+        const double cnt = s[9] + 1.0;
+        s[9] = cnt;
+        hm[0] = s[4], hm[1] = cnt;
+    }
 }
 template <class T>
 __global__ void k_scal_v(size_t n, T a, T* x)
@@ -941,28 +966,44 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
     else if (kind == 2) {
         T* z = L.tmp.p;
         double* s = dscal.p + 40;
-        scaler(L.initialResidual.p, z);
-        double zTrk0 = dot_host(n3, z, L.initialResidual.p);
-        scaler(r, z);
-        copy(n3, z, du);
-        double zTrk = dot_host(n3, z, r);
-        double tol = (double)(T)(zTrk0 * 0.25); // cgratio = 0.5 hard-wired (:203-209)
-        HOT_HIP(hipMemcpyAsync(s, &zTrk, sizeof(double), hipMemcpyHostToDevice, stream));
-        int cnt = 0;
         const bool cg_unfused = ab_flag("HOT_CG_UNFUSED"); // A/B build only: one launch per vector operation
-        if (!cg_unfused && !(level == 0 && !cfg.systemBCProject) && !L.part) { // (partitioned level: the generic path below, whose SpMV exchanges)
-            HOT_HIP(hipMemsetAsync(s + 1, 0, 6 * sizeof(double), stream));
-            for (; iterations--;) {
-                if (zTrk < tol) break;
-                HOT_LAUNCH(this, lname("spmv", L.id).c_str(), k_cg_spmv_dot<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, du, dAu, L.n, s, gred(div_up(L.n, 4)));
-                HOT_LAUNCH(this, "cg_update", k_cg_update<T>, div_up(L.n, 256), 256, 0, L.diagInv.p, du, dAu, u, r, z, L.n, s, gred(div_up(L.n, 256)));
-                HOT_LAUNCH(this, "cg_direction", k_cg_direction<T>, div_up(n3, 256), 256, 0, n3, z, du, s);
-                HOT_HIP(hipMemcpyAsync(hscal + 40, s + 4, sizeof(double), hipMemcpyDeviceToHost, stream));
+        const bool fused = !cg_unfused && !(level == 0 && !cfg.systemBCProject) && !L.part; // (partitioned level: the generic path below, whose SpMV exchanges)
+        int cnt = 0;
+        double zTrk = 0, tol = 0;
+        if (fused) {
+            // no host round trip before the first iteration and one per group of iterations afterwards (see k_cg_setup)
+            scaler(L.initialResidual.p, z);
+            dot_to(n3, z, L.initialResidual.p, s + 7);
+            scaler(r, z);
+            copy(n3, z, du);
+            dot_to(n3, z, r, s);
+            HOT_LAUNCH(this, "cg_setup", k_cg_setup<T>, 1, 1, 0, s, hscal + 40);
+            int group = std::max(1, std::min(cg_group, 16)); // as many iterations as the previous solve on this level needed
+            bool active = true;
+            while (iterations > 0 && active) {
+                const int g = std::min(group, iterations);
+                for (int k = 0; k < g; ++k) {
+                    HOT_LAUNCH(this, lname("spmv", L.id).c_str(), k_cg_spmv_dot<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, du, dAu, L.n, s, gred(div_up(L.n, 4)));
+                    HOT_LAUNCH(this, "cg_update", k_cg_update<T>, div_up(L.n, 256), 256, 0, L.diagInv.p, du, dAu, u, r, z, L.n, s, gred(div_up(L.n, 256)));
+                    HOT_LAUNCH(this, "cg_direction", k_cg_direction<T>, div_up(n3, 256), 256, 0, n3, z, du, s, hscal + 40);
+                }
+                iterations -= g;
                 sync();
-                zTrk = hscal[40];
-                ++cnt;
+                active = !(hscal[40] < hscal[42]);
+                group = 2;
             }
+            cnt = (int)hscal[41];
+            cg_group = cnt;
             iterations = 0;
+        }
+        else {
+            scaler(L.initialResidual.p, z);
+            double zTrk0 = dot_host(n3, z, L.initialResidual.p);
+            scaler(r, z);
+            copy(n3, z, du);
+            zTrk = dot_host(n3, z, r);
+            tol = (double)(T)(zTrk0 * 0.25); // cgratio = 0.5 hard-wired (:203-209)
+            HOT_HIP(hipMemcpyAsync(s, &zTrk, sizeof(double), hipMemcpyHostToDevice, stream));
         }
         for (; iterations-- > 0;) {
             if (zTrk < tol) break;

@@ -82,6 +82,12 @@ __global__ __launch_bounds__(256) void k_lbfgs_fused(size_t n, double* s, int in
         grid_sum_store(t, 0.0, 1, gr, s + out_slot, nullptr, red);
     }
 }
+// rho of a new curvature pair: s[dst] = 1 / (y's) in the arithmetic of the host code it replaces ((T)1 / (T)d, LBFGS.h:424-434)
+template <class T>
+__global__ void k_lbfgs_rho(double* s, int src, int dst)
+{
+    s[dst] = (double)((T)1 / (T)s[src]);
+}
 // dst = src (optional) and dot_out += z . src in the same pass
 template <class T>
 __global__ __launch_bounds__(256) void k_copy_dot(size_t n, double* s, int out_slot, const T* __restrict__ src, T* __restrict__ dst, const T* __restrict__ z, GridRed gr)
@@ -105,9 +111,8 @@ bool Ctx<T>::should_exit(const T* r)
     if (Nn == 0) return true;
     {
         const int grid = std::min(div_up(Nn, 256), 1024);
-        HOT_LAUNCH(this, "exit_norm", k_scaled_norm<T>, grid, 256, 0, r, cnTol.p, Nn, cfg.useCN, dscal.p + 90, gred(grid));
+        HOT_LAUNCH(this, "exit_norm", k_scaled_norm<T>, grid, 256, 0, r, cnTol.p, Nn, cfg.useCN, dscal.p + 90, gred(grid, hscal + 90));
     }
-    HOT_HIP(hipMemcpyAsync(hscal + 90, dscal.p + 90, sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
     double v = hscal[90];
     HOT_CHECK(v == v, HOT_ERR_NUMERIC, "NaN in the residual norm");
@@ -182,9 +187,25 @@ bool Ctx<T>::lbfgs_solve()
     };
     push_back();
     double* s = dscal.p;
+    // The curvature y's of a new pair is reduced on the device (1 / y's goes to the pair's slot there as well); the host needs its sign
+    // only to keep or drop the pair, which it decides at the next stream sync — the exit test of the following iteration — instead of
+    // in a sync of its own.  Nothing in between depends on the decision.
+    bool pending = false;
+    auto resolve_pair = [&]() {
+        if (!pending) return;
+        pending = false;
+        T dgTdx = (T)1 / (T)hscal[91];
+        if (dgTdx <= (T)0 || !(dgTdx == dgTdx)) {
+            if (!(dgTdx <= (T)0)) HOT_CHECK(false, HOT_ERR_NUMERIC, "NaN curvature in L-BFGS");
+            pop_back();
+            stats.dropped_pairs++;
+        }
+        push_back();
+    };
     for (int it = 0; it < cfg.max_iterations; ++it) {
         stats.iterations = it;
         bool ex = should_exit(residual);
+        resolve_pair();
         if (ab_flag("HOT_DEBUG")) fprintf(stderr, "[hot] lbfgs it=%d scaled_res=%.6e Ek=%.12e hist=%d\n", it, stats.final_scaled_residual, Ek, (int)order.size() - 1);
         if (ex) {
             stats.converged = 1;
@@ -246,20 +267,12 @@ bool Ctx<T>::lbfgs_solve()
             residual_dev(residual);
         }
         axpy(n3, (T)-1, residual, hist_dg[wk].p);
-        double d = dot_host(n3, hist_dg[wk].p, hist_dx[wk].p);
-        T dgTdx = (T)1 / (T)d;
-        if (dgTdx <= (T)0 || !(dgTdx == dgTdx)) {
-            if (!(dgTdx <= (T)0)) HOT_CHECK(false, HOT_ERR_NUMERIC, "NaN curvature in L-BFGS");
-            pop_back();
-            stats.dropped_pairs++;
-        }
-        else {
-            double v = (double)dgTdx;
-            HOT_HIP(hipMemcpyAsync(s + 60 + wk, &v, sizeof(double), hipMemcpyHostToDevice, stream));
-            sync();
-        }
-        push_back();
+        dot_to(n3, hist_dg[wk].p, hist_dx[wk].p, s + 71, hscal + 91);
+        HOT_LAUNCH(this, "lbfgs_rho", k_lbfgs_rho<T>, 1, 1, 0, s, 71, 60 + wk);
+        pending = true;
     }
+    sync();
+    resolve_pair();
     stats.iterations = cfg.max_iterations;
     return false;
 }
