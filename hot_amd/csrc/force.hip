@@ -529,10 +529,20 @@ __global__ __launch_bounds__(256) void k_inertia_energy(const T* __restrict__ dv
 {
     __shared__ double red[4];
     double ke = 0, ge = 0;
-    for (int n = blockIdx.x * 256 + threadIdx.x; n < nn; n += gridDim.x * 256) {
-        T a = dv[3 * n], b = dv[3 * n + 1], c = dv[3 * n + 2], m = mass[n];
-        ke += (double)((a * a + b * b + c * c) * m);
-        ge += (double)((g0 * a + g1 * b + g2 * c) * m);
+    const int stride = gridDim.x * 256;
+    for (int n0 = blockIdx.x * 256 + threadIdx.x; n0 < nn; n0 += 4 * stride) { // four strided nodes per trip in flight
+        T a[4], b[4], c[4], m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = n0 + u * stride < nn ? n0 + u * stride : n0;
+            a[u] = dv[3 * n], b[u] = dv[3 * n + 1], c[u] = dv[3 * n + 2], m[u] = mass[n];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (n0 + u * stride < nn) {
+                ke += (double)((a[u] * a[u] + b[u] * b[u] + c[u] * c[u]) * m[u]);
+                ge += (double)((g0 * a[u] + g1 * b[u] + g2 * c[u]) * m[u]);
+            }
     }
     double k = block_sum_256<double>(ke, red);
     double gg = block_sum_256<double>(ge, red);
@@ -562,10 +572,10 @@ double Ctx<T>::state_pass(const T* dv_in, bool want_force)
         group_nb.p, tileDof.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p, gred(Ng, hscal)); // the sums land in the pinned host slots too: one stream sync, no copy
     if (want_force) force_pass();
     {
-        const int grid = std::min(div_up(Nn, 256), 1024);
-        HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, grid, 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1, gred(grid, hscal + 1));
+        const int grid = std::min(div_up(Nn, 1024), 1024);
+        HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, grid, 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1, gred(grid, hscal + 1, true));
     }
-    sync();
+    wait_ticket();
     if (sharded()) c_allreduce(hscal, 1, HOT_COMM_F64, HOT_COMM_SUM, false); // the shards' strain energies; the inertia terms are computed from replicated vectors
     double result = (double)(T)hscal[0];
     result += hscal[1] / 2;

@@ -217,8 +217,16 @@ __device__ inline T block_sum_256(T v, T* sm4)
 struct GridRed {
     double* part; // >= 2 * gridDim.x
     unsigned* count;
-    double* mirror; // optional: pinned host memory that also receives the result(s), so that the host needs a stream sync but no copy
+    double* mirror; // optional: pinned host memory that also receives the result(s), so that the host needs no copy
+    double* ticket; // optional (with mirror): pinned host word that receives ticket_val after the results — the host spins on it
+    double ticket_val; //   instead of paying a hipStreamSynchronize wake-up (Ctx::wait_ticket)
 };
+// results first, then the ticket.  A system-scope release is needed here: s_waitcnt vmcnt(0) only waits for the L2's acknowledgement
+// of the result stores, and the ticket (another cache line, another channel) can overtake them on the way to host memory.
+__device__ __forceinline__ void host_ticket_store(double* ticket, double val)
+{
+    __hip_atomic_store(ticket, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ inline void grid_sum_store(double t0, double t1, int nv, GridRed gr, double* o0, double* o1, double* sm4)
 {
     __shared__ int s_last;
@@ -245,6 +253,7 @@ __device__ inline void grid_sum_store(double t0, double t1, int nv, GridRed gr, 
         if (gr.mirror) {
             gr.mirror[0] = a;
             if (nv > 1) gr.mirror[1] = b;
+            if (gr.ticket) host_ticket_store(gr.ticket, gr.ticket_val);
         }
         __hip_atomic_store(gr.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -2,6 +2,7 @@
 // hessian.hip / mg_build.hip / mg_solve.hip / solve.hip and explicitly instantiated there for float and double.
 #pragma once
 #include "hot_ctx.h"
+#include <atomic>
 #include <functional>
 
 namespace hot {
@@ -162,13 +163,38 @@ struct Ctx : CtxBase {
     DBuf<T> speed_part; // block maxima of calculate_dt
     DBuf<double> red_part; // grid_sum_store deposits (2 per workgroup)
     DBuf<unsigned> red_count; // its arrival counter (always 0 between launches)
-    GridRed gred(size_t grid, double* mirror = nullptr) // mirror: a slot of hscal (pinned, device-visible)
+    // mirror: a slot of hscal (pinned, device-visible) that receives the result too.  ticket: the launch also stamps hscal[251] with a
+    // fresh number after the results, and the host waits for that stamp with wait_ticket() instead of a stream synchronisation
+    GridRed gred(size_t grid, double* mirror = nullptr, bool ticket = false)
     {
         if (2 * grid > red_part.cap) {
             HOT_HIP(hipStreamSynchronize(stream)); // a launch still summing the old deposits must be done before they are freed
             red_part.reserve(2 * grid, 1.5);
         }
-        return GridRed{ red_part.p, red_count.p, mirror };
+        GridRed g{ red_part.p, red_count.p, mirror, nullptr, 0.0 };
+        if (ticket) g.ticket = hscal + 251, g.ticket_val = new_ticket();
+        return g;
+    }
+    double last_ticket = 0;
+    double new_ticket() { return last_ticket += 1.0; }
+    // Wait until the launch that carries the newest ticket has delivered its results to the pinned host slots.  Every earlier launch on
+    // the stream is complete by then.  Spinning on host memory costs ~2 us after the store; hipStreamSynchronize wakes the thread up
+    // 30-45 us after the kernel ends.  Falls back to the stream synchronisation if the stamp does not arrive (device error, stall).
+    void wait_ticket()
+    {
+        const double want = last_ticket;
+        volatile double* t = hscal + 251;
+        const double t0 = wall_ms();
+        for (unsigned spin = 0; *t != want; ++spin) {
+            __builtin_ia32_pause();
+            if ((spin & 1023u) == 1023u && wall_ms() - t0 > 20.0) {
+                HOT_HIP(hipStreamSynchronize(stream));
+                HOT_CHECK(*t == want, HOT_ERR_DEVICE, "a reduction launch did not deliver its result");
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (*(volatile int*)(hscal + 250) != 0) sync(); // k_gs_sweep timed out somewhere before: the usual path (throws ERR_RETRY)
     }
     int cg_group = 2; // iterations the last fused top-level PCG took: size of the first group of launches of the next one
     int gs_epoch = 0; // sweep number, never reused inside a context

@@ -47,7 +47,18 @@ __global__ __launch_bounds__(256) void k_dot(size_t n, const T* __restrict__ x, 
 {
     __shared__ double red[4];
     double s = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += (double)(x[i] * y[i]);
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) { // four strided elements per trip in flight
+        T xv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = i0 + u * stride, ic = i < n ? i : i0;
+            xv[u] = x[ic], yv[u] = y[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * stride < n) s += (double)(xv[u] * yv[u]);
+    }
     double t = block_sum_256<double>(s, red);
     grid_sum_store(t, 0.0, 1, gr, out, nullptr, red);
 }
@@ -86,8 +97,9 @@ void Ctx<T>::dot_to(size_t n, const T* x, const T* y, double* out, double* mirro
 template <class T>
 double Ctx<T>::dot_host(size_t n, const T* x, const T* y)
 {
-    dot_to(n, x, y, dscal.p + 100, hscal + 100); // the summing workgroup also writes the pinned host slot: no copy, one stream sync
-    sync();
+    const int grid = std::min(div_up(n, 1024), 256);
+    HOT_LAUNCH(this, "dot", k_dot<T>, grid, 256, 0, n, x, y, dscal.p + 100, gred(grid, hscal + 100, true)); // the summing workgroup also writes the pinned host slot
+    wait_ticket();
     return hscal[100];
 }
 
@@ -215,17 +227,19 @@ __global__ __launch_bounds__(256) void k_cg_update(const T* __restrict__ Dinv, c
 }
 // du = z + b du      (b = s[4] / s[0])
 template <class T>
-__global__ void k_cg_direction(size_t n3, const T* __restrict__ z, T* __restrict__ du, double* s, double* hm)
+__global__ void k_cg_direction(size_t n3, const T* __restrict__ z, T* __restrict__ du, double* s, double* hm, double* ticket, double ticket_val)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (!cg_active(s[0], s[8])) return;
-    const T b = (T)(s[4] / s[0]);
-    if (i < n3) du[i] = z[i] + b * du[i];
+    const bool act = cg_active(s[0], s[8]);
+    if (act && i < n3) du[i] = z[i] + (T)(s[4] / s[0]) * du[i];
     if (i == 0) { // nobody reads s[6] / s[9] in this launch
-        s[6] = 1.0;
-        const double cnt = s[9] + 1.0;
-        s[9] = cnt;
-        hm[0] = s[4], hm[1] = cnt;
+        if (act) {
+            s[6] = 1.0;
+            const double cnt = s[9] + 1.0;
+            s[9] = cnt;
+            hm[0] = s[4], hm[1] = cnt;
+        }
+        if (ticket) host_ticket_store(ticket, ticket_val); // last launch of a group: the host is waiting for hm (Ctx::wait_ticket)
     }
 }
 template <class T>
@@ -253,12 +267,19 @@ __global__ void k_restrict(const int32_t* __restrict__ child, const T* __restric
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 3 * nc) return;
     int I = e / 3, d = e - 3 * I;
+    // all 27 child ids first, then all 27 values (clamped index, dropped by the select): two rounds of independent loads instead of
+    // 27 dependent pairs; the sum keeps the child order
+    int ci[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) ci[q] = child[I * 27 + q];
+    T fv[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) fv[q] = fine[3 * (int64_t)(ci[q] < 0 ? 0 : ci[q]) + d];
     T s = 0;
+#pragma unroll
     for (int q = 0; q < 27; ++q) {
-        int ci = child[I * 27 + q];
-        if (ci < 0) continue;
-        T w = ((q / 9 != 1) ? (T)0.5 : (T)1) * (((q / 3) % 3 != 1) ? (T)0.5 : (T)1) * ((q % 3 != 1) ? (T)0.5 : (T)1);
-        s += w * fine[3 * (int64_t)ci + d];
+        const T w = ((q / 9 != 1) ? (T)0.5 : (T)1) * (((q / 3) % 3 != 1) ? (T)0.5 : (T)1) * ((q % 3 != 1) ? (T)0.5 : (T)1);
+        s = ci[q] < 0 ? s : s + w * fv[q];
     }
     coarse[e] = s;
 }
@@ -985,10 +1006,11 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 for (int k = 0; k < g; ++k) {
                     HOT_LAUNCH(this, lname("spmv", L.id).c_str(), k_cg_spmv_dot<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, du, dAu, L.n, s, gred(div_up(L.n, 4)));
                     HOT_LAUNCH(this, "cg_update", k_cg_update<T>, div_up(L.n, 256), 256, 0, L.diagInv.p, du, dAu, u, r, z, L.n, s, gred(div_up(L.n, 256)));
-                    HOT_LAUNCH(this, "cg_direction", k_cg_direction<T>, div_up(n3, 256), 256, 0, n3, z, du, s, hscal + 40);
+                    const bool last = k + 1 == g;
+                    HOT_LAUNCH(this, "cg_direction", k_cg_direction<T>, div_up(n3, 256), 256, 0, n3, z, du, s, hscal + 40, last ? hscal + 251 : (double*)nullptr, last ? new_ticket() : 0.0);
                 }
                 iterations -= g;
-                sync();
+                wait_ticket();
                 active = !(hscal[40] < hscal[42]);
                 group = 2;
             }

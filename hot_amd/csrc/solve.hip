@@ -26,11 +26,19 @@ __global__ __launch_bounds__(256) void k_scaled_norm(const T* __restrict__ r, co
 {
     __shared__ double red[4];
     double s = 0;
-    for (int n = blockIdx.x * 256 + threadIdx.x; n < nn; n += gridDim.x * 256) {
-        T a = r[3 * n], b = r[3 * n + 1], c = r[3 * n + 2];
-        T q = a * a + b * b + c * c;
-        if (useCN) q = q / (tol[n] * tol[n]);
+    const int stride = gridDim.x * 256;
+    for (int n0 = blockIdx.x * 256 + threadIdx.x; n0 < nn; n0 += 2 * stride) { // two nodes per trip in flight
+        const int n1 = n0 + stride < nn ? n0 + stride : n0;
+        const T a0 = r[3 * n0], b0 = r[3 * n0 + 1], c0 = r[3 * n0 + 2], t0 = useCN ? tol[n0] : (T)1;
+        const T a1 = r[3 * n1], b1 = r[3 * n1 + 1], c1 = r[3 * n1 + 2], t1 = useCN ? tol[n1] : (T)1;
+        T q = a0 * a0 + b0 * b0 + c0 * c0;
+        if (useCN) q = q / (t0 * t0);
         s += (double)q;
+        if (n1 != n0) {
+            T q1 = a1 * a1 + b1 * b1 + c1 * c1;
+            if (useCN) q1 = q1 / (t1 * t1);
+            s += (double)q1;
+        }
     }
     double t = block_sum_256<double>(s, red);
     grid_sum_store(t, 0.0, 1, gr, out, nullptr, red);
@@ -72,12 +80,54 @@ __global__ __launch_bounds__(256) void k_lbfgs_fused(size_t n, double* s, int in
     if (what == 0 && blockIdx.x == 0 && threadIdx.x == 0) s[50 + ph] = coef;
     const T c = (T)(what == 0 ? -1.0 * coef : 1.0 * coef);
     double acc = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        T yn = y[i] + c * v[i];
-        y[i] = yn;
-        if (z) acc += (double)(z[i] * yn);
+    // four independent strided elements per trip: the loads of a trip are in flight together (a plain grid-stride loop waits for each)
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        T yv[4], vv[4], zv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = i0 + u * stride, ic = i < n ? i : i0;
+            yv[u] = y[ic], vv[u] = v[ic], zv[u] = z ? z[ic] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = i0 + u * stride;
+            if (i < n) {
+                const T yn = yv[u] + c * vv[u];
+                y[i] = yn;
+                if (z) acc += (double)(zv[u] * yn);
+            }
+        }
     }
     if (z) { // kernel-uniform
+        double t = block_sum_256<double>(acc, red);
+        grid_sum_store(t, 0.0, 1, gr, s + out_slot, nullptr, red);
+    }
+}
+// dst = src (optional) and dot_out += z . src in the same pass
+template <class T>
+__global__ __launch_bounds__(256) void k_copy_dot(size_t n, double* s, int out_slot, const T* __restrict__ src, T* __restrict__ dst, const T* __restrict__ z, GridRed gr)
+{
+    __shared__ double red[4];
+    double acc = 0;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        T av[4], zv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = i0 + u * stride, ic = i < n ? i : i0;
+            av[u] = src[ic], zv[u] = z ? z[ic] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = i0 + u * stride;
+            if (i < n) {
+                if (dst) dst[i] = av[u];
+                if (z) acc += (double)(zv[u] * av[u]);
+            }
+        }
+    }
+    if (z) {
         double t = block_sum_256<double>(acc, red);
         grid_sum_store(t, 0.0, 1, gr, s + out_slot, nullptr, red);
     }
@@ -88,32 +138,16 @@ __global__ void k_lbfgs_rho(double* s, int src, int dst)
 {
     s[dst] = (double)((T)1 / (T)s[src]);
 }
-// dst = src (optional) and dot_out += z . src in the same pass
-template <class T>
-__global__ __launch_bounds__(256) void k_copy_dot(size_t n, double* s, int out_slot, const T* __restrict__ src, T* __restrict__ dst, const T* __restrict__ z, GridRed gr)
-{
-    __shared__ double red[4];
-    double acc = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        T a = src[i];
-        if (dst) dst[i] = a;
-        if (z) acc += (double)(z[i] * a);
-    }
-    if (z) {
-        double t = block_sum_256<double>(acc, red);
-        grid_sum_store(t, 0.0, 1, gr, s + out_slot, nullptr, red);
-    }
-}
 
 template <class T>
 bool Ctx<T>::should_exit(const T* r)
 {
     if (Nn == 0) return true;
     {
-        const int grid = std::min(div_up(Nn, 256), 1024);
-        HOT_LAUNCH(this, "exit_norm", k_scaled_norm<T>, grid, 256, 0, r, cnTol.p, Nn, cfg.useCN, dscal.p + 90, gred(grid, hscal + 90));
+        const int grid = std::min(div_up(Nn, 512), 1024);
+        HOT_LAUNCH(this, "exit_norm", k_scaled_norm<T>, grid, 256, 0, r, cnTol.p, Nn, cfg.useCN, dscal.p + 90, gred(grid, hscal + 90, true));
     }
-    sync();
+    wait_ticket();
     double v = hscal[90];
     HOT_CHECK(v == v, HOT_ERR_NUMERIC, "NaN in the residual norm");
     if (!cfg.useCN) {
@@ -221,7 +255,7 @@ bool Ctx<T>::lbfgs_solve()
         int wk = order.back();
         const int m = (int)order.size() - 1; // stored curvature pairs
         const bool unfused = ab_flag("HOT_LBFGS_UNFUSED"); // A/B build only: dot / scalar / axpy as separate launches
-        const int vgrid = (int)std::min<size_t>(div_up(n3, 1024), 512);
+        const int vgrid = (int)std::min<size_t>(div_up(n3, 1024), 2048); // four elements per thread and trip
         if (unfused) {
             copy(n3, residual, hist_dg[wk].p);
             for (int i = m - 1; i >= 0; --i) {
