@@ -196,6 +196,9 @@ struct Ctx : CtxBase {
         std::atomic_thread_fence(std::memory_order_acquire);
         if (*(volatile int*)(hscal + 250) != 0) sync(); // k_gs_sweep timed out somewhere before: the usual path (throws ERR_RETRY)
     }
+    DBuf<uint64_t> col_hk; // mark_colors scratch (block hash map, colour block heads)
+    DBuf<unsigned long long> col_hr;
+    DBuf<int32_t> col_hi, col_cb;
     int cg_group = 2; // iterations the last fused top-level PCG took: size of the first group of launches of the next one
     int gs_epoch = 0; // sweep number, never reused inside a context
     bool attr_tiles_set = false, attr_gs_set = false; // dynamic-LDS limits raised on this context's device (hipFuncSetAttribute is per device)

@@ -311,9 +311,10 @@ static void mark_colors(Ctx<T>* ctx, Level<T>& L)
     // block map (temporary)
     uint32_t cap = 1024;
     while (cap < 2u * (uint32_t)n + 16u) cap <<= 1;
-    DBuf<uint64_t> hk;
-    DBuf<unsigned long long> hr;
-    DBuf<int32_t> hi;
+    // (context-owned scratch: a local buffer would cost a hipMalloc and a synchronising hipFree per level and time step)
+    DBuf<uint64_t>& hk = ctx->col_hk;
+    DBuf<unsigned long long>& hr = ctx->col_hr;
+    DBuf<int32_t>& hi = ctx->col_hi;
     hk.reserve(cap), hr.reserve(cap), hi.reserve(cap);
     HashMap h{ hk.p, hr.p, hi.p, cap - 1 };
     HOT_LAUNCH(ctx, "mg_hash_clear", k_hash_clear2, div_up(cap, 256), 256, 0, h);
@@ -334,7 +335,7 @@ static void mark_colors(Ctx<T>* ctx, Level<T>& L)
     HOT_LAUNCH(ctx, "color_heads", k_color_heads, div_up(n, 256), 256, 0, ctx->keys2.p, ctx->flags.p, n);
     L.nblocks = ctx->exclusive_scan_i32(ctx->flags.p, ctx->scan.p, n);
     L.gs_order.reserve(n), L.gs_block_start.reserve(L.nblocks + 1), L.ckey.reserve(n);
-    DBuf<int32_t> cb;
+    DBuf<int32_t>& cb = ctx->col_cb;
     cb.reserve(16);
     HOT_LAUNCH(ctx, "color_finish", k_color_finish, div_up(n, 256), 256, 0, ctx->keys2.p, ctx->flags.p, ctx->scan.p, L.gs_order.p, L.gs_block_start.p, cb.p, n, L.nblocks);
     HOT_LAUNCH(ctx, "color_ckey", k_color_ckey, div_up(n, 256), 256, 0, ctx->keys2.p, ctx->scan.p, L.gs_block_start.p, L.ckey.p, n);
