@@ -92,7 +92,10 @@ int32_t cb_alltoallv(void* user, const void* send, const int64_t* soff, const in
 {
     Rccl* r = (Rccl*)user;
     if (!on_device) return 1; // the library only exchanges device payloads this way
-    bool ok = api().GroupStart() == ncclSuccess;
+    bool ok = true;
+    if (sbytes[r->rank] > 0) // a rank's message to itself (the library sends none today; the contract allows it)
+        ok = hipMemcpyAsync((char*)recv + roff[r->rank], (const char*)send + soff[r->rank], (size_t)sbytes[r->rank], hipMemcpyDeviceToDevice, r->stream) == hipSuccess;
+    ok = ok && api().GroupStart() == ncclSuccess;
     for (int p = 0; p < r->size && ok; ++p) {
         if (p == r->rank) continue;
         if (rbytes[p] > 0) ok = ok && api().Recv((char*)recv + roff[p], (size_t)rbytes[p], ncclChar, p, r->comm, r->stream) == ncclSuccess;
