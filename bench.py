@@ -14,7 +14,8 @@ variants ("faithful": serial where the reference is serial; "fair": those sectio
 N > 1: one process per GPU (launched by torch.distributed.run, or spawned here when WORLD_SIZE is unset), RCCL through
 torch.distributed.  ONE connected body is sharded over the ranks (hot_set_comm, hot_amd/dist.py): particle
 ranges of the global sort order per rank, node tiles summed with all-reduces, matrix rows owned by one rank each,
-colour-synchronous Gauss-Seidel.  Weak scaling: the body grows so that every GPU keeps C2's particle count
+coloured Gauss-Seidel rank-local (processor-block: one exchange per symmetric sweep; --shard-gs 0 = colour-synchronous, the
+single-rank iterates at sixteen exchanges per sweep).  Weak scaling: the body grows so that every GPU keeps C2's particle count
 (N = 8: a 126^3-cell body of 16 M particles, BASELINE config 4's size).
 """
 import argparse
@@ -129,6 +130,8 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo with --share-gpu on a one-GPU box)")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N > 1: native stream-ordered RCCL communicator of the library (falls back to torch if RCCL "
                     "cannot be attached) or hot_amd.dist.TorchComm (torch.distributed collectives, host-synchronous)")
+    ap.add_argument("--shard-gs", type=int, default=1, choices=[0, 1], help="N > 1, coloured GS across ranks: 1 = processor-block (one exchange per symmetric sweep; default), "
+                    "0 = colour-synchronous (the single-rank iterates, sixteen exchanges per symmetric sweep)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on device 0 (functional check of the N > 1 path on a one-GPU box, not a measurement)")
     return ap.parse_args()
 
@@ -186,7 +189,7 @@ def main():
     s = 8 if cfg["dtype"] == np.float64 else 4
     dt = cfg["dt"]
 
-    ctx = make_ctx(lib, cloud, cfg, device=local, comm=comm)
+    ctx = make_ctx(lib, cloud, cfg, device=local, comm=comm, **(dict(shard_gs=args.shard_gs) if world > 1 else {}))
     for _ in range(args.warmup):
         ctx.advance(dt)
     barrier()
@@ -303,7 +306,7 @@ def main():
                                    f"-lsolver 3 -mg_level {cfg['levelCnt']} -smoother 5 -coarseSolver 2 --project --linesearch --bcproject --usecn -cneps 1e-7",
                        "particles_per_gpu": int(total_particles / world), "particles_total": int(total_particles), "nodes_total": stats[-1]["num_nodes"], "levels": stats[-1]["num_levels"],
                        "parallelism": "1 GPU" if world == 1 else f"one connected body sharded over {world} ranks: particle ranges of the sort order, all-reduced node tiles, "
-                                                                 f"row-partitioned operators with colour-synchronous Gauss-Seidel ({args.backend})"},
+                                                                 f"row-partitioned operators, coloured Gauss-Seidel {'rank-local (processor-block), one exchange per symmetric sweep' if args.shard_gs else 'colour-synchronous across ranks'} ({args.backend})"},
             "iterations_per_step": iters / max(args.steps, 1),
             "hessian_mg_build_ms_per_step": build_ms / max(args.steps, 1),
             "ms_per_iter_build_amortised": solve_ms / max(iters, 1),

@@ -913,7 +913,8 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
 // r_i = sum over the nl slots preceding row i of A_ik (h - du)_k   (rows regrouped by k_gs_split_rows)
 template <class T>
 __global__ __launch_bounds__(256) void k_gs_residual(const int32_t* __restrict__ col, const T* __restrict__ val, const int32_t* __restrict__ rowcnt, const T* __restrict__ h,
-    const T* __restrict__ du, T* __restrict__ r, int n, const uint8_t* __restrict__ own)
+    const T* __restrict__ du, T* __restrict__ r, int n, const uint8_t* __restrict__ own, const uint8_t* __restrict__ owner /*rank-local GS (hot_config.shard_gs): owning rank of every row, else null*/,
+    int me)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -922,13 +923,23 @@ __global__ __launch_bounds__(256) void k_gs_residual(const int32_t* __restrict__
     const int32_t* c = col + (int64_t)row * 125;
     const T* v = val + (int64_t)row * 1125;
     T s0 = 0, s1 = 0, s2 = 0;
-    for (int k = lane; k < nl; k += 64) {
-        int j = c[k];
+    auto add = [&](int k, int j) {
         const T* b = v + k * 9;
         T x0 = h[3 * (int64_t)j] - du[3 * (int64_t)j], x1 = h[3 * (int64_t)j + 1] - du[3 * (int64_t)j + 1], x2 = h[3 * (int64_t)j + 2] - du[3 * (int64_t)j + 2];
         s0 += b[0] * x0 + b[3] * x1 + b[6] * x2;
         s1 += b[1] * x0 + b[4] * x1 + b[7] * x2;
         s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
+    };
+    for (int k = lane; k < nl; k += 64) add(k, c[k]);
+    if (owner) {
+        // rank-local sweeps: the identity r - A du = L (h - du) holds for the rank's own diagonal block of A.  What is left of A du are the
+        // couplings to other ranks' rows: those preceding the row are in the loop above already (h is zero there: never computed here, never
+        // exchanged), those following it are picked out of the following half here, with the same expression
+        const int ub = nl + 1 + rowcnt[4 * row + 2], ue = ub + rowcnt[4 * row + 3];
+        for (int k = ub + lane; k < ue; k += 64) {
+            const int j = c[k];
+            if (owner[j] != me) add(k, j);
+        }
     }
     s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
     if (lane == 0) r[3 * (int64_t)row] = s0, r[3 * (int64_t)row + 1] = s1, r[3 * (int64_t)row + 2] = s2;
@@ -1077,6 +1088,9 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         HOT_CHECK(L.nblocks > 0, HOT_ERR_INVALID, "GS smoother requested but the level was built without colouring");
         T* hdu = L.tmp.p;
         const bool simple_gs = ab_flag("HOT_SIMPLE_GS"); // A/B build only: one-wave-per-block reference kernel
+        // hot_config.shard_gs = 1 on a row-partitioned level: a rank sweeps its own rows against its own rows only (processor-block GS: the
+        // symmetric GS of the rank's diagonal block of A); one exchange per symmetric sweep instead of one per colour and direction
+        const bool rank_local = L.part && cfg.shard_gs != 0;
         const int env_sb = cfg.gs_sub_block; // tuning override: sub-block size 16 / 32 / 64 (0 = by level size)
         const bool no_lres = ab_flag("HOT_GS_FULL_RESIDUAL"); // A/B build only: r -= A du by a full SpMV
         if (!attr_gs_set) {
@@ -1117,7 +1131,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 {
                     if (L.part && last) ctx->exchange(L, x, c);
                 }
-            } after{ this, L, xx, c, nmerge > 1 || (fwd ? h == nsub - 1 : h == 0) };
+            } after{ this, L, xx, c, !rank_local && (nmerge > 1 || (fwd ? h == nsub - 1 : h == 0)) };
             if (L.part) {
                 const int R1 = comm.size + 1;
                 b0 += L.csplit[c * R1 + comm.rank], nb = L.csplit[c * R1 + comm.rank + 1] - L.csplit[c * R1 + comm.rank];
@@ -1204,7 +1218,9 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         iterations = ((iterations + 1) >> 1);
         for (; iterations--;) {
             prof.count(lname("gs_symsweeps", L.id));
-            // no memset of hdu / du: a sweep writes every node before any later node reads it (only preceding nodes are read)
+            // no memset of hdu / du: a sweep writes every node before any later node reads it (only preceding nodes are read) —
+            // except with rank-local sweeps, where the other ranks' unknowns are read as the zeros the sweep starts from
+            if (rank_local) zero(n3, hdu), zero(n3, du);
             if (dataflow)
                 sweep(true);
             else
@@ -1216,12 +1232,14 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             else
                 for (int c = 7; c >= 0; --c)
                     for (int h = nsub - 1; h >= 0; --h) pass(false, c, h);
+            if (rank_local) exchange(L, du, -1); // the one hand-off of a rank-local symmetric sweep: every rank's du
             if (simple_gs || L.part) axpy(n3, (T)1, du, u); // partitioned level: du is complete on every rank after the colour exchanges, u stays replicated
             if (!final_residual && iterations == 0) break;
             if (L.split && !simple_gs && !(level == 0 && !cfg.systemBCProject) && !no_lres) {
                 // r - A du = L (h - du): with (D+L) h = r and (D+U) du = D h the full product A du collapses to the
                 // strictly-preceding half of the matrix applied to (h - du) (same value, half the bytes of an SpMV)
-                HOT_LAUNCH(this, lname("gs_residual", L.id).c_str(), k_gs_residual<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.rowcnt.p, hdu, du, r, L.n, L.mask());
+                HOT_LAUNCH(this, lname("gs_residual", L.id).c_str(), k_gs_residual<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.rowcnt.p, hdu, du, r, L.n, L.mask(),
+                    rank_local ? L.owner.p : (const uint8_t*)nullptr, comm.rank);
                 exchange(L, r, -1); // partitioned level: the restriction / the next smoother read all of r
             }
             else {

@@ -76,7 +76,11 @@ typedef struct hot_config {
     int32_t useBaselineMultigrid; /* --baseline: geometric multigrid, every coarse level a real MPM grid of spacing 2^l dx whose matrix is re-rasterised from the particles */
     int32_t gs_chain; /* tuning override of the coloured-GS launch structure: 0 = by level size (default), 1 = one launch per colour, 2 = one chained launch per half sweep */
     int32_t gs_sub_block; /* tuning override: nodes of a 4^3 colour block one workgroup substitutes at a time, 0 = by level size, or 16 / 32 / 64 */
-    int32_t reserved[3];
+    int32_t shard_gs; /* sharded runs (hot_set_comm), coloured GS on a row-partitioned level: 0 = colour-synchronous (default): after every colour the
+                         owners' new values are handed to all ranks, i.e. the reference's update order and single-rank iterates; 1 = processor-block:
+                         a rank sweeps its own rows against its own rows only (couplings to other ranks' rows enter through the residual), one
+                         exchange per symmetric sweep instead of sixteen; a different (still symmetric positive definite) smoother — see DESIGN.md §7 */
+    int32_t reserved[2];
 } hot_config;
 
 typedef struct hot_stats {

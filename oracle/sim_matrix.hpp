@@ -514,7 +514,11 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
         // particles first touch it); after each colour the owners' values are handed to everybody (colour-synchronous: the
         // sequence of updates every node sees is the single-rank one).  The exchange here is the simplest possible: an all-reduce
         // of a vector that is zero off the rank's own blocks.
+        // hot_config.shard_gs = 1 (processor-block GS): no hand-off between the colours — a rank's rows see the other ranks' unknowns as
+        // the zeros the sweep started from, i.e. the sweep is the symmetric GS of the rank's own diagonal block of A — and ONE exchange of
+        // du after the backward sweep.  The couplings across ranks enter through the residual update r -= A du below (full rows).
         const bool part = partitioned(level);
+        const bool rank_local = part && cfg.shard_gs != 0;
         auto mine = [&](const std::vector<int>& blockNodes) { return !part || owner_of(level, blockNodes[0]) == comm.rank; };
         auto exchange_colour = [&](std::vector<TV>& x, int c) {
             if (!part) return;
@@ -544,7 +548,7 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
                         hdu[i] = A.diagonalBlock[i] * (r[i] - sigma);
                     }
                 }
-                exchange_colour(hdu, c);
+                if (!rank_local) exchange_colour(hdu, c);
             }
             HOT_FAIR_FOR
             for (int i = 0; i < n; ++i) hdu[i] = A.diagonalVal[i] * hdu[i];
@@ -564,7 +568,14 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
                         du[i] = A.diagonalBlock[i] * (hdu[i] - sigma);
                     }
                 }
-                exchange_colour(du, c);
+                if (!rank_local) exchange_colour(du, c);
+            }
+            if (rank_local) { // the one hand-off of a rank-local symmetric sweep: every rank's du (zero off its own blocks) summed
+                std::vector<T> buf((size_t)n * 3);
+                for (int i = 0; i < n; ++i)
+                    for (int d = 0; d < 3; ++d) buf[3 * (size_t)i + d] = du[i](d);
+                allreduce(buf.data(), (int64_t)buf.size(), REAL);
+                for (int i = 0; i < n; ++i) du[i] = TV{ { buf[3 * (size_t)i], buf[3 * (size_t)i + 1], buf[3 * (size_t)i + 2] } };
             }
             HOT_FAIR_FOR
             for (int i = 0; i < n; ++i) u[i] += du[i];

@@ -36,6 +36,28 @@ def test_one_body_over_ranks_hip(hotlib, oracle, world, n, dtype, kw, minrows, t
         assert calls["alltoallv"] > 0  # partial Hessian rows crossed the shard boundary
 
 
+@pytest.mark.parametrize("world,n,kw,minrows", [
+    (2, 8, dict(lsolver=3, levelCnt=3, max_iterations=5, cneps=1e-7, shard_gs=1), 1),
+    (3, 10, dict(lsolver=3, levelCnt=3, max_iterations=4, cneps=1e-7, shard_gs=1, gs_sub_block=32), 200),
+], ids=["two_ranks_all_partitioned", "three_ranks_mixed_half_blocks"])
+def test_rank_local_gs_over_ranks_hip_against_oracle(world, n, kw, minrows):
+    """hot_config.shard_gs = 1 (processor-block GS, one exchange per symmetric sweep): not the single-rank iterates, so the partner
+    is the CPU oracle run the same way on the same number of ranks: dv after a fixed number of iterations, one V-cycle and the
+    counters agree to round-off, and the replicated data is bit-identical across the HIP ranks."""
+    hip = mw.launch(world, "hip", n, 1, kw, partition_min_rows=minrows)
+    cpu = mw.launch(world, "oracle", n, 1, kw, partition_min_rows=minrows)
+    for r in hip[1:]:
+        assert np.array_equal(r["dv"], hip[0]["dv"]) and np.array_equal(r["vcycle"], hip[0]["vcycle"])
+    assert np.array_equal(hip[0]["id2coord"], cpu[0]["id2coord"])
+    for k in ("iterations", "linesearch_trials", "vcycles", "linear_iterations", "dropped_pairs"):
+        assert hip[0]["stats"][k] == cpu[0]["stats"][k], (k, hip[0]["stats"], cpu[0]["stats"])
+    assert mw.rel(hip[0]["vcycle"], cpu[0]["vcycle"]) < 1e-10
+    assert mw.rel(hip[0]["dv"], cpu[0]["dv"]) < 1e-9
+    exact = mw.launch(world, "hip", n, 1, dict(kw, shard_gs=0), partition_min_rows=minrows)
+    assert mw.rel(hip[0]["vcycle"], exact[0]["vcycle"]) > 1e-6  # it IS a different smoother
+    assert hip[0]["comm_calls"]["allgather"] < 0.6 * exact[0]["comm_calls"]["allgather"], (hip[0]["comm_calls"], exact[0]["comm_calls"])
+
+
 def test_whole_steps_over_ranks_with_migration_hip(hotlib):
     """Four whole time steps on three ranks: the body falls and spins, particles change SPGrid pages every step and are handed to
     the rank of their page range at each hot_sort (hot_amd/csrc/shard.hip migrate_particles); the union of the ranks' particles,

@@ -37,6 +37,33 @@ def test_one_body_three_ranks_whole_steps_gloo_oracle():
     mw.compare(ranks, ref, 1e-9, tolp=1e-8, exact_counts=False)
 
 
+def test_rank_local_gs_two_and_three_ranks_gloo_oracle():
+    """hot_config.shard_gs = 1 (processor-block GS: a rank's coloured sweeps see only its own rows, one exchange per symmetric sweep
+    instead of sixteen).  It is a different smoother, so the iterates are not the single-rank ones; what must hold: every rank still
+    computes identical replicated data, the solve converges to the same minimiser (dv within the termination tolerance's reach),
+    the number of L-BFGS iterations stays within 12 % of the colour-synchronous run on this small body (8^3 cells cut in 2 or 3: most nodes
+    sit next to a cut; DESIGN.md §7 has the measured drift at larger sizes), and the collectives per V-cycle drop."""
+    from tests import multirank_worker as mw
+    from tests.oracle_lib import load_oracle
+    kw = dict(lsolver=3, levelCnt=3, cneps=1e-10, max_iterations=400)
+    ref = mw.single(load_oracle(), 8, 1, kw)
+    exact = mw.launch(2, "oracle", 8, 1, kw)
+    assert exact[0]["stats"]["iterations"] == ref["stats"]["iterations"] and ref["stats"]["converged"] == 1
+    for world in (2, 3):
+        ranks = mw.launch(world, "oracle", 8, 1, dict(kw, shard_gs=1))
+        st = ranks[0]["stats"]
+        for r in ranks[1:]:
+            assert np.array_equal(r["dv"], ranks[0]["dv"]) and r["stats"]["iterations"] == st["iterations"]  # replicated decisions
+        assert st["converged"] == 1
+        drift = st["iterations"] - ref["stats"]["iterations"]
+        print("rank-local GS, %d ranks: %d L-BFGS iterations (colour-synchronous / single rank: %d), collectives %s (colour-synchronous, 2 ranks: %s)"
+              % (world, st["iterations"], ref["stats"]["iterations"], ranks[0]["comm_calls"], exact[0]["comm_calls"]))
+        assert abs(drift) <= 0.12 * ref["stats"]["iterations"], (st["iterations"], ref["stats"]["iterations"])
+        assert mw.rel(ranks[0]["dv"], ref["dv"]) < 1e-3, mw.rel(ranks[0]["dv"], ref["dv"])  # both stopped by the same test at cneps = 1e-10 (measured 7e-5; 5e-2 at cneps = 1e-7)
+        if world == 2:  # (the CPU engine hands a colour over with an all-reduce)
+            assert ranks[0]["comm_calls"]["allreduce"] < 0.5 * exact[0]["comm_calls"]["allreduce"]
+
+
 def test_shard_by_page_order_partitions_in_sort_order():
     from hot_amd import dist as hdist, synth
     from tests.oracle_lib import load_oracle
