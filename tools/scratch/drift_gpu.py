@@ -1,9 +1,20 @@
+"""Iteration drift of the rank-local (processor-block) GS against the colour-synchronous one: PN + MG-PCG, 6 Newton steps, outer PCG
+iterations (= V-cycles).  Ranks share the one GPU of the test box (gloo).  python tools/scratch/drift_gpu.py <cells> <ranks> <partition_min_rows>"""
 import sys
 sys.path.insert(0, "/root/repo")
 from tests import multirank_worker as mw
-import hot_amd
-n = int(sys.argv[1]); world = int(sys.argv[2])
-kw = dict(lsolver=3, levelCnt=3, cneps=1e-7, max_iterations=400)
-ref = mw.single(hot_amd.load(), n, 1, kw)
-r = mw.launch(world, "hip", n, 1, dict(kw, shard_gs=1), partition_min_rows=1)
-print("n", n, "world", world, "single", ref["stats"]["iterations"], "rank-local", r[0]["stats"]["iterations"], "rel dv", mw.rel(r[0]["dv"], ref["dv"]), "allgathers", r[0]["comm_calls"]["allgather"], flush=True)
+
+
+def main():
+    n, world, minrows = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    kw = dict(lsolver=2, levelCnt=3, cneps=1e-8, max_iterations=6)
+    out = []
+    for mode in (0, 1):
+        r = mw.launch(world, "hip", n, 1, dict(kw, shard_gs=mode), partition_min_rows=minrows, timeout=280)
+        s = r[0]["stats"]
+        out.append((s["vcycles"], s["linear_iterations"], r[0]["comm_calls"]["allgather"]))
+    print("n", n, "ranks", world, "V-cycles / top-level PCG iterations / all-gathers: colour-synchronous", out[0], "rank-local", out[1], flush=True)
+
+
+if __name__ == "__main__":
+    main()
