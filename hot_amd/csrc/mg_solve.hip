@@ -664,6 +664,29 @@ __device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int3
 //   3. gathers the remaining columns, reduces the row sums, runs phase B, publishes (write-through stores, then the stamp).
 // Progress: workgroups are dispatched in index order (per XCD), so every workgroup a resident one waits for has been
 // dispatched before it and waits on nothing itself that is not; the spin is bounded anyway and reports through `err`.
+// "not written yet in this half sweep": signalling-NaN payloads that no arithmetic result carries (a computed NaN is the canonical quiet one)
+template <class T>
+struct GsUnset;
+template <>
+struct GsUnset<double> {
+    static constexpr unsigned long long bits = 0x7ff4dead0badf00dull;
+    static __device__ __forceinline__ bool is(double v) { return (unsigned long long)__double_as_longlong(v) == bits; }
+};
+template <>
+struct GsUnset<float> {
+    static constexpr unsigned bits = 0x7fa0f00du;
+    static __device__ __forceinline__ bool is(float v) { return (unsigned)__float_as_int(v) == bits; }
+};
+template <class T>
+__global__ void k_gs_fill_unset(size_t n, T* x)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if constexpr (sizeof(T) == 8)
+        ((unsigned long long*)x)[i] = GsUnset<double>::bits;
+    else
+        ((unsigned*)x)[i] = GsUnset<float>::bits;
+}
 struct GsPasses {
     int npass;
     int wg_begin[34]; // first workgroup of pass p ; wg_begin[npass] = grid size
@@ -675,11 +698,30 @@ struct GsPasses {
 template <class T, bool FWD, int SB>
 __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
     const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, GsPasses P,
-    const int32_t* __restrict__ rowcnt, int* done, int* err, const int32_t* __restrict__ nbr, int* flag, int epoch)
+    const int32_t* __restrict__ rowcnt, int* done, int* err, const int32_t* __restrict__ nbr, int* flag, int epoch, int dataflag)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     constexpr int TRI = GsLds<T, SB>::TRI;
     constexpr int RQ = 4, NW = SB / RQ; // rows per wave, waves per workgroup (blockDim.x == 64 * NW)
+    // dataflag: the unknowns are their own flags.  The host fills x with a bit pattern no computation produces (GsUnset) before the
+    // sweep; a reader of another block's unknown re-loads it until it is something else.  No flag array, no "data, wait for the
+    // acknowledgement, flag" on the producer's side and no "flag, then data" round trip on the consumer's: a value is used the
+    // moment it lands.  Every node is written exactly once per half sweep, so no stale value can be mistaken for a new one.
+    auto ld3 = [&](int64_t j, T& x0, T& x1, T& x2) {
+        x0 = __hip_atomic_load(x + 3 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(x + 3 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+        x2 = __hip_atomic_load(x + 3 * j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!dataflag) return;
+        int spins = 0;
+        while (GsUnset<T>::is(x0) || GsUnset<T>::is(x1) || GsUnset<T>::is(x2)) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 21) || ((spins & 1023) == 0 && *(volatile int*)err)) {
+                *(volatile int*)err = 1;
+                break;
+            }
+            x0 = __hip_atomic_load(x + 3 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(x + 3 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+            x2 = __hip_atomic_load(x + 3 * j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     T* tri = (T*)gs_smem; // [9][TRI]
     T* sv = tri + 9 * TRI; // [SB][3]
     int32_t* nodes = (int32_t*)(sv + 3 * SB);
@@ -783,7 +825,9 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
             }
         }
     };
-    if (nbr)
+    if (dataflag) {
+    }
+    else if (nbr)
         wait_blocks(early_idx);
     else if (p > 1 && tid == 0) {
         const int need2 = P.wg_begin[p - 1] - P.wg_begin[p - 2];
@@ -808,8 +852,8 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
         T e0 = 0, e1 = 0, e2 = 0;
         if (jj[q] >= 0 && !late[q]) {
             const int64_t j = jj[q];
-            const T x0 = __hip_atomic_load(x + 3 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(x + 3 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                    x2 = __hip_atomic_load(x + 3 * j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            T x0, x1, x2;
+            ld3(j, x0, x1, x2);
             e0 = bv[q][0] * x0 + bv[q][3] * x1 + bv[q][6] * x2;
             e1 = bv[q][1] * x0 + bv[q][4] * x1 + bv[q][7] * x2;
             e2 = bv[q][2] * x0 + bv[q][5] * x1 + bv[q][8] * x2;
@@ -832,8 +876,8 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
             else if (is_late(keyj))
                 tl = true;
             else {
-                const T x0 = __hip_atomic_load(x + 3 * (int64_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(x + 3 * (int64_t)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                        x2 = __hip_atomic_load(x + 3 * (int64_t)j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                T x0, x1, x2;
+                ld3(j, x0, x1, x2);
                 e0 += bb[0] * x0 + bb[3] * x1 + bb[6] * x2;
                 e1 += bb[1] * x0 + bb[4] * x1 + bb[7] * x2;
                 e2 += bb[2] * x0 + bb[5] * x1 + bb[8] * x2;
@@ -844,7 +888,7 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
         if (lane == 0) srhs[3 * ii] -= e0, srhs[3 * ii + 1] -= e1, srhs[3 * ii + 2] -= e2;
     }
     // ---- 2b. wait for the previous pass
-    {
+    if (!dataflag) {
         if (nbr)
             wait_blocks(late_idx);
         else if (p > 0 && tid == 0) {
@@ -873,8 +917,8 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
         T s0 = 0, s1 = 0, s2 = 0;
         if (jj[q] >= 0 && late[q]) {
             const int64_t j = jj[q];
-            const T x0 = __hip_atomic_load(x + 3 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(x + 3 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                    x2 = __hip_atomic_load(x + 3 * j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            T x0, x1, x2;
+            ld3(j, x0, x1, x2);
             s0 = bv[q][0] * x0 + bv[q][3] * x1 + bv[q][6] * x2;
             s1 = bv[q][1] * x0 + bv[q][4] * x1 + bv[q][7] * x2;
             s2 = bv[q][2] * x0 + bv[q][5] * x1 + bv[q][8] * x2;
@@ -886,8 +930,8 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
                 const uint32_t keyj = ckey[j], keyi = ckey[i];
                 const int l = (int)(keyj & 127u) - 1 - lo;
                 if (!((keyj >> 7) == (keyi >> 7) && l >= 0 && l < SB) && is_late(keyj)) {
-                    const T x0 = __hip_atomic_load(x + 3 * (int64_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(x + 3 * (int64_t)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                            x2 = __hip_atomic_load(x + 3 * (int64_t)j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    T x0, x1, x2;
+                    ld3(j, x0, x1, x2);
                     s0 += bb[0] * x0 + bb[3] * x1 + bb[6] * x2;
                     s1 += bb[1] * x0 + bb[4] * x1 + bb[7] * x2;
                     s2 += bb[2] * x0 + bb[5] * x1 + bb[8] * x2;
@@ -901,6 +945,7 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     if (w != 0) return;
     if (cnt > 0) gs_phase_b<T, FWD, SB, true>(tri, sv, nodes, cnt, lane, diagVal, diagBlockInv, x, hD, sD);
     // ---- publish: the write-through stores of every lane have left the CU before lane 0 bumps the pass counter
+    if (dataflag) return; // the write-through stores of phase B are the publication
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
         if (nbr)
@@ -1194,15 +1239,19 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             T* hD = fwd ? dAu : (simple_gs ? (T*)nullptr : u); // backward block kernels add du to u themselves
             // hand-off between passes: point-to-point block flags when a block is one sub-block (A/B switch: pass counters)
             const bool pass_counters = ab_flag("HOT_GS_PASS_COUNTERS");
+            const bool block_flags = ab_flag("HOT_GS_BLOCK_FLAGS"); // A/B build only: per-block sweep stamps instead of the unknowns being their own flags
             const bool p2p = !pass_counters;
-            if (p2p)
+            const int dataflag = (pass_counters || block_flags) ? 0 : 1;
+            if (dataflag)
+                HOT_LAUNCH(this, "gs_fill_unset", k_gs_fill_unset<T>, div_up(n3, 256), 256, 0, n3, xx);
+            else if (p2p)
                 ++gs_epoch;
             else
                 HOT_HIP(hipMemsetAsync(gs_done.p, 0, 40 * sizeof(int), stream));
             const int grid = P.wg_begin[P.npass];
 #define HOT_GS_CASE(F, S)                                                                                                                                              \
     HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_sweep<T, F, S>), grid, 16 * S, (GsLds<T, S>::bytes + 21 * S * sizeof(T)), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
-        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, P, rc, gs_done.p, (int*)(hscal + 250), p2p ? L.gs_nbr.p : (const int32_t*)nullptr, L.gs_flag.p, gs_epoch)
+        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, P, rc, gs_done.p, (int*)(hscal + 250), p2p ? L.gs_nbr.p : (const int32_t*)nullptr, L.gs_flag.p, gs_epoch, dataflag)
             if (fwd) {
                 if (sb == 64) HOT_GS_CASE(true, 64);
                 else if (sb == 32) HOT_GS_CASE(true, 32);

@@ -231,7 +231,7 @@ Ctx<T>::Ctx(const hot_config& c)
     dscal.reserve(256);
     red_part.reserve(4096), red_count.reserve(4);
     HOT_HIP(hipMemset(red_count.p, 0, 4 * sizeof(unsigned)));
-    HOT_HIP(hipHostMalloc((void**)&hscal, 256 * sizeof(double)));
+    HOT_HIP(hipHostMalloc((void**)&hscal, 256 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)); // fine-grained: kernels publish results and tickets here while they run (wait_ticket)
     std::memset(hscal, 0, 256 * sizeof(double)); // hscal[250] doubles as the device-written k_gs_sweep wait-timeout flag
     std::memset(&stats, 0, sizeof(stats));
 }
