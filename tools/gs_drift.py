@@ -1,5 +1,5 @@
 """Iteration drift of the rank-local (processor-block) GS against the colour-synchronous one: PN + MG-PCG, 6 Newton steps, outer PCG
-iterations (= V-cycles).  Ranks share the one GPU of the test box (gloo).  python tools/scratch/drift_gpu.py <cells> <ranks> <partition_min_rows>"""
+iterations (= V-cycles).  Ranks share the one GPU of the test box (gloo).  python tools/gs_drift.py <cells> <ranks> <partition_min_rows>"""
 import sys
 sys.path.insert(0, "/root/repo")
 from tests import multirank_worker as mw
