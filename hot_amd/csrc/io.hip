@@ -127,13 +127,17 @@ void Ctx<T>::read_restart(const char* path)
         const uint64_t nr = get<uint64_t>(in), rb = get<uint64_t>(in);
         in.seekg((std::streamoff)(nr * rb), std::ios::cur); // the ranges: one contiguous range is all this library writes
         const uint64_t cnt = get<uint64_t>(in), bytes = get<uint64_t>(in);
-        HOT_CHECK((int64_t)cnt == count && bytes % sizeof(T) == 0, HOT_ERR_INVALID, "hot_read_restart: array '" + name + "' has the wrong length or scalar type (the file was written with the other precision?)");
+        HOT_CHECK((int64_t)cnt == count && bytes % sizeof(T) == 0 && bytes <= 9 * sizeof(T), HOT_ERR_INVALID, "hot_read_restart: array '" + name + "' has the wrong length or scalar type (the file was written with the other precision?)");
         std::vector<T>& v = col[name];
         v.resize(cnt * (bytes / sizeof(T)));
         in.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(v.size() * sizeof(T)));
         HOT_CHECK(in.good(), HOT_ERR_INVALID, "hot_read_restart: truncated file");
     }
-    for (const char* k : { "m", "P", "V", "C", "F", "element measure", "mu", "lambda", "Jp" }) HOT_CHECK(col.count(k) == 1, HOT_ERR_INVALID, std::string("hot_read_restart: array missing: ") + k);
+    const std::pair<const char*, int> want[] = { { "m", 1 }, { "P", 3 }, { "V", 3 }, { "C", 9 }, { "F", 9 }, { "element measure", 1 }, { "mu", 1 }, { "lambda", 1 }, { "Jp", 1 } };
+    for (const auto& kw : want) {
+        HOT_CHECK(col.count(kw.first) == 1, HOT_ERR_INVALID, std::string("hot_read_restart: array missing: ") + kw.first);
+        HOT_CHECK((int64_t)col[kw.first].size() == count * kw.second, HOT_ERR_INVALID, std::string("hot_read_restart: array has the wrong width: ") + kw.first);
+    }
     set_particles(count, col["P"].data(), col["V"].data(), col["m"].data(), col["C"].data(), col["F"].data(), col["element measure"].data(), col["mu"].data(), col["lambda"].data(), col["Jp"].data());
 }
 

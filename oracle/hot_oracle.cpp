@@ -537,11 +537,14 @@ int hoto_read_restart(hoto_ctx* c, const char* path)
             std::string name(len, ' ');
             if (fread(&name[0], 1, len, f) != len || fread(&lg, 4, 1, f) != 1 || fread(&nr, 8, 1, f) != 1 || fread(&rb, 8, 1, f) != 1) { rc = HOT_ERR_INVALID; break; }
             fseek(f, (long)(nr * rb), SEEK_CUR);
-            if (fread(&cnt, 8, 1, f) != 1 || fread(&bytes, 8, 1, f) != 1 || (int64_t)cnt != n || bytes % sizeof(T)) { rc = HOT_ERR_INVALID; break; }
+            if (fread(&cnt, 8, 1, f) != 1 || fread(&bytes, 8, 1, f) != 1 || (int64_t)cnt != n || bytes % sizeof(T) || bytes > 9 * sizeof(T)) { rc = HOT_ERR_INVALID; break; }
             auto& v = col[name];
             v.resize(cnt * (bytes / sizeof(T)));
             if (fread(v.data(), sizeof(T), v.size(), f) != v.size()) rc = HOT_ERR_INVALID;
         }
+        const std::pair<const char*, int> want[] = { { "m", 1 }, { "P", 3 }, { "V", 3 }, { "C", 9 }, { "F", 9 }, { "element measure", 1 }, { "mu", 1 }, { "lambda", 1 }, { "Jp", 1 } };
+        for (const auto& kw : want)
+            if (rc == 0 && (!col.count(kw.first) || (int64_t)col[kw.first].size() != (int64_t)n * kw.second)) rc = HOT_ERR_INVALID;
         if (rc == 0 && col.size() == 9)
             S.set_particles(n, col["P"].data(), col["V"].data(), col["m"].data(), col["C"].data(), col["F"].data(), col["element measure"].data(), col["mu"].data(), col["lambda"].data(), col["Jp"].data());
         else

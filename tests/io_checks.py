@@ -70,4 +70,17 @@ def check_io(lib, dtype, tmp_path):
     a, b = ctx.get_particles(), ctx2.get_particles()
     for k in ("X", "V", "C", "F", "mu", "lam", "Jp"):
         assert np.array_equal(a[k], b[k]), k
+    # damaged files are refused with an error (no crash, no out-of-bounds read): truncated, wrong precision, absurd element width
+    from hot_amd.binding import HotError
+    import pytest
+    raw = open(pr, "rb").read()
+    bad = str(tmp_path / "bad.dat")
+    for blob in (raw[: len(raw) // 2], raw[:40], b"", raw[:12] + b"\xff" * 64 + raw[76:]):
+        open(bad, "wb").write(blob)
+        with pytest.raises(HotError):
+            lib.context(dtype=dtype, dx=c["dx"]).read_restart(bad)
+    with pytest.raises(HotError):
+        lib.context(dtype=1 - dtype, dx=c["dx"]).read_restart(pr)
+    with pytest.raises(HotError):
+        lib.context(dtype=dtype, dx=c["dx"]).read_restart(str(tmp_path / "does_not_exist.dat"))
     return open(pb, "rb").read(), open(pr, "rb").read()
