@@ -73,6 +73,26 @@ def test_whole_steps_over_ranks_with_migration_hip(hotlib):
     mw.compare(ranks, ref, 1e-7, tolp=1e-6, exact_counts=False)
 
 
+def test_whole_steps_rank_local_gs_with_migration_hip(hotlib):
+    """What `bench.py --gpus N` runs: whole time steps (sort with migration -> P2G -> solve to convergence -> G2P) with the
+    processor-block GS.  Not the single-rank iterates, but every step converges, the ranks stay balanced, the trajectory stays close to
+    the single-rank one (both solve each step to the same tolerance) and the iteration counts stay within 15 % (+2)."""
+    kw = dict(lsolver=3, levelCnt=2, cneps=1e-6)
+    ranks = mw.launch(3, "hip", 10, 1, dict(kw, shard_gs=1), steps=3, partition_min_rows=1)
+    ref = mw.single(hotlib, 10, 1, kw, steps=3)
+    assert all(o["stats"]["converged"] == 1 for o in ranks) and ref["stats"]["converged"] == 1
+    assert all(o["iterations"] == ranks[0]["iterations"] for o in ranks)
+    for a, b in zip(ranks[0]["iterations"], ref["iterations"]):
+        assert abs(a - b) <= 0.15 * b + 2, (ranks[0]["iterations"], ref["iterations"])
+    sizes = [len(o["ids"]) for o in ranks]
+    assert max(sizes) - min(sizes) < 0.25 * sum(sizes) / 3, sizes
+    ids = np.concatenate([o["ids"] for o in ranks])
+    assert np.array_equal(np.sort(ids), np.arange(len(ref["particles"]["X"])))  # every particle is held by exactly one rank
+    X = np.concatenate([o["particles"]["X"] for o in ranks])[np.argsort(ids)]
+    assert np.isfinite(X).all()
+    assert np.abs(X - ref["particles"]["X"]).max() < 1e-3 * 0.01 * 10  # a thousandth of the body's edge (10 cells of dx = 0.01)
+
+
 def test_whole_steps_over_two_ranks_hip(hotlib):
     kw = dict(lsolver=3, levelCnt=3, cneps=1e-6)
     ranks = mw.launch(2, "hip", 8, 1, kw, steps=2, partition_min_rows=1)
