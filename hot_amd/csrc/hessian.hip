@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_hessian(const T* __restrict__ X, const 
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int c = 0; c < 9; ++c) accm[s][c] = (T)0;
-    int cur[3] = { -1 << 30, 0, 0 };
+    int cur[3] = { -(1 << 30), 0, 0 };
     bool have_cell = false;
 
     auto flush = [&]() {
