@@ -604,7 +604,7 @@ void Ctx<T>::solve(hot_stats* st)
     prof.collect();
     stats.num_nodes = Nn;
     stats.num_levels = (int)levels.size();
-    stats.energy = Ek;
+    stats.energy = cfg.linesearch ? Ek : 0.0; // the incremental potential at the last accepted line-search point; without a line search nobody evaluates it there (ImplicitSolver.h:237-252)
     stats.ms_solve = wall_ms() - t0;
     if (st) *st = stats;
 }

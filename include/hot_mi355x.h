@@ -93,7 +93,7 @@ typedef struct hot_stats {
     int32_t num_nodes;
     int32_t num_levels;
     double final_scaled_residual; /* sqrt(sum |r_i|^2/tol_i^2 / Nn) if useCN else |r|_2 */
-    double energy;
+    double energy; /* incremental potential at the last accepted line-search point (0 when cfg.linesearch == 0: nothing evaluates it then) */
     double ms_sort, ms_p2g, ms_begin, ms_hessian, ms_mg_build, ms_solve, ms_g2p, ms_total; /* host wall clock, device-synchronised */
 } hot_stats;
 
