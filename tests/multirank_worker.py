@@ -11,8 +11,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def scene(n, dtype, cells=None):
+    """n > 0: a solid cube of n^3 cells.  n < 0: an irregular body carved out of a |n|^3 cube — a hollow ball with a bar through it and
+    random holes (cells with few or no particles, ragged colour blocks, coarse levels with gaps), 8 or 2 particles per cell by octant."""
     from hot_amd import synth
-    return synth.cube_cloud(n, ppc=8, dtype=np.float64 if dtype == 1 else np.float32, cells=cells)
+    c = synth.cube_cloud(abs(n), ppc=8, dtype=np.float64 if dtype == 1 else np.float32, cells=cells)
+    if n > 0:
+        return c
+    X = c["X"].astype(np.float64)
+    ctr = X.mean(0)
+    r = np.linalg.norm(X - ctr, axis=1)
+    ext = (X.max(0) - X.min(0)).min()
+    keep = ((r < 0.48 * ext) & (r > 0.2 * ext)) | ((np.abs(X[:, 0] - ctr[0]) < 0.012) & (np.abs(X[:, 1] - ctr[1]) < 0.012))
+    rng = np.random.default_rng(17)
+    keep &= (rng.random(len(X)) < 0.25) | (X[:, 2] > ctr[2])  # thinned lower half
+    return {k: (v[keep] if isinstance(v, np.ndarray) else v) for k, v in c.items()}
 
 
 def run_case(lib, cloud, comm, cfgkw, steps, dt=1.0 / 24):

@@ -26,6 +26,17 @@ def test_one_body_two_ranks_gloo_oracle(kw):
     assert ranks[0]["comm_calls"]["allreduce"] > 0 and ranks[0]["comm_calls"]["allgather"] > 0
 
 
+def test_irregular_body_three_ranks_gloo_oracle():
+    """A hollow ball with a bar through it and a thinned half, cut into three shards: ragged colour blocks, uneven colours, coarse
+    levels with gaps, rows near the cuts assembled from two ranks' particles."""
+    from tests import multirank_worker as mw
+    from tests.oracle_lib import load_oracle
+    kw = dict(lsolver=3, levelCnt=3, max_iterations=3, cneps=1e-7)
+    ranks = mw.launch(3, "oracle", -10, 1, kw)
+    ref = mw.single(load_oracle(), -10, 1, kw)
+    mw.compare(ranks, ref, 1e-11)
+
+
 def test_one_body_three_ranks_whole_steps_gloo_oracle():
     """Two whole time steps (sort -> P2G -> solve to convergence -> G2P) on three ranks: same iteration counts, same particles."""
     from tests import multirank_worker as mw
