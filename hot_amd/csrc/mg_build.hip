@@ -551,6 +551,7 @@ void Ctx<T>::build_mg()
         need(k == 0 || k == 1 || k == 2 || k == 5 || k == 6, "smoother/coarseSolver must be 0, 1, 2, 5 or 6 (7 = Eigen IncompleteCholesky: not built; 3/4 are not selectable in the reference either)");
     const bool baseline = cfg.useBaselineMultigrid != 0;
     if (baseline) {
+        need(!sharded(), "useBaselineMultigrid is a single-rank mode: its coarse levels are whole MPM grids re-rasterised from ALL particles (hot_set_comm with size > 1 is not supported with it)");
         need(cfg.Ainv == 1, "useBaselineMultigrid scales with the inverse diagonal blocks (MultigridSimulation.inl:446): set Ainv = 1");
         need(!cfg.topDownMGS, "useBaselineMultigrid fixes the V-cycle schedule (MultigridSimulation.inl:447-454); topDownMGS does not apply");
     }
