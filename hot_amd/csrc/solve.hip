@@ -171,17 +171,20 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
         HOT_LAUNCH(this, "linesearch_combine", k_combine<T>, div_up(n3, 256), 256, 0, n3, dv0.p, alpha, ddv, dvnew);
         copy(n3, dvnew, dv.p); // moveNodes
         Ek = state_pass(dv.p, false); // a trial needs the energy only; the force is rasterised once, at the accepted point
-        if (!(Ek == Ek)) {
-            // diagnostics for the error message: is the search direction itself already non-finite?
-            double dd = dot_host(n3, ddv, ddv), d0 = dot_host(n3, dv0.p, dv0.p);
-            char msg[256];
-            snprintf(msg, sizeof(msg), "NaN energy in line search (iteration %d, trial %d, alpha %g, |direction|^2 %g, |dv|^2 %g, E0 %g)", stats.iterations, guard, (double)alpha, dd, d0, Ek0);
-            HOT_CHECK(false, HOT_ERR_NUMERIC, msg);
-        }
         stats.linesearch_trials++;
         alpha *= (T)0.5;
         if (ab_flag("HOT_DEBUG")) fprintf(stderr, "[hot]   linesearch alpha=%g Ek=%.12e Ek0=%.12e\n", (double)alpha * 2, Ek, Ek0);
-    } while (Ek > Ek0 && ++guard < 60);
+        // `Ek > Ek0` in the reference (ImplicitSolver.h:325), written so that a NaN energy — an exploded L-BFGS direction in float puts
+        // the trial point outside anything representable — is a rejection like any other and the step is halved; the reference would
+        // end the search there with NaN accepted.  Identical for every finite energy.
+    } while (!(Ek <= Ek0) && ++guard < 60);
+    if (!(Ek == Ek)) {
+        // sixty halvings and still no number: is the search direction itself non-finite?
+        double dd = dot_host(n3, ddv, ddv), d0 = dot_host(n3, dv0.p, dv0.p);
+        char msg[256];
+        snprintf(msg, sizeof(msg), "NaN energy in line search (iteration %d, after %d halvings, |direction|^2 %g, |dv|^2 %g, E0 %g)", stats.iterations, guard, dd, d0, Ek0);
+        HOT_CHECK(false, HOT_ERR_NUMERIC, msg);
+    }
     alpha *= 2;
     HOT_LAUNCH(this, "scal", k_scal<T>, div_up(n3, 256), 256, 0, n3, alpha, ddv);
     transform_dev(ddv, false); // transformResidual

@@ -50,13 +50,17 @@ T Sim<T>::line_search(std::vector<TV>& ddv, std::vector<TV>& residual, T alpha)
     std::vector<TV> dvnew(ddv.size());
     recover_solution(ddv);
     double Ek0 = Ek;
+    int guard = 0;
     do {
         HOT_FAIR_FOR
         for (size_t i = 0; i < ddv.size(); ++i) dvnew[i] = dv0[i] + ddv[i] * alpha;
         update_state(dvnew);
         stats.linesearch_trials++;
         alpha *= (T)0.5;
-    } while (Ek > Ek0);
+        // `Ek > Ek0` in the reference.  Written so that a NaN energy (an exploded L-BFGS direction in float: the trial point is
+        // outside anything representable) counts as a rejection and the step is halved, instead of ending the search with NaN
+        // accepted; identical for every finite energy.  At most 60 halvings (2^-60 of the step is no step).
+    } while (!(Ek <= Ek0) && ++guard < 60);
     alpha *= 2;
     HOT_FAIR_FOR
     for (size_t i = 0; i < ddv.size(); ++i) ddv[i] = ddv[i] * alpha;

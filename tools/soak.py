@@ -10,10 +10,12 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 lib = hot_amd.load()
 cfg = dict(synth.CONFIGS[name])
 cloud = parallel.shard_cloud(cfg, 0, 1, n=cfg["n"])
-ctx = bench.make_ctx(lib, cloud, cfg)
+over = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("HOT_SOAK_CFG", "").split(",") if kv)}  # e.g. HOT_SOAK_CFG=gs_chain=1
+ctx = bench.make_ctx(lib, cloud, cfg, **over)
 its, ms = [], []
 for s in range(steps):
     st = ctx.advance(cfg["dt"])
+    print("step", s, "iterations", st["iterations"], "trials", st["linesearch_trials"], "dropped", st["dropped_pairs"], "E %.6g" % st["energy"], "ms %.1f" % st["ms_total"], flush=True)
     assert st["converged"] == 1, (s, st)
     its.append(st["iterations"]), ms.append(st["ms_total"])
 p = ctx.get_particles()
