@@ -70,6 +70,18 @@ def check_io(lib, dtype, tmp_path):
     a, b = ctx.get_particles(), ctx2.get_particles()
     for k in ("X", "V", "C", "F", "mu", "lam", "Jp"):
         assert np.array_equal(a[k], b[k]), k
+    # ... and steps on identically: the file holds the complete particle state (the grid is rebuilt from it every step)
+    from hot_amd import synth as _synth
+    o, nrm = _synth.sticky_floor(5.0, c["dx"])
+    sts = []
+    for cx in (ctx, ctx2):
+        cx.set_sticky_halfspaces(o, nrm)
+        sts.append(cx.advance(1.0 / 24))
+    a, b = ctx.get_particles(), ctx2.get_particles()
+    assert sts[0]["iterations"] == sts[1]["iterations"]
+    tol = 1e-12 if dtype == 1 else 1e-5
+    for k in ("X", "V", "F"):
+        assert np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() <= tol * max(1.0, np.abs(a[k]).max()), k
     # damaged files are refused with an error (no crash, no out-of-bounds read): truncated, wrong precision, absurd element width
     from hot_amd.binding import HotError
     import pytest

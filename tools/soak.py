@@ -9,7 +9,8 @@ name = sys.argv[1] if len(sys.argv) > 1 else "C2"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 lib = hot_amd.load()
 cfg = dict(synth.CONFIGS[name])
-cloud = parallel.shard_cloud(cfg, 0, 1, n=cfg["n"])
+ncells = int(os.environ.get("HOT_SOAK_CELLS", cfg["n"]))  # e.g. a per-GPU share of C4 / C5
+cloud = parallel.shard_cloud(cfg, 0, 1, n=ncells)
 over = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("HOT_SOAK_CFG", "").split(",") if kv)}  # e.g. HOT_SOAK_CFG=gs_chain=1
 ctx = bench.make_ctx(lib, cloud, cfg, **over)
 its, ms = [], []
