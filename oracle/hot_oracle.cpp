@@ -89,11 +89,14 @@ void hoto_default_config(hot_config* c)
     c->snow[0] = 10, c->snow[1] = 2e-2, c->snow[2] = 7.5e-3, c->snow[3] = 0.6, c->snow[4] = 20;
 }
 
+void hoto_set_wide(int on) { hot_oracle::wide_flag() = on != 0; } // tests/oracle_lib.py wide_sums(): restore the process-wide flag
+
 int hoto_create(const hot_config* cfg, hoto_ctx** out)
 {
     hoto_ctx* c = new hoto_ctx;
     c->dtype = cfg->dtype;
     hot_oracle::fair_flag() = getenv("HOT_ORACLE_FAIR") != nullptr; // CPU-baseline variant (sim_core.hpp), timing only
+    hot_oracle::wide_flag() = getenv("HOT_ORACLE_WIDE") != nullptr; // fp32: node sums and dot products accumulated in double (sim_core.hpp)
     DISPATCH(c, {
         auto* s = new Sim<T>();
         s->cfg = *cfg;

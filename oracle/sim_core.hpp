@@ -37,6 +37,18 @@ inline bool& fair_flag()
 }
 #define HOT_FAIR_FOR _Pragma("omp parallel for schedule(static) if (hot_oracle::fair_flag())")
 
+// "wide sums" variant (HOT_ORACLE_WIDE=1 at hoto_create; a no-op for T = double): every node sum of a particle scatter (P2G mass /
+// momentum, force, CN tolerance, Hessian blocks, matrix-free block diagonal) and every dot product / norm is accumulated in double
+// and rounded to T once, instead of in T like the reference (MpmSimulationBase.cpp:611-656 adds floats into GridState<float>; the
+// energy is double in the reference too, MpmForceBase.cpp:355-364).  The HIP library's fp32 build does the same by construction (its
+// LDS node tiles and grid reductions are double, hot_common.h AccT / grid_sum_store), so against this variant the fp32 parity bound
+// measures the kernels and not the summation type.  The default (narrow) variant stays the restatement of the reference.
+inline bool& wide_flag()
+{
+    static bool f = false;
+    return f;
+}
+
 template <class T>
 struct EllMat { // reference Projects/multigrid/SquareMatrix.h:27-34
     int colsize = 0, nrows = 0;
@@ -117,6 +129,9 @@ struct Sim {
     std::vector<std::array<int, 8>> group_nb; // block ids of the 2x2x2 pages each group scatters into
     // ---- grid
     std::vector<Node> nodes; // blocks.size()*EPB, block-major, memory order inside a block
+    std::vector<double> wacc; // wide-sums variant: double shadow of the node quantity being scattered (slot-major)
+    static constexpr bool IS_F32 = sizeof(T) == 4;
+    bool wide() const { return IS_F32 && wide_flag(); }
     int num_nodes = 0;
     std::vector<int> dof_slot;
     std::vector<std::array<int, 3>> id2coord;
@@ -417,6 +432,8 @@ struct Sim {
     // reference MpmSimulationBase.cpp:611-656 (particlesToGridHelper<true,false>) + :521-532
     void particles_to_grid()
     {
+        const bool wd = wide();
+        if (wd) wacc.assign(nodes.size() * 4, 0.0);
         for_each_particle_colored([&](int g, int i) {
             const TV& Xp = X[i];
             T m = mass[i];
@@ -428,10 +445,19 @@ struct Sim {
                 TV d{ { node[0] * dx - Xp(0), node[1] * dx - Xp(1), node[2] * dx - Xp(2) } };
                 // velocity_delta = [C m | m v ; 0 | m] * [xi - xp ; 1] * w
                 TV dvel = (Cm * d + momentum) * w;
+                if (wd) {
+                    double* a = &wacc[(size_t)(&gs - nodes.data()) * 4];
+                    a[0] += (double)(m * w), a[1] += (double)dvel(0), a[2] += (double)dvel(1), a[3] += (double)dvel(2);
+                    return;
+                }
                 gs.m += m * w;
                 gs.v += dvel;
             });
         });
+        if (wd) {
+#pragma omp parallel for schedule(static)
+            for (size_t s = 0; s < nodes.size(); ++s) nodes[s].m = (T)wacc[4 * s], nodes[s].v = TV{ { (T)wacc[4 * s + 1], (T)wacc[4 * s + 2], (T)wacc[4 * s + 3] } };
+        }
         if (sharded()) { // sum the shards' partial node masses / momenta (every rank then numbers the same nodes)
             std::vector<T> buf(nodes.size() * 4);
             for (size_t s = 0; s < nodes.size(); ++s) buf[4 * s] = nodes[s].m, buf[4 * s + 1] = nodes[s].v(0), buf[4 * s + 2] = nodes[s].v(1), buf[4 * s + 3] = nodes[s].v(2);

@@ -96,14 +96,25 @@ template <class T>
 void Sim<T>::rasterize_force(T scale, std::vector<TV>& force)
 {
     iterate_grid([&](const int*, Node& g) { g.new_v = TV::zero(); });
+    const bool wd = wide();
+    if (wd) wacc.assign(nodes.size() * 3, 0.0);
     for_each_particle_colored([&](int g, int i) {
         const TM& stress = scratch_stress[i];
         Spline s;
         compute_spline(X[i], s);
         iterate_kernel(s, g, particle_base_offset[i], [&](const int*, T w, const TV& dw, Node& gs) {
             TV delta = stress * dw; // fp == 0 for F-based MPM forces
+            if (wd) {
+                double* a = &wacc[(size_t)(&gs - nodes.data()) * 3];
+                for (int d = 0; d < 3; ++d) a[d] -= (double)(delta(d) * scale);
+                return;
+            }
             gs.new_v -= delta * scale;
         });
+    });
+    if (wd) iterate_grid([&](const int*, Node& g) {
+        const double* a = &wacc[(size_t)(&g - nodes.data()) * 3];
+        g.new_v = TV{ { (T)a[0], (T)a[1], (T)a[2] } };
     });
     if (sharded()) {
         std::vector<T> buf(nodes.size() * 3);
@@ -152,6 +163,8 @@ void Sim<T>::evaluate_cn_tolerance()
     }
     allreduce(&max_nrm, 1, REAL, HOT_COMM_MAX);
     max_cn_tolerance = (T)cfg.cneps * dt * 24 * std::sqrt((T)num_nodes) * dx * dx * max_nrm;
+    const bool wd = wide();
+    if (wd) wacc.assign(num_nodes, 0.0);
     for_each_particle_colored([&](int g, int i) {
         CorotatedScratch<T> s;
         corotated_update_scratch(TM::identity(), mu[i], lambda[i], proj, s);
@@ -164,9 +177,14 @@ void Sim<T>::evaluate_cn_tolerance()
         compute_spline(X[i], sp);
         iterate_kernel(sp, g, particle_base_offset[i], [&](const int*, T w, const TV&, Node& gs) {
             if (gs.idx < 0) return;
-            nodeCNTol[gs.idx] += w * mass[i] * nrm;
+            if (wd)
+                wacc[gs.idx] += (double)(w * mass[i] * nrm);
+            else
+                nodeCNTol[gs.idx] += w * mass[i] * nrm;
         });
     });
+    if (wd)
+        for (int n = 0; n < num_nodes; ++n) nodeCNTol[n] = (T)wacc[n];
     allreduce(nodeCNTol.data(), num_nodes, REAL);
     T eps = (T)cfg.cneps;
 #pragma omp parallel for schedule(static)

@@ -32,6 +32,9 @@ void Sim<T>::build_matrix()
     // force term
     T force_scale = dt * dt;
     bool proj = cfg.project != 0;
+    const bool wd = wide();
+    std::vector<double> wval; // wide-sums variant: the force term of every block in double, added to the inertia term and rounded once
+    if (wd) wval.assign((size_t)num_nodes * 125 * 9, 0.0);
     for_each_particle_colored([&](int g, int i) {
         CorotatedScratch<T> s;
         corotated_update_scratch(F[i], mu[i], lambda[i], proj, s);
@@ -69,15 +72,28 @@ void Sim<T>::build_matrix()
                 TM delta = dFdX * (force_scale * vol[i]);
                 size_t sij = (size_t)dofi * 125 + linear_offset125(cached_node[a][0] - cached_node[b][0], cached_node[a][1] - cached_node[b][1], cached_node[a][2] - cached_node[b][2]);
                 A.entryCol[sij] = dofj;
-                A.entryVal[sij] += delta;
+                if (wd)
+                    for (int k = 0; k < 9; ++k) wval[sij * 9 + k] += (double)delta.a[k];
+                else
+                    A.entryVal[sij] += delta;
                 if (dofi != dofj) {
                     size_t sji = (size_t)dofj * 125 + linear_offset125(cached_node[b][0] - cached_node[a][0], cached_node[b][1] - cached_node[a][1], cached_node[b][2] - cached_node[a][2]);
                     A.entryCol[sji] = dofi;
-                    A.entryVal[sji] += delta.transpose();
+                    TM dT = delta.transpose();
+                    if (wd)
+                        for (int k = 0; k < 9; ++k) wval[sji * 9 + k] += (double)dT.a[k];
+                    else
+                        A.entryVal[sji] += dT;
                 }
             }
         }
     });
+    if (wd) {
+#pragma omp parallel for schedule(static)
+        for (size_t e = 0; e < A.entryVal.size(); ++e)
+            for (int k = 0; k < 9; ++k) A.entryVal[e].a[k] = (T)((double)A.entryVal[e].a[k] + wval[e * 9 + k]);
+        std::vector<double>().swap(wval);
+    }
     if (sharded()) {
         allreduce(A.entryVal.data(), (int64_t)A.entryVal.size() * 9, REAL);
         allreduce(A.entryCol.data(), (int64_t)A.entryCol.size(), HOT_COMM_I32, HOT_COMM_MAX); // -1 where no rank's particle couples the pair
@@ -426,6 +442,11 @@ static inline T dot_product(const std::vector<V3<T>>& a, const std::vector<V3<T>
 {
     // reference dotProduct is a serial Eigen reduction (MultigridPreconditioner.h:155-158)
     T s = 0;
+    if (sizeof(T) == 4 && wide_flag()) { // wide-sums variant (sim_core.hpp): the products in T, their sum in double
+        double w = 0;
+        for (size_t i = 0; i < a.size(); ++i) w += (double)(a[i].a[0] * b[i].a[0]) + (double)(a[i].a[1] * b[i].a[1]) + (double)(a[i].a[2] * b[i].a[2]);
+        return (T)w;
+    }
     if (fair_flag()) {
 #pragma omp parallel for schedule(static) reduction(+ : s)
         for (size_t i = 0; i < a.size(); ++i) s += a[i].dot(b[i]);

@@ -29,6 +29,17 @@ void Sim<T>::precondition(const std::vector<TV>& in, std::vector<TV>& out)
 template <class T>
 bool Sim<T>::should_exit(const std::vector<TV>& residual)
 {
+    if (wide()) { // wide-sums variant (sim_core.hpp): per-node terms in T, their sum in double
+        double sn = 0;
+        for (int i = 0; i < num_nodes; ++i) sn += (double)(cfg.useCN ? residual[i].squaredNorm() / (nodeCNTol[i] * nodeCNTol[i]) : residual[i].squaredNorm());
+        if (!cfg.useCN) {
+            stats.final_scaled_residual = std::sqrt(sn);
+            return std::sqrt(sn) < cfg.cneps;
+        }
+        if (num_nodes == 0) return true;
+        stats.final_scaled_residual = std::sqrt(sn / num_nodes);
+        return sn < num_nodes;
+    }
     if (!cfg.useCN) {
         T ns = 0;
         for (int i = 0; i < num_nodes; ++i) ns += residual[i].squaredNorm();
@@ -268,6 +279,8 @@ void Sim<T>::compute_step(const std::vector<TV>& residual, std::vector<TV>& step
         HOT_FAIR_FOR
         for (int n = 0; n < num_nodes; ++n) diag[n] = (sharded() && comm.rank != 0) ? TM::zero() : TM::identity() * mass_matrix[n];
         bool proj = cfg.project != 0;
+        const bool wd = wide();
+        if (wd) wacc.assign((size_t)num_nodes * 9, 0.0);
         for_each_particle_colored([&](int g, int i) {
             CorotatedScratch<T> s;
             corotated_update_scratch(F[i], mu[i], lambda[i], proj, s);
@@ -284,9 +297,17 @@ void Sim<T>::compute_step(const std::vector<TV>& residual, std::vector<TV>& step
                     for (int v = 0; v < 3; ++v)
                         for (int r = 0; r < 3; ++r)
                             for (int c = 0; c < 3; ++c) dFdX(r, c) += ddF[(3 * v + r) + 9 * (3 * q + c)] * wi(v) * wi(q);
+                if (wd) {
+                    TM dl = dFdX * (dt * dt * vol[i]);
+                    for (int k = 0; k < 9; ++k) wacc[(size_t)gs.idx * 9 + k] += (double)dl.a[k];
+                    return;
+                }
                 diag[gs.idx] += dFdX * (dt * dt * vol[i]);
             });
         });
+        if (wd)
+            for (int n = 0; n < num_nodes; ++n)
+                for (int k = 0; k < 9; ++k) diag[n].a[k] = (T)((double)diag[n].a[k] + wacc[(size_t)n * 9 + k]);
         allreduce(diag.data(), (int64_t)num_nodes * 9, REAL);
         std::vector<TM> dinv(num_nodes);
         for (int n = 0; n < num_nodes; ++n) {

@@ -37,6 +37,27 @@ def raw():
     return load_oracle().lib
 
 
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def wide_sums(on=True):
+    """Oracle contexts CREATED AND USED inside this block run the "wide sums" variant (oracle/sim_core.hpp wide_flag): fp32 node sums
+    of the particle scatters and all dot products are accumulated in double and rounded once — what the HIP library's fp32 build does
+    by construction — instead of in float like the reference.  The flag is process-wide in the oracle: it is read when a context is
+    created and consulted while it runs, so do not interleave wide and narrow contexts."""
+    old = os.environ.pop("HOT_ORACLE_WIDE", None)
+    if on:
+        os.environ["HOT_ORACLE_WIDE"] = "1"
+    try:
+        yield
+    finally:
+        os.environ.pop("HOT_ORACLE_WIDE", None)
+        if old is not None:
+            os.environ["HOT_ORACLE_WIDE"] = old
+        load_oracle().lib.hoto_set_wide(1 if old is not None else 0)
+
+
 def linear_offset(dtype, ijk):
     ijk = np.ascontiguousarray(ijk, np.int32).reshape(-1, 3)
     out = np.empty(len(ijk), np.uint64)

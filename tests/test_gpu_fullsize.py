@@ -56,6 +56,9 @@ FULL = {
     "C3": ("C3", 100),  # 8.0 M particles fp32, 3 levels
     "C4_per_gpu": ("C4", 79),  # 16 M fp64 over 4 GPUs -> 3.9 M per GPU, 4 levels
     "C5_per_gpu": ("C5", 100),  # 64 M fp32 over 8 GPUs -> 8.0 M per GPU, 3 levels
+    # the whole bodies of C4 / C5 as BASELINE.json states them, on ONE MI355X (they fit 288 GB: C4 ~ 45 GB, C5 ~ 85 GB):
+    "C4_full": ("C4", 126),  # 16.0 M particles fp64, 2.15 M nodes, 4 levels, von Mises 240 MPa
+    "C5_full": ("C5", 200),  # 64.0 M particles fp32, 8.30 M nodes, 3 levels, snow plasticity  (Nn * 125 < 2^31, Np < 2^26)
 }
 
 
@@ -150,7 +153,7 @@ def test_gs_colour_launch_equals_sub_block_launches(hotlib, cname, n):
     assert all(np.array_equal(a[0], y) for y in a[1:] + b)
 
 
-@pytest.mark.parametrize("name", ["C4_per_gpu", "C5_per_gpu"])
+@pytest.mark.parametrize("name", ["C4_per_gpu", "C5_per_gpu", "C4_full", "C5_full"])
 def test_fullsize_plastic_return_mapping(hotlib, name):
     """C4 / C5 with their return mapping (MultigridInit3D.h:3313-3331 von Mises, :3056-3061 snow) at the per-GPU size: G2P with
     the mapping switched on equals G2P without it followed by the oracle's element-wise projectStrain (PlasticityApplier.cpp:18-50,
