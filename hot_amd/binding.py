@@ -25,7 +25,7 @@ class hot_config(C.Structure):
         ("useCN", C.c_int32), ("project", C.c_int32), ("systemBCProject", C.c_int32), ("linesearch", C.c_int32),
         ("matrixFree", C.c_int32), ("boundaryType", C.c_int32), ("useAdaptiveHessian", C.c_int32),
         ("topDownMGS", C.c_int32), ("max_iterations", C.c_int32), ("plasticity", C.c_int32),
-        ("yield_stress", C.c_double), ("snow", C.c_double * 5), ("profile", C.c_int32), ("debug_store", C.c_int32), ("useBaselineMultigrid", C.c_int32), ("gs_chain", C.c_int32), ("gs_sub_block", C.c_int32), ("shard_gs", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("yield_stress", C.c_double), ("snow", C.c_double * 5), ("profile", C.c_int32), ("debug_store", C.c_int32), ("useBaselineMultigrid", C.c_int32), ("gs_chain", C.c_int32), ("gs_sub_block", C.c_int32), ("shard_gs", C.c_int32), ("shard_replicated", C.c_int32), ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -45,7 +45,7 @@ class hot_stats(C.Structure):
         ("num_nodes", C.c_int32), ("num_levels", C.c_int32), ("final_scaled_residual", C.c_double),
         ("energy", C.c_double), ("ms_sort", C.c_double), ("ms_p2g", C.c_double), ("ms_begin", C.c_double),
         ("ms_hessian", C.c_double), ("ms_mg_build", C.c_double), ("ms_solve", C.c_double), ("ms_g2p", C.c_double),
-        ("ms_total", C.c_double),
+        ("ms_total", C.c_double), ("comm_calls", C.c_int64), ("comm_bytes_index", C.c_int64), ("comm_bytes_data", C.c_int64),
     ]
 
     def as_dict(self):

@@ -256,7 +256,7 @@ void Ctx<T>::begin_step(double dt_)
     HOT_LAUNCH(this, "begin_step", k_begin<T>, div_up(Nn, 256), 256, 0, nodeV.p, bcIdx.p, bcDv.p, bcHasDv.p, dv.p, vn.p, dv0.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dt);
     HOT_HIP(hipMemcpyAsync(pFn.p, pF.p, 9 * (size_t)Np * sizeof(T), hipMemcpyDeviceToDevice, stream));
     updated = false;
-    release_levels();
+    release_levels(halo_mode() ? 1 : 0); // halo mode: level 0 (coordinates, row ownership, exchange lists) was set up by hot_p2g and lasts for the step
     stats.ms_begin = wall_ms() - t0;
 }
 
@@ -264,6 +264,7 @@ template <class T>
 void Ctx<T>::get_dv(void* out)
 {
     need(Nn > 0, "no grid");
+    if (halo_mode()) gather_all(*levels[0], dv.p); // the C ABI hands out complete vectors
     download(out, dv.p, 3 * (size_t)Nn);
     sync();
 }
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
             int base[3];
             T w[3][3], dw[3][3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+            for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xp[d]), base[d], w[d], dw[d]);
             const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
             T gv[9];
 #pragma unroll
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void k_force_scatter(const T* __restrict__ X, 
         int base[3];
         T w[3][3], dw[3][3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+        for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xp[d]), base[d], w[d], dw[d]);
         T S[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) S[c] = scale * stress[(int64_t)c * Np + p];
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(FORCE_THREADS) void k_force_cells(const T* __restri
             for (int d = 0; d < 3; ++d) {
                 int base;
                 T w[3], dw[3];
-                bspline<T>(one_over_dx * X[(int64_t)d * Np + p], base, w, dw);
+                bspline<T>(mul_rn(one_over_dx, X[(int64_t)d * Np + p]), base, w, dw);
                 sbase[d][tid] = base;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) sp[9 + 3 * d + q][tid] = w[q], sp[18 + 3 * d + q][tid] = dw[q];
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(FORCE_THREADS) void k_force_cells(const T* __restri
 }
 
 template <class T>
-__global__ __launch_bounds__(256) void k_inertia_energy(const T* __restrict__ dv, const T* __restrict__ mass, int nn, T g0, T g1, T g2, double* out, GridRed gr)
+__global__ __launch_bounds__(256) void k_inertia_energy(const T* __restrict__ dv, const T* __restrict__ mass, int nn, T g0, T g1, T g2, double* out, GridRed gr, const uint8_t* __restrict__ mask)
 {
     __shared__ double red[4];
     double ke = 0, ge = 0;
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(256) void k_inertia_energy(const T* __restrict__ dv
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (n0 + u * stride < nn) {
+            if (n0 + u * stride < nn && (!mask || mask[n0 + u * stride])) { // mask: the rows this rank owns (sharded, halo mode)
                 ke += (double)((a[u] * a[u] + b[u] * b[u] + c[u] * c[u]) * m[u]);
                 ge += (double)((g0 * a[u] + g1 * b[u] + g2 * c[u]) * m[u]);
             }
@@ -562,21 +563,30 @@ void Ctx<T>::force_pass()
 #endif
         HOT_LAUNCH(this, "force_scatter", k_force_cells<T>, Ng, FORCE_THREADS, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, (T)1 / dx, dt);
     reduce_tiles(3, gF.p, gF.p + slots, gF.p + 2 * slots, nullptr, nullptr, "force_reduce");
-    if (sharded()) allreduce_tiles(gF.p, 3);
+    if (halo_mode()) {
+        T* arr[3] = { gF.p, gF.p + slots, gF.p + 2 * slots };
+        tile_exchange(arr, 3); // the ranks that share a block add their partial forces; every block this rank covers is complete afterwards
+    }
+    else if (sharded())
+        allreduce_tiles(gF.p, 3);
 }
 
 template <class T>
 double Ctx<T>::state_pass(const T* dv_in, bool want_force)
 {
+    if (halo_mode()) halo_gather(*levels[0], const_cast<T*>(dv_in)); // dv at the nodes of this rank's particle tiles that other ranks own
     HOT_LAUNCH(this, "state_update", k_state<T>, Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, pFt.p, pStress.p, keep_debug ? pGradV.p : (T*)nullptr, Np, group_first.p, group_origin.p,
         group_nb.p, tileDof.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p, gred(Ng, hscal)); // the sums land in the pinned host slots too: one stream sync, no copy
     if (want_force) force_pass();
     {
         const int grid = std::min(div_up(Nn, 1024), 1024);
-        HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, grid, 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1, gred(grid, hscal + 1, true));
+        HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, grid, 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1, gred(grid, hscal + 1, true), vmask);
     }
     wait_ticket();
-    if (sharded()) c_allreduce(hscal, 1, HOT_COMM_F64, HOT_COMM_SUM, false); // the shards' strain energies; the inertia terms are computed from replicated vectors
+    if (halo_mode())
+        c_allreduce(hscal, 3, HOT_COMM_F64, HOT_COMM_SUM, false); // strain energy of the shards, inertia terms of the rows every rank owns
+    else if (sharded())
+        c_allreduce(hscal, 1, HOT_COMM_F64, HOT_COMM_SUM, false); // the shards' strain energies; the inertia terms are computed from replicated vectors
     double result = (double)(T)hscal[0];
     result += hscal[1] / 2;
     result -= (double)dt * hscal[2];
@@ -708,6 +718,7 @@ void Ctx<T>::residual(void* r)
 {
     need(Nn > 0 && dt > 0, "hot_residual before hot_begin_step/hot_update_state");
     residual_dev(work0.p);
+    if (halo_mode()) gather_all(*levels[0], work0.p); // the C ABI hands out complete vectors
     download(r, work0.p, 3 * (size_t)Nn);
     sync();
 }
@@ -767,6 +778,7 @@ void Ctx<T>::cn_tolerance(void* tol)
     need(Nn > 0 && dt > 0, "hot_cn_tolerance before hot_begin_step");
     need(cfg.useCN, "hot_cn_tolerance needs cfg.useCN (the accumulation is fused into P2G)");
     cn_tolerance_dev();
+    if (halo_mode()) gather_all(*levels[0], cnTol.p, 1);
     download(tol, cnTol.p, Nn);
     sync();
 }
@@ -801,7 +813,7 @@ __global__ __launch_bounds__(256) void k_matfree(const T* __restrict__ X, const 
         int base[3];
         T w[3][3], dw[3][3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+        for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xp[d]), base[d], w[d], dw[d]);
         const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
         Mat3<T> gx;
 #pragma unroll
@@ -861,10 +873,16 @@ void Ctx<T>::matfree_dev(const T* x, T* y)
     int64_t slots = (int64_t)Nb * EPB;
     DBuf<T>& tile = ap; // scratch tile array (3*slots); `ap` is otherwise only used while building the hierarchy
     tile.reserve(3 * slots);
+    if (halo_mode()) halo_gather(*levels[0], const_cast<T*>(x)); // x at the nodes of this rank's particle tiles
     HOT_LAUNCH(this, "matfree_hessian_product", k_matfree<T>, Ng, 256, 0, pX.p, pFn.p, pFt.p, pVol.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gIdx.p, x, gPart.p, dx,
         (T)1 / dx, dt, cfg.project);
     reduce_tiles(3, tile.p, tile.p + slots, tile.p + 2 * slots, nullptr, nullptr, "matfree_reduce");
-    if (sharded()) allreduce_tiles(tile.p, 3);
+    if (halo_mode()) {
+        T* arr[3] = { tile.p, tile.p + slots, tile.p + 2 * slots };
+        tile_exchange(arr, 3);
+    }
+    else if (sharded())
+        allreduce_tiles(tile.p, 3);
     HOT_LAUNCH(this, "matfree_finish", k_matfree_finish<T>, div_up(Nn, 256), 256, 0, tile.p, dofSlot.p, mass.p, x, y, Nn, slots);
 }
 template <class T>
@@ -873,6 +891,7 @@ void Ctx<T>::matfree_multiply(const void* x, void* y)
     need(Nn > 0 && dt > 0, "hot_matfree_multiply before hot_update_state");
     HOT_HIP(hipMemcpyAsync(work0.p, x, 3 * (size_t)Nn * sizeof(T), hipMemcpyDefault, stream));
     matfree_dev(work0.p, work1.p);
+    if (halo_mode()) gather_all(*levels[0], work1.p);
     download(y, work1.p, 3 * (size_t)Nn);
     sync();
 }

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_hessian(const T* __restrict__ X, const 
                 int base[3];
                 T w[3][3], dw[3][3];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+                for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xp[d]), base[d], w[d], dw[d]);
                 int i = tid / 9, j = (tid / 3) % 3, k = tid % 3;
                 T g0 = one_over_dx * dw[0][i] * w[1][j] * w[2][k], g1 = w[0][i] * one_over_dx * dw[1][j] * w[2][k], g2 = w[0][i] * w[1][j] * one_over_dx * dw[2][k];
                 // Fn^T g
@@ -309,7 +309,7 @@ void Ctx<T>::build_diagonal(Level<T>& L)
 {
     L.diagVal.reserve(9 * (size_t)L.n), L.diagInv.reserve(9 * (size_t)L.n), L.diagBlockInv.reserve(9 * (size_t)L.n);
     HOT_LAUNCH(this, "build_diagonal", k_diag<T>, div_up(L.n, 256), 256, 0, L.col.p, L.val.p, L.diagVal.p, L.diagInv.p, L.diagBlockInv.p, L.n, cfg.Ainv, L.split ? 0 : 1, L.mask());
-    if (L.part) // the diagonal blocks are used by the replicated vector algebra of the smoothers (scalers) as well: every rank gets all of them
+    if (L.part && !halo_mode()) // first-generation sharding: the diagonal blocks are used by the replicated vector algebra of the smoothers (scalers) as well: every rank gets all of them
         exchange(L, L.diagVal.p, -1, 9), exchange(L, L.diagInv.p, -1, 9), exchange(L, L.diagBlockInv.p, -1, 9);
 }
 
@@ -348,15 +348,19 @@ void Ctx<T>::build_hessian()
 {
     need(Nn > 0 && dt > 0, "hot_build_hessian before hot_update_state");
     double t0 = wall_ms();
-    release_levels();
-    Level<T>* L = acquire_level(0);
-    levels.push_back(L);
+    const bool keep0 = halo_mode() && !levels.empty() && levels[0]->halo.built && levels[0]->n == Nn; // halo mode: level 0 was set up by hot_p2g
+    release_levels(keep0 ? 1 : 0);
+    Level<T>* L = keep0 ? levels[0] : acquire_level(0);
+    if (!keep0) levels.push_back(L);
     L->n = Nn;
+    L->built = false, L->split = false;
     size_t ne = (size_t)Nn * 125;
     L->col.reserve(ne), L->val.reserve(ne * 9), L->coord.reserve(3 * (size_t)Nn);
-    HOT_HIP(hipMemcpyAsync(L->coord.p, id2coord.p, 3 * (size_t)Nn * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
-    L->part = false, L->colored = false;
-    if (sharded()) { // row ownership of level 0 (always partitioned): needs the colouring, which only reads the coordinates
+    if (!keep0) {
+        HOT_HIP(hipMemcpyAsync(L->coord.p, id2coord.p, 3 * (size_t)Nn * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+        L->part = false, L->colored = false;
+    }
+    if (sharded() && !keep0) { // row ownership of level 0 (always partitioned): needs the colouring, which only reads the coordinates
         L->nstart = nstart0;
         color_level(*L);
         level_ownership(*L);

@@ -137,6 +137,14 @@ __host__ __device__ inline int int_floor(T x)
 template <class T>
 __host__ __device__ inline int base_node(T x_index_space) { return int_floor<T>(x_index_space - (T)0.5); }
 
+// The index-space coordinate X / dx is a ROUNDED product in the reference (BSplineWeights::compute stores one_over_dx * X, takes its
+// floor and subtracts the floor from the stored value, BSplines.h:16-29, MpmGrid.h:55-78).  With -ffp-contract=fast the compiler would
+// fuse `one_over_dx * x - base` into one fma, i.e. keep the product exact: 3e-5 of a cell more accurate than the reference in float at
+// x / dx ~ 500, which is the whole fp32 single-pass deviation from the oracle (weights, grad v, stresses).  An explicitly rounded
+// multiply is never contracted.
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+
 // quadratic B-spline weights and derivatives of one axis: reference BSplines.h:55-81
 template <class T>
 __device__ inline void bspline(T x, int& base, T (&w)[3], T (&dw)[3])
@@ -255,6 +263,38 @@ __device__ inline void grid_sum_store(double t0, double t1, int nv, GridRed gr, 
             if (nv > 1) gr.mirror[1] = b;
             if (gr.ticket) host_ticket_store(gr.ticket, gr.ticket_val);
         }
+        __hip_atomic_store(gr.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The same for up to NVMAX sums per launch (the L-BFGS dot batches): deposits are laid out [k][workgroup]; `tot` holds the block
+// totals in thread 0.  gr.part must hold nv * gridDim.x doubles (Ctx::gred_n).
+template <int NVMAX>
+__device__ inline void grid_sum_store_n(const double (&tot)[NVMAX], int nv, GridRed gr, double* out, double* sm4)
+{
+    __shared__ int s_last_n;
+    const unsigned nb = gridDim.x;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NVMAX; ++k)
+            if (k < nv) __hip_atomic_store(gr.part + (size_t)k * nb + blockIdx.x, tot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(gr.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last_n = prev == nb - 1u;
+    }
+    __syncthreads();
+    if (!s_last_n) return; // workgroup-uniform
+    for (int k = 0; k < nv; ++k) {
+        double a = 0;
+        for (unsigned i = threadIdx.x; i < nb; i += 256) a += __hip_atomic_load(gr.part + (size_t)k * nb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a = block_sum_256<double>(a, sm4);
+        if (threadIdx.x == 0) {
+            out[k] = a;
+            if (gr.mirror) gr.mirror[k] = a;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (gr.mirror && gr.ticket) host_ticket_store(gr.ticket, gr.ticket_val);
         __hip_atomic_store(gr.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

@@ -57,6 +57,16 @@ struct Level {
     DBuf<int32_t> dxtab; // the same two tables on the device (xbeg | xcnt)
     int xmax_full = 0, xmax_col[8] = { 0 }; // largest per-rank counts (padded all-gather slots)
     const uint8_t* mask() const { return part ? own.p : nullptr; }
+    // ---- halo mode (hot_config.shard_replicated == 0): the entries of a DOF vector of this level this rank reads but does not own, and
+    // who owns them; both lists are ordered by (owner | reader, colour, position in gs_order), so one colour of a GS sweep is a sub-range
+    struct Halo {
+        bool built = false;
+        std::vector<int64_t> scnt, soff, rcnt, roff; // [ranks] nodes this rank sends to / receives from every peer, offsets into send / recv
+        std::vector<int64_t> scol, rcol; // [ranks * 9] colour segment offsets inside a peer's range
+        DBuf<int32_t> send, recv; // node ids
+        DBuf<uint8_t> need; // n: 1 = read here, owned elsewhere
+        int64_t stot = 0, rtot = 0;
+    } halo;
 };
 
 template <class T>
@@ -158,6 +168,46 @@ struct Ctx : CtxBase {
     void exchange(Level<T>& L, T* x, int colour, int ncomp = 3); // owners' entries of x (ncomp values per node; all colours: colour < 0) to every rank
     void exchange_rows(Level<T>& L, const uint8_t* touched); // partial matrix rows -> their owners, summed there
     void allreduce_tiles(T* tiles, int q); // q * Nb * EPB node-tile values, summed over the ranks
+    // ---- halo mode
+    bool halo_mode() const { return sharded() && !cfg.shard_replicated; }
+    int64_t comm_calls = 0, comm_bytes_index = 0, comm_bytes_data = 0; // since the last hot_sort
+    bool comm_index_phase = false; // the collectives called now carry integers that describe the grid, not field data
+    struct IndexPhase {
+        Ctx<T>* c;
+        bool old;
+        IndexPhase(Ctx<T>* c_) : c(c_), old(c_->comm_index_phase) { c->comm_index_phase = true; }
+        ~IndexPhase() { c->comm_index_phase = old; }
+    };
+    void account(int64_t bytes) { ++comm_calls, (comm_index_phase ? comm_bytes_index : comm_bytes_data) += bytes; }
+    void export_comm_stats() { stats.comm_calls = comm_calls, stats.comm_bytes_index = comm_bytes_index, stats.comm_bytes_data = comm_bytes_data; }
+    // node tiles: the ranks whose particle groups cover a block ("sharers") exchange their partial tiles and add them in rank order
+    DBuf<uint8_t> touch; // Nb: this rank's tiles cover the block
+    DBuf<uint64_t> sharers; // Nb: bit r = rank r covers the block
+    DBuf<int32_t> tpos; // ranks * Nb: position of the block in the list shared with rank q, or -1
+    DBuf<int32_t> tlist; // the shared-block lists, peer after peer (ascending block id)
+    std::vector<int64_t> tcnt, toff; // [ranks] blocks shared with every peer, offsets into tlist
+    void build_tile_plan(); // sort(): after the global block list
+    void tile_exchange(T* const* arrays, int q); // q slot arrays (Nb * EPB each): summed over the sharers of every block
+    void build_halo(Level<T>& L, const std::function<void(uint8_t*)>& mark_extra); // mark_extra: additional readers of the level's vectors (device flags)
+    void halo_gather(Level<T>& L, T* x, int colour = -1, int ncomp = 3); // owners' values of x -> this rank's halo entries (one colour, or all)
+    void gather_colour(Level<T>& L, T* x, int colour, int ncomp); // one padded all-gather: every rank gets every owner's entries of one colour (or of all)
+    void gather_all(Level<T>& L, T* x, int ncomp = 3); // every rank gets every owner's entries (C ABI getters, first-generation mode)
+    void replicate_numbering(); // p2g(): node coordinates of the blocks this rank does not cover, slot <-> id tables
+    void level0_ownership(); // p2g(): level 0 exists (coordinates, colouring, row ownership, halo) before the first vector operation of the step
+    void mark_stencil(Level<T>& L, uint8_t* need); // the 125-stencil neighbours of the rows this rank owns
+    // partitioned vector algebra (sharded, halo mode): level-0 solver vectors are valid on the rows this rank owns; kernels skip the
+    // other rows (vmask) and every batch of inner products is summed over the ranks once (reduce_scalars)
+    const uint8_t* vmask = nullptr;
+    struct MaskScope {
+        Ctx<T>* c;
+        const uint8_t* old;
+        MaskScope(Ctx<T>* c_, const uint8_t* m) : c(c_), old(c_->vmask) { c->vmask = m; }
+        ~MaskScope() { c->vmask = old; }
+    };
+    void reduce_scalars(double* dev, int n)
+    {
+        if (vmask && n > 0) c_allreduce(dev, n, HOT_COMM_F64, HOT_COMM_SUM, true);
+    }
     static constexpr int REAL = sizeof(T) == 4 ? HOT_COMM_F32 : HOT_COMM_F64;
     DBuf<double> dscal; // device scalars
     DBuf<T> speed_part; // block maxima of calculate_dt
@@ -174,6 +224,14 @@ struct Ctx : CtxBase {
         GridRed g{ red_part.p, red_count.p, mirror, nullptr, 0.0 };
         if (ticket) g.ticket = hscal + 251, g.ticket_val = new_ticket();
         return g;
+    }
+    GridRed gred_n(size_t grid, int nv) // grid_sum_store_n: nv deposits per workgroup
+    {
+        if ((size_t)nv * grid > red_part.cap) {
+            HOT_HIP(hipStreamSynchronize(stream));
+            red_part.reserve((size_t)nv * grid, 1.5);
+        }
+        return GridRed{ red_part.p, red_count.p, nullptr, nullptr, 0.0 };
     }
     double last_ticket = 0;
     double new_ticket() { return last_ticket += 1.0; }
@@ -220,7 +278,7 @@ struct Ctx : CtxBase {
         }
         else
             l = new Level<T>();
-        l->id = id, l->n = 0, l->nnzb = 0, l->nblocks = 0, l->built = false, l->split = false, l->part = false, l->colored = false;
+        l->id = id, l->n = 0, l->nnzb = 0, l->nblocks = 0, l->built = false, l->split = false, l->part = false, l->colored = false, l->halo.built = false;
         return l;
     }
     void release_levels(size_t keep = 0)

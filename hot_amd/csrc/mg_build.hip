@@ -541,6 +541,71 @@ Ctx<T>* Ctx<T>::build_gmg_grid(int level)
     return g;
 }
 
+__global__ void k_mark_tiles(const int32_t* __restrict__ tileDof, int64_t n, const uint8_t* __restrict__ own, uint8_t* __restrict__ need)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int32_t j = tileDof[e];
+    if (j >= 0 && !own[j]) need[j] = 1;
+}
+__global__ void k_mark_table_rows(const int32_t* __restrict__ ids, int width, int nrows, const uint8_t* __restrict__ row_own, const uint8_t* __restrict__ own, uint8_t* __restrict__ need)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)nrows * width) return;
+    if (!row_own[e / width]) return;
+    const int32_t j = ids[e];
+    if (j >= 0 && !own[j]) need[j] = 1;
+}
+// Halo mode: (re)builds the exchange lists of level `level` from everything that reads its vectors on this rank as the hierarchy stands:
+// the 125-stencil of the owned rows (always), the nodes of the particle tiles (level 0), the 27 children of the coarse rows this rank
+// owns on the next level (restriction, when that level is partitioned) and the 4^3 coarse windows of the rows it owns on the finer level
+// (prolongation and r -= (A P) e).
+template <class T>
+static void rebuild_halo(Ctx<T>* ctx, int level)
+{
+    Level<T>& L = *ctx->levels[level];
+    if (!L.part) return;
+    ctx->build_halo(L, [&](uint8_t* need) {
+        if (level == 0) {
+            constexpr int TILE = (Geo<T>::BX + 2) * (Geo<T>::BY + 2) * (Geo<T>::BZ + 2);
+            const int64_t nt = (int64_t)ctx->Ng * TILE;
+            HOT_LAUNCH(ctx, "halo_mark", k_mark_tiles, div_up((size_t)nt, 256), 256, 0, ctx->tileDof.p, nt, L.own.p, need);
+        }
+        if (level + 1 < (int)ctx->levels.size() && ctx->levels[level + 1]->part) {
+            Level<T>& C = *ctx->levels[level + 1];
+            HOT_LAUNCH(ctx, "halo_mark", k_mark_table_rows, div_up((size_t)C.n * 27, 256), 256, 0, C.child.p, 27, C.n, C.own.p, L.own.p, need);
+        }
+        if (level > 0) {
+            Level<T>& F = *ctx->levels[level - 1];
+            HOT_LAUNCH(ctx, "halo_mark", k_mark_table_rows, div_up((size_t)F.n * 64, 256), 256, 0, F.apc.p, 64, F.n, F.own.p, L.own.p, need);
+        }
+    });
+}
+
+// Halo mode, end of hot_p2g: level 0 of the hierarchy is created right away — coordinates, coordinate map, colouring, row ownership and
+// exchange lists depend on the numbering only — because every vector operation of the step (begin_step, the exit test, the state pass)
+// already works on partitioned vectors.  hot_build_hessian fills in the matrix later.
+template <class T>
+void Ctx<T>::level0_ownership()
+{
+    release_levels();
+    Level<T>* L = acquire_level(0);
+    levels.push_back(L);
+    L->n = Nn;
+    L->coord.reserve(3 * (size_t)Nn);
+    HOT_HIP(hipMemcpyAsync(L->coord.p, id2coord.p, 3 * (size_t)Nn * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+    L->nstart = nstart0;
+    {
+        IndexPhase ip(this);
+        build_coord_map(this, *L);
+        color_level(*L);
+        level_ownership(*L);
+    }
+    rebuild_halo(this, 0);
+    vmask = L->own.p;
+    gs_no_chain = true; // a chained sweep's timeout would be rank-local and desynchronise the collectives
+}
+
 template <class T>
 void Ctx<T>::build_mg()
 {
@@ -634,6 +699,7 @@ void Ctx<T>::build_mg()
                 touched.reserve(nc);
                 HOT_LAUNCH(this, "shard_coarse_touched", k_coarse_touched, div_up(nc, 256), 256, 0, C.child.p, F.own.p, touched.p, C.n);
                 exchange_rows(C, touched.p);
+                if (halo_mode()) rebuild_halo(this, level + 1), rebuild_halo(this, level); // C: stencil + the windows of this rank's fine rows; F: + the children of its coarse rows
             }
             else
                 c_allreduce(C.val.p, (int64_t)nc * 1125, REAL, HOT_COMM_SUM, true);

@@ -43,21 +43,23 @@ __global__ void k_xpay_dev(size_t n, const double* a, const T* __restrict__ x, T
     if (i < n) y[i] = x[i] + s * y[i];
 }
 template <class T>
-__global__ __launch_bounds__(256) void k_dot(size_t n, const T* __restrict__ x, const T* __restrict__ y, double* out, GridRed gr)
+__global__ __launch_bounds__(256) void k_dot(size_t n, const T* __restrict__ x, const T* __restrict__ y, double* out, GridRed gr, const uint8_t* __restrict__ mask)
 {
     __shared__ double red[4];
     double s = 0;
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) { // four strided elements per trip in flight
         T xv[4], yv[4];
+        bool on[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const size_t i = i0 + u * stride, ic = i < n ? i : i0;
-            xv[u] = x[ic], yv[u] = y[ic];
+            on[u] = i < n && (!mask || mask[ic / 3]); // sharded, halo mode: the rows this rank owns
+            xv[u] = on[u] ? x[ic] : (T)0, yv[u] = on[u] ? y[ic] : (T)0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i0 + u * stride < n) s += (double)(xv[u] * yv[u]);
+            if (on[u]) s += (double)(xv[u] * yv[u]);
     }
     double t = block_sum_256<double>(s, red);
     grid_sum_store(t, 0.0, 1, gr, out, nullptr, red);
@@ -92,14 +94,21 @@ template <class T>
 void Ctx<T>::dot_to(size_t n, const T* x, const T* y, double* out, double* mirror)
 {
     const int grid = std::min(div_up(n, 1024), 256);
-    HOT_LAUNCH(this, "dot", k_dot<T>, grid, 256, 0, n, x, y, out, gred(grid, mirror)); // <= 256 deposits, summed in index order
+    if (vmask) { // partitioned vectors: local sum over the owned rows, summed over the ranks, then (if asked for) handed to the host slot
+        HOT_LAUNCH(this, "dot", k_dot<T>, grid, 256, 0, n, x, y, out, gred(grid), vmask);
+        reduce_scalars(out, 1);
+        if (mirror) HOT_HIP(hipMemcpyAsync(mirror, out, sizeof(double), hipMemcpyDeviceToHost, stream));
+        return;
+    }
+    HOT_LAUNCH(this, "dot", k_dot<T>, grid, 256, 0, n, x, y, out, gred(grid, mirror), (const uint8_t*)nullptr); // <= 256 deposits, summed in index order
 }
 template <class T>
 double Ctx<T>::dot_host(size_t n, const T* x, const T* y)
 {
     const int grid = std::min(div_up(n, 1024), 256);
-    HOT_LAUNCH(this, "dot", k_dot<T>, grid, 256, 0, n, x, y, dscal.p + 100, gred(grid, hscal + 100, true)); // the summing workgroup also writes the pinned host slot
+    HOT_LAUNCH(this, "dot", k_dot<T>, grid, 256, 0, n, x, y, dscal.p + 100, gred(grid, hscal + 100, true), vmask); // the summing workgroup also writes the pinned host slot
     wait_ticket();
+    if (vmask) c_allreduce(hscal + 100, 1, HOT_COMM_F64, HOT_COMM_SUM, false); // partitioned vectors: the ranks' sums over their own rows
     return hscal[100];
 }
 
@@ -256,17 +265,19 @@ void Ctx<T>::scal(size_t n, T a, T* x)
 template <class T>
 void Ctx<T>::spmv_dev(Level<T>& L, const T* x, T* y)
 {
+    if (L.part && halo_mode()) halo_gather(L, const_cast<T*>(x)); // the entries of x the owned rows couple to
     HOT_LAUNCH(this, lname("spmv", L.id).c_str(), k_spmv<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, x, y, L.n, L.mask());
-    exchange(L, y, -1); // sharded: every rank computed the rows it owns; all of y is needed by the replicated vector algebra
+    if (!halo_mode()) exchange(L, y, -1); // first-generation sharding: every rank computed the rows it owns; all of y is needed by the replicated vector algebra
 }
 
 // ------------------------------------------------------------------------------------------------ transfers
 template <class T>
-__global__ void k_restrict(const int32_t* __restrict__ child, const T* __restrict__ fine, T* coarse, int nc)
+__global__ void k_restrict(const int32_t* __restrict__ child, const T* __restrict__ fine, T* coarse, int nc, const uint8_t* __restrict__ coarse_own, const uint8_t* __restrict__ fine_own)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 3 * nc) return;
     int I = e / 3, d = e - 3 * I;
+    if (coarse_own && !coarse_own[I]) return; // sharded, both levels partitioned: the coarse rows this rank owns (their children are in the fine halo)
     // all 27 child ids first, then all 27 values (clamped index, dropped by the select): two rounds of independent loads instead of
     // 27 dependent pairs; the sum keeps the child order
     int ci[27];
@@ -279,16 +290,17 @@ __global__ void k_restrict(const int32_t* __restrict__ child, const T* __restric
 #pragma unroll
     for (int q = 0; q < 27; ++q) {
         const T w = ((q / 9 != 1) ? (T)0.5 : (T)1) * (((q / 3) % 3 != 1) ? (T)0.5 : (T)1) * ((q % 3 != 1) ? (T)0.5 : (T)1);
-        s = ci[q] < 0 ? s : s + w * fv[q];
+        s = (ci[q] < 0 || (fine_own && !fine_own[ci[q]])) ? s : s + w * fv[q]; // fine_own: partial sum over this rank's fine rows (replicated coarse level, all-reduced)
     }
     coarse[e] = s;
 }
 template <class T>
-__global__ void k_prolong(const int32_t* __restrict__ pcol, const T* __restrict__ pw, const T* __restrict__ coarse, T* fine, int n)
+__global__ void k_prolong(const int32_t* __restrict__ pcol, const T* __restrict__ pw, const T* __restrict__ coarse, T* fine, int n, const uint8_t* __restrict__ own)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 3 * n) return;
     int i = e / 3, d = e - 3 * i;
+    if (own && !own[i]) return;
     T s = 0;
     for (int l = 0; l < 8; ++l) s += pw[8 * (int64_t)i + l] * coarse[3 * (int64_t)pcol[8 * (int64_t)i + l] + d];
     fine[e] = s;
@@ -297,13 +309,28 @@ template <class T>
 void Ctx<T>::restrict_dev(int level, const T* fine, T* coarse)
 {
     Level<T>& C = *levels[level + 1];
-    HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n);
+    Level<T>& F = *levels[level];
+    if (F.part && halo_mode()) {
+        if (C.part) { // owner of a coarse row sums its 27 children: those owned elsewhere come with the fine level's halo
+            halo_gather(F, const_cast<T*>(fine));
+            HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n, C.own.p, (const uint8_t*)nullptr);
+        }
+        else { // replicated coarse level: every rank sums the children it owns, one all-reduce of the (small) coarse vector completes the rows
+            HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n, (const uint8_t*)nullptr, F.own.p);
+            c_allreduce(coarse, 3 * (int64_t)C.n, REAL, HOT_COMM_SUM, true);
+        }
+        return;
+    }
+    HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n, (const uint8_t*)nullptr, (const uint8_t*)nullptr);
 }
 template <class T>
 void Ctx<T>::prolong_dev(int level, const T* coarse, T* fine)
 {
     Level<T>& F = *levels[level];
-    HOT_LAUNCH(this, "prolong", k_prolong<T>, div_up(3 * (size_t)F.n, 256), 256, 0, F.pcol.p, F.pw.p, coarse, fine, F.n);
+    Level<T>& C = *levels[level + 1];
+    const bool hm = F.part && halo_mode();
+    if (hm && C.part) halo_gather(C, const_cast<T*>(coarse)); // the parents / window columns of the fine rows this rank owns (also read by the k_apmv_sub that follows)
+    HOT_LAUNCH(this, "prolong", k_prolong<T>, div_up(3 * (size_t)F.n, 256), 256, 0, F.pcol.p, F.pw.p, coarse, fine, F.n, hm ? F.own.p : (const uint8_t*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ smoothers
@@ -344,6 +371,7 @@ __global__ void k_div1(T* v, T c, size_t n3)
 template <class T>
 void Ctx<T>::estimate_2norm(Level<T>& L, double tol)
 {
+    MaskScope mscope(this, halo_mode() ? L.mask() : nullptr); // this level's vectors (halo mode: the rows the rank owns)
     constexpr int MaxIters = 512;
     size_t n3 = 3 * (size_t)L.n;
     T *v = L.du.p, *x = L.dAu.p; // work vectors of the level, free while the hierarchy is being built
@@ -1012,6 +1040,8 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
 {
     Level<T>& L = *levels[level];
     size_t n3 = 3 * (size_t)L.n;
+    MaskScope mscope(this, halo_mode() ? L.mask() : nullptr); // halo mode: this level's vectors live on the rows the rank owns (replicated level: everywhere)
+    const bool hm = L.part && halo_mode();
     auto Aproject = [&](T* v) {
         if (level == 0 && !cfg.systemBCProject) project_dev(v);
     };
@@ -1281,7 +1311,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             else
                 for (int c = 7; c >= 0; --c)
                     for (int h = nsub - 1; h >= 0; --h) pass(false, c, h);
-            if (rank_local) exchange(L, du, -1); // the one hand-off of a rank-local symmetric sweep: every rank's du
+            if (rank_local) exchange(L, du, -1); // the one hand-off of a rank-local symmetric sweep: every rank's du (halo mode: the entries this rank reads)
             if (simple_gs || L.part) axpy(n3, (T)1, du, u); // partitioned level: du is complete on every rank after the colour exchanges, u stays replicated
             if (!final_residual && iterations == 0) break;
             if (L.split && !simple_gs && !(level == 0 && !cfg.systemBCProject) && !no_lres) {
@@ -1289,7 +1319,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 // strictly-preceding half of the matrix applied to (h - du) (same value, half the bytes of an SpMV)
                 HOT_LAUNCH(this, lname("gs_residual", L.id).c_str(), k_gs_residual<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.rowcnt.p, hdu, du, r, L.n, L.mask(),
                     rank_local ? L.owner.p : (const uint8_t*)nullptr, comm.rank);
-                exchange(L, r, -1); // partitioned level: the restriction / the next smoother read all of r
+                if (!hm) exchange(L, r, -1); // first-generation sharding: the restriction / the next smoother read all of r (halo mode: r is needed on owned rows only; restrict_dev fetches what it reads)
             }
             else {
                 spmv_dev(L, du, dAu);
@@ -1354,7 +1384,7 @@ void Ctx<T>::vcycle_dev(const T* in, T* out)
         }
         else
             HOT_LAUNCH(this, lname("apmv", L.id).c_str(), k_apmv_sub<T>, div_up(L.n, 4), 256, 0, L.apc.p, L.apv.p, levels[level + 1]->sol.p, L.residual.p, L.n, L.mask());
-        if (L.part && (level < splitLevel ? (baseline ? 5 : cfg.smoother) : (baseline ? 2 : cfg.coarseSolver)) != 5)
+        if (L.part && !halo_mode() && (level < splitLevel ? (baseline ? 5 : cfg.smoother) : (baseline ? 2 : cfg.coarseSolver)) != 5)
             exchange(L, L.residual.p, -1); // a GS post-smoother reads only the rows it owns; every other smoother runs replicated vector algebra on all of r
         run(level < splitLevel, level, sol, level < splitLevel ? downIter(level) : topIter(level), false);
     }
@@ -1378,6 +1408,7 @@ void Ctx<T>::spmv(int32_t level, const void* x, void* y)
     a.reserve(n3), b.reserve(n3);
     HOT_HIP(hipMemcpyAsync(a.p, x, n3 * sizeof(T), hipMemcpyDefault, stream));
     spmv_dev(L, a.p, b.p);
+    if (halo_mode()) gather_all(L, b.p); // the C ABI hands out complete vectors
     download(y, b.p, n3);
     sync();
 }
@@ -1390,6 +1421,7 @@ void Ctx<T>::restrict_(int32_t level, const void* fine, void* coarse)
     a.reserve(nf), b.reserve(nc);
     HOT_HIP(hipMemcpyAsync(a.p, fine, nf * sizeof(T), hipMemcpyDefault, stream));
     restrict_dev(level, a.p, b.p);
+    if (halo_mode()) gather_all(*levels[level + 1], b.p);
     download(coarse, b.p, nc);
     sync();
 }
@@ -1402,6 +1434,7 @@ void Ctx<T>::prolong(int32_t level, const void* coarse, void* fine)
     a.reserve(nc), b.reserve(nf);
     HOT_HIP(hipMemcpyAsync(a.p, coarse, nc * sizeof(T), hipMemcpyDefault, stream));
     prolong_dev(level, a.p, b.p);
+    if (halo_mode()) gather_all(*levels[level], b.p);
     download(fine, b.p, nf);
     sync();
 }
@@ -1419,6 +1452,7 @@ void Ctx<T>::smooth(int32_t level, int32_t kind, int32_t iterations, double tol,
         HOT_HIP(hipMemcpyAsync(dr_.p, r, n3 * sizeof(T), hipMemcpyDefault, stream));
         HOT_HIP(hipMemcpyAsync(L.initialResidual.p, r0_.p, n3 * sizeof(T), hipMemcpyDeviceToDevice, stream));
         smooth_dev(level, kind, iterations, (T)tol, du_.p, dr_.p, L.du.p, L.dAu.p);
+        if (halo_mode()) gather_all(L, du_.p), gather_all(L, dr_.p);
         sync();
     });
     download(u, du_.p, n3);
@@ -1433,6 +1467,7 @@ void Ctx<T>::vcycle(const void* in, void* out)
     HOT_HIP(hipMemcpyAsync(work0.p, in, n3 * sizeof(T), hipMemcpyDefault, stream));
     with_gs_retry([&] {
         vcycle_dev(work0.p, work1.p);
+        if (halo_mode()) gather_all(*levels[0], work1.p);
         sync();
     });
     download(out, work1.p, n3);

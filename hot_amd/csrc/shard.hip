@@ -27,6 +27,7 @@ void Ctx<T>::set_comm(const hot_comm* c)
     else
         comm = hot_comm{};
     block_first.clear();
+    vmask = nullptr;
 }
 template <class T>
 void Ctx<T>::c_allreduce(void* buf, int64_t n, int dtype, int op, bool on_device)
@@ -34,6 +35,7 @@ void Ctx<T>::c_allreduce(void* buf, int64_t n, int dtype, int op, bool on_device
     if (!sharded() || n <= 0) return;
     if (on_device && !comm.stream_ordered) HOT_HIP(hipStreamSynchronize(stream));
     prof.count(on_device ? "comm_allreduce" : "comm_allreduce_scalars");
+    account(n * (dtype == HOT_COMM_F32 || dtype == HOT_COMM_I32 ? 4 : 8));
     HOT_CHECK(comm.allreduce(comm.user, buf, n, dtype, op, on_device ? 1 : 0) == 0, HOT_ERR_DEVICE, "hot_comm.allreduce failed");
 }
 template <class T>
@@ -41,6 +43,7 @@ void Ctx<T>::c_allgather(const void* send, void* recv, int64_t bytes, bool on_de
 {
     if (on_device && !comm.stream_ordered) HOT_HIP(hipStreamSynchronize(stream));
     prof.count("comm_allgather");
+    account(bytes);
     HOT_CHECK(comm.allgather(comm.user, send, recv, bytes, on_device ? 1 : 0) == 0, HOT_ERR_DEVICE, "hot_comm.allgather failed");
 }
 template <class T>
@@ -48,6 +51,11 @@ void Ctx<T>::c_alltoallv(const void* send, const int64_t* soff, const int64_t* s
 {
     if (!comm.stream_ordered) HOT_HIP(hipStreamSynchronize(stream));
     prof.count("comm_alltoallv");
+    {
+        int64_t b = 0;
+        for (int q = 0; q < comm.size; ++q) b += sbytes[q];
+        account(b);
+    }
     HOT_CHECK(comm.alltoallv(comm.user, send, soff, sbytes, recv, roff, rbytes, 1) == 0, HOT_ERR_DEVICE, "hot_comm.alltoallv failed");
 }
 template <class T>
@@ -245,6 +253,20 @@ template <class T>
 void Ctx<T>::exchange(Level<T>& L, T* x, int colour, int ncomp)
 {
     if (!L.part) return;
+    if (halo_mode()) {
+        halo_gather(L, x, colour, ncomp);
+        return;
+    }
+    gather_colour(L, x, colour, ncomp);
+}
+template <class T>
+void Ctx<T>::gather_all(Level<T>& L, T* x, int ncomp)
+{
+    if (L.part) gather_colour(L, x, -1, ncomp);
+}
+template <class T>
+void Ctx<T>::gather_colour(Level<T>& L, T* x, int colour, int ncomp)
+{
     const int R = comm.size, me = comm.rank;
     const int maxc = colour < 0 ? L.xmax_full : L.xmax_col[colour];
     if (maxc == 0) return;
@@ -253,6 +275,288 @@ void Ctx<T>::exchange(Level<T>& L, T* x, int colour, int ncomp)
     HOT_LAUNCH(this, "xchg_pack", k_xchg_pack<T>, div_up(maxc, 256), 256, 0, x, L.gs_order.p, L.dxtab.p, R, me, colour, (T*)xsend.p, maxc, ncomp);
     c_allgather(xsend.p, xrecv.p, (int64_t)slot, true);
     HOT_LAUNCH(this, "xchg_unpack", k_xchg_unpack<T>, div_up((size_t)R * maxc, 256), 256, 0, x, L.gs_order.p, L.dxtab.p, R, me, colour, (const T*)xrecv.p, maxc, ncomp);
+}
+
+// ================================================================================================ halo mode
+// hot_config.shard_replicated == 0.  The INDEX structure of the grid stays replicated (block list, node numbering, coordinates,
+// colouring, coarse numbering, transfer tables: integers every rank derives from the same small all-gathered inputs), so every
+// exchange list below is computed locally or with one handshake per step.  FIELD data is not replicated:
+//   * node tiles (P2G, force, CN quantity, matrix-free products): the ranks whose particle groups cover a block exchange their
+//     partial tiles pairwise and add them in ascending rank order — every sharer ends with the same bits, nobody else gets anything;
+//   * DOF vectors: valid on the rows a rank owns and, after halo_gather, on the entries it reads (the 125-stencil of its rows, the
+//     nodes of its particle tiles, the transfer-operator partners of its rows);
+//   * reductions: local sums over owned rows, one all-reduce per batch of scalars (reduce_scalars).
+// Bytes per exchange scale with the cut surface, not with the body.
+
+// ------------------------------------------------------------------------------------------------ shared node tiles
+template <class T>
+__global__ void k_touch_blocks(const int32_t* __restrict__ group_nb, int ng, uint8_t* __restrict__ touch)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < ng * 8 && group_nb[e] >= 0) touch[group_nb[e]] = 1;
+}
+// fp64: a 4^3 colour block (the unit of row ownership) is two SPGrid blocks (2 x 4 x 4) side by side in x; a rank that covers one of
+// them takes part in the sums of the other as well, so the owner of a colour block always holds the node data of all its rows
+template <class T>
+__global__ void k_touch_companions(HashMap h, const uint64_t* __restrict__ blocks, const uint8_t* __restrict__ touch, uint8_t* __restrict__ out, int nb)
+{
+    using G = Geo<T>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb || !touch[b]) return;
+    out[b] = 1;
+    if (G::BX == 4) return;
+    int i, j, k;
+    G::linear_to_coord(blocks[b], i, j, k);
+    const int32_t c = hash_find_id(h, G::linear_offset(i ^ 2, j, k) >> 12);
+    if (c >= 0) out[c] = 1;
+}
+struct PeerSegs { // per peer: [begin, begin + count) of a list, and where the peer's packed payload starts (in list entries)
+    int64_t lbeg[64], cnt[64], obeg[64];
+};
+// out[((k * q + a) * EPB) + e] = arrays[a][list[k] * EPB + e]
+template <class T>
+struct TileArrays {
+    T* a[9];
+};
+template <class T>
+__global__ void k_tile_pack(TileArrays<T> arr, int q, const int32_t* __restrict__ list, int64_t nlist, T* __restrict__ out)
+{
+    constexpr int EPB = Geo<T>::EPB;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nlist * q * EPB) return;
+    const int64_t k = e / (q * EPB);
+    const int r = (int)(e - k * q * EPB), a = r / EPB, l = r - a * EPB;
+    out[e] = arr.a[a][(int64_t)list[k] * EPB + l];
+}
+// every block this rank shares: the sharers' partial tiles added in ascending rank order (its own at its rank's position)
+template <class T>
+__global__ void k_tile_sum(TileArrays<T> arr, int q, const uint64_t* __restrict__ sharers, const int32_t* __restrict__ tpos, const T* __restrict__ recv, PeerSegs seg, int R, int me, int nb)
+{
+    constexpr int EPB = Geo<T>::EPB;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)nb * q * EPB) return;
+    const int b = (int)(e / (q * EPB));
+    const uint64_t sh = sharers[b];
+    if (!((sh >> me) & 1ULL) || (sh & (sh - 1)) == 0) return; // not mine, or nobody else's
+    const int r = (int)(e - (int64_t)b * q * EPB), a = r / EPB, l = r - a * EPB;
+    T* cell = arr.a[a] + (int64_t)b * EPB + l;
+    T acc = (T)0;
+    bool first = true;
+    for (int p = 0; p < R; ++p) {
+        if (!((sh >> p) & 1ULL)) continue;
+        const T v = p == me ? *cell : recv[((seg.obeg[p] + tpos[(int64_t)p * nb + b]) * q + a) * EPB + l];
+        acc = first ? v : acc + v;
+        first = false;
+    }
+    *cell = acc;
+}
+
+template <class T>
+void Ctx<T>::build_tile_plan()
+{
+    IndexPhase ip(this);
+    const int R = comm.size, me = comm.rank;
+    touch.reserve(2 * (size_t)Nb);
+    HOT_HIP(hipMemsetAsync(touch.p, 0, 2 * (size_t)Nb, stream));
+    HOT_LAUNCH(this, "shard_touch", k_touch_blocks<T>, div_up((size_t)Ng * 8, 256), 256, 0, group_nb.p, Ng, touch.p);
+    HOT_LAUNCH(this, "shard_touch", k_touch_companions<T>, div_up(Nb, 256), 256, 0, block_map, blocks.p, touch.p, touch.p + Nb, Nb);
+    std::vector<uint8_t> mine(Nb), all((size_t)Nb * R);
+    HOT_HIP(hipMemcpyAsync(mine.data(), touch.p + Nb, Nb, hipMemcpyDeviceToHost, stream));
+    HOT_HIP(hipMemcpyAsync(touch.p, touch.p + Nb, Nb, hipMemcpyDeviceToDevice, stream));
+    sync();
+    c_allgather(mine.data(), all.data(), Nb, false);
+    std::vector<uint64_t> sh(Nb, 0);
+    for (int r = 0; r < R; ++r)
+        for (int b = 0; b < Nb; ++b)
+            if (all[(size_t)r * Nb + b]) sh[b] |= 1ULL << r;
+    std::vector<int32_t> pos((size_t)R * Nb, -1), list;
+    tcnt.assign(R, 0), toff.assign(R, 0);
+    for (int q = 0; q < R; ++q) {
+        toff[q] = (int64_t)list.size();
+        if (q == me) continue;
+        for (int b = 0; b < Nb; ++b)
+            if (((sh[b] >> q) & 1ULL) && ((sh[b] >> me) & 1ULL)) pos[(size_t)q * Nb + b] = (int32_t)tcnt[q]++, list.push_back(b);
+    }
+    sharers.reserve(Nb), tpos.reserve((size_t)R * Nb), tlist.reserve(std::max<size_t>(list.size(), 1));
+    HOT_HIP(hipMemcpyAsync(sharers.p, sh.data(), (size_t)Nb * 8, hipMemcpyHostToDevice, stream));
+    HOT_HIP(hipMemcpyAsync(tpos.p, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, stream));
+    if (!list.empty()) HOT_HIP(hipMemcpyAsync(tlist.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, stream));
+    sync(); // the host vectors go out of scope
+}
+
+// q slot arrays (Nb * EPB each) hold this rank's partial node sums; afterwards every block this rank covers holds the body's
+template <class T>
+void Ctx<T>::tile_exchange(T* const* arrays, int q)
+{
+    const int R = comm.size, me = comm.rank;
+    HOT_CHECK(q >= 1 && q <= 9 && (int)tcnt.size() == R, HOT_ERR_INVALID, "tile_exchange: no tile plan (hot_sort)");
+    TileArrays<T> arr{};
+    for (int a = 0; a < q; ++a) arr.a[a] = arrays[a];
+    const int64_t per = (int64_t)q * EPB; // values per shared block
+    int64_t tot = 0;
+    PeerSegs seg{};
+    std::vector<int64_t> off(R, 0), bytes(R, 0);
+    for (int p = 0; p < R; ++p) seg.lbeg[p] = toff[p], seg.cnt[p] = tcnt[p], seg.obeg[p] = tot, off[p] = tot * per * (int64_t)sizeof(T), bytes[p] = tcnt[p] * per * (int64_t)sizeof(T), tot += tcnt[p];
+    if (tot == 0) return; // this rank shares no block (all ranks call the collective only if they share something: the lists are symmetric)
+    xsend.reserve((size_t)tot * per * sizeof(T)), xrecv.reserve((size_t)tot * per * sizeof(T));
+    HOT_LAUNCH(this, "tile_pack", k_tile_pack<T>, div_up((size_t)tot * per, 256), 256, 0, arr, q, tlist.p, tot, (T*)xsend.p);
+    c_alltoallv(xsend.p, off.data(), bytes.data(), xrecv.p, off.data(), bytes.data()); // symmetric lists: what goes to a peer and what comes from it have the same layout
+    HOT_LAUNCH(this, "tile_sum", k_tile_sum<T>, div_up((size_t)Nb * per, 256), 256, 0, arr, q, sharers.p, tpos.p, (const T*)xrecv.p, seg, R, me, Nb);
+}
+
+// ------------------------------------------------------------------------------------------------ DOF-vector halos
+__global__ void k_mark_stencil(HashMap h, const int32_t* __restrict__ coord, const uint8_t* __restrict__ own, uint8_t* __restrict__ need, int n)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)n * 125) return;
+    const int i = (int)(e / 125), k = (int)(e - (int64_t)i * 125);
+    if (!own[i]) return;
+    const int x = coord[3 * i] + k / 25 - 2, y = coord[3 * i + 1] + (k / 5) % 5 - 2, z = coord[3 * i + 2] + k % 5 - 2;
+    if ((x | y | z) < 0) return;
+    const int32_t j = hash_find_id(h, coord_key(x, y, z));
+    if (j >= 0 && !own[j]) need[j] = 1;
+}
+__global__ void k_mark_list(const int32_t* __restrict__ ids, int64_t n, const uint8_t* __restrict__ own, uint8_t* __restrict__ need)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int32_t j = ids[e];
+    if (j >= 0 && !own[j]) need[j] = 1;
+}
+// ids[row * width + k] for the rows this rank owns only
+__global__ void k_mark_rows(const int32_t* __restrict__ ids, int width, int nrows, const uint8_t* __restrict__ row_own, const uint8_t* __restrict__ own, uint8_t* __restrict__ need)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)nrows * width) return;
+    if (row_own && !row_own[e / width]) return;
+    const int32_t j = ids[e];
+    if (j >= 0 && !own[j]) need[j] = 1;
+}
+// flags over the POSITIONS of gs_order (colour-major): the halo entries owned by rank q
+__global__ void k_need_flags(const int32_t* __restrict__ gs_order, const uint8_t* __restrict__ need, const uint8_t* __restrict__ owner, int q, int32_t* __restrict__ flags, int n)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int i = gs_order[p];
+    flags[p] = (need[i] && owner[i] == (uint8_t)q) ? 1 : 0;
+}
+__global__ void k_need_compact(const int32_t* __restrict__ gs_order, const int32_t* __restrict__ flags, const int32_t* __restrict__ scan, int32_t* __restrict__ out, int n)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && flags[p]) out[scan[p]] = gs_order[p];
+}
+template <class T>
+__global__ void k_halo_pack(const T* __restrict__ x, const int32_t* __restrict__ list, int64_t cnt, int ncomp, T* __restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= cnt * ncomp) return;
+    const int64_t k = e / ncomp;
+    out[e] = x[(int64_t)list[k] * ncomp + (e - k * ncomp)];
+}
+template <class T>
+__global__ void k_halo_unpack(T* __restrict__ x, const int32_t* __restrict__ list, int64_t cnt, int ncomp, const T* __restrict__ in)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= cnt * ncomp) return;
+    const int64_t k = e / ncomp;
+    x[(int64_t)list[k] * ncomp + (e - k * ncomp)] = in[e];
+}
+
+template <class T>
+void Ctx<T>::mark_stencil(Level<T>& L, uint8_t* need)
+{
+    HOT_LAUNCH(this, "halo_mark", k_mark_stencil, div_up((size_t)L.n * 125, 256), 256, 0, L.map, L.coord.p, L.own.p, need, L.n);
+}
+
+// The exchange lists of one level.  `need` = entries read here and owned elsewhere: the 125-stencil of the owned rows (needs L.map)
+// plus whatever mark_extra adds.  The readers tell the owners once per step (counts, then ids); both sides keep the lists in
+// (peer, colour, gs_order position) order, so a colour of a Gauss-Seidel sweep is one contiguous piece per peer.
+template <class T>
+void Ctx<T>::build_halo(Level<T>& L, const std::function<void(uint8_t*)>& mark_extra)
+{
+    IndexPhase ip(this);
+    HOT_CHECK(L.part && L.colored, HOT_ERR_INVALID, "build_halo: the level is not partitioned");
+    const int R = comm.size, me = comm.rank, n = L.n;
+    auto& H = L.halo;
+    H.need.reserve(n);
+    HOT_HIP(hipMemsetAsync(H.need.p, 0, n, stream));
+    mark_stencil(L, H.need.p);
+    if (mark_extra) mark_extra(H.need.p);
+    // positions of gs_order where every colour starts
+    std::vector<int32_t> bstart(L.nblocks + 1);
+    HOT_HIP(hipMemcpyAsync(bstart.data(), L.gs_block_start.p, (size_t)(L.nblocks + 1) * 4, hipMemcpyDeviceToHost, stream));
+    sync();
+    int cpos[9];
+    for (int c = 0; c <= 8; ++c) cpos[c] = bstart[L.color_block_begin[c]];
+    flags.reserve(n + 1), scan.reserve(n + 1);
+    H.rcnt.assign(R, 0), H.roff.assign(R, 0), H.rcol.assign((size_t)R * 9, 0);
+    H.recv.reserve(std::max(n, 1));
+    int64_t rt = 0;
+    std::vector<int32_t> hscan(9);
+    for (int q = 0; q < R; ++q) {
+        H.roff[q] = rt;
+        if (q == me) continue;
+        HOT_LAUNCH(this, "halo_flags", k_need_flags, div_up(n, 256), 256, 0, L.gs_order.p, H.need.p, L.owner.p, q, flags.p, n);
+        const int c = exclusive_scan_i32(flags.p, scan.p, n);
+        if (c > 0) {
+            HOT_LAUNCH(this, "halo_compact", k_need_compact, div_up(n, 256), 256, 0, L.gs_order.p, flags.p, scan.p, H.recv.p + rt, n);
+            for (int k = 0; k < 8; ++k)
+                if (cpos[k] < n)
+                    HOT_HIP(hipMemcpyAsync(&hscan[k], scan.p + cpos[k], 4, hipMemcpyDeviceToHost, stream));
+                else
+                    hscan[k] = c;
+            sync();
+            for (int k = 0; k < 8; ++k) H.rcol[(size_t)q * 9 + k] = hscan[k];
+            H.rcol[(size_t)q * 9 + 8] = c;
+        }
+        H.rcnt[q] = c, rt += c;
+    }
+    H.rtot = rt;
+    // handshake: every rank learns, per colour, how many of its rows each peer reads; then which
+    std::vector<int64_t> mine((size_t)R * 9), all((size_t)R * R * 9);
+    for (size_t k = 0; k < mine.size(); ++k) mine[k] = H.rcol[k];
+    c_allgather(mine.data(), all.data(), (int64_t)R * 9 * sizeof(int64_t), false);
+    H.scnt.assign(R, 0), H.soff.assign(R, 0), H.scol.assign((size_t)R * 9, 0);
+    int64_t stot = 0;
+    for (int p = 0; p < R; ++p) {
+        H.soff[p] = stot;
+        if (p == me) continue;
+        for (int k = 0; k < 9; ++k) H.scol[(size_t)p * 9 + k] = all[((size_t)p * R + me) * 9 + k];
+        H.scnt[p] = H.scol[(size_t)p * 9 + 8], stot += H.scnt[p];
+    }
+    H.stot = stot;
+    H.send.reserve(std::max<int64_t>(stot, 1));
+    {
+        std::vector<int64_t> so(R), sb(R), ro(R), rb(R);
+        for (int p = 0; p < R; ++p) so[p] = H.roff[p] * 4, sb[p] = H.rcnt[p] * 4, ro[p] = H.soff[p] * 4, rb[p] = H.scnt[p] * 4;
+        c_alltoallv(H.recv.p, so.data(), sb.data(), H.send.p, ro.data(), rb.data()); // my read lists go out, the peers' read lists of my rows come in
+    }
+    sync();
+    H.built = true;
+}
+
+template <class T>
+void Ctx<T>::halo_gather(Level<T>& L, T* x, int colour, int ncomp)
+{
+    if (!L.part) return;
+    auto& H = L.halo;
+    HOT_CHECK(H.built, HOT_ERR_INVALID, "halo_gather: the level has no exchange lists");
+    const int R = comm.size;
+    std::vector<int64_t> so(R, 0), sb(R, 0), ro(R, 0), rb(R, 0), sl(R, 0), rl(R, 0), sc(R, 0), rc(R, 0);
+    int64_t st = 0, rt = 0;
+    const int64_t eb = (int64_t)ncomp * sizeof(T);
+    for (int p = 0; p < R; ++p) {
+        const int64_t s0 = colour < 0 ? 0 : H.scol[(size_t)p * 9 + colour], s1 = colour < 0 ? H.scnt[p] : H.scol[(size_t)p * 9 + colour + 1];
+        const int64_t r0 = colour < 0 ? 0 : H.rcol[(size_t)p * 9 + colour], r1 = colour < 0 ? H.rcnt[p] : H.rcol[(size_t)p * 9 + colour + 1];
+        sl[p] = H.soff[p] + s0, sc[p] = s1 - s0, so[p] = st * eb, sb[p] = sc[p] * eb, st += sc[p];
+        rl[p] = H.roff[p] + r0, rc[p] = r1 - r0, ro[p] = rt * eb, rb[p] = rc[p] * eb, rt += rc[p];
+    }
+    xsend.reserve((size_t)std::max<int64_t>(st, 1) * eb), xrecv.reserve((size_t)std::max<int64_t>(rt, 1) * eb);
+    for (int p = 0; p < R; ++p)
+        if (sc[p] > 0) HOT_LAUNCH(this, "halo_pack", k_halo_pack<T>, div_up((size_t)sc[p] * ncomp, 256), 256, 0, x, H.send.p + sl[p], sc[p], ncomp, (T*)(xsend.p + so[p]));
+    c_alltoallv(xsend.p, so.data(), sb.data(), xrecv.p, ro.data(), rb.data());
+    for (int p = 0; p < R; ++p)
+        if (rc[p] > 0) HOT_LAUNCH(this, "halo_unpack", k_halo_unpack<T>, div_up((size_t)rc[p] * ncomp, 256), 256, 0, x, H.recv.p + rl[p], rc[p], ncomp, (const T*)(xrecv.p + ro[p]));
 }
 
 // ------------------------------------------------------------------------------------------------ partial matrix rows
@@ -410,10 +714,37 @@ void Ctx<T>::migrate_particles()
     std::vector<uint64_t> samp((size_t)S * R);
     HOT_HIP(hipMemcpyAsync(samp.data(), xrecv.p, samp.size() * 8, hipMemcpyDeviceToHost, stream));
     sync();
-    std::sort(samp.begin(), samp.end());
+    // every rank contributes S samples whatever it holds: a sample of rank r stands for Np_r / S particles.  Splitters = weighted
+    // quantiles, so that a skewed distribution (a body drifting out of some ranks' page ranges) is re-balanced instead of re-derived
+    std::vector<int64_t> cnts(R, 0);
+    {
+        int64_t mine = n;
+        c_allgather(&mine, cnts.data(), sizeof(int64_t), false);
+    }
+    std::vector<std::pair<uint64_t, double>> ws;
+    ws.reserve(samp.size());
+    double wtot = 0;
+    for (int r = 0; r < R; ++r)
+        for (int k = 0; k < S; ++k) ws.emplace_back(samp[(size_t)r * S + k], (double)cnts[r] / S), wtot += (double)cnts[r] / S;
+    std::sort(ws.begin(), ws.end(), [](const std::pair<uint64_t, double>& a, const std::pair<uint64_t, double>& b) { return a.first < b.first; });
     Splitters sp{};
     sp.n = R - 1;
-    for (int r = 1; r < R; ++r) sp.v[r - 1] = samp[(size_t)r * samp.size() / R];
+    {
+        double acc = 0;
+        size_t k = 0;
+        uint64_t prev = 0;
+        for (int r = 1; r < R; ++r) {
+            const double want = wtot * r / R;
+            while (k < ws.size() && acc + ws[k].second <= want) acc += ws[k].second, ++k;
+            uint64_t v = k < ws.size() ? ws[k].first : ws.back().first + 1;
+            if (r > 1 && v <= prev) { // equal splitters (few pages, many ranks): advance to the next distinct page so that no range is empty by construction
+                size_t j = k;
+                while (j < ws.size() && ws[j].first <= prev) ++j;
+                v = j < ws.size() ? ws[j].first : prev + 1;
+            }
+            sp.v[r - 1] = prev = v;
+        }
+    }
     // ---- who goes where: one compacted list per destination (ascending slot order), the kept particles included
     DBuf<int32_t> lists;
     lists.reserve(n);
@@ -441,7 +772,7 @@ void Ctx<T>::migrate_particles()
         if (src != me) rcnt[src] = all[(size_t)src * R + me], incoming += rcnt[src];
     }
     const int64_t nnew = kept + incoming, nout = n - kept;
-    HOT_CHECK(nnew > 0, HOT_ERR_INVALID, "particle migration left this rank without particles");
+    HOT_CHECK(nnew > 0, HOT_ERR_INVALID, "particle migration left this rank without particles (fewer occupied SPGrid pages than ranks: use fewer ranks for a body this small)");
     constexpr int index_bits = 32 - G::block_bits;
     HOT_CHECK(nnew < (1LL << index_bits), HOT_ERR_CAPACITY, "particle count of this rank exceeds 2^(32-block_bits) after migration");
     // ---- outgoing records: [NC scalars] per particle in list order (the kept run of the list is skipped by the offsets), ids apart

@@ -22,13 +22,26 @@
 namespace hot {
 
 template <class T>
-__global__ __launch_bounds__(256) void k_scaled_norm(const T* __restrict__ r, const T* __restrict__ tol, int nn, int useCN, double* out, GridRed gr)
+__global__ __launch_bounds__(256) void k_scaled_norm(const T* __restrict__ r, const T* __restrict__ tol, int nn, int useCN, double* out, GridRed gr, const uint8_t* __restrict__ mask)
 {
     __shared__ double red[4];
     double s = 0;
     const int stride = gridDim.x * 256;
     for (int n0 = blockIdx.x * 256 + threadIdx.x; n0 < nn; n0 += 2 * stride) { // two nodes per trip in flight
         const int n1 = n0 + stride < nn ? n0 + stride : n0;
+        if (mask) { // sharded, halo mode: the rows this rank owns (the other entries of r are not maintained here)
+            double q = 0;
+            for (int u = 0; u < 2; ++u) {
+                const int n = u ? n1 : n0;
+                if ((u && n1 == n0) || !mask[n]) continue;
+                const T a = r[3 * n], b = r[3 * n + 1], c = r[3 * n + 2], t = useCN ? tol[n] : (T)1;
+                T qq = a * a + b * b + c * c;
+                if (useCN) qq = qq / (t * t);
+                q += (double)qq;
+            }
+            s += q;
+            continue;
+        }
         const T a0 = r[3 * n0], b0 = r[3 * n0 + 1], c0 = r[3 * n0 + 2], t0 = useCN ? tol[n0] : (T)1;
         const T a1 = r[3 * n1], b1 = r[3 * n1 + 1], c1 = r[3 * n1 + 2], t1 = useCN ? tol[n1] : (T)1;
         T q = a0 * a0 + b0 * b0 + c0 * c0;
@@ -65,72 +78,138 @@ __global__ void k_lbfgs_scalar(double* s, int i, int what)
         s[80] = s[50 + i] - s[70] * s[60 + i];
 }
 
-// One step of the two-loop recursion in one pass over the vectors (LBFGS.h:359-392):
-//   what 0 (first loop):  ksi = rho[ph] * dot_in ; y -= ksi * v ; dot_out += z . y
-//   what 1 (second loop): coef = ksi[ph] - rho[ph] * dot_in ; y += coef * v ; dot_out += z . y
-// dot_in was accumulated by the previous launch (k_dot_only or this kernel), dot_out is the inner product the next
-// step needs, taken on the freshly updated y (z == nullptr on the last step).  Same arithmetic as the unfused
-// dot / k_lbfgs_scalar / axpy sequence, one third of the launches and two thirds of the bytes.
+// ---- L-BFGS two-loop recursion (LBFGS.h:359-392) in five launches per nonlinear iteration, whatever the history length.
+// The recursion is sequential in the reference: ksi_i = rho_i <dx_i, q>, q -= ksi_i dg_i for the newest pair first, then the second
+// loop oldest first; written like that it costs one dependent launch (or one dependent all-reduce, sharded) per stored pair and loop.
+// Every inner product it needs is an inner product of the CURRENT vector with a history vector, and the current vector is the loop's
+// start vector minus a combination of history vectors, so with the Gram matrix M[i][j] = <dx_i, dg_j> of the stored pairs (two new
+// rows / columns per iteration, k_lbfgs_pair) the recursion runs on scalars:
+//   first loop   b_i = <dx_i, r>  (one batch of m dots),   ksi_i = rho_i (b_i - sum_{j>i} ksi_j M[i][j]),   q = r - sum ksi_i dg_i
+//   second loop  e_i = <dg_i, z0> (one batch of m dots),   c_i = ksi_i - rho_i (e_i + sum_{j<i} c_j M[j][i]),   z = z0 + sum c_i dx_i
+// The same recursion in the same order (the vector updates are applied element-wise in the reference's order); what changes is the
+// rounding of the inner products (a difference of products instead of a product with a difference), far below the parity tolerance.
+// Sharded runs (hot_set_comm) all-reduce each batch once: three small all-reduces per iteration instead of 2 m + 1.
+constexpr int LB_MAXV = 17; // 2 * historySize + 1 dots in the largest batch
+constexpr int LB_B = 512, LB_E = 536, LB_G = 560, LB_M = 600; // dscal slots: first-loop dots, second-loop dots, new-pair dots, Gram matrix (9 x 9 physical slots)
 template <class T>
-__global__ __launch_bounds__(256) void k_lbfgs_fused(size_t n, double* s, int in_slot, int out_slot, int ph, int what, const T* __restrict__ v, T* __restrict__ y, const T* __restrict__ z, GridRed gr)
+struct LbVecs {
+    const T* dx[8]; // stored pairs, oldest first
+    const T* dg[8];
+    int ph[8]; // their physical history slots
+    int m;
+};
+// out[k] = <a_k, y> for the m stored pairs (a = dx: first loop, a = dg: second loop); mask: rows this rank owns (sharded), or null
+template <class T>
+__global__ __launch_bounds__(256) void k_lbfgs_dots(size_t n, LbVecs<T> hv, int use_dg, const T* __restrict__ y, double* out, GridRed gr, const uint8_t* __restrict__ mask)
 {
     __shared__ double red[4];
-    const double tmp = s[in_slot];
-    const double coef = what == 0 ? tmp * s[60 + ph] : s[50 + ph] - tmp * s[60 + ph];
-    if (what == 0 && blockIdx.x == 0 && threadIdx.x == 0) s[50 + ph] = coef;
-    const T c = (T)(what == 0 ? -1.0 * coef : 1.0 * coef);
-    double acc = 0;
-    // four independent strided elements per trip: the loads of a trip are in flight together (a plain grid-stride loop waits for each)
+    double acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0;
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {
-        T yv[4], vv[4], zv[4];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        if (mask && !mask[i / 3]) continue;
+        const T yv = y[i];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const size_t i = i0 + u * stride, ic = i < n ? i : i0;
-            yv[u] = y[ic], vv[u] = v[ic], zv[u] = z ? z[ic] : (T)0;
+        for (int k = 0; k < 8; ++k)
+            if (k < hv.m) acc[k] += (double)((use_dg ? hv.dg[k][i] : hv.dx[k][i]) * yv);
+    }
+    double tot[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot[k] = k < hv.m ? block_sum_256<double>(acc[k], red) : 0.0;
+    grid_sum_store_n<8>(tot, hv.m, gr, out, red);
+}
+// mode 0: q = r - sum ksi_i dg_i (newest pair first), ksi stored at s[50 + ph]; optional keep[i] = r[i] (the working pair's dg starts as
+// the old residual).  mode 1: z = z0 + sum c_i dx_i (oldest first).  Every workgroup runs the scalar recursion itself (m <= 8).
+template <class T>
+__global__ __launch_bounds__(256) void k_lbfgs_apply(size_t n, double* s, LbVecs<T> hv, int mode, T* __restrict__ y, T* __restrict__ keep, const uint8_t* __restrict__ mask)
+{
+    __shared__ double coef[8];
+    if (threadIdx.x == 0) {
+        const int m = hv.m;
+        double t[8];
+        if (mode == 0) {
+            for (int i = m - 1; i >= 0; --i) {
+                double v = s[LB_B + i];
+                for (int j = i + 1; j < m; ++j) v -= t[j] * s[LB_M + 9 * hv.ph[i] + hv.ph[j]];
+                t[i] = v * s[60 + hv.ph[i]];
+                coef[i] = -t[i];
+                if (blockIdx.x == 0) s[50 + hv.ph[i]] = t[i];
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const size_t i = i0 + u * stride;
-            if (i < n) {
-                const T yn = yv[u] + c * vv[u];
-                y[i] = yn;
-                if (z) acc += (double)(zv[u] * yn);
+        else {
+            for (int i = 0; i < m; ++i) {
+                double v = s[LB_E + i];
+                for (int j = 0; j < i; ++j) v += t[j] * s[LB_M + 9 * hv.ph[j] + hv.ph[i]];
+                t[i] = s[50 + hv.ph[i]] - s[60 + hv.ph[i]] * v;
+                coef[i] = t[i];
             }
         }
     }
-    if (z) { // kernel-uniform
-        double t = block_sum_256<double>(acc, red);
-        grid_sum_store(t, 0.0, 1, gr, s + out_slot, nullptr, red);
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        if (mask && !mask[i / 3]) continue;
+        T v = y[i];
+        if (keep) keep[i] = v;
+        if (mode == 0) {
+#pragma unroll
+            for (int k = 7; k >= 0; --k)
+                if (k < hv.m) v = v + (T)coef[k] * hv.dg[k][i];
+        }
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < hv.m) v = v + (T)coef[k] * hv.dx[k][i];
+        }
+        y[i] = v;
     }
 }
-// dst = src (optional) and dot_out += z . src in the same pass
+// The new curvature pair of slot wk: dg_wk -= r_new, then out[0] = <dx_wk, dg_wk>, out[1 + j] = <dx_wk, dg_j>, out[1 + m + j] = <dx_j, dg_wk>
 template <class T>
-__global__ __launch_bounds__(256) void k_copy_dot(size_t n, double* s, int out_slot, const T* __restrict__ src, T* __restrict__ dst, const T* __restrict__ z, GridRed gr)
+__global__ __launch_bounds__(256) void k_lbfgs_pair(size_t n, LbVecs<T> hv, const T* __restrict__ dxw, T* __restrict__ dgw, const T* __restrict__ rnew, double* out, GridRed gr, const uint8_t* __restrict__ mask)
 {
     __shared__ double red[4];
-    double acc = 0;
+    double acc[LB_MAXV];
+#pragma unroll
+    for (int k = 0; k < LB_MAXV; ++k) acc[k] = 0;
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {
-        T av[4], zv[4];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        if (mask && !mask[i / 3]) continue;
+        const T g = dgw[i] - rnew[i], x = dxw[i];
+        dgw[i] = g;
+        acc[0] += (double)(g * x);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const size_t i = i0 + u * stride, ic = i < n ? i : i0;
-            av[u] = src[ic], zv[u] = z ? z[ic] : (T)0;
-        }
+        for (int k = 0; k < 8; ++k)
+            if (k < hv.m) acc[1 + k] += (double)(x * hv.dg[k][i]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const size_t i = i0 + u * stride;
-            if (i < n) {
-                if (dst) dst[i] = av[u];
-                if (z) acc += (double)(zv[u] * av[u]);
-            }
+        for (int k = 0; k < 8; ++k)
+            if (k < hv.m) acc[9 + k] += (double)(hv.dx[k][i] * g);
+    }
+    // compact order of the deposits: [0] | [1, m] | [m + 1, 2 m]
+    double tot[LB_MAXV];
+    const int m = hv.m;
+#pragma unroll
+    for (int k = 0; k < LB_MAXV; ++k) tot[k] = 0;
+    tot[0] = block_sum_256<double>(acc[0], red);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < m) {
+            const double a = block_sum_256<double>(acc[1 + k], red), b = block_sum_256<double>(acc[9 + k], red);
+            if (threadIdx.x == 0) tot[1 + k] = a, tot[1 + m + k] = b;
         }
-    }
-    if (z) {
-        double t = block_sum_256<double>(acc, red);
-        grid_sum_store(t, 0.0, 1, gr, s + out_slot, nullptr, red);
-    }
+    grid_sum_store_n<LB_MAXV>(tot, 2 * m + 1, gr, out, red);
+}
+// files the (all-reduced, when sharded) dots of k_lbfgs_pair: curvature -> s[71] and the pinned host slot, rho -> s[60 + wk] in the
+// arithmetic of the host code it replaces ((T)1 / (T)d, LBFGS.h:424-434), Gram rows / columns of slot wk
+template <class T>
+__global__ void k_lbfgs_file(double* s, LbVecs<T> hv, int wk, double* host_curv)
+{
+    const double* g = s + LB_G;
+    s[71] = g[0];
+    *host_curv = g[0];
+    s[60 + wk] = (double)((T)1 / (T)g[0]);
+    for (int j = 0; j < hv.m; ++j) s[LB_M + 9 * wk + hv.ph[j]] = g[1 + j], s[LB_M + 9 * hv.ph[j] + wk] = g[1 + hv.m + j];
 }
 // rho of a new curvature pair: s[dst] = 1 / (y's) in the arithmetic of the host code it replaces ((T)1 / (T)d, LBFGS.h:424-434)
 template <class T>
@@ -145,9 +224,10 @@ bool Ctx<T>::should_exit(const T* r)
     if (Nn == 0) return true;
     {
         const int grid = std::min(div_up(Nn, 512), 1024);
-        HOT_LAUNCH(this, "exit_norm", k_scaled_norm<T>, grid, 256, 0, r, cnTol.p, Nn, cfg.useCN, dscal.p + 90, gred(grid, hscal + 90, true));
+        HOT_LAUNCH(this, "exit_norm", k_scaled_norm<T>, grid, 256, 0, r, cnTol.p, Nn, cfg.useCN, dscal.p + 90, gred(grid, hscal + 90, true), vmask);
     }
     wait_ticket();
+    if (vmask) c_allreduce(hscal + 90, 1, HOT_COMM_F64, HOT_COMM_SUM, false); // partitioned vectors: the ranks' sums over their own rows
     double v = hscal[90];
     HOT_CHECK(v == v, HOT_ERR_NUMERIC, "NaN in the residual norm");
     if (!cfg.useCN) {
@@ -258,7 +338,8 @@ bool Ctx<T>::lbfgs_solve()
         int wk = order.back();
         const int m = (int)order.size() - 1; // stored curvature pairs
         const bool unfused = ab_flag("HOT_LBFGS_UNFUSED"); // A/B build only: dot / scalar / axpy as separate launches
-        const int vgrid = (int)std::min<size_t>(div_up(n3, 1024), 2048); // four elements per thread and trip
+        const int vgrid = (int)std::min<size_t>(div_up(n3, 1024), 1024);
+        LbVecs<T> hv{};
         if (unfused) {
             copy(n3, residual, hist_dg[wk].p);
             for (int i = m - 1; i >= 0; --i) {
@@ -269,13 +350,13 @@ bool Ctx<T>::lbfgs_solve()
             }
         }
         else {
-            // dot slots: 140 + k for step k of the first loop, 160 + k for the second (each written by exactly one launch)
-            HOT_LAUNCH(this, "lbfgs_copy_dot", k_copy_dot<T>, vgrid, 256, 0, n3, s, 140, residual, hist_dg[wk].p, m > 0 ? hist_dx[order[m - 1]].p : (const T*)nullptr, gred(vgrid));
-            for (int k = 0; k < m; ++k) {
-                int ph = order[m - 1 - k];
-                const T* znext = k + 1 < m ? hist_dx[order[m - 2 - k]].p : (const T*)nullptr;
-                HOT_LAUNCH(this, "lbfgs_fused", k_lbfgs_fused<T>, vgrid, 256, 0, n3, s, 140 + k, 141 + k, ph, 0, hist_dg[ph].p, residual, znext, gred(vgrid));
+            for (int i = 0; i < m; ++i) hv.dx[i] = hist_dx[order[i]].p, hv.dg[i] = hist_dg[order[i]].p, hv.ph[i] = order[i];
+            hv.m = m;
+            if (m > 0) {
+                HOT_LAUNCH(this, "lbfgs_dots", k_lbfgs_dots<T>, vgrid, 256, 0, n3, hv, 0, residual, s + LB_B, gred_n(vgrid, 8), vmask);
+                reduce_scalars(s + LB_B, m);
             }
+            HOT_LAUNCH(this, "lbfgs_apply", k_lbfgs_apply<T>, vgrid, 256, 0, n3, s, hv, 0, residual, hist_dg[wk].p, vmask);
         }
         precondition_dev(residual, hist_dx[wk].p);
         project_dev(hist_dx[wk].p);
@@ -288,12 +369,9 @@ bool Ctx<T>::lbfgs_solve()
             }
         }
         else if (m > 0) {
-            HOT_LAUNCH(this, "lbfgs_copy_dot", k_copy_dot<T>, vgrid, 256, 0, n3, s, 160, hist_dx[wk].p, (T*)nullptr, hist_dg[order[0]].p, gred(vgrid));
-            for (int k = 0; k < m; ++k) {
-                int ph = order[k];
-                const T* znext = k + 1 < m ? hist_dg[order[k + 1]].p : (const T*)nullptr;
-                HOT_LAUNCH(this, "lbfgs_fused", k_lbfgs_fused<T>, vgrid, 256, 0, n3, s, 160 + k, 161 + k, ph, 1, hist_dx[ph].p, hist_dx[wk].p, znext, gred(vgrid));
-            }
+            HOT_LAUNCH(this, "lbfgs_dots", k_lbfgs_dots<T>, vgrid, 256, 0, n3, hv, 1, hist_dx[wk].p, s + LB_E, gred_n(vgrid, 8), vmask);
+            reduce_scalars(s + LB_E, m);
+            HOT_LAUNCH(this, "lbfgs_apply", k_lbfgs_apply<T>, vgrid, 256, 0, n3, s, hv, 1, hist_dx[wk].p, (T*)nullptr, vmask);
         }
         if (cfg.linesearch) line_search(hist_dx[wk].p, residual, (T)1);
         transform_dev(hist_dx[wk].p, true); // recoverSolution
@@ -303,9 +381,16 @@ bool Ctx<T>::lbfgs_solve()
             Ek = state_pass(x, true);
             residual_dev(residual);
         }
-        axpy(n3, (T)-1, residual, hist_dg[wk].p);
-        dot_to(n3, hist_dg[wk].p, hist_dx[wk].p, s + 71, hscal + 91);
-        HOT_LAUNCH(this, "lbfgs_rho", k_lbfgs_rho<T>, 1, 1, 0, s, 71, 60 + wk);
+        if (unfused) {
+            axpy(n3, (T)-1, residual, hist_dg[wk].p);
+            dot_to(n3, hist_dg[wk].p, hist_dx[wk].p, s + 71, hscal + 91);
+            HOT_LAUNCH(this, "lbfgs_rho", k_lbfgs_rho<T>, 1, 1, 0, s, 71, 60 + wk);
+        }
+        else {
+            HOT_LAUNCH(this, "lbfgs_pair", k_lbfgs_pair<T>, vgrid, 256, 0, n3, hv, hist_dx[wk].p, hist_dg[wk].p, residual, s + LB_G, gred_n(vgrid, LB_MAXV), vmask);
+            reduce_scalars(s + LB_G, 2 * m + 1);
+            HOT_LAUNCH(this, "lbfgs_file", k_lbfgs_file<T>, 1, 1, 0, s, hv, wk, hscal + 91);
+        }
         pending = true;
     }
     sync();
@@ -531,6 +616,7 @@ void Ctx<T>::line_search_api(void* ddv, void* residual, double alpha, double* al
     size_t n3 = 3 * (size_t)Nn;
     HOT_HIP(hipMemcpyAsync(work0.p, ddv, n3 * sizeof(T), hipMemcpyDefault, stream));
     T a = line_search(work0.p, work1.p, (T)alpha);
+    if (halo_mode()) gather_all(*levels[0], work0.p), gather_all(*levels[0], work1.p); // the C ABI hands out complete vectors
     download(ddv, work0.p, n3), download(residual, work1.p, n3);
     sync();
     if (alpha_out) *alpha_out = (double)a;
@@ -564,8 +650,9 @@ void Ctx<T>::compute_step_api(const void* residual, void* step)
     nw_step.reserve(n3, 1.25);
     HOT_HIP(hipMemcpyAsync(work2.p, residual, n3 * sizeof(T), hipMemcpyDefault, stream));
     with_gs_retry([&] {
-        release_levels();
+        release_levels(halo_mode() ? 1 : 0);
         compute_step_dev(work2.p, nw_step.p);
+        if (halo_mode()) gather_all(*levels[0], nw_step.p);
         sync();
     });
     download(step, nw_step.p, n3);
@@ -597,7 +684,7 @@ void Ctx<T>::solve(hot_stats* st)
             updated = false, Ek = Ek_in, stats = stats_in; // the state pass is redone from dv (the failed attempt overwrote the force tiles)
         }
         first_try = false;
-        release_levels();
+        release_levels(halo_mode() ? 1 : 0); // halo mode: level 0 (coordinates, row ownership, exchange lists) exists since hot_p2g
         if (cfg.lsolver == 3)
             lbfgs_solve();
         else
@@ -606,9 +693,10 @@ void Ctx<T>::solve(hot_stats* st)
     });
     prof.collect();
     stats.num_nodes = Nn;
-    stats.num_levels = (int)levels.size();
+    stats.num_levels = (halo_mode() && cfg.matrixFree) ? 0 : (int)levels.size(); // halo mode keeps a matrix-less level 0 (row ownership, exchange lists) also for the matrix-free solvers
     stats.energy = cfg.linesearch ? Ek : 0.0; // the incremental potential at the last accepted line-search point; without a line search nobody evaluates it there (ImplicitSolver.h:237-252)
     stats.ms_solve = wall_ms() - t0;
+    export_comm_stats();
     if (st) *st = stats;
 }
 
@@ -623,6 +711,7 @@ void Ctx<T>::advance(double dt_, hot_stats* st)
     int32_t f = 0;
     g2p(dt_, &f);
     stats.ms_total = wall_ms() - t0;
+    export_comm_stats();
     if (st) *st = stats;
 }
 

@@ -67,6 +67,27 @@ __global__ void k_make_keys(const T* __restrict__ X, const int32_t* __restrict__
     vals[p] = (uint32_t)p;
 }
 
+// Sharded runs break ties inside a cell by the GLOBAL particle id, which need not fit the 32 - block_bits index field of the key (64 M
+// particles per GPU of a weak-scaled body exceed it on the second rank): two stable passes instead — by id, then by cell with the index
+// field left zero — give the same order for ids of any size.
+__global__ void k_id_keys(const int32_t* __restrict__ gid, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int64_t n)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) keys[p] = (uint64_t)(uint32_t)gid[p], vals[p] = (uint32_t)p;
+}
+template <class T>
+__global__ void k_make_keys_in_order(const T* __restrict__ X, const uint32_t* __restrict__ visit, uint64_t* keys, uint32_t* vals, int64_t n, T one_over_dx)
+{
+    using G = Geo<T>;
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t p = visit[k];
+    int b0 = base_node<T>(X[p] * one_over_dx), b1 = base_node<T>(X[n + p] * one_over_dx), b2 = base_node<T>(X[2 * n + p] * one_over_dx);
+    constexpr int index_bits = 32 - G::block_bits;
+    keys[k] = (G::linear_offset(b0, b1, b2) >> G::data_bits) << index_bits;
+    vals[k] = (uint32_t)p;
+}
+
 template <class U>
 __global__ void k_gather(const U* __restrict__ src, U* __restrict__ dst, const uint32_t* __restrict__ perm, int64_t n, int comps)
 {
@@ -228,7 +249,7 @@ Ctx<T>::Ctx(const hot_config& c)
     HOT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     prof.on = c.profile != 0;
     keep_debug = c.debug_store != 0;
-    dscal.reserve(256);
+    dscal.reserve(1024); // [0,256) solver scalars, [512, 1024) L-BFGS two-loop: dot batches and the Gram matrix (solve.hip)
     red_part.reserve(4096), red_count.reserve(4);
     HOT_HIP(hipMemset(red_count.p, 0, 4 * sizeof(unsigned)));
     HOT_HIP(hipHostMalloc((void**)&hscal, 256 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)); // fine-grained: kernels publish results and tickets here while they run (wait_ticket)
@@ -345,22 +366,37 @@ void Ctx<T>::sort()
 {
     need(Np > 0, "hot_sort: no particles");
     double t0 = wall_ms();
+    comm_calls = comm_bytes_index = comm_bytes_data = 0; // hot_stats.comm_*: since this call
+    vmask = nullptr; // no row ownership until hot_p2g has numbered the nodes
     if (sharded()) migrate_particles(); // every particle to the rank that holds its SPGrid page range (changes Np)
     int64_t n = Np;
     keys.reserve(n), keys2.reserve(n), vals.reserve(n), vals2.reserve(n), flags.reserve(std::max<size_t>(n, 64)), scan.reserve(std::max<size_t>(n, 64));
     T one_over_dx = (T)1 / dx;
     // tie-break inside a cell: the caller's particle index — in a sharded run the global particle id, so that the order inside
     // a cell is the single-rank one whatever the shard looks like
-    HOT_LAUNCH(this, "make_keys", k_make_keys<T>, div_up(n, 256), 256, 0, pX.p, sharded() ? pGid.p : slot2orig.p, keys.p, vals.p, n, one_over_dx);
     size_t bytes = 0;
     HOT_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)n, 0, 64, stream));
     if (bytes > sort_tmp_bytes) {
         sort_tmp.reserve(bytes);
         sort_tmp_bytes = sort_tmp.cap;
     }
-    prof.begin("radix_sort_pairs", stream);
-    HOT_HIP(rocprim::radix_sort_pairs(sort_tmp.p, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)n, 0, 64, stream));
-    prof.end(stream);
+    constexpr int index_bits = 32 - G::block_bits;
+    if (sharded()) { // (cell, global id) order in two stable passes: ids of any size (see k_id_keys)
+        HOT_LAUNCH(this, "make_keys", k_id_keys, div_up(n, 256), 256, 0, pGid.p, keys.p, vals.p, n);
+        prof.begin("radix_sort_pairs", stream);
+        HOT_HIP(rocprim::radix_sort_pairs(sort_tmp.p, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)n, 0, 32, stream));
+        prof.end(stream);
+        HOT_LAUNCH(this, "make_keys", k_make_keys_in_order<T>, div_up(n, 256), 256, 0, pX.p, vals2.p, keys.p, vals.p, n, one_over_dx);
+        prof.begin("radix_sort_pairs", stream);
+        HOT_HIP(rocprim::radix_sort_pairs(sort_tmp.p, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)n, index_bits, 64, stream));
+        prof.end(stream);
+    }
+    else {
+        HOT_LAUNCH(this, "make_keys", k_make_keys<T>, div_up(n, 256), 256, 0, pX.p, slot2orig.p, keys.p, vals.p, n, one_over_dx);
+        prof.begin("radix_sort_pairs", stream);
+        HOT_HIP(rocprim::radix_sort_pairs(sort_tmp.p, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)n, 0, 64, stream));
+        prof.end(stream);
+    }
     // physical reorder of every per-particle array into sorted order
     auto reorder = [&](DBuf<T>& a, DBuf<T>& spare, int comps) {
         HOT_LAUNCH(this, "reorder_gather", k_gather<T>, div_up(n, 256), 256, 0, a.p, spare.p, vals2.p, n, comps);
@@ -393,8 +429,12 @@ void Ctx<T>::sort()
     Nb = exclusive_scan_i32(flags.p, scan.p, cand);
     blocks.reserve(Nb);
     HOT_LAUNCH(this, "block_assign", k_block_assign<T>, div_up(cand, 256), 256, 0, block_map, group_origin.p, flags.p, scan.p, blocks.p, Ng);
-    if (sharded()) merge_block_lists(); // the global Set_Page order: block ids, Nb and block_map are global from here on
+    if (sharded()) {
+        IndexPhase ip(this);
+        merge_block_lists(); // the global Set_Page order: block ids, Nb and block_map are global from here on
+    }
     HOT_LAUNCH(this, "group_nb", k_group_nb<T>, div_up(cand, 256), 256, 0, block_map, group_origin.p, group_nb.p, Ng);
+    if (halo_mode()) build_tile_plan(); // which ranks cover which block: the pairwise tile exchanges of the step
     // node tiles
     size_t slots = (size_t)Nb * EPB;
     gM.reserve(slots, 1.25), gMV.reserve(3 * slots, 1.25), gF.reserve(3 * slots, 1.25), gCN.reserve(slots, 1.25), gIdx.reserve(slots, 1.25), block_count.reserve(Nb + 1, 1.25);

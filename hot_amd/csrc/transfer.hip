@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_p2g(const T* __restrict__ X, const T* _
         int base[3];
         T w[3][3], dw[3][3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+        for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xp[d]), base[d], w[d], dw[d]);
         T cn = (T)0;
         if (WITH_CN) {
             // |dP/dF(F = I)|_F of the fixed-corotated model: A = 2 mu I + lambda 11^T, B blocks = mu [[1,1],[1,1]]
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
                 const T x = X[(int64_t)d * Np + p];
                 int base;
                 T w[3], dw[3];
-                bspline<T>(one_over_dx * x, base, w, dw);
+                bspline<T>(mul_rn(one_over_dx, x), base, w, dw);
                 sp[d][tid] = x, sp[4 + d][tid] = m * V[(int64_t)d * Np + p], sbase[d][tid] = base;
                 sp[16 + 3 * d][tid] = w[0], sp[17 + 3 * d][tid] = w[1], sp[18 + 3 * d][tid] = w[2];
             }
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_p2g_cells2(const T* __restrict__ X, con
                 const T x0 = sp[0][l], x1 = sp[1][l], x2 = sp[2][l];
                 // 1-D quadratic B-spline weights, the arithmetic of bspline() (BSplines.h:55-81) for the needed components
                 auto w1 = [&](T x, T fb, int q) {
-                    const T d0 = one_over_dx * x - fb;
+                    const T d0 = mul_rn(one_over_dx, x) - fb;
                     if (q == 0) {
                         const T z = (T)1.5 - d0;
                         return (T)0.5 * z * z;
@@ -382,7 +382,11 @@ void Ctx<T>::p2g()
     else
         HOT_LAUNCH(this, "p2g", (k_p2g_cells2<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
     reduce_tiles(nq, gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p, "p2g_reduce");
-    if (sharded()) { // the shards' partial node sums -> the body's (one all-reduce of nq values per node slot)
+    if (halo_mode()) { // the ranks that share a block add their partial sums: complete on every block this rank covers, zero on the others
+        T* arr[5] = { gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p };
+        tile_exchange(arr, nq);
+    }
+    else if (sharded()) { // the shards' partial node sums -> the body's (one all-reduce of nq values per node slot)
         DBuf<T>& st = ap; // scratch, otherwise used only while the hierarchy is built
         st.reserve((size_t)nq * slots);
         copy(slots, gM.p, st.p), copy(3 * (size_t)slots, gMV.p, st.p + slots);
@@ -392,6 +396,10 @@ void Ctx<T>::p2g()
         if (nq == 5) copy(slots, st.p + 4 * slots, gCN.p);
     }
     HOT_LAUNCH(this, "block_count", k_block_count<T>, div_up(Nb, 4), 256, 0, gM.p, block_count.p, Nb);
+    if (halo_mode()) { // node counts of the blocks this rank does not cover (0 here) from the ranks that do
+        IndexPhase ip(this);
+        c_allreduce(block_count.p, Nb, HOT_COMM_I32, HOT_COMM_MAX, true);
+    }
     scan.reserve(Nb + 1);
     Nn = exclusive_scan_i32(block_count.p, scan.p, Nb);
     HOT_CHECK((int64_t)Nn * 125 < (1LL << 31), HOT_ERR_CAPACITY, "num_nodes*125 overflows int32 (ImplicitSolver.h:479-480)");
@@ -406,18 +414,69 @@ void Ctx<T>::p2g()
         sync();
     }
     HOT_LAUNCH(this, "number_nodes", k_number_nodes<T>, div_up(Nb, 4), 256, 0, gM.p, gMV.p, gIdx.p, scan.p, blocks.p, dofSlot.p, id2coord.p, mass.p, nodeV.p, Nb, slots);
+    if (halo_mode()) replicate_numbering(); // coordinates of ALL nodes (index structure), slot <-> id tables rebuilt from them
     {
         constexpr int TILE = (G::BX + 2) * (G::BY + 2) * (G::BZ + 2);
         tileDof.reserve((size_t)Ng * TILE, 1.25);
         HOT_LAUNCH(this, "tile_dof", k_tile_dof<T>, div_up((size_t)Ng * TILE, 256), 256, 0, group_nb.p, gIdx.p, tileDof.p, Ng);
     }
+    if (halo_mode()) level0_ownership(); // level 0 exists from here on: row ownership, exchange lists, the mask of the solver's vector algebra
     stats.ms_p2g = wall_ms() - t0;
+}
+
+// Halo mode: a rank numbers the nodes of the blocks it covers (their masses are complete there); the coordinates of the other nodes —
+// needed by the replicated index structure: colouring, coarse numbering, stencil columns — come from the ranks that first touch
+// them: rank r's first-touch blocks are the id range [nstart0[r], nstart0[r + 1]), one padded all-gather of 3 ints per node.
+__global__ void k_ids_pack(const int32_t* __restrict__ id2coord, int first, int cnt, int32_t* __restrict__ out, int maxc)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 3 * maxc) out[e] = e < 3 * cnt ? id2coord[3 * (int64_t)first + e] : 0;
+}
+struct IdRanges {
+    int first[65];
+};
+__global__ void k_ids_unpack(int32_t* __restrict__ id2coord, IdRanges rg, int R, int me, const int32_t* __restrict__ in, int maxc)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)R * 3 * maxc) return;
+    const int r = (int)(e / (3 * maxc)), k = (int)(e - (int64_t)r * 3 * maxc);
+    if (r == me || k >= 3 * (rg.first[r + 1] - rg.first[r])) return;
+    id2coord[3 * (int64_t)rg.first[r] + k] = in[e];
+}
+template <class T>
+__global__ void k_slots_from_coords(HashMap bm, const int32_t* __restrict__ id2coord, int32_t* __restrict__ dofSlot, int32_t* __restrict__ gIdx, int nn)
+{
+    using G = Geo<T>;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nn) return;
+    const uint64_t off = G::linear_offset(id2coord[3 * n], id2coord[3 * n + 1], id2coord[3 * n + 2]);
+    const int32_t b = hash_find_id(bm, off >> 12);
+    const int64_t s = (int64_t)b * G::EPB + (int)((off & 0xfff) >> G::data_bits);
+    dofSlot[n] = (int32_t)s;
+    gIdx[s] = n;
+}
+template <class T>
+void Ctx<T>::replicate_numbering()
+{
+    IndexPhase ip(this);
+    const int R = comm.size, me = comm.rank;
+    int maxc = 0;
+    IdRanges rg{};
+    for (int r = 0; r <= R; ++r) rg.first[r] = nstart0[r];
+    for (int r = 0; r < R; ++r) maxc = std::max(maxc, nstart0[r + 1] - nstart0[r]);
+    if (maxc == 0) return;
+    xsend.reserve((size_t)3 * maxc * 4), xrecv.reserve((size_t)3 * maxc * 4 * R);
+    HOT_LAUNCH(this, "ids_pack", k_ids_pack, div_up(3 * (size_t)maxc, 256), 256, 0, id2coord.p, nstart0[me], nstart0[me + 1] - nstart0[me], (int32_t*)xsend.p, maxc);
+    c_allgather(xsend.p, xrecv.p, (int64_t)3 * maxc * 4, true);
+    HOT_LAUNCH(this, "ids_unpack", k_ids_unpack, div_up((size_t)R * 3 * maxc, 256), 256, 0, id2coord.p, rg, R, me, (const int32_t*)xrecv.p, maxc);
+    HOT_LAUNCH(this, "slots_from_coords", k_slots_from_coords<T>, div_up(Nn, 256), 256, 0, block_map, id2coord.p, dofSlot.p, gIdx.p, Nn);
 }
 
 template <class T>
 void Ctx<T>::get_grid(int32_t* ic, void* m, void* v)
 {
     need(Nn > 0, "hot_get_grid before hot_p2g");
+    if (halo_mode()) gather_all(*levels[0], mass.p, 1), gather_all(*levels[0], nodeV.p, 3); // the C ABI hands out complete arrays
     download(ic, id2coord.p, 3 * (size_t)Nn);
     download(m, mass.p, Nn);
     download(v, nodeV.p, 3 * (size_t)Nn);
@@ -456,7 +515,7 @@ __global__ __launch_bounds__(256) void k_g2p(T* __restrict__ X, T* __restrict__ 
         int base[3];
         T w[3][3], dw[3][3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx * xp[d], base[d], w[d], dw[d]);
+        for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xp[d]), base[d], w[d], dw[d]);
         const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
         T pic[3] = { 0, 0, 0 };
         T B[9], gv[9];
@@ -536,6 +595,7 @@ void Ctx<T>::g2p(double dt_, int32_t* flags)
     int32_t* dflags = (int32_t*)(dscal.p + 200);
     HOT_HIP(hipMemsetAsync(dflags, 0, 4, stream));
     T one_over_dx = (T)1 / dx;
+    if (halo_mode()) halo_gather(*levels[0], dv.p); // dv at the nodes of this rank's particle tiles that other ranks own
 #define G2P_ARGS pX.p, pV.p, pC.p, pF.p, pFn.p, (keep_debug ? pGradV.p : (T*)nullptr), pMu.p, pLam.p, pJp.p, Np, group_first.p, group_origin.p, group_nb.p, gIdx.p, nodeV.p, dv.p, dx, \
                  one_over_dx, (T)dt_, (T)cfg.apic_rpic_ratio, (T)cfg.cfl, (T)cfg.yield_stress, (T)cfg.snow[0], (T)cfg.snow[1], (T)cfg.snow[2], (T)cfg.snow[3], (T)cfg.snow[4], dflags
     if (cfg.plasticity == 1)

@@ -80,7 +80,10 @@ typedef struct hot_config {
                          owners' new values are handed to all ranks, i.e. the reference's update order and single-rank iterates; 1 = processor-block:
                          a rank sweeps its own rows against its own rows only (couplings to other ranks' rows enter through the residual), one
                          exchange per symmetric sweep instead of sixteen; a different (still symmetric positive definite) smoother — see DESIGN.md §7 */
-    int32_t reserved[2];
+    int32_t shard_replicated; /* sharded runs: 0 (default) = halo mode: DOF vectors live on the rows a rank owns plus the halo it reads, node tiles are summed
+                                 between the ranks that share a block, inner products are summed with one small all-reduce per batch; 1 = the first-generation
+                                 decomposition: every DOF vector replicated, whole-array all-reduce per scatter and all-gather per operator (kept for A/B) */
+    int32_t reserved[1];
 } hot_config;
 
 typedef struct hot_stats {
@@ -95,6 +98,9 @@ typedef struct hot_stats {
     double final_scaled_residual; /* sqrt(sum |r_i|^2/tol_i^2 / Nn) if useCN else |r|_2 */
     double energy; /* incremental potential at the last accepted line-search point (0 when cfg.linesearch == 0: nothing evaluates it then) */
     double ms_sort, ms_p2g, ms_begin, ms_hessian, ms_mg_build, ms_solve, ms_g2p, ms_total; /* host wall clock, device-synchronised */
+    /* sharded runs: what this rank handed to the collectives of hot_comm since the last hot_sort (hot_advance: during the step).  "index": integers that
+     * describe the grid (block lists, node numbering, exchange lists: once per step); "data": floating-point payloads (tiles, halos, matrix rows, scalars) */
+    int64_t comm_calls, comm_bytes_index, comm_bytes_data;
 } hot_stats;
 
 void hot_default_config(hot_config* cfg); /* HOT's tog.sh command set: -lsolver 3 -Ainv 1 --project --linesearch --bcproject -mg_level 3 -mg_times 1 -coarseSolver 2 -smoother 5 --usecn -cneps 1e-7 */

@@ -1,8 +1,10 @@
 """One connected body over several ranks on the GPU: the HIP library with hot_set_comm + hot_amd/dist.py.  The test box has one
 MI355X, so the ranks share device 0 and talk through gloo (device payloads staged through host tensors by TorchComm); the
-library code that runs — shard merge, partial-tile all-reduces, partial-row exchange, row-partitioned operators, colour-
-synchronous Gauss-Seidel — is exactly what runs with RCCL on a multi-GPU node, where only TorchComm's backend differs.
-Each case is compared with the single-rank HIP run AND with the single-rank CPU oracle."""
+library code that runs — shard merge, pairwise tile sums between the ranks that share a block, partial-row exchange, row-partitioned
+operators with halo gathers, partitioned vector algebra with all-reduced scalars, colour-synchronous Gauss-Seidel — is exactly what
+runs with RCCL on a multi-GPU node, where only TorchComm's backend differs.  Each case is compared with the single-rank HIP run AND
+with the single-rank CPU oracle.  Default = halo mode (hot_config.shard_replicated = 0); the first-generation decomposition
+(replicated vectors, whole-array collectives) is kept as shard_replicated = 1 and re-run here on two cases."""
 import numpy as np
 import pytest
 
@@ -21,8 +23,11 @@ CASES = [
     (2, 8, 0, dict(lsolver=3, levelCnt=3, max_iterations=3, cneps=1e-4), 1, 2e-4),  # fp32
     (3, -14, 1, dict(lsolver=3, levelCnt=3, max_iterations=4, cneps=1e-7), 1, 1e-11),  # irregular body (hollow ball, bar, thinned half): ragged blocks, uneven shards
     (2, -12, 1, dict(lsolver=2, levelCnt=2, max_iterations=2, cneps=1e-7, gs_sub_block=32), 300, 1e-11),
+    (2, 8, 1, dict(lsolver=3, levelCnt=3, max_iterations=5, cneps=1e-7, shard_replicated=1), 1, 1e-11),  # first-generation decomposition
+    (3, 10, 1, dict(lsolver=3, levelCnt=3, max_iterations=4, cneps=1e-7, gs_sub_block=32, shard_replicated=1), 200, 1e-11),
 ]
-IDS = ["lbfgs_mg3_all_partitioned", "lbfgs_mg3_coarse_replicated", "three_ranks_mixed", "pn_mgpcg", "pn_matfree", "jacobi_pcg", "fp32", "irregular_three_ranks", "irregular_pn_two_ranks"]
+IDS = ["lbfgs_mg3_all_partitioned", "lbfgs_mg3_coarse_replicated", "three_ranks_mixed", "pn_mgpcg", "pn_matfree", "jacobi_pcg", "fp32", "irregular_three_ranks", "irregular_pn_two_ranks",
+       "replicated_vectors_two_ranks", "replicated_vectors_three_ranks"]
 
 
 @pytest.mark.parametrize("world,n,dtype,kw,minrows,tol", CASES, ids=IDS)
@@ -34,8 +39,9 @@ def test_one_body_over_ranks_hip(hotlib, oracle, world, n, dtype, kw, minrows, t
         mw.compare(ranks, mw.single(oracle, n, 1, kw), tol)
     calls = ranks[0]["comm_calls"]
     assert calls["allreduce"] > 0 and calls["allgather"] > 0
-    if not kw.get("matrixFree"):
-        assert calls["alltoallv"] > 0  # partial Hessian rows crossed the shard boundary
+    assert calls["alltoallv"] > 0  # partial Hessian rows (and, in halo mode, tiles and halos) crossed the shard boundary
+    st = ranks[0]["stats"]
+    assert st["comm_calls"] > 0 and st["comm_bytes_data"] > 0 and st["comm_bytes_index"] > 0
 
 
 @pytest.mark.parametrize("world,n,kw,minrows", [
@@ -57,7 +63,28 @@ def test_rank_local_gs_over_ranks_hip_against_oracle(world, n, kw, minrows):
     assert mw.rel(hip[0]["dv"], cpu[0]["dv"]) < 1e-9
     exact = mw.launch(world, "hip", n, 1, dict(kw, shard_gs=0), partition_min_rows=minrows)
     assert mw.rel(hip[0]["vcycle"], exact[0]["vcycle"]) > 1e-6  # it IS a different smoother
-    assert hip[0]["comm_calls"]["allgather"] < 0.6 * exact[0]["comm_calls"]["allgather"], (hip[0]["comm_calls"], exact[0]["comm_calls"])
+    assert hip[0]["comm_calls"]["alltoallv"] < 0.6 * exact[0]["comm_calls"]["alltoallv"], (hip[0]["comm_calls"], exact[0]["comm_calls"])  # halo gathers are personalised exchanges
+
+
+def test_halo_bytes_scale_with_the_cut_surface():
+    """Halo mode: what a rank hands to the collectives during a fixed amount of solver work grows with the cut surface (edge^2), not with
+    the body (edge^3): a 24^3 and a 48^3 cube over two ranks, three L-BFGS iterations each.  The first-generation decomposition
+    (shard_replicated = 1) moves whole arrays and grows with the volume.  hot_stats.comm_bytes_data counts the floating-point payloads
+    (tiles, halos, partial matrix rows, scalars), comm_bytes_index the integers that describe the grid (once per step)."""
+    kw = dict(lsolver=3, levelCnt=2, max_iterations=3, cneps=1e-9)
+    out = {}
+    for n in (24, 48):
+        for rep in (0, 1):
+            r = mw.launch(2, "hip", n, 1, dict(kw, shard_replicated=rep), partition_min_rows=1, timeout=1800)
+            st = r[0]["stats"]
+            assert st["iterations"] == 3
+            out[(n, rep)] = (st["comm_bytes_data"], st["comm_bytes_index"], st["comm_calls"])
+    print("comm bytes (data, index, calls):", out)
+    halo_growth = out[(48, 0)][0] / out[(24, 0)][0]
+    repl_growth = out[(48, 1)][0] / out[(24, 1)][0]
+    assert halo_growth < 5.5, out  # surface: 4 x (measured 5.1: the particle-tile shell is two blocks thick whatever the body)
+    assert repl_growth > 5.8, out  # volume: 8 x for the arrays, the partial matrix rows of the cut (surface) are part of both (measured 6.1)
+    assert out[(48, 0)][0] < 0.3 * out[(48, 1)][0], out
 
 
 def test_whole_steps_over_ranks_with_migration_hip(hotlib):
@@ -114,6 +141,9 @@ def test_c2_size_body_over_two_ranks_hip(hotlib, shard_gs):
     assert mw.rel(ranks[0]["spmv"], ref["spmv"]) < 1e-10 and mw.rel(ranks[0]["r0"], ref["r0"]) < 1e-10
     assert ranks[0]["stats"]["iterations"] == 3 and ranks[0]["stats"]["energy"] < ranks[0]["e0"]
     assert mw.rel(ranks[0]["dv"], ref["dv"]) < 1e-2, mw.rel(ranks[0]["dv"], ref["dv"])
+    st = ranks[0]["stats"]
+    print("C2-size body, 2 ranks, 3 iterations: data bytes %.1f MB, index bytes %.1f MB, %d collective calls" % (st["comm_bytes_data"] / 1e6, st["comm_bytes_index"] / 1e6, st["comm_calls"]))
+    assert st["comm_bytes_data"] + st["comm_bytes_index"] < 100e6, st  # 1.1 GB per step with replicated vectors
 
 
 def test_whole_steps_over_two_ranks_hip(hotlib):
