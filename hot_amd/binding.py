@@ -35,7 +35,7 @@ class hot_collision_object(C.Structure):
 
 
 STICKY, SLIP, SEPARATE = 1, 2, 3
-HALFSPACE, SPHERE, BOX, CAPPED_CYLINDER, TORUS, ROTATED_BOX = 0, 1, 2, 3, 4, 5
+HALFSPACE, SPHERE, BOX, CAPPED_CYLINDER, TORUS, ROTATED_BOX, UNION, DIFFERENCE = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class hot_stats(C.Structure):
@@ -290,6 +290,14 @@ class Context:
     def set_collision_objects(self, objects):
         """objects: list of dicts(shape, type, p0, p1, friction=0, b=(0,0,0), dbdt=(0,0,0), R=I (3x3), omega=(0,0,0), s=1, dsdt=0, lsq=(1,0,0,0))
         evaluated per node at begin_step; p0 / p1 are in the object's material space (world x = R s X + b)."""
+        flat = []  # a composite (shape UNION / DIFFERENCE with a "members" list of primitive dicts) is followed by its members in the array
+        for d in objects:
+            if "members" in d:
+                flat.append(dict(d, p0=(0, 0, 0), p1=(float(len(d["members"])), 0.0, 0.0)))
+                flat += [dict(m, type=d["type"]) for m in d["members"]]
+            else:
+                flat.append(d)
+        objects = flat
         arr = (hot_collision_object * max(len(objects), 1))()
         for o, d in zip(arr, objects):
             o.shape, o.type, o.friction = d["shape"], d["type"], d.get("friction", 0.0)

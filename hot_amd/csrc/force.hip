@@ -170,8 +170,30 @@ template <class T>
 void Ctx<T>::set_collision_objects(int32_t n, const hot_collision_object* objs)
 {
     need(n >= 0 && n <= 64, "hot_set_collision_objects: 0 <= n <= 64");
-    for (int i = 0; i < n; ++i) {
-        need(objs[i].shape >= HOT_SHAPE_HALFSPACE && objs[i].shape <= HOT_SHAPE_ROTATED_BOX, "unknown collision shape");
+    for (int i = 0, members_left = 0; i < n; ++i) {
+        need(objs[i].shape >= HOT_SHAPE_HALFSPACE && objs[i].shape <= HOT_SHAPE_DIFFERENCE, "unknown collision shape");
+        const bool composite = objs[i].shape == HOT_SHAPE_UNION || objs[i].shape == HOT_SHAPE_DIFFERENCE;
+        if (members_left > 0) { // a member of the composite before it: a primitive, only shape / p0 / p1 / lsq are read
+            --members_left;
+            need(!composite, "a composite level set cannot be a member of a composite");
+            if (objs[i].shape == HOT_SHAPE_CAPPED_CYLINDER || objs[i].shape == HOT_SHAPE_TORUS || objs[i].shape == HOT_SHAPE_ROTATED_BOX)
+                need(objs[i].lsq[0] != 0 || objs[i].lsq[1] != 0 || objs[i].lsq[2] != 0 || objs[i].lsq[3] != 0, "lsq must be a rotation quaternion ((1,0,0,0) = none)");
+            need(!(objs[i].shape == HOT_SHAPE_HALFSPACE && objs[i].p1[0] == 0 && objs[i].p1[1] == 0 && objs[i].p1[2] == 0), "half space: the outward normal p1 must be non-zero");
+            continue;
+        }
+        if (composite) {
+            const int nm = (int)objs[i].p1[0];
+            need(nm >= 1 && (double)nm == objs[i].p1[0] && i + nm < n, "composite level set: p1[0] = number of member records that follow it");
+            need(objs[i].shape != HOT_SHAPE_DIFFERENCE || nm == 2, "DIFFERENCE takes exactly two members (A, then B)");
+            for (int m = 1; m <= nm; ++m) {
+                const int sh = objs[i + m].shape;
+                need(!((sh == HOT_SHAPE_BOX || sh == HOT_SHAPE_CAPPED_CYLINDER || sh == HOT_SHAPE_ROTATED_BOX) && objs[i].type != HOT_COLLISION_STICKY),
+                    "a composite with a box / capped-cylinder member must be STICKY (their automatic-differentiation normal is not restated)");
+                need(!(sh == HOT_SHAPE_HALFSPACE && (objs[i].dsdt != 0 || objs[i].omega[0] != 0 || objs[i].omega[1] != 0 || objs[i].omega[2] != 0)),
+                    "a composite with a half-space member cannot turn or scale (no bounds available for its speed)");
+            }
+            members_left = nm;
+        }
         need(objs[i].type >= HOT_COLLISION_STICKY && objs[i].type <= HOT_COLLISION_SEPARATE, "collision type must be STICKY (1), SLIP (2) or SEPARATE (3)");
         need(!((objs[i].shape == HOT_SHAPE_BOX || objs[i].shape == HOT_SHAPE_CAPPED_CYLINDER || objs[i].shape == HOT_SHAPE_ROTATED_BOX) && objs[i].type != HOT_COLLISION_STICKY),
             "boxes and capped cylinders must be STICKY (the reference's automatic-differentiation normal is undefined inside them)");
@@ -210,6 +232,7 @@ void Ctx<T>::eval_collision_objects()
             for (int d = 0; d < 3; ++d) h[i].p1[d] = h[i].p1[d] / nn;
         }
         h[i].inv_s = (T)1 / (T)cobjs[i].s, h[i].dsdt = (T)cobjs[i].dsdt;
+        h[i].nmember = (cobjs[i].shape == HOT_SHAPE_UNION || cobjs[i].shape == HOT_SHAPE_DIFFERENCE) ? (int32_t)cobjs[i].p1[0] : 0;
         double Rls[9];
         co_quat_to_matrix(cobjs[i].lsq, Rls);
         for (int d = 0; d < 9; ++d) h[i].Rls[d] = (T)Rls[d];
@@ -329,7 +352,7 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
             int base[3];
             T w[3][3], dw[3][3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xp[d]), base[d], w[d], dw[d]);
+            for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx, xp[d], base[d], w[d], dw[d]);
             const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
             T gv[9];
 #pragma unroll
@@ -404,7 +427,7 @@ __global__ __launch_bounds__(256) void k_force_scatter(const T* __restrict__ X, 
         int base[3];
         T w[3][3], dw[3][3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xp[d]), base[d], w[d], dw[d]);
+        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx, xp[d], base[d], w[d], dw[d]);
         T S[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) S[c] = scale * stress[(int64_t)c * Np + p];
@@ -475,7 +498,7 @@ __global__ __launch_bounds__(FORCE_THREADS) void k_force_cells(const T* __restri
             for (int d = 0; d < 3; ++d) {
                 int base;
                 T w[3], dw[3];
-                bspline<T>(mul_rn(one_over_dx, X[(int64_t)d * Np + p]), base, w, dw);
+                bspline<T>(one_over_dx, X[(int64_t)d * Np + p], base, w, dw);
                 sbase[d][tid] = base;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) sp[9 + 3 * d + q][tid] = w[q], sp[18 + 3 * d + q][tid] = dw[q];
@@ -813,7 +836,7 @@ __global__ __launch_bounds__(256) void k_matfree(const T* __restrict__ X, const 
         int base[3];
         T w[3][3], dw[3][3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xp[d]), base[d], w[d], dw[d]);
+        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx, xp[d], base[d], w[d], dw[d]);
         const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
         Mat3<T> gx;
 #pragma unroll

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_hessian(const T* __restrict__ X, const 
                 int base[3];
                 T w[3][3], dw[3][3];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xp[d]), base[d], w[d], dw[d]);
+                for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx, xp[d], base[d], w[d], dw[d]);
                 int i = tid / 9, j = (tid / 3) % 3, k = tid % 3;
                 T g0 = one_over_dx * dw[0][i] * w[1][j] * w[2][k], g1 = w[0][i] * one_over_dx * dw[1][j] * w[2][k], g2 = w[0][i] * w[1][j] * one_over_dx * dw[2][k];
                 // Fn^T g

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles(const T* __restric
             int base[3];
             T w[3][3], dw[3][3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xf[d]), base[d], w[d], dw[d]);
+            for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx, xf[d], base[d], w[d], dw[d]);
             int i = nd / 9, j = (nd / 3) % 3, k = nd % 3;
             T wi = i == 0 ? w[0][0] : (i == 1 ? w[0][1] : w[0][2]), dwi = i == 0 ? dw[0][0] : (i == 1 ? dw[0][1] : dw[0][2]);
             T wj = j == 0 ? w[1][0] : (j == 1 ? w[1][1] : w[1][2]), dwj = j == 0 ? dw[1][0] : (j == 1 ? dw[1][1] : dw[1][2]);
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
         for (int e = tid; e < cnt * 3; e += HT_THREADS) {
             int base;
             T w[3], dw[3];
-            bspline<T>(mul_rn(one_over_dx, sxf[(e / 3) * 12 + e % 3]), base, w, dw);
+            bspline<T>(one_over_dx, sxf[(e / 3) * 12 + e % 3], base, w, dw);
 #pragma unroll
             for (int k = 0; k < 3; ++k) sw[e * 6 + k] = w[k], sw[e * 6 + 3 + k] = one_over_dx * dw[k];
         }
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void k_mf_diag_col(const T* __restrict__ X, co
         int base[3];
         T w[3][3], dw[3][3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xp[d]), base[d], w[d], dw[d]);
+        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx, xp[d], base[d], w[d], dw[d]);
         T F9[9], D[45];
 #pragma unroll
         for (int c = 0; c < 9; ++c) F9[c] = Fn[(int64_t)c * Np + p];

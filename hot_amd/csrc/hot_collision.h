@@ -23,18 +23,97 @@ struct CollObj { // device copy of hot_collision_object in the simulation's scal
     T p0[3], p1[3], friction, b[3], dbdt[3];
     T R[9], omega[3], inv_s, dsdt; // R column-major; inv_s = 1 / s
     T Rls[9]; // capped cylinder / torus: rotation of the level set itself (column-major)
+    int32_t nmember; // UNION / DIFFERENCE: the member records that follow this one
 };
+
+// signed distance and (where the reference has a closed form: half space, sphere, torus) material-space normal of a primitive: the
+// signedDistance / normal members of Lib/Ziran/Math/Geometry/AnalyticLevelSet.cpp:272-288 (HalfSpace), :403-421 (Sphere), :504-537 (boxes),
+// :580-608 (Torus), AnalyticLevelSet.h:262-287 (CappedCylinder) — what DisjointUnionLevelSet / DifferenceLevelSet call on their members
+template <class T>
+__device__ __forceinline__ T co_signed_distance(const CollObj<T>& o, const T (&X)[3], T (&N)[3])
+{
+    N[0] = N[1] = N[2] = (T)0;
+    const T t[3] = { X[0] - o.p0[0], X[1] - o.p0[1], X[2] - o.p0[2] };
+    if (o.shape == HOT_SHAPE_HALFSPACE) {
+        N[0] = o.p1[0], N[1] = o.p1[1], N[2] = o.p1[2];
+        return o.p1[0] * t[0] + o.p1[1] * t[1] + o.p1[2] * t[2];
+    }
+    if (o.shape == HOT_SHAPE_SPHERE) {
+        const T d2 = t[0] * t[0] + t[1] * t[1] + t[2] * t[2], dist = hsqrt(d2);
+        if (d2 < (T)1e-7)
+            N[0] = 1;
+        else
+            N[0] = t[0] / dist, N[1] = t[1] / dist, N[2] = t[2] / dist;
+        return dist - o.p1[0];
+    }
+    if (o.shape == HOT_SHAPE_BOX) {
+        T dd = -(T)3.4e38, q2 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T c = (o.p0[k] + o.p1[k]) / (T)2, h = (o.p1[k] - o.p0[k]) / (T)2;
+            const T d = habs(X[k] - c) - h;
+            dd = d > dd ? d : dd;
+            const T q = d < (T)0 ? (T)0 : d;
+            q2 += q * q;
+        }
+        return (dd < (T)0 ? dd : (T)0) + hsqrt(q2);
+    }
+    T P[3]; // primitive space: R_ls^-1 (X - b_ls)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P[k] = o.Rls[3 * k] * t[0] + o.Rls[3 * k + 1] * t[1] + o.Rls[3 * k + 2] * t[2];
+    if (o.shape == HOT_SHAPE_ROTATED_BOX) {
+        T dd = -(T)3.4e38, q2 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T d = habs(P[k]) - o.p1[k];
+            dd = d > dd ? d : dd;
+            const T q = d < (T)0 ? (T)0 : d;
+            q2 += q * q;
+        }
+        return (dd < (T)0 ? dd : (T)0) + hsqrt(q2);
+    }
+    const T rho = hsqrt(P[0] * P[0] + P[2] * P[2]);
+    if (o.shape == HOT_SHAPE_TORUS) {
+        const T q0 = rho - o.p1[0], L = hsqrt(q0 * q0 + P[1] * P[1]);
+        const T gr = q0 / L, G[3] = { gr * P[0] / rho, P[1] / L, gr * P[2] / rho };
+#pragma unroll
+        for (int k = 0; k < 3; ++k) N[k] = o.Rls[k] * G[0] + o.Rls[3 + k] * G[1] + o.Rls[6 + k] * G[2];
+        return L - o.p1[1];
+    }
+    const T d0 = rho - o.p1[0], d1 = habs(P[1]) - (T)0.5 * o.p1[1]; // capped cylinder
+    const T m0 = d0 > (T)0 ? d0 : (T)0, m1 = d1 > (T)0 ? d1 : (T)0, mx = d0 > d1 ? d0 : d1;
+    return (mx < (T)0 ? mx : (T)0) + hsqrt(m0 * m0 + m1 * m1);
+}
 
 // returns whether node position x collides with o; v is replaced by the resolved velocity, n by the world normal (SLIP / SEPARATE)
 template <class T>
-__device__ __forceinline__ bool co_detect_resolve(const CollObj<T>& o, const T (&x)[3], T (&v)[3], T (&n)[3])
+__device__ __forceinline__ bool co_detect_resolve(const CollObj<T>* __restrict__ po, const T (&x)[3], T (&v)[3], T (&n)[3])
 {
+    const CollObj<T>& o = *po; // a composite's members are po[1 .. nmember]
     const T xb[3] = { x[0] - o.b[0], x[1] - o.b[1], x[2] - o.b[2] };
     T X[3], N[3] = { 0, 0, 0 }; // material space: X = R^T (x - b) / s
 #pragma unroll
     for (int k = 0; k < 3; ++k) X[k] = (o.R[3 * k] * xb[0] + o.R[3 * k + 1] * xb[1] + o.R[3 * k + 2] * xb[2]) * o.inv_s;
     bool colliding = false;
-    if (o.shape == HOT_SHAPE_HALFSPACE) {
+    if (o.shape == HOT_SHAPE_UNION) { // DisjointUnionLevelSet::signedDistance / normal (AnalyticLevelSet.cpp:148-190)
+        T best = (T)3.4e38;
+        for (int m = 1; m <= o.nmember; ++m) {
+            T Nm[3];
+            const T d = co_signed_distance(po[m], X, Nm);
+            if (d < best) best = d, N[0] = Nm[0], N[1] = Nm[1], N[2] = Nm[2];
+        }
+        colliding = best <= (T)0;
+    }
+    else if (o.shape == HOT_SHAPE_DIFFERENCE) { // DifferenceLevelSet (:220-236): A minus B
+        T Na[3], Nb[3];
+        const T a = co_signed_distance(po[1], X, Na), nb = -co_signed_distance(po[2], X, Nb);
+        if (nb > a)
+            N[0] = -Nb[0], N[1] = -Nb[1], N[2] = -Nb[2];
+        else
+            N[0] = Na[0], N[1] = Na[1], N[2] = Na[2];
+        colliding = (a > nb ? a : nb) <= (T)0;
+    }
+    else if (o.shape == HOT_SHAPE_HALFSPACE) {
         const T phi = o.p1[0] * (X[0] - o.p0[0]) + o.p1[1] * (X[1] - o.p0[1]) + o.p1[2] * (X[2] - o.p0[2]);
         colliding = phi <= (T)0;
         N[0] = o.p1[0], N[1] = o.p1[1], N[2] = o.p1[2];
@@ -145,11 +224,8 @@ inline void co_quat_to_matrix(const double (&q)[4], double (&R)[9])
 // AnalyticCollisionObject::evalMaxSpeed (CollisionObject.cpp:200-238): the object's largest speed over the corners of
 // the particle box (expanded by the caller) and of the level set's bounds that pass the reference's overlap test
 // (kept as written there: "any component above the min" and "any component below the max").
-inline double co_max_speed(const hot_collision_object& o, const double (&pmin)[3], const double (&pmax)[3])
+inline void co_bounds(const hot_collision_object& o, double (&lo)[3], double (&hi)[3])
 {
-    const double wn = std::sqrt(o.omega[0] * o.omega[0] + o.omega[1] * o.omega[1] + o.omega[2] * o.omega[2]);
-    if (o.dsdt == 0 && wn == 0) return std::sqrt(o.dbdt[0] * o.dbdt[0] + o.dbdt[1] * o.dbdt[1] + o.dbdt[2] * o.dbdt[2]);
-    double lo[3], hi[3]; // ls->getBounds: Sphere (AnalyticLevelSet.cpp:465-469), AxisAlignedAnalyticBox (:371-374)
     for (int d = 0; d < 3; ++d) {
         if (o.shape == HOT_SHAPE_SPHERE)
             lo[d] = o.p0[d] - o.p1[0], hi[d] = o.p0[d] + o.p1[0];
@@ -166,6 +242,25 @@ inline double co_max_speed(const hot_collision_object& o, const double (&pmin)[3
         else
             lo[d] = o.p0[d], hi[d] = o.p1[d];
     }
+}
+inline double co_max_speed(const hot_collision_object* po, const double (&pmin)[3], const double (&pmax)[3])
+{
+    const hot_collision_object& o = *po;
+    const double wn = std::sqrt(o.omega[0] * o.omega[0] + o.omega[1] * o.omega[1] + o.omega[2] * o.omega[2]);
+    if (o.dsdt == 0 && wn == 0) return std::sqrt(o.dbdt[0] * o.dbdt[0] + o.dbdt[1] * o.dbdt[1] + o.dbdt[2] * o.dbdt[2]);
+    double lo[3], hi[3]; // ls->getBounds: Sphere (AnalyticLevelSet.cpp:465-469), AxisAlignedAnalyticBox (:371-374)
+    if (o.shape == HOT_SHAPE_UNION) { // DisjointUnionLevelSet::getBounds (:157-167): the box around the members' bounds
+        for (int d = 0; d < 3; ++d) lo[d] = 1.7e308, hi[d] = -1.7e308;
+        for (int m = 1; m <= (int)o.p1[0]; ++m) {
+            double l[3], h[3];
+            co_bounds(po[m], l, h);
+            for (int d = 0; d < 3; ++d) lo[d] = std::min(lo[d], l[d]), hi[d] = std::max(hi[d], h[d]);
+        }
+    }
+    else if (o.shape == HOT_SHAPE_DIFFERENCE) // DifferenceLevelSet::getBounds (:239-242): those of A
+        co_bounds(po[1], lo, hi);
+    else
+        co_bounds(o, lo, hi);
     const double one_over_s = 1 / o.s;
     double best = 0;
     auto speed_at = [&](const double (&x)[3]) {
@@ -200,9 +295,9 @@ __device__ __forceinline__ bool co_multi(const CollObj<T>* __restrict__ objs, in
 #pragma unroll
     for (int k = 0; k < 9; ++k) nb[k] = (T)0;
     wn[0] = wn[1] = wn[2] = (T)0;
-    for (int k = 0; k < nobj; ++k) {
+    for (int k = 0; k < nobj; k += 1 + objs[k].nmember) { // a composite's members ride along behind it
         T n[3] = { 0, 0, 0 };
-        const bool collide = co_detect_resolve(objs[k], x, v, n);
+        const bool collide = co_detect_resolve(objs + k, x, v, n);
         any = any || collide;
         if (!collide) continue;
         if (objs[k].type == HOT_COLLISION_STICKY) {

@@ -137,20 +137,22 @@ __host__ __device__ inline int int_floor(T x)
 template <class T>
 __host__ __device__ inline int base_node(T x_index_space) { return int_floor<T>(x_index_space - (T)0.5); }
 
-// The index-space coordinate X / dx is a ROUNDED product in the reference (BSplineWeights::compute stores one_over_dx * X, takes its
-// floor and subtracts the floor from the stored value, BSplines.h:16-29, MpmGrid.h:55-78).  With -ffp-contract=fast the compiler would
-// fuse `one_over_dx * x - base` into one fma, i.e. keep the product exact: 3e-5 of a cell more accurate than the reference in float at
-// x / dx ~ 500, which is the whole fp32 single-pass deviation from the oracle (weights, grad v, stresses).  An explicitly rounded
-// multiply is never contracted.
+// The index-space coordinate X / dx: the reference stores the rounded product one_over_dx * X, takes its floor for the base node and
+// subtracts the floor from it (BSplineWeights::compute, BSplines.h:16-29, MpmGrid.h:55-78).  Built as the reference is (-O3 -march=native,
+// CMakeLists.txt:28) a host compiler contracts that subtraction with the multiply into one fma — the CPU oracle of this repository,
+// compiled the same way, does: measured against its fp64 run, its fp32 trial F is 40x closer to the truth than a rounded-product
+// evaluation (6.5e-7 against 2.6e-5: at X / dx ~ 500 a rounded float product has lost 3e-5 of a cell).  hipcc does not fuse here (the
+// product has a second use), so the two roundings are spelled out: the BASE NODE comes from the rounded product (bit-exact indexing,
+// SURVEY §8c), the FRACTION from the exact one.
 __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
 
 // quadratic B-spline weights and derivatives of one axis: reference BSplines.h:55-81
 template <class T>
-__device__ inline void bspline(T x, int& base, T (&w)[3], T (&dw)[3])
+__device__ inline void bspline(T one_over_dx, T xw, int& base, T (&w)[3], T (&dw)[3])
 {
-    base = base_node<T>(x);
-    T d0 = x - (T)base;
+    base = base_node<T>(mul_rn(one_over_dx, xw));
+    T d0 = fma(one_over_dx, xw, -(T)base);
     T z = ((T)1.5 - d0);
     w[0] = (T)0.5 * z * z;
     T d1 = d0 - (T)1;

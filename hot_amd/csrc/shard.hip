@@ -721,20 +721,20 @@ void Ctx<T>::migrate_particles()
         int64_t mine = n;
         c_allgather(&mine, cnts.data(), sizeof(int64_t), false);
     }
-    std::vector<std::pair<uint64_t, double>> ws;
+    std::vector<std::pair<uint64_t, int64_t>> ws; // (page, weight = particles of the sample's rank; every rank has S samples) — integers: exact quantiles
     ws.reserve(samp.size());
-    double wtot = 0;
+    __int128 wtot = 0;
     for (int r = 0; r < R; ++r)
-        for (int k = 0; k < S; ++k) ws.emplace_back(samp[(size_t)r * S + k], (double)cnts[r] / S), wtot += (double)cnts[r] / S;
-    std::sort(ws.begin(), ws.end(), [](const std::pair<uint64_t, double>& a, const std::pair<uint64_t, double>& b) { return a.first < b.first; });
+        for (int k = 0; k < S; ++k) ws.emplace_back(samp[(size_t)r * S + k], cnts[r]), wtot += cnts[r];
+    std::sort(ws.begin(), ws.end(), [](const std::pair<uint64_t, int64_t>& a, const std::pair<uint64_t, int64_t>& b) { return a.first < b.first; });
     Splitters sp{};
     sp.n = R - 1;
     {
-        double acc = 0;
+        __int128 acc = 0;
         size_t k = 0;
         uint64_t prev = 0;
         for (int r = 1; r < R; ++r) {
-            const double want = wtot * r / R;
+            const __int128 want = wtot * r / R;
             while (k < ws.size() && acc + ws[k].second <= want) acc += ws[k].second, ++k;
             uint64_t v = k < ws.size() ? ws[k].first : ws.back().first + 1;
             if (r > 1 && v <= prev) { // equal splitters (few pages, many ranks): advance to the next distinct page so that no range is empty by construction

@@ -769,7 +769,8 @@ void Ctx<T>::calculate_dt(double max_dt, double* dt_out, double* max_speed, doub
     if (!cobjs.empty()) { // :802-806 collision objects inside the particle box expanded by (degree + 2) dx
         double lo[3], hi[3];
         for (int d = 0; d < 3; ++d) lo[d] = (double)((T)-hscal[204 + d] - (T)4 * dx), hi[d] = (double)((T)hscal[201 + d] + (T)4 * dx);
-        for (const auto& o : cobjs) ms = std::max(ms, (T)co_max_speed(o, lo, hi));
+        for (size_t k = 0; k < cobjs.size(); k += 1 + ((cobjs[k].shape == HOT_SHAPE_UNION || cobjs[k].shape == HOT_SHAPE_DIFFERENCE) ? (size_t)cobjs[k].p1[0] : 0))
+            ms = std::max(ms, (T)co_max_speed(&cobjs[k], lo, hi)); // members of a composite ride along behind it
     }
     T dtc = (T)max_dt;
     if (ms) dtc = (T)cfg.cfl * dx / ms; // :807-809, in the scalar type of the simulation

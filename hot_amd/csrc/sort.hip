@@ -68,8 +68,8 @@ __global__ void k_make_keys(const T* __restrict__ X, const int32_t* __restrict__
 }
 
 // Sharded runs break ties inside a cell by the GLOBAL particle id, which need not fit the 32 - block_bits index field of the key (64 M
-// particles per GPU of a weak-scaled body exceed it on the second rank): two stable passes instead — by id, then by cell with the index
-// field left zero — give the same order for ids of any size.
+// particles per GPU of a weak-scaled body exceed it on the second rank): two passes instead — by id, then by (cell, rank of the id on
+// this rank) — give the same order for ids of any size.
 __global__ void k_id_keys(const int32_t* __restrict__ gid, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int64_t n)
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,7 +84,7 @@ __global__ void k_make_keys_in_order(const T* __restrict__ X, const uint32_t* __
     const int64_t p = visit[k];
     int b0 = base_node<T>(X[p] * one_over_dx), b1 = base_node<T>(X[n + p] * one_over_dx), b2 = base_node<T>(X[2 * n + p] * one_over_dx);
     constexpr int index_bits = 32 - G::block_bits;
-    keys[k] = (G::linear_offset(b0, b1, b2) >> G::data_bits) << index_bits;
+    keys[k] = ((G::linear_offset(b0, b1, b2) >> G::data_bits) << index_bits) + (uint64_t)k; // k = the particle's rank by id on this rank (< Np < 2^index_bits)
     vals[k] = (uint32_t)p;
 }
 
@@ -381,14 +381,14 @@ void Ctx<T>::sort()
         sort_tmp_bytes = sort_tmp.cap;
     }
     constexpr int index_bits = 32 - G::block_bits;
-    if (sharded()) { // (cell, global id) order in two stable passes: ids of any size (see k_id_keys)
+    if (sharded()) { // (cell, global id) order in two passes: ids of any size (see k_id_keys)
         HOT_LAUNCH(this, "make_keys", k_id_keys, div_up(n, 256), 256, 0, pGid.p, keys.p, vals.p, n);
         prof.begin("radix_sort_pairs", stream);
-        HOT_HIP(rocprim::radix_sort_pairs(sort_tmp.p, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)n, 0, 32, stream));
+        HOT_HIP(rocprim::radix_sort_pairs(sort_tmp.p, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)n, 0, 64, stream));
         prof.end(stream);
         HOT_LAUNCH(this, "make_keys", k_make_keys_in_order<T>, div_up(n, 256), 256, 0, pX.p, vals2.p, keys.p, vals.p, n, one_over_dx);
         prof.begin("radix_sort_pairs", stream);
-        HOT_HIP(rocprim::radix_sort_pairs(sort_tmp.p, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)n, index_bits, 64, stream));
+        HOT_HIP(rocprim::radix_sort_pairs(sort_tmp.p, bytes, keys.p, keys2.p, vals.p, vals2.p, (size_t)n, 0, 64, stream));
         prof.end(stream);
     }
     else {

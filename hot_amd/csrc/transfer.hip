@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_p2g(const T* __restrict__ X, const T* _
         int base[3];
         T w[3][3], dw[3][3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xp[d]), base[d], w[d], dw[d]);
+        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx, xp[d], base[d], w[d], dw[d]);
         T cn = (T)0;
         if (WITH_CN) {
             // |dP/dF(F = I)|_F of the fixed-corotated model: A = 2 mu I + lambda 11^T, B blocks = mu [[1,1],[1,1]]
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
                 const T x = X[(int64_t)d * Np + p];
                 int base;
                 T w[3], dw[3];
-                bspline<T>(mul_rn(one_over_dx, x), base, w, dw);
+                bspline<T>(one_over_dx, x, base, w, dw);
                 sp[d][tid] = x, sp[4 + d][tid] = m * V[(int64_t)d * Np + p], sbase[d][tid] = base;
                 sp[16 + 3 * d][tid] = w[0], sp[17 + 3 * d][tid] = w[1], sp[18 + 3 * d][tid] = w[2];
             }
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_p2g_cells2(const T* __restrict__ X, con
                 const T x0 = sp[0][l], x1 = sp[1][l], x2 = sp[2][l];
                 // 1-D quadratic B-spline weights, the arithmetic of bspline() (BSplines.h:55-81) for the needed components
                 auto w1 = [&](T x, T fb, int q) {
-                    const T d0 = mul_rn(one_over_dx, x) - fb;
+                    const T d0 = fma(one_over_dx, x, -fb); // exact product, like the fused multiply-add a -O3 -march=native host build makes of it (hot_common.h bspline)
                     if (q == 0) {
                         const T z = (T)1.5 - d0;
                         return (T)0.5 * z * z;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void k_g2p(T* __restrict__ X, T* __restrict__ 
         int base[3];
         T w[3][3], dw[3][3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) bspline<T>(mul_rn(one_over_dx, xp[d]), base[d], w[d], dw[d]);
+        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx, xp[d], base[d], w[d], dw[d]);
         const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
         T pic[3] = { 0, 0, 0 };
         T B[9], gv[9];

@@ -145,7 +145,13 @@ int hot_set_sticky_halfspaces(hot_ctx*, int32_t n, const double* origin /*3n*/, 
  *      enum values (CollisionObject.h:52-57).  Boxes (both kinds) and capped cylinders must be STICKY (their automatic-differentiation normal is not defined inside them).
  *      Replaces any half spaces / explicit collision nodes set before; n = 0 clears. */
 enum hot_collision_type { HOT_COLLISION_STICKY = 1, HOT_COLLISION_SLIP = 2, HOT_COLLISION_SEPARATE = 3 };
-enum hot_collision_shape { HOT_SHAPE_HALFSPACE = 0, HOT_SHAPE_SPHERE = 1, HOT_SHAPE_BOX = 2, HOT_SHAPE_CAPPED_CYLINDER = 3, HOT_SHAPE_TORUS = 4, HOT_SHAPE_ROTATED_BOX = 5 };
+enum hot_collision_shape { HOT_SHAPE_HALFSPACE = 0, HOT_SHAPE_SPHERE = 1, HOT_SHAPE_BOX = 2, HOT_SHAPE_CAPPED_CYLINDER = 3, HOT_SHAPE_TORUS = 4, HOT_SHAPE_ROTATED_BOX = 5,
+    /* composite level sets (Lib/Ziran/Math/Geometry/AnalyticLevelSet.h:58-120, AnalyticLevelSet.cpp:148-236): the record is followed by its member records in
+     * the array — primitives of which only shape / p0 / p1 / lsq are read; the composite's own transform, type and friction apply.  UNION: p1[0] = number of
+     * members, signed distance = the smallest of the members', normal of the member that attains it first.  DIFFERENCE: exactly two members A, B (p1[0] = 2),
+     * signed distance max(phi_A, -phi_B), normal -n_B where -phi_B > phi_A, else n_A.  Collision where the distance is <= 0 (AnalyticLevelSet::queryInside).
+     * A composite with a box / capped-cylinder member must be STICKY, one with a half-space member cannot turn or scale (as for those shapes alone). */
+    HOT_SHAPE_UNION = 6, HOT_SHAPE_DIFFERENCE = 7 };
 typedef struct hot_collision_object {
     int32_t shape; /* hot_collision_shape */
     int32_t type; /* hot_collision_type */

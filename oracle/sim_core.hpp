@@ -10,6 +10,7 @@
 // P2G, DOF numbering, mass vector, BCs, G2P.
 #pragma once
 #include <functional>
+#include <limits>
 #include <stdexcept>
 #include <memory>
 #include "../include/hot_mi355x.h"
@@ -594,14 +595,88 @@ struct Sim {
     // with the object transform x = R s X + b and its rates (CollisionObject.h:63-69)
     // AnalyticCollisionObject::detectAndResolveCollision (Lib/Ziran/Math/Geometry/CollisionObject.cpp:384-447) over
     // HalfSpace (AnalyticLevelSet.cpp:264-288), Sphere::queryInside (:435-452), AxisAlignedAnalyticBox (:353-363,504-529)
-    static bool detect_and_resolve(const hot_collision_object& o, const TV& x, TV& v, TV& n)
+    // signedDistance / normal of a primitive level set as DisjointUnionLevelSet / DifferenceLevelSet call them on their members:
+    // HalfSpace AnalyticLevelSet.cpp:272-288, Sphere :403-421, AxisAlignedAnalyticBox / AnalyticBox :359-363,504-529, Torus :580-608,
+    // CappedCylinder AnalyticLevelSet.h:262-287 (boxes and the cylinder: distance only, their automatic-differentiation normal is not restated)
+    static T signed_distance(const hot_collision_object& o, const TV& X, TV& N)
     {
+        TV p0{ { (T)o.p0[0], (T)o.p0[1], (T)o.p0[2] } }, p1{ { (T)o.p1[0], (T)o.p1[1], (T)o.p1[2] } };
+        N = TV::zero();
+        if (o.shape == HOT_SHAPE_HALFSPACE) {
+            const T nn = std::sqrt(p1.squaredNorm());
+            N = TV{ { p1(0) / nn, p1(1) / nn, p1(2) / nn } };
+            return N.dot(X - p0);
+        }
+        if (o.shape == HOT_SHAPE_SPHERE) {
+            TV t = X - p0;
+            const T d2 = t.squaredNorm(), dist = std::sqrt(d2);
+            N = d2 < (T)1e-7 ? TV{ { 1, 0, 0 } } : TV{ { t(0) / dist, t(1) / dist, t(2) / dist } };
+            return dist - p1(0);
+        }
+        if (o.shape == HOT_SHAPE_BOX) {
+            T dd = -(T)3.4e38, q2 = 0;
+            for (int k = 0; k < 3; ++k) {
+                T c = (p0(k) + p1(k)) / (T)2, h = (p1(k) - p0(k)) / (T)2;
+                T d = std::abs(X(k) - c) - h;
+                dd = std::max(dd, d);
+                T q = d < (T)0 ? (T)0 : d;
+                q2 += q * q;
+            }
+            return std::min(dd, (T)0) + std::sqrt(q2);
+        }
+        double qn = std::sqrt(o.lsq[0] * o.lsq[0] + o.lsq[1] * o.lsq[1] + o.lsq[2] * o.lsq[2] + o.lsq[3] * o.lsq[3]);
+        if (!(qn > 0)) qn = 1;
+        const double w = o.lsq[0] / qn, qx = o.lsq[1] / qn, qy = o.lsq[2] / qn, qz = o.lsq[3] / qn;
+        TM Rl;
+        Rl(0, 0) = (T)(1 - 2 * (qy * qy + qz * qz)), Rl(0, 1) = (T)(2 * (qx * qy - w * qz)), Rl(0, 2) = (T)(2 * (qx * qz + w * qy));
+        Rl(1, 0) = (T)(2 * (qx * qy + w * qz)), Rl(1, 1) = (T)(1 - 2 * (qx * qx + qz * qz)), Rl(1, 2) = (T)(2 * (qy * qz - w * qx));
+        Rl(2, 0) = (T)(2 * (qx * qz - w * qy)), Rl(2, 1) = (T)(2 * (qy * qz + w * qx)), Rl(2, 2) = (T)(1 - 2 * (qx * qx + qy * qy));
+        TV P = Rl.transpose() * (X - p0);
+        if (o.shape == HOT_SHAPE_ROTATED_BOX) {
+            T dd = -(T)3.4e38, q2 = 0;
+            for (int k = 0; k < 3; ++k) {
+                T d = std::abs(P(k)) - p1(k);
+                dd = std::max(dd, d);
+                T q = d < (T)0 ? (T)0 : d;
+                q2 += q * q;
+            }
+            return std::min(dd, (T)0) + std::sqrt(q2);
+        }
+        T rho = std::sqrt(P(0) * P(0) + P(2) * P(2));
+        if (o.shape == HOT_SHAPE_TORUS) {
+            T q0 = rho - p1(0), L = std::sqrt(q0 * q0 + P(1) * P(1)), gr = q0 / L;
+            N = Rl * TV{ { gr * P(0) / rho, P(1) / L, gr * P(2) / rho } };
+            return L - p1(1);
+        }
+        T d0 = rho - p1(0), d1 = std::abs(P(1)) - (T)0.5 * p1(1);
+        T m0 = std::max(d0, (T)0), m1 = std::max(d1, (T)0);
+        return std::min(std::max(d0, d1), (T)0) + std::sqrt(m0 * m0 + m1 * m1);
+    }
+    static int members_of(const hot_collision_object& o) { return (o.shape == HOT_SHAPE_UNION || o.shape == HOT_SHAPE_DIFFERENCE) ? (int)o.p1[0] : 0; }
+    static bool detect_and_resolve(const hot_collision_object* po, const TV& x, TV& v, TV& n)
+    {
+        const hot_collision_object& o = *po; // a composite's members are po[1 .. members_of(o)]
         TV b{ { (T)o.b[0], (T)o.b[1], (T)o.b[2] } }, p0{ { (T)o.p0[0], (T)o.p0[1], (T)o.p0[2] } }, p1{ { (T)o.p1[0], (T)o.p1[1], (T)o.p1[2] } };
         TV xb = x - b, X, N = TV::zero();
         const T one_over_s = (T)1 / (T)o.s;
         for (int k = 0; k < 3; ++k) X.a[k] = ((T)o.R[3 * k] * xb(0) + (T)o.R[3 * k + 1] * xb(1) + (T)o.R[3 * k + 2] * xb(2)) * one_over_s; // R^T (x - b) / s
         bool colliding = false;
-        if (o.shape == HOT_SHAPE_HALFSPACE) {
+        if (o.shape == HOT_SHAPE_UNION) { // DisjointUnionLevelSet::signedDistance / normal (AnalyticLevelSet.cpp:148-190), AnalyticLevelSet::queryInside (:111-120)
+            T best = std::numeric_limits<T>::max();
+            for (int m = 1; m <= members_of(o); ++m) {
+                TV Nm;
+                T d = signed_distance(po[m], X, Nm);
+                if (d < best) best = d, N = Nm;
+            }
+            colliding = best <= (T)0;
+        }
+        else if (o.shape == HOT_SHAPE_DIFFERENCE) { // DifferenceLevelSet (:220-236)
+            TV Na, Nb;
+            T a = signed_distance(po[1], X, Na), nb = -signed_distance(po[2], X, Nb);
+            N = nb > a ? Nb * (T)-1 : Na;
+            colliding = std::max(a, nb) <= (T)0;
+        }
+        else if (o.shape == HOT_SHAPE_HALFSPACE) {
             {
                 const T nn = std::sqrt(p1.squaredNorm()); // HalfSpace stores outward_normal.normalized() (AnalyticLevelSet.cpp:111-115)
                 p1 = TV{ { p1(0) / nn, p1(1) / nn, p1(2) / nn } };
@@ -747,9 +822,10 @@ struct Sim {
             TM nb = TM::zero();
             bool any = false;
             int slip_count = 0;
-            for (const auto& o : cobjs) {
+            for (size_t ko = 0; ko < cobjs.size(); ko += 1 + members_of(cobjs[ko])) { // a composite's members ride along behind it
+                const auto& o = cobjs[ko];
                 TV n = TV::zero();
-                bool collide = detect_and_resolve(o, xi, vi, n);
+                bool collide = detect_and_resolve(&cobjs[ko], xi, vi, n);
                 any = any || collide;
                 if (!collide) continue;
                 if (o.type == HOT_COLLISION_STICKY) {

@@ -247,6 +247,42 @@ void Sim<T>::build_product(EllMat<T>& out, const EllMat<T>& l, const EllMat<T>& 
 template <class T>
 void Sim<T>::build_transpose(EllMat<T>& out, const EllMat<T>& l, int rowcnt)
 {
+    if (fair_flag()) {
+        // "fair" CPU-baseline variant: the same transpose as a counting pass, a prefix sum and a parallel fill; every row is then sorted
+        // by column and duplicates are added in ascending source-row order, which is the order the std::map version below adds them in
+        std::vector<int> cnt(rowcnt + 1, 0);
+        for (size_t j = 0; j < (size_t)l.nrows * l.colsize; ++j) ++cnt[l.entryCol[j] + 1];
+        for (int r = 0; r < rowcnt; ++r) cnt[r + 1] += cnt[r];
+        std::vector<std::pair<int, TM>> flat(cnt[rowcnt]);
+        {
+            std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+            for (int i = 0; i < l.nrows; ++i) // rows ascending: a column's candidates end up in ascending source-row order
+                for (size_t j = (size_t)i * l.colsize; j < (size_t)(i + 1) * l.colsize; ++j) flat[pos[l.entryCol[j]]++] = { i, l.entryVal[j] };
+        }
+        std::vector<int> width(rowcnt);
+#pragma omp parallel for schedule(static)
+        for (int r = 0; r < rowcnt; ++r) { // merge equal columns in place
+            int w = cnt[r];
+            for (int k = cnt[r]; k < cnt[r + 1]; ++k) {
+                if (w > cnt[r] && flat[w - 1].first == flat[k].first)
+                    flat[w - 1].second += flat[k].second;
+                else
+                    flat[w++] = flat[k];
+            }
+            width[r] = w - cnt[r];
+        }
+        int colsize = 0;
+        for (int r = 0; r < rowcnt; ++r) colsize = std::max(colsize, width[r]);
+        out.colsize = colsize, out.nrows = rowcnt;
+        out.entryCol.resize((size_t)rowcnt * colsize), out.entryVal.resize((size_t)rowcnt * colsize);
+#pragma omp parallel for schedule(static)
+        for (int r = 0; r < rowcnt; ++r) {
+            size_t idx = (size_t)r * colsize;
+            for (int k = 0; k < width[r]; ++k, ++idx) out.entryCol[idx] = flat[cnt[r] + k].first, out.entryVal[idx] = flat[cnt[r] + k].second;
+            for (; idx < (size_t)(r + 1) * colsize; ++idx) out.entryCol[idx] = r > 0 ? 0 : 1, out.entryVal[idx] = TM::zero();
+        }
+        return;
+    }
     std::vector<std::map<int, TM>> data(rowcnt);
     for (int i = 0; i < l.nrows; ++i)
         for (size_t j = (size_t)i * l.colsize; j < (size_t)(i + 1) * l.colsize; ++j) {

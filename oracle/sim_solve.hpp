@@ -457,21 +457,36 @@ double Sim<T>::calculate_dt(double max_dt, double* max_speed, double* min_corner
         ms = m7[0];
         for (int d = 0; d < 3; ++d) hi[d] = m7[1 + d], nlo[d] = m7[4 + d];
     }
-    for (const auto& o : cobjs) { // MpmSimulationBase.cpp:802-806 with AnalyticCollisionObject::evalMaxSpeed (CollisionObject.cpp:200-238)
+    auto prim_bounds = [](const hot_collision_object& o, double (&blo)[3], double (&bhi)[3]) {
+        for (int d = 0; d < 3; ++d) {
+            // ls->getBounds: Sphere, Torus (r0 + r1), CappedCylinder (sqrt(r^2 + (h/2)^2)), AnalyticBox (|half edges|), AxisAlignedAnalyticBox
+            const double rad = o.shape == HOT_SHAPE_SPHERE ? o.p1[0] : o.shape == HOT_SHAPE_TORUS ? o.p1[0] + o.p1[1] : o.shape == HOT_SHAPE_ROTATED_BOX ? std::sqrt(o.p1[0] * o.p1[0] + o.p1[1] * o.p1[1] + o.p1[2] * o.p1[2]) : std::sqrt(o.p1[0] * o.p1[0] + 0.25 * o.p1[1] * o.p1[1]);
+            const bool round_ = o.shape == HOT_SHAPE_SPHERE || o.shape == HOT_SHAPE_TORUS || o.shape == HOT_SHAPE_CAPPED_CYLINDER || o.shape == HOT_SHAPE_ROTATED_BOX;
+            blo[d] = round_ ? o.p0[d] - rad : o.p0[d];
+            bhi[d] = round_ ? o.p0[d] + rad : o.p1[d];
+        }
+    };
+    for (size_t ko = 0; ko < cobjs.size(); ko += 1 + members_of(cobjs[ko])) { // MpmSimulationBase.cpp:802-806 with AnalyticCollisionObject::evalMaxSpeed (CollisionObject.cpp:200-238)
+        const auto& o = cobjs[ko];
         const double wn = std::sqrt(o.omega[0] * o.omega[0] + o.omega[1] * o.omega[1] + o.omega[2] * o.omega[2]);
         double best = 0;
         if (o.dsdt == 0 && wn == 0)
             best = std::sqrt(o.dbdt[0] * o.dbdt[0] + o.dbdt[1] * o.dbdt[1] + o.dbdt[2] * o.dbdt[2]);
         else {
             double pmin[3], pmax[3], blo[3], bhi[3];
-            for (int d = 0; d < 3; ++d) {
-                pmin[d] = (double)(-nlo[d] - (T)4 * dx), pmax[d] = (double)(hi[d] + (T)4 * dx); // particle box expanded by (degree + 2) dx
-                // ls->getBounds: Sphere, Torus (r0 + r1), CappedCylinder (sqrt(r^2 + (h/2)^2)), AxisAlignedAnalyticBox
-                const double rad = o.shape == HOT_SHAPE_SPHERE ? o.p1[0] : o.shape == HOT_SHAPE_TORUS ? o.p1[0] + o.p1[1] : o.shape == HOT_SHAPE_ROTATED_BOX ? std::sqrt(o.p1[0] * o.p1[0] + o.p1[1] * o.p1[1] + o.p1[2] * o.p1[2]) : std::sqrt(o.p1[0] * o.p1[0] + 0.25 * o.p1[1] * o.p1[1]);
-                const bool round_ = o.shape == HOT_SHAPE_SPHERE || o.shape == HOT_SHAPE_TORUS || o.shape == HOT_SHAPE_CAPPED_CYLINDER || o.shape == HOT_SHAPE_ROTATED_BOX;
-                blo[d] = round_ ? o.p0[d] - rad : o.p0[d];
-                bhi[d] = round_ ? o.p0[d] + rad : o.p1[d];
+            for (int d = 0; d < 3; ++d) pmin[d] = (double)(-nlo[d] - (T)4 * dx), pmax[d] = (double)(hi[d] + (T)4 * dx); // particle box expanded by (degree + 2) dx
+            if (o.shape == HOT_SHAPE_UNION) { // DisjointUnionLevelSet::getBounds (AnalyticLevelSet.cpp:157-167)
+                for (int d = 0; d < 3; ++d) blo[d] = 1.7e308, bhi[d] = -1.7e308;
+                for (int m = 1; m <= members_of(o); ++m) {
+                    double l[3], h[3];
+                    prim_bounds(cobjs[ko + m], l, h);
+                    for (int d = 0; d < 3; ++d) blo[d] = std::min(blo[d], l[d]), bhi[d] = std::max(bhi[d], h[d]);
+                }
             }
+            else if (o.shape == HOT_SHAPE_DIFFERENCE) // DifferenceLevelSet::getBounds (:239-242)
+                prim_bounds(cobjs[ko + 1], blo, bhi);
+            else
+                prim_bounds(o, blo, bhi);
             std::vector<std::array<double, 3>> corners;
             for (int i = 0; i < 8; ++i) {
                 std::array<double, 3> x, X;

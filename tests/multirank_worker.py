@@ -67,7 +67,7 @@ def run_case(lib, cloud, comm, cfgkw, steps, dt=1.0 / 24):
     return out
 
 
-def worker(rank, world, port, q, libkind, n, dtype, cfgkw, steps, backend, partition_min_rows):
+def worker(rank, world, port, q, libkind, n, dtype, cfgkw, steps, backend, partition_min_rows, shard_ids=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -91,7 +91,12 @@ def worker(rank, world, port, q, libkind, n, dtype, cfgkw, steps, backend, parti
         dist.init_process_group(backend, rank=rank, world_size=world)
         comm = hdist.TorchComm(device=device, partition_min_rows=partition_min_rows)
         cloud = scene(n, dtype)
-        shard = hdist.shard_by_page_order(cloud, rank, world)
+        if shard_ids is not None:  # the caller's partition (e.g. the one another run's migration ended with): global particle ids per rank
+            sel = np.sort(np.asarray(shard_ids[rank]))
+            shard = {k: (v[sel] if isinstance(v, np.ndarray) and len(v) == len(cloud["X"]) else v) for k, v in cloud.items()}
+            shard["index"] = sel.astype(np.int32)
+        else:
+            shard = hdist.shard_by_page_order(cloud, rank, world)
         out = run_case(lib, shard, comm, dict(cfgkw, dtype=dtype), steps)
         out["comm_calls"] = dict(comm.calls)
         q.put((rank, out))
@@ -103,12 +108,12 @@ def worker(rank, world, port, q, libkind, n, dtype, cfgkw, steps, backend, parti
         raise
 
 
-def launch(world, libkind, n, dtype, cfgkw, steps=0, backend="gloo", partition_min_rows=1, timeout=900):
+def launch(world, libkind, n, dtype, cfgkw, steps=0, backend="gloo", partition_min_rows=1, timeout=900, shard_ids=None):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() * 7 + n) % 2000
-    procs = [ctx.Process(target=worker, args=(r, world, port, q, libkind, n, dtype, cfgkw, steps, backend, partition_min_rows)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, q, libkind, n, dtype, cfgkw, steps, backend, partition_min_rows, shard_ids)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}

@@ -185,13 +185,14 @@ def test_fullsize_plastic_return_mapping(hotlib, name):
         assert rel(got["mu"][sel], mu) < tol * 10 and rel(got["lam"][sel], lam) < tol * 10 and rel(got["Jp"][sel], Jp) < tol * 10
 
 
-@pytest.mark.parametrize("cname,n,tol", [("C2", 63, 1e-9), ("C3", 100, 2e-2)])
+@pytest.mark.parametrize("cname,n,tol", [("C2", 63, 1e-9), ("C3", 100, 1e-3)])
 def test_fullsize_fixed_iterations_against_oracle(hotlib, oracle, cname, n, tol):
     """C2 and C3 at full size against the oracle itself: three L-BFGS iterations of one time step (Hessian + 3-level Galerkin
     hierarchy + three V-cycles + line searches), same control flow, dv compared.  fp64: round-off.  fp32 (C3, E = 1e9): both
-    sides run in float on a level-0 system of cond ~ 1 / eps_float, the HIP path additionally sums its node tiles in double
-    (hot_common.h AccT) where the oracle, like the reference, sums in float — the stated bound is 2 % of max|dv| after three
-    iterations, with the energies agreeing to 1e-4."""
+    sides run in float on a level-0 system of cond ~ 1 / eps_float; the HIP path sums its node tiles and inner products in double
+    (hot_common.h AccT) where the oracle, like the reference, sums in float.  Bound: 1e-3 of max|dv| after three iterations (round 2:
+    2e-2, before the B-spline fraction was evaluated with the exact product; measured 3e-5 on a 40^3 body, 1e-5 against the oracle's
+    wide-sums variant; 3.2e-4 here), energies to 1e-4 (measured 5e-5)."""
     cfg = synth.CONFIGS[cname]
     out = {}
     for name, lib in (("gpu", hotlib), ("cpu", oracle)):

@@ -169,20 +169,20 @@ def test_three_time_steps_against_oracle(hotlib, oracle):
 
 
 def test_three_time_steps_fp32_against_fp32_oracle(hotlib, oracle):
-    """fp32 whole steps against the oracle's own float arithmetic.  The level-0 system has cond ~ 1e8 ~ 1 / eps_float (low-mass
-    boundary nodes), so float trajectories of two correct implementations drift apart chaotically as soon as ONE discrete decision
-    differs (a line-search halving, one more top-level PCG iteration), and cannot be compared point-wise after that.  What is
-    comparable: a bounded number of iterations from one and the same state, for as long as the discrete decisions agree.  At the
-    start of each of three consecutive time steps (the trajectory itself is advanced by the HIP library's converged fp32 solve) both
-    sides take k = 1..4 L-BFGS iterations from identical particle data; while their counters (line-search trials, linear iterations,
-    dropped pairs) agree, dv must agree within 0.5 % of max|dv| and the energies within 1e-3 (relative, floor 1e-3) (the HIP path sums
-    node tiles in double and rounds once, the oracle sums in float like the reference - hot_common.h AccT; measured
-    0.005 - 0.06 % and 1e-6 - 1e-4).  The first iteration (no history, no decision yet) must always agree; in total at least 9 of the 12 (step, k)
-    pairs must have been comparable.  dt = 0.03 keeps the steps in the regime where the line search accepts the first trial: with
-    dt = 1/24 this soft cube needs up to seven halvings per iteration from the second step on, the two sides disagree on one PCG
-    iteration there, and a step later the oracle's own float solve breaks down (NaN).  The bounded runs use cneps = 1e-7 so that they
-    do not terminate early; the trajectory is advanced with the HIP library's converged solve at cneps = 1e-4, which must
-    converge and stay finite."""
+    """fp32 whole steps against the oracle's own float arithmetic, at the BASELINE time step dt = 1/24.  The level-0 system has
+    cond ~ 1e8 ~ 1 / eps_float (low-mass boundary nodes), so float trajectories of two correct implementations drift apart chaotically as
+    soon as ONE discrete decision differs (a line-search halving, one more top-level PCG iteration), and cannot be compared point-wise
+    after that.  What is comparable: a bounded number of iterations from one and the same state, for as long as the discrete decisions
+    agree.  At the start of each of three consecutive time steps (the trajectory itself is advanced by the HIP library's converged fp32
+    solve) both sides take k = 1..4 L-BFGS iterations from identical particle data; while their counters (line-search trials, linear
+    iterations, dropped pairs) agree, dv must agree within 1e-4 of max|dv| and the energies within 1e-5 on the first step, 5e-3 / 1e-2 on
+    the later ones (relative, floor 1e-3).  The
+    oracle runs its wide-sums variant (node sums and inner products in double, like the HIP build: tests/oracle_lib.py wide_sums).
+    Round 2 needed dt = 0.03 and 5e-3 here: the B-spline fraction was then evaluated from the rounded product X / dx (3e-5 of a cell in
+    float at X / dx ~ 500) where the host-compiled oracle fuses it into an fma (hot_common.h bspline); measured now 1e-6 - 1e-4.  The
+    first iteration (no history, no decision yet) must always agree; in total at least 9 of the 12 (step, k) pairs must have been
+    comparable.  The bounded runs use cneps = 1e-7 so that they do not terminate early; the trajectory is advanced with the HIP
+    library's converged solve at cneps = 1e-4, which must converge and stay finite."""
     T = np.float32
     from hot_amd import synth
     c = synth.cube_cloud(8, ppc=8, dtype=T)
@@ -195,18 +195,21 @@ def test_three_time_steps_fp32_against_fp32_oracle(hotlib, oracle):
         ctx.set_sticky_halfspaces(o, nrm)
         return ctx
 
-    DT = 0.03
+    DT = 1.0 / 24
     compared = 0
+    from tests.oracle_lib import wide_sums
     counters = ("iterations", "linesearch_trials", "linear_iterations", "dropped_pairs", "vcycles", "num_nodes")
     for step in range(3):
         e4 = None
         for its in (1, 2, 3, 4):
             res = {}
             for name, lib in (("gpu", hotlib), ("cpu", oracle)):
-                ctx = ctx_for(lib, max_iterations=its, cneps=1e-7)
-                pc.prepare(ctx, DT)
-                st = ctx.solve()
-                res[name] = (ctx.get_dv().astype(np.float64), st)
+                with wide_sums(name == "cpu"):
+                    ctx = ctx_for(lib, max_iterations=its, cneps=1e-7)
+                    pc.prepare(ctx, DT)
+                    st = ctx.solve()
+                    res[name] = (ctx.get_dv().astype(np.float64), st)
+                    del ctx
             (dg, sg), (dc, sc) = res["gpu"], res["cpu"]
             assert np.isfinite(dg).all() and np.isfinite(sg["energy"]) and sg["iterations"] == its
             e4 = sg["energy"]
@@ -219,8 +222,10 @@ def test_three_time_steps_fp32_against_fp32_oracle(hotlib, oracle):
             assert same or its > 1, (sg, sc)
             if not same:
                 break
-            assert err < 5e-3, err
-            assert abs(sg["energy"] - sc["energy"]) < 1e-3 * max(abs(sc["energy"]), 1e-3)
+            # first step (F = I, one line-search trial per iteration): round-off; later steps need up to seven halvings per iteration at this
+            # time step and the float errors are amplified by the solve (measured 3e-6 - 2.3e-3 and 1e-7 - 5e-3)
+            assert err < (1e-4 if step == 0 else 5e-3), err
+            assert abs(sg["energy"] - sc["energy"]) < (1e-5 if step == 0 else 1e-2) * max(abs(sc["energy"]), 1e-3)
             compared += 1
         full = ctx_for(hotlib, max_iterations=300, cneps=1e-4)
         stf = full.advance(DT)
@@ -374,6 +379,60 @@ def test_analytic_collision_objects_against_oracle(hotlib, oracle, boundaryType)
     for k in ("iterations", "linesearch_trials", "linear_iterations", "vcycles"):
         assert g[2][k] == c_[2][k], (k, g[2], c_[2])
     assert rel(g[1], c_[1]) < 1e-9
+
+
+def test_composite_level_sets_against_oracle(hotlib, oracle):
+    """DisjointUnionLevelSet / DifferenceLevelSet over the primitives (AnalyticLevelSet.h:58-120, AnalyticLevelSet.cpp:148-236): a slip union
+    of two spheres and a torus moving into the body, a sticky box with a spherical pocket cut out of it (difference), and a turning union.
+    The collision-node set is also checked against a numpy evaluation of min / max of the members' signed distances."""
+    from hot_amd.binding import BOX, DIFFERENCE, SLIP, SPHERE, STICKY, TORUS, UNION
+    objs = [
+        dict(shape=UNION, type=SLIP, friction=0.2, dbdt=(0.0, -0.3, 0.0), members=[
+            dict(shape=SPHERE, p0=(5.02, 5.085, 5.02), p1=0.025), dict(shape=SPHERE, p0=(5.055, 5.09, 5.05), p1=0.03),
+            dict(shape=TORUS, p0=(5.04, 5.08, 5.04), p1=(0.03, 0.012, 0), lsq=(0.9, 0.1, 0.3, 0.2))]),
+        dict(shape=DIFFERENCE, type=STICKY, members=[
+            dict(shape=BOX, p0=(4.97, 4.97, 4.97), p1=(5.09, 5.0151, 5.09)), dict(shape=SPHERE, p0=(5.04, 5.0151, 5.04), p1=0.022)]),
+        dict(shape=UNION, type=STICKY, b=(5.0, 5.0, 5.0), R=_rot((0, 1, 0), 0.3), omega=(0, 2.0, 0), members=[
+            dict(shape=SPHERE, p0=(0.075, 0.04, 0.01), p1=0.02), dict(shape=SPHERE, p0=(0.01, 0.05, 0.075), p1=0.018)]),
+    ]
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=8, bc=False, levelCnt=2, cneps=1e-7, max_iterations=4, boundaryType=1)
+        ctx.set_collision_objects(objs)
+        pc.prepare(ctx)
+        dv0 = ctx.get_dv()
+        grid = ctx.grid()
+        st = ctx.solve()
+        d = ctx.calculate_dt(1.0)
+        out[name] = (dv0, ctx.get_dv(), st, grid, d)
+    g, c_ = out["gpu"], out["cpu"]
+    assert rel(g[0], c_[0]) < 1e-13
+    for k in ("iterations", "linesearch_trials", "linear_iterations", "vcycles"):
+        assert g[2][k] == c_[2][k], (k, g[2], c_[2])
+    assert rel(g[1], c_[1]) < 1e-9
+    assert abs(g[4]["dt"] - c_[4]["dt"]) < 1e-12 * c_[4]["dt"] and g[4]["max_speed"] > 0.3  # the turning union's corner speed enters the CFL step
+    # independent evaluation of the three composites' signed distances at the grid nodes
+    x = g[3]["id2coord"].astype(np.float64) * 0.01
+    sph = lambda X, c, r: np.linalg.norm(X - np.asarray(c), axis=1) - r
+    q = np.array([0.9, 0.1, 0.3, 0.2])
+    q /= np.linalg.norm(q)
+    w, a, b, cq = q
+    Rl = np.array([[1 - 2 * (b * b + cq * cq), 2 * (a * b - w * cq), 2 * (a * cq + w * b)], [2 * (a * b + w * cq), 1 - 2 * (a * a + cq * cq), 2 * (b * cq - w * a)],
+                   [2 * (a * cq - w * b), 2 * (b * cq + w * a), 1 - 2 * (a * a + b * b)]])
+    P = (x - np.array([5.04, 5.08, 5.04])) @ Rl
+    tor = np.hypot(np.hypot(P[:, 0], P[:, 2]) - 0.03, P[:, 1]) - 0.012
+    u1 = np.minimum(np.minimum(sph(x, (5.02, 5.085, 5.02), 0.025), sph(x, (5.055, 5.09, 5.05), 0.03)), tor)
+    lo, hi = np.array([4.97, 4.97, 4.97]), np.array([5.09, 5.0151, 5.09])
+    dd = np.abs(x - (lo + hi) / 2) - (hi - lo) / 2
+    box = np.minimum(dd.max(1), 0) + np.linalg.norm(np.maximum(dd, 0), axis=1)
+    dif = np.maximum(box, -sph(x, (5.04, 5.0151, 5.04), 0.022))
+    Xm = (x - 5.0) @ _rot((0, 1, 0), 0.3)  # R^T (x - b)
+    u3 = np.minimum(sph(Xm, (0.075, 0.04, 0.01), 0.02), sph(Xm, (0.01, 0.05, 0.075), 0.018))
+    inside = (u1 <= 0) | (dif <= 0) | (u3 <= 0)
+    margin = np.minimum(np.minimum(np.abs(u1), np.abs(dif)), np.abs(u3)) > 1e-9  # nodes not sitting on a surface
+    moved = np.abs(g[0] - np.array([0, -9.8 / 24, 0])).max(axis=1) > 1e-12
+    assert inside.sum() > 100 and (u1 <= 0).sum() > 5 and (u3 <= 0).sum() > 5 and ((box <= 0) & (dif > 0)).sum() > 3  # the pocket really removes nodes
+    assert np.array_equal(moved[margin & ~((u1 <= 0) & ~(dif <= 0) & ~(u3 <= 0))], inside[margin & ~((u1 <= 0) & ~(dif <= 0) & ~(u3 <= 0))])  # (slip-only nodes may keep dv = g dt by chance: excluded)
 
 
 def _rot(axis, angle):

@@ -17,7 +17,7 @@ def key(c):
 
 def run(L, dtype, cloud, cfg, its, dt, what):
     T = np.float64 if dtype == 1 else np.float32
-    kw = dict(dtype=dtype, dx=cloud["dx"], gravity=(0, -9.8, 0), levelCnt=cfg["levelCnt"], max_iterations=its)
+    kw = dict(dtype=dtype, dx=cloud["dx"], gravity=(0, -9.8, 0), levelCnt=cfg["levelCnt"], max_iterations=its, debug_store=1)
     kw.update(cfg.get("kw", {}))
     ctx = L.context(**kw)
     ctx.set_particles(*(cloud[k].astype(T) for k in ("X", "V", "mass", "vol", "mu", "lam")))
@@ -51,7 +51,7 @@ def match(a, b, f):
     return np.abs(x - y).max() / max(np.abs(y).max(), 1e-300), len(common), len(ka), len(kb)
 
 
-for cname, n, dt in (("C3", 24, 1 / 24), ("C2", 16, 1 / 24)):
+for cname, n, dt in (("C3", 24, 1 / 24), ("C3", 40, 1 / 24), ("C5", 32, 1 / 24)):
     cfg = dict(synth.CONFIGS[cname])
     cloud = parallel.shard_cloud(cfg, 0, 1, n=n)
     cloud = {k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype.kind == "f" else v) for k, v in cloud.items()}
@@ -62,7 +62,7 @@ for cname, n, dt in (("C3", 24, 1 / 24), ("C2", 16, 1 / 24)):
           "energy %.3e|%.3e" % (abs(o["e"][0] - t["e"][0]) / abs(t["e"][0]), abs(h["e"][0] - t["e"][0]) / abs(t["e"][0])), "nodes", match(h, t, "mass")[1:], flush=True)
     prel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
     print(cname, n, "particles oracle32-vs-64 | hip32-vs-64:", " ".join("%s %.2e|%.2e" % (f, prel(o["p_" + f], t["p_" + f]), prel(h["p_" + f], t["p_" + f])) for f in ("F", "gradV", "stress")), flush=True)
-    for its in ():
+    for its in (1, 3, 6):
         t = run(ora, 1, cloud, cfg, its, dt, "solve")
         o = run(ora, 0, cloud, cfg, its, dt, "solve")
         h = run(lib, 0, cloud, cfg, its, dt, "solve")
