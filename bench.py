@@ -8,14 +8,16 @@ Prints ONE JSON line on rank 0.  `value` = ms per nonlinear (L-BFGS) iteration, 
 `roofline` = the kernel (device symbol) with the largest share of the timed region, from HIP events recorded on the
 library's launch stream (hot_config.profile); its `avg_launch_ms` is what rocprofv3 --kernel-trace --stats reports
 for the same symbol (profiles/).  `cpu_baseline` = the CPU oracle (a port of the reference's TBB decomposition to
-OpenMP) timed on the GPU box's host cores on the headline configuration itself: one whole time step in each of two
-variants ("faithful": serial where the reference is serial; "fair": those sections parallelised as well), ~1 minute.
+OpenMP), REBUILT ON THE BENCH HOST (-O3 -march=native there, like the reference's CMakeLists.txt:28) and timed on its cores on the
+headline configuration itself: the first --cpu-iters L-BFGS iterations (default 12) of the first time step, Hessian + hierarchy build
+timed separately, in each of two variants ("faithful": serial where the reference is serial; "fair": those sections parallelised as
+well); the GPU takes the same bounded step beside it.  ~30 s of CPU work.
 
 N > 1: one process per GPU (launched by torch.distributed.run, or spawned here when WORLD_SIZE is unset), RCCL through
 torch.distributed.  ONE connected body is sharded over the ranks (hot_set_comm, hot_amd/dist.py): particle
-ranges of the global sort order per rank, node tiles summed with all-reduces, matrix rows owned by one rank each,
-coloured Gauss-Seidel rank-local (processor-block: one exchange per symmetric sweep; --shard-gs 0 = colour-synchronous, the
-single-rank iterates at sixteen exchanges per sweep).  Weak scaling: the body grows so that every GPU keeps C2's particle count
+ranges of the global sort order per rank, node tiles summed between the ranks that share a block, matrix rows owned by one rank
+each, DOF vectors on owned rows + halos, inner products all-reduced in batches, coloured Gauss-Seidel rank-local (processor-block:
+one halo exchange per symmetric sweep; --shard-gs 0 = colour-synchronous, the single-rank iterates at sixteen exchanges per sweep).  Weak scaling: the body grows so that every GPU keeps C2's particle count
 (N = 8: a 126^3-cell body of 16 M particles, BASELINE config 4's size).
 """
 import argparse
@@ -127,6 +129,7 @@ def parse_args():
     ap.add_argument("--cells", type=int, default=0, help="override the cube edge (cells) of the per-GPU body for quick runs")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=0, help="cube edge of the CPU baseline's sample; 0 = the benchmark configuration itself")
+    ap.add_argument("--cpu-iters", type=int, default=12, help="L-BFGS iterations of the CPU baseline's bounded sample (0 = the whole first time step, ~70 s per variant at C2)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo with --share-gpu on a one-GPU box)")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N > 1: native stream-ordered RCCL communicator of the library (falls back to torch if RCCL "
                     "cannot be attached) or hot_amd.dist.TorchComm (torch.distributed collectives, host-synchronous)")
@@ -258,9 +261,13 @@ def main():
     # (SURVEY.md §8d): "faithful" leaves serial what the reference leaves serial, "fair" parallelises those sections too.
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
+        import subprocess
+        # the checker is rebuilt here, on the host that times it: -march=native must mean THIS machine's cores
+        rebuilt = subprocess.call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"]) == 0
         from tests.oracle_lib import load_oracle
         ora = load_oracle()
         nc = args.cpu_cells or n1
+        cap = dict(max_iterations=args.cpu_iters) if args.cpu_iters > 0 else {}
         sample = cloud if nc == n1 else parallel.shard_cloud(cfg, 0, 1, n=nc)
 
         def per_iter(st):
@@ -270,12 +277,12 @@ def main():
             if nm == "fair":
                 os.environ["HOT_ORACLE_FAIR"] = "1"  # read by the oracle when the context is created
             try:
-                c = make_ctx(ora, sample, cfg, device=local)
+                c = make_ctx(ora, sample, cfg, device=local, **cap)
                 res[nm] = c.advance(dt)  # the first step of the run (the GPU's first step is timed beside it below)
                 del c
             finally:
                 os.environ.pop("HOT_ORACLE_FAIR", None)
-        g = make_ctx(lib, sample, cfg, device=local)
+        g = make_ctx(lib, sample, cfg, device=local, **cap)
         res["gpu"] = g.advance(dt)
         del g
         try:
@@ -283,10 +290,12 @@ def main():
         except Exception:
             model = "unknown"
         f, fa, gp = res["faithful"], res["fair"], res["gpu"]
-        cpu = {"value": per_iter(f), "unit": "ms per L-BFGS iteration", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port", "variant": "faithful",
-               "cpu_model": model, "host_cores_visible": cores,
-               "sample": f"{args.config} itself: {nc}^3-cell cube, {sample['X'].shape[0]} particles, {f['num_nodes']} nodes, the first time step of the run "
-                         f"({f['iterations']} L-BFGS iterations, same solver knobs), one step per variant, no warm-up",
+        threads = int(ora.lib.hoto_num_threads())
+        cpu = {"value": per_iter(f), "unit": "ms per L-BFGS iteration", "cores": threads, "kind": "port", "variant": "faithful",
+               "cpu_model": model, "host_cores_visible": cores, "omp_threads": threads, "oracle_rebuilt_on_this_host": rebuilt,
+               "sample": f"{args.config} itself: {nc}^3-cell cube, {sample['X'].shape[0]} particles, {f['num_nodes']} nodes, "
+                         + (f"the first {f['iterations']} L-BFGS iterations of the first time step" if cap else f"the whole first time step ({f['iterations']} L-BFGS iterations)")
+                         + ", same solver knobs, one run per variant, no warm-up; Hessian + hierarchy build timed separately (cpu_build_ms)",
                "fair_value": per_iter(fa), "fair_iterations": fa["iterations"], "iterations": f["iterations"],
                "gpu_same_step_ms_per_iter": per_iter(gp), "gpu_iterations": gp["iterations"],
                "speedup_per_iteration_vs_faithful": per_iter(f) / max(per_iter(gp), 1e-9), "speedup_per_iteration_vs_fair": per_iter(fa) / max(per_iter(gp), 1e-9),
@@ -303,16 +312,18 @@ def main():
             "ms_per_step": elapsed * 1e3 / max(args.steps, 1), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if s == 8 else "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: one {n}^3-cell cube x {cfg['ppc']} ppc ({n1}^3 cells per GPU), fixed-corotated E={cfg['E']:g} nu={cfg['nu']}, dx=0.01, dt=1/24, "
-                                   f"-lsolver 3 -mg_level {cfg['levelCnt']} -smoother 5 -coarseSolver 2 --project --linesearch --bcproject --usecn -cneps 1e-7",
+                                   f"-lsolver 3 -mg_level {cfg['levelCnt']} -smoother 5 -coarseSolver 2 --project --linesearch --bcproject --usecn -cneps 1e-7"
+                                   + ({1: f", von Mises return mapping (yield {cfg.get('yield_stress', 0):g})", 2: ", snow plasticity return mapping"}.get(cfg.get("plasticity", 0), "")),
                        "particles_per_gpu": int(total_particles / world), "particles_total": int(total_particles), "nodes_total": stats[-1]["num_nodes"], "levels": stats[-1]["num_levels"],
-                       "parallelism": "1 GPU" if world == 1 else f"one connected body sharded over {world} ranks: particle ranges of the sort order, all-reduced node tiles, "
-                                                                 f"row-partitioned operators, coloured Gauss-Seidel {'rank-local (processor-block), one exchange per symmetric sweep' if args.shard_gs else 'colour-synchronous across ranks'} ({args.backend})"},
+                       "parallelism": "1 GPU" if world == 1 else f"one connected body sharded over {world} ranks: particle ranges of the sort order, node tiles summed between the ranks sharing a block, "
+                                                                 f"row-partitioned operators with halo gathers, partitioned vector algebra, coloured Gauss-Seidel {'rank-local (processor-block), one exchange per symmetric sweep' if args.shard_gs else 'colour-synchronous across ranks'} ({args.backend})"},
             "iterations_per_step": iters / max(args.steps, 1),
             "hessian_mg_build_ms_per_step": build_ms / max(args.steps, 1),
             "ms_per_iter_build_amortised": solve_ms / max(iters, 1),
             "p2g_g2p_mparticles_per_s": transfers["mparticles_per_s"] if transfers else None,
             "communicator": (None if comm is None else ("native RCCL on the context's stream" if isinstance(comm, str) and not hasattr(ctx, "_fallback_comm") else f"torch.distributed ({args.backend})")),
             "comm_calls_per_step": ({k: v / max(args.steps + args.warmup, 1) for k, v in comm.calls.items()} if (comm is not None and not isinstance(comm, str)) else None),
+            "comm_per_step_rank0": ({"collective_calls": stats[-1]["comm_calls"], "index_bytes": stats[-1]["comm_bytes_index"], "data_bytes": stats[-1]["comm_bytes_data"]} if world > 1 else None),
             "roofline": roof, "transfers": transfers, "cpu_baseline": cpu, "kernel_ms_per_step_top": prof_top,
         }
         print(json.dumps(out))

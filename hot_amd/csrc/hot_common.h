@@ -139,9 +139,9 @@ __host__ __device__ inline int base_node(T x_index_space) { return int_floor<T>(
 
 // The index-space coordinate X / dx: the reference stores the rounded product one_over_dx * X, takes its floor for the base node and
 // subtracts the floor from it (BSplineWeights::compute, BSplines.h:16-29, MpmGrid.h:55-78).  Built as the reference is (-O3 -march=native,
-// CMakeLists.txt:28) a host compiler contracts that subtraction with the multiply into one fma — the CPU oracle of this repository,
-// compiled the same way, does: measured against its fp64 run, its fp32 trial F is 40x closer to the truth than a rounded-product
-// evaluation (6.5e-7 against 2.6e-5: at X / dx ~ 500 a rounded float product has lost 3e-5 of a cell).  hipcc does not fuse here (the
+// CMakeLists.txt:28) a host compiler contracts that subtraction with the multiply into one fma — g++ does for the CPU restatement this
+// repository's tests compare with: measured against an fp64 run of the same inputs, the fp32 trial F of that build is 40x closer to the
+// truth than a rounded-product evaluation (6.5e-7 against 2.6e-5: at X / dx ~ 500 a rounded float product has lost 3e-5 of a cell).  hipcc does not fuse here (the
 // product has a second use), so the two roundings are spelled out: the BASE NODE comes from the rounded product (bit-exact indexing,
 // SURVEY §8c), the FRACTION from the exact one.
 __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }

@@ -95,7 +95,7 @@ int32_t cb_alltoallv(void* user, const void* send, const int64_t* soff, const in
     bool ok = true;
     if (sbytes[r->rank] > 0) // a rank's message to itself (the library sends none today; the contract allows it)
         ok = hipMemcpyAsync((char*)recv + roff[r->rank], (const char*)send + soff[r->rank], (size_t)sbytes[r->rank], hipMemcpyDeviceToDevice, r->stream) == hipSuccess;
-    ok = ok && api().GroupStart() == ncclSuccess;
+    if (!ok || api().GroupStart() != ncclSuccess) return 1; // no GroupEnd without a GroupStart
     for (int p = 0; p < r->size && ok; ++p) {
         if (p == r->rank) continue;
         if (rbytes[p] > 0) ok = ok && api().Recv((char*)recv + roff[p], (size_t)rbytes[p], ncclChar, p, r->comm, r->stream) == ncclSuccess;
@@ -130,7 +130,18 @@ int hot_rccl_attach(hot_ctx* ctx, const void* unique_id128, int32_t rank, int32_
         return HOT_ERR_DEVICE;
     }
     (void)hipSetDevice(ctx->impl->cfg.device);
-    Rccl* r = new Rccl;
+    if (ctx->impl->native_comm) { // a second attach: the previous communicator (and its scratch) goes first — nothing may still be enqueued on it
+        (void)hipStreamSynchronize(ctx->impl->stream);
+        try {
+            ctx->impl->set_comm(nullptr);
+        }
+        catch (...) {
+        }
+        if (ctx->impl->native_comm_free) ctx->impl->native_comm_free(ctx->impl->native_comm);
+        ctx->impl->native_comm = nullptr, ctx->impl->native_comm_free = nullptr;
+    }
+    Rccl* r = new (std::nothrow) Rccl;
+    if (!r) return HOT_ERR_DEVICE;
     r->rank = rank, r->size = size, r->stream = ctx->impl->stream;
     ncclUniqueId id;
     std::memcpy(&id, unique_id128, sizeof(id));
@@ -153,6 +164,18 @@ int hot_rccl_attach(hot_ctx* ctx, const void* unique_id128, int32_t rank, int32_
         (void)api().CommDestroy(r->comm);
         delete r;
         return e.code;
+    }
+    catch (const std::exception& e) { // nothing may cross the extern "C" boundary
+        ctx->err = e.what();
+        (void)api().CommDestroy(r->comm);
+        delete r;
+        return HOT_ERR_DEVICE;
+    }
+    catch (...) {
+        ctx->err = "hot_rccl_attach: unknown exception";
+        (void)api().CommDestroy(r->comm);
+        delete r;
+        return HOT_ERR_DEVICE;
     }
     ctx->impl->native_comm = r;
     ctx->impl->native_comm_free = [](void* p) {

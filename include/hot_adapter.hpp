@@ -156,12 +156,18 @@ public:
         : simulation(s) {}
     hot_ctx* c() const { return simulation.ctx; }
     int64_t numNodes() const { return simulation.numNodes(); }
-    void resetLSFlag() { updated = false; } // startBackwardEuler (MultigridSimulation.h:167-186)
+    void resetLSFlag() { updated = false, x_alias = nullptr; } // startBackwardEuler (MultigridSimulation.h:167-186); the solver's x of the previous step is forgotten
+    // The solver's iterate x IS simulation.dv in the reference (LBFGS / Newton are handed `simulation.dv` by reference), so lineSearch moves it.
+    // Here x lives in the caller's memory: name it once per solve with setX (mutable, must stay alive and un-reallocated until the solve
+    // returns).  Without setX, lineSearch falls back to the pointer of the last updateState call — which then must be that same vector.
+    void setX(T* x) { x_alias = x, x_explicit = true; }
+    template <class Vec, class = decltype(std::declval<Vec&>().data())>
+    void setX(Vec& x) { setX(x.data()); }
 
     // ---- raw pointers
     void updateState(const T* dv)
     {
-        x_alias = const_cast<T*>(dv);
+        if (!x_explicit) x_alias = const_cast<T*>(dv); // legacy aliasing rule (see setX)
         if (updated) return;
         double e = 0;
         check(c(), hot_update_state(c(), dv, &e), "hot_update_state");
@@ -234,6 +240,7 @@ public:
 
 private:
     T* x_alias = nullptr;
+    bool x_explicit = false;
 };
 
 // void (*smoothFunc)(TVStack& u, TVStack& r, TVStack& du, TVStack& dAu, MPMSpMat& A, int iterations, T tolerance):

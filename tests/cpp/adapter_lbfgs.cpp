@@ -138,6 +138,7 @@ int main()
         Vec x;
         x.v.resize(3 * (size_t)simB.numNodes());
         simB.getDv(x.data());
+        obj.setX(x); // the solver's iterate: lineSearch moves it, as it moves simulation.dv in the reference
         {   // by hand, once: updateState -> computeResidual -> HinvApproxInit -> precondition -> project (state unchanged: x is dv)
             Vec r, z;
             r.resizeLike(x), z.resizeLike(x);
