@@ -33,6 +33,12 @@ struct Level {
     DBuf<int32_t> gs_pad; // nblocks*64*8: per (colour block, position) {node or -1, the row's four class counts, pad}: the GS kernels' header in one load
     DBuf<int32_t> rowcnt; // 4n: (precede-off, precede-in, follow-in, follow-off) slot counts of the regrouped rows
     bool split = false;
+    // coarseSolver 7 (mg_ic.hip): block incomplete Cholesky of a top level.  ic_l: the strictly lower blocks by stencil slot; (ic_col, ic_val)
+    // the factor as a sweepable matrix (lower: L_ij, upper: L_ji^T), regrouped like (col, val) with its own class counts / block headers
+    DBuf<int32_t> ic_col, ic_rowcnt, ic_pad;
+    DBuf<T> ic_val, ic_l, ic_d, ic_dinv, ic_dinvT;
+    bool ic_ready = false;
+    double ic_shift = 0;
     int color_block_begin[9] = { 0 }; // blocks of colour c are [color_block_begin[c], color_block_begin[c+1])
     int nblocks = 0;
     // prolongation to this level from the next coarser one (P has 8 slots/row), restriction = P^T as child table
@@ -178,7 +184,21 @@ struct Ctx : CtxBase {
         IndexPhase(Ctx<T>* c_) : c(c_), old(c_->comm_index_phase) { c->comm_index_phase = true; }
         ~IndexPhase() { c->comm_index_phase = old; }
     };
-    void account(int64_t bytes) { ++comm_calls, (comm_index_phase ? comm_bytes_index : comm_bytes_data) += bytes; }
+    const char* comm_tag = "other"; // what the collectives called now carry (profile records "commMB_<tag>": calls, megabytes handed in)
+    struct CommTag {
+        Ctx<T>* c;
+        const char* old;
+        CommTag(Ctx<T>* c_, const char* t) : c(c_), old(c_->comm_tag) { c->comm_tag = t; }
+        ~CommTag() { c->comm_tag = old; }
+    };
+    void account(int64_t bytes)
+    {
+        ++comm_calls, (comm_index_phase ? comm_bytes_index : comm_bytes_data) += bytes;
+        if (prof.on) {
+            auto& r = prof.recs[std::string("commMB_") + (comm_index_phase ? "index" : comm_tag)];
+            r.calls++, r.ms += (double)bytes * 1e-6;
+        }
+    }
     void export_comm_stats() { stats.comm_calls = comm_calls, stats.comm_bytes_index = comm_bytes_index, stats.comm_bytes_data = comm_bytes_data; }
     // node tiles: the ranks whose particle groups cover a block ("sharers") exchange their partial tiles and add them in rank order
     DBuf<uint8_t> touch; // Nb: this rank's tiles cover the block
@@ -206,7 +226,9 @@ struct Ctx : CtxBase {
     };
     void reduce_scalars(double* dev, int n)
     {
-        if (vmask && n > 0) c_allreduce(dev, n, HOT_COMM_F64, HOT_COMM_SUM, true);
+        if (!vmask || n <= 0) return;
+        CommTag tag(this, "scalars");
+        c_allreduce(dev, n, HOT_COMM_F64, HOT_COMM_SUM, true);
     }
     static constexpr int REAL = sizeof(T) == 4 ? HOT_COMM_F32 : HOT_COMM_F64;
     DBuf<double> dscal; // device scalars
@@ -278,7 +300,7 @@ struct Ctx : CtxBase {
         }
         else
             l = new Level<T>();
-        l->id = id, l->n = 0, l->nnzb = 0, l->nblocks = 0, l->built = false, l->split = false, l->part = false, l->colored = false, l->halo.built = false;
+        l->id = id, l->n = 0, l->nnzb = 0, l->nblocks = 0, l->built = false, l->split = false, l->part = false, l->colored = false, l->halo.built = false, l->ic_ready = false;
         return l;
     }
     void release_levels(size_t keep = 0)
@@ -391,6 +413,7 @@ struct Ctx : CtxBase {
     void transform_dev(T* v, bool inverse); // transformResidual / recoverSolution
     void cn_tolerance_dev();
     void build_diagonal(Level<T>& L);
+    void build_ic(Level<T>& L); // coarseSolver 7: block incomplete Cholesky of the top level (mg_ic.hip)
     void count_nnzb(Level<T>& L);
     std::string lname(const char* base, int level) { return std::string(base) + "_L" + std::to_string(level); }
     void spmv_dev(Level<T>& L, const T* x, T* y);

@@ -613,7 +613,9 @@ void Ctx<T>::build_mg()
     need(!(!cfg.systemBCProject && cfg.levelCnt > 1), "levelCnt > 1 requires systemBCProject (ImplicitSolver.h:339)");
     need(cfg.levelCnt >= 1 && cfg.levelCnt <= 10, "levelCnt must be in [1,10] (MultigridPreconditioner.h:369)");
     for (int k : { cfg.smoother, cfg.coarseSolver })
-        need(k == 0 || k == 1 || k == 2 || k == 5 || k == 6, "smoother/coarseSolver must be 0, 1, 2, 5 or 6 (7 = Eigen IncompleteCholesky: not built; 3/4 are not selectable in the reference either)");
+        need(k == 0 || k == 1 || k == 2 || k == 5 || k == 6 || k == 7, "smoother/coarseSolver must be 0, 1, 2, 5, 6 or (coarseSolver only) 7; 3/4 are not selectable in the reference either");
+    need(!(cfg.smoother == 7 && cfg.levelCnt > 1), "Do not use IC solver as smoother in the multigrid! (MultigridPreconditioner.h:614,686)");
+    need(!(cfg.coarseSolver == 7 && cfg.useBaselineMultigrid), "coarseSolver 7 with useBaselineMultigrid: the baseline fixes its own top solver (MultigridSimulation.inl:447-454)");
     const bool baseline = cfg.useBaselineMultigrid != 0;
     if (baseline) {
         need(!sharded(), "useBaselineMultigrid is a single-rank mode: its coarse levels are whole MPM grids re-rasterised from ALL particles (hot_set_comm with size > 1 is not supported with it)");
@@ -622,7 +624,7 @@ void Ctx<T>::build_mg()
     }
     double t0 = wall_ms();
     release_levels(1);
-    bool colors = baseline || cfg.smoother == 5 || cfg.coarseSolver == 5 || sharded(); // baseline: GS smoother, PCG on top (:447-448); sharded: row ownership follows the colour blocks
+    bool colors = baseline || cfg.smoother == 5 || cfg.coarseSolver == 5 || cfg.coarseSolver == 7 || sharded(); // baseline: GS smoother, PCG on top (:447-448); sharded: row ownership follows the colour blocks
     Level<T>& L0 = *levels[0];
     alloc_work(L0);
     if (colors) color_level(L0);
@@ -691,7 +693,7 @@ void Ctx<T>::build_mg()
         if (F.part) {
             // every rank has summed its own fine rows into ALL coarse rows (zeros where it owns no child).  Large coarse levels
             // stay partitioned: partial rows go to their owners; small ones are replicated: one all-reduce of the whole matrix
-            const int minrows = comm.partition_min_rows > 0 ? comm.partition_min_rows : 32768;
+            const int minrows = comm.partition_min_rows > 0 ? comm.partition_min_rows : 4096;
             if (C.n >= minrows) {
                 color_level(C);
                 level_ownership(C);
@@ -701,8 +703,10 @@ void Ctx<T>::build_mg()
                 exchange_rows(C, touched.p);
                 if (halo_mode()) rebuild_halo(this, level + 1), rebuild_halo(this, level); // C: stencil + the windows of this rank's fine rows; F: + the children of its coarse rows
             }
-            else
+            else {
+                CommTag tag(this, "coarse_matrix_allreduce");
                 c_allreduce(C.val.p, (int64_t)nc * 1125, REAL, HOT_COMM_SUM, true);
+            }
         }
         build_diagonal(C);
         C.nnzb = -1; // counted on request (hot_get_level_nnzb)
@@ -710,6 +714,13 @@ void Ctx<T>::build_mg()
         if (colors) color_level(C);
         if (!baseline && ((cfg.coarseSolver == 6 && level + 2 == cfg.levelCnt) || (cfg.smoother == 6 && level + 2 < cfg.levelCnt))) estimate_2norm(C, 1e-6); // :682-683
         if (colors) split_rows(this, F); // level `level` is no longer needed in stencil-slot order
+    }
+    if (cfg.coarseSolver == 7) { // incomplete-Cholesky top solver: factor while the top level is still in stencil-slot order, then regroup the factor like the matrix
+        Level<T>& Top = *levels.back();
+        build_ic(Top);
+        Top.ic_rowcnt.reserve(4 * (size_t)Top.n), Top.ic_pad.reserve(512 * (size_t)Top.nblocks);
+        HOT_LAUNCH(this, "gs_split_rows", k_gs_split_rows<T>, div_up(Top.n, 4), 256, 0, Top.ic_col.p, Top.ic_val.p, Top.ckey.p, Top.ic_rowcnt.p, Top.n, (const uint8_t*)nullptr);
+        HOT_LAUNCH(this, "gs_pad", k_gs_pad, div_up((size_t)Top.nblocks * 64, 256), 256, 0, Top.gs_block_start.p, Top.gs_order.p, Top.ic_rowcnt.p, Top.ic_pad.p, Top.nblocks);
     }
     if (colors) split_rows(this, *levels.back());
     sync();

@@ -317,6 +317,7 @@ void Ctx<T>::restrict_dev(int level, const T* fine, T* coarse)
         }
         else { // replicated coarse level: every rank sums the children it owns, one all-reduce of the (small) coarse vector completes the rows
             HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n, (const uint8_t*)nullptr, F.own.p);
+            CommTag tag(this, "coarse_vector_allreduce");
             c_allreduce(coarse, 3 * (int64_t)C.n, REAL, HOT_COMM_SUM, true);
         }
         return;
@@ -517,6 +518,14 @@ __device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int3
     const T* ldsD = nullptr);
 
 // six waves per SIMD (three 512-thread workgroups per CU: a colour of the finest level is resident in one round) = at most 80 VGPRs
+#ifdef HOT_AB_KERNELS
+// A/B build only, TIMING experiments with wrong results (tools/gs_where.py): bit 0 skip the substitution phase, bit 1 no x gathers,
+// bit 2 no matrix value loads, bit 3 no phase A at all
+__device__ int gs_dbg_flags = 0;
+#define GS_DBG(bit) (gs_dbg_flags & (bit))
+#else
+#define GS_DBG(bit) 0
+#endif
 template <class T, bool FWD, int SB>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_gs_block(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
     const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, int block0, int sub,
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
     __syncthreads();
     // ---------------- phase A: RQ rows of this wave are in flight at once (lane = slot of the needed half row)
     constexpr int RQ = 2;
-    for (int t0 = 0; w + nwaves * t0 < cnt; t0 += RQ) {
+    for (int t0 = 0; w + nwaves * t0 < cnt && !GS_DBG(8); t0 += RQ) {
         T bv[RQ][9];
         int jj[RQ], rowi[RQ], kb[RQ], ke[RQ], ib[RQ], ie[RQ];
 #pragma unroll
@@ -572,8 +581,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
                 const int k = kbeg + lane, kc = max(min(k, kend - 1), 0);
                 const int jl = col[(int64_t)i * 125 + kc];
                 const T* bb = val + ((int64_t)i * 125 + kc) * 9;
+                if (!GS_DBG(4)) {
 #pragma unroll
-                for (int e = 0; e < 9; ++e) bv[q][e] = bb[e];
+                    for (int e = 0; e < 9; ++e) bv[q][e] = bb[e];
+                }
                 jj[q] = k < kend ? jl : -1;
             }
         }
@@ -598,7 +609,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
                 if (lj >= 0)
                     gs_store_tri<T>(tri, TRI, FWD ? gs_tri_fwd<SB>(ii, lj) : gs_tri_bwd(ii, lj), di, b9);
                 else {
-                    const T x0 = x[3 * (int64_t)j], x1 = x[3 * (int64_t)j + 1], x2 = x[3 * (int64_t)j + 2];
+                    const T x0 = GS_DBG(2) ? (T)1 : x[3 * (int64_t)j], x1 = GS_DBG(2) ? (T)1 : x[3 * (int64_t)j + 1], x2 = GS_DBG(2) ? (T)1 : x[3 * (int64_t)j + 2];
                     s0 += b9[0] * x0 + b9[3] * x1 + b9[6] * x2;
                     s1 += b9[1] * x0 + b9[4] * x1 + b9[7] * x2;
                     s2 += b9[2] * x0 + b9[5] * x1 + b9[8] * x2;
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
         }
     }
     __syncthreads();
-    if (w == 0) gs_phase_b<T, FWD, SB>(tri, sv, nodes, cnt, lane, diagVal, diagBlockInv, x, hD);
+    if (w == 0 && !GS_DBG(1)) gs_phase_b<T, FWD, SB>(tri, sv, nodes, cnt, lane, diagVal, diagBlockInv, x, hD);
     }
 }
 
@@ -1159,6 +1170,31 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             axpy(n3, -alpha, dAu, r);
         }
     }
+    else if (kind == 7) {
+        // IC_smooth (MultigridPreconditioner.h:320-323): u = (L L^T)^-1 r, once; r is left alone.  The two triangular solves are block-GS
+        // sweeps over the factor (mg_ic.hip): forward with D := L_ii writes y, backward with D := L_ii^T writes u
+        HOT_CHECK(L.ic_ready && L.split, HOT_ERR_INVALID, "coarseSolver 7: the level has no incomplete-Cholesky factor (hot_build_mg)");
+        if (!attr_gs_set) {
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T))));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T))));
+            attr_gs_set = true;
+        }
+        T* y = L.tmp.p;
+        for (int c = 0; c < 8; ++c) {
+            const int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
+            if (nb > 0)
+                HOT_LAUNCH(this, lname("ic_forward", L.id).c_str(), (k_gs_block<T, true, 64>), nb, 1024, (GsLds<T, 64>::bytes), L.ic_col.p, L.ic_val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p,
+                    L.ic_d.p, L.ic_dinv.p, r, y, dAu, b0, 0 | (1 << 16), L.ic_rowcnt.p, L.ic_pad.p);
+        }
+        for (int c = 7; c >= 0; --c) {
+            const int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
+            if (nb > 0)
+                HOT_LAUNCH(this, lname("ic_backward", L.id).c_str(), (k_gs_block<T, false, 64>), nb, 1024, (GsLds<T, 64>::bytes), L.ic_col.p, L.ic_val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p,
+                    L.ic_d.p, L.ic_dinvT.p, y, u, (T*)nullptr, b0, 0 | (1 << 16), L.ic_rowcnt.p, L.ic_pad.p);
+        }
+    }
     else if (kind == 5) {
         HOT_CHECK(L.nblocks > 0, HOT_ERR_INVALID, "GS smoother requested but the level was built without colouring");
         T* hdu = L.tmp.p;
@@ -1174,6 +1210,12 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T))));
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T))));
             attr_gs_set = true;
+#ifdef HOT_AB_KERNELS
+            if (const char* e = getenv("HOT_GS_DBG")) {
+                const int f = atoi(e);
+                HOT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gs_dbg_flags), &f, sizeof(int)));
+            }
+#endif
         }
         // sub-block size: levels whose colours hold more blocks than the chip has CUs run half blocks (36 KB LDS, 4
         // workgroups per CU, one round per launch); small levels are latency-bound per launch and keep whole blocks

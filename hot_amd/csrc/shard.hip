@@ -267,6 +267,7 @@ void Ctx<T>::gather_all(Level<T>& L, T* x, int ncomp)
 template <class T>
 void Ctx<T>::gather_colour(Level<T>& L, T* x, int colour, int ncomp)
 {
+    CommTag tag(this, "allgather_vectors");
     const int R = comm.size, me = comm.rank;
     const int maxc = colour < 0 ? L.xmax_full : L.xmax_col[colour];
     if (maxc == 0) return;
@@ -388,6 +389,7 @@ void Ctx<T>::build_tile_plan()
 template <class T>
 void Ctx<T>::tile_exchange(T* const* arrays, int q)
 {
+    CommTag tag(this, "tiles");
     const int R = comm.size, me = comm.rank;
     HOT_CHECK(q >= 1 && q <= 9 && (int)tcnt.size() == R, HOT_ERR_INVALID, "tile_exchange: no tile plan (hot_sort)");
     TileArrays<T> arr{};
@@ -539,6 +541,7 @@ template <class T>
 void Ctx<T>::halo_gather(Level<T>& L, T* x, int colour, int ncomp)
 {
     if (!L.part) return;
+    CommTag tag(this, "halos");
     auto& H = L.halo;
     HOT_CHECK(H.built, HOT_ERR_INVALID, "halo_gather: the level has no exchange lists");
     const int R = comm.size;
@@ -593,6 +596,7 @@ __global__ void k_rows_add(T* __restrict__ val, const int32_t* __restrict__ rows
 template <class T>
 void Ctx<T>::exchange_rows(Level<T>& L, const uint8_t* touched)
 {
+    CommTag tag(this, L.id == 0 ? "rows_level0" : "rows_coarse");
     const int R = comm.size, me = comm.rank, n = L.n;
     flags.reserve(n), scan.reserve(n);
     DBuf<int32_t> sendrows, recvrows;
@@ -701,6 +705,7 @@ __global__ void k_rank_of(const uint32_t* __restrict__ sorted_slot, int32_t* __r
 template <class T>
 void Ctx<T>::migrate_particles()
 {
+    CommTag tag(this, "migration");
     const int R = comm.size, me = comm.rank;
     constexpr int S = 1024, NC = 29;
     const int64_t n = Np;

@@ -493,12 +493,23 @@ __global__ __launch_bounds__(256) void k_g2p(T* __restrict__ X, T* __restrict__ 
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
     __shared__ T nv[3][TILE];
-    __shared__ int32_t nb8[8];
     const int g = blockIdx.x;
-    if (threadIdx.x < 8) nb8[threadIdx.x] = group_nb[g * 8 + threadIdx.x];
-    __syncthreads();
+    const int first = group_first[g], last = group_first[g + 1];
+    // position and Fn of this thread's first particle are requested before the tile gather, and the tile's DOF ids come from the
+    // per-group table (tileDof) instead of the nb8 -> gIdx chain: the workgroup's dependent round trips (indices -> nodal values, particle
+    // data) run side by side (the same prologue as k_state)
+    const int p0 = first + threadIdx.x;
+    T xpre[3] = { 0, 0, 0 }, fpre[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) fpre[c] = (T)0;
+    if (p0 < last) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xpre[d] = X[(int64_t)d * Np + p0];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) fpre[c] = Fn[(int64_t)c * Np + p0];
+    }
     for (int t = threadIdx.x; t < TILE; t += 256) {
-        int idx = gIdx[tile_slot<T>(t, nb8)];
+        int idx = gIdx[(int64_t)g * TILE + t]; // gIdx here = tileDof
         T a = 0, b = 0, c = 0;
         if (idx >= 0) {
             a = nodeV[3 * idx] + dv[3 * idx], b = nodeV[3 * idx + 1] + dv[3 * idx + 1], c = nodeV[3 * idx + 2] + dv[3 * idx + 2];
@@ -506,12 +517,24 @@ __global__ __launch_bounds__(256) void k_g2p(T* __restrict__ X, T* __restrict__ 
         nv[0][t] = a, nv[1][t] = b, nv[2][t] = c;
     }
     __syncthreads();
-    const int first = group_first[g], last = group_first[g + 1];
     const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
     const T D_inverse = (T)4 / (dx * dx);
     int myflags = 0;
     for (int p = first + threadIdx.x; p < last; p += 256) {
-        T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
+        T xp[3];
+        Mat3<T> Fo;
+        if (p == p0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xp[d] = xpre[d];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) Fo.a[c] = fpre[c];
+        }
+        else { // groups of more than 256 particles
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xp[d] = X[(int64_t)d * Np + p];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) Fo.a[c] = Fn[(int64_t)c * Np + p];
+        }
         int base[3];
         T w[3][3], dw[3][3];
 #pragma unroll
@@ -563,9 +586,9 @@ __global__ __launch_bounds__(256) void k_g2p(T* __restrict__ X, T* __restrict__ 
 #pragma unroll
             for (int c = 0; c < 9; ++c) gradV_out[(int64_t)c * Np + p] = gv[c];
         // F = (I + dt gradV) Fn   (restoreStrain + evolveStrain)
-        Mat3<T> A, Fo, Fnew;
+        Mat3<T> A, Fnew;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) A.a[c] = dt * gv[c] + ((c % 4 == 0) ? (T)1 : (T)0), Fo.a[c] = Fn[(int64_t)c * Np + p];
+        for (int c = 0; c < 9; ++c) A.a[c] = dt * gv[c] + ((c % 4 == 0) ? (T)1 : (T)0);
         Fnew = m3_mul(A, Fo);
         if (PLASTIC == 1) {
             von_mises_project(Fnew, Mu[p], Lam[p], yield_stress);
@@ -596,7 +619,7 @@ void Ctx<T>::g2p(double dt_, int32_t* flags)
     HOT_HIP(hipMemsetAsync(dflags, 0, 4, stream));
     T one_over_dx = (T)1 / dx;
     if (halo_mode()) halo_gather(*levels[0], dv.p); // dv at the nodes of this rank's particle tiles that other ranks own
-#define G2P_ARGS pX.p, pV.p, pC.p, pF.p, pFn.p, (keep_debug ? pGradV.p : (T*)nullptr), pMu.p, pLam.p, pJp.p, Np, group_first.p, group_origin.p, group_nb.p, gIdx.p, nodeV.p, dv.p, dx, \
+#define G2P_ARGS pX.p, pV.p, pC.p, pF.p, pFn.p, (keep_debug ? pGradV.p : (T*)nullptr), pMu.p, pLam.p, pJp.p, Np, group_first.p, group_origin.p, group_nb.p, tileDof.p, nodeV.p, dv.p, dx, \
                  one_over_dx, (T)dt_, (T)cfg.apic_rpic_ratio, (T)cfg.cfl, (T)cfg.yield_stress, (T)cfg.snow[0], (T)cfg.snow[1], (T)cfg.snow[2], (T)cfg.snow[3], (T)cfg.snow[4], dflags
     if (cfg.plasticity == 1)
         HOT_LAUNCH(this, "g2p", (k_g2p<T, 1>), Ng, 256, 0, G2P_ARGS);

@@ -51,8 +51,9 @@ typedef struct hot_config {
     double cfl; /* 0.6 */
     int32_t lsolver; /* 1 = projected Newton + MINRES, 2 = projected Newton + inexact (MG-)PCG, 3 = L-BFGS with MG initial Hessian (HOT) */
     int32_t Ainv; /* 0 inverse diagonal entries, 1 inverse 3x3 diagonal block, 2 lumped mass (lsolver 1 / 2 only, no hierarchy) */
-    int32_t smoother; /* 0 damped Jacobi, 1 optimal Jacobi, 2 PCG, 5 symmetric coloured GS, 6 Chebyshev (7 = Eigen IncompleteCholesky: rejected) */
-    int32_t coarseSolver; /* same option space, applied on the top level */
+    int32_t smoother; /* 0 damped Jacobi, 1 optimal Jacobi, 2 PCG, 5 symmetric coloured GS, 6 Chebyshev; 7 (incomplete Cholesky) is a top solver only: rejected as smoother inside a hierarchy, like the reference (MultigridPreconditioner.h:614) */
+    int32_t coarseSolver; /* same option space, applied on the top level; 7 = incomplete Cholesky applied once (IC_smooth, MultigridPreconditioner.h:320-323): NOT Eigen's AMD-ordered IC, which cannot be
+                             restated without Eigen, but block IC(0) on the stencil pattern in the smoother's order with Eigen's shift strategy (hot_amd/csrc/mg_ic.hip): parity on converged solutions only */
     int32_t levelCnt; /* -mg_level */
     int32_t times; /* -mg_times */
     int32_t levelscale; /* -mg_scale */
@@ -271,7 +272,7 @@ typedef struct hot_comm {
      * at recv + recv_off[r]; both sides know all counts (host arrays of `size` entries); a rank sends nothing to itself */
     int32_t (*alltoallv)(void* user, const void* send, const int64_t* send_off, const int64_t* send_bytes, void* recv, const int64_t* recv_off, const int64_t* recv_bytes,
         int32_t on_device);
-    int32_t partition_min_rows; /* coarse levels with fewer rows are replicated instead of partitioned; 0 = default (32768) */
+    int32_t partition_min_rows; /* coarse levels with fewer rows are replicated instead of partitioned; 0 = default (4096: a replicated level costs one all-reduce of its whole matrix per build, 9 KB per row, and of a vector per restriction; a partitioned one only halo exchanges) */
     int32_t stream_ordered; /* 1: the callbacks enqueue device-payload collectives on the context's own HIP stream (hot_get_stream) and
                                return without waiting, so the library does not synchronise its stream around them; 0: host-synchronous */
     int32_t reserved[2];

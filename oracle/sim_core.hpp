@@ -59,6 +59,11 @@ struct EllMat { // reference Projects/multigrid/SquareMatrix.h:27-34
     std::array<std::vector<std::vector<int>>, 8> coloredBlockDofs;
     std::vector<std::array<int, 3>> colorOrder;
     T lMin = (T)1e-8, lMax = (T)1e2;
+    // coarseSolver 7: block incomplete Cholesky of the level (setup_ic): strictly lower blocks by stencil slot (125 per row), L_ii and
+    // its inverse, the stencil neighbours' ids (-1 = absent) and the rows in factorisation order
+    std::vector<M3<T>> icL, icD, icDinv;
+    std::vector<int> icNbr, icOrder;
+    T icShift = 0;
 };
 
 template <class T>
@@ -104,7 +109,7 @@ struct Sim {
     std::vector<std::vector<int>> level_nstart; // per level [size+1]: rank r's id prefix = nodes first touched by ranks < r
     bool partitioned(int level) const
     {
-        const int minrows = comm.partition_min_rows > 0 ? comm.partition_min_rows : 32768;
+        const int minrows = comm.partition_min_rows > 0 ? comm.partition_min_rows : 4096;
         return sharded() && level < (int)level_nstart.size() && level < (int)sysmats.size() && sysmats[level].nrows >= minrows;
     }
     int owner_of(int level, int node) const // rank whose id prefix holds `node`
@@ -986,6 +991,8 @@ struct Sim {
     void matfree_multiply(const std::vector<TV>& x, std::vector<TV>& b);
     void build_matrix();
     static void build_diagonal(EllMat<T>& m, int opt);
+    void setup_ic(EllMat<T>& m, const std::vector<std::array<int, 3>>& coords);
+    void solve_ic(const EllMat<T>& m, const std::vector<TV>& r, std::vector<TV>& u) const;
     static void multiply(const EllMat<T>& m, const std::vector<TV>& x, std::vector<TV>& b);
     static void mark_colors(const std::vector<std::array<int, 3>>& coords, EllMat<T>& m);
     static void build_product(EllMat<T>& out, const EllMat<T>& l, const EllMat<T>& r);

@@ -362,9 +362,10 @@ void Sim<T>::build_mg()
     promats.clear(), resmats.clear();
     level_coords.resize(1);
     const bool baseline = cfg.useBaselineMultigrid != 0;
-    bool colors = baseline || (cfg.coarseSolver == 5 || cfg.smoother == 5);
+    bool colors = baseline || (cfg.coarseSolver == 5 || cfg.smoother == 5) || cfg.coarseSolver == 7; // (7: the factorisation runs in the smoother's order)
     build_diagonal(sysmats[0], cfg.Ainv);
     if (colors) mark_colors(level_coords[0], sysmats[0]);
+    if (cfg.coarseSolver == 7 && levelCnt == 1) setup_ic(sysmats[0], level_coords[0]); // :612-613
     if (!baseline && ((cfg.coarseSolver == 6 && levelCnt == 1) || (cfg.smoother == 6 && levelCnt > 1))) estimate_2norm(sysmats[0], (T)1e-6); // :610-611
     const T w1d[2][3] = { { 0, 1, 0 }, { 0, (T)0.5, (T)0.5 } };
     for (int level = 0; level < levelCnt - 1; ++level) {
@@ -448,6 +449,7 @@ void Sim<T>::build_mg()
         }
         build_diagonal(RAP, cfg.Ainv);
         if (colors) mark_colors(new_coords, RAP);
+        if (cfg.coarseSolver == 7 && level + 2 == levelCnt) setup_ic(RAP, new_coords); // :684-685
         if (!baseline && ((cfg.coarseSolver == 6 && level + 2 == levelCnt) || (cfg.smoother == 6 && level + 2 < levelCnt))) estimate_2norm(RAP, (T)1e-6); // :682-683
         promats.push_back(std::move(P));
         resmats.push_back(std::move(R));
@@ -502,6 +504,131 @@ static inline int color_comp(const std::array<int, 3>& a, const std::array<int, 
     return 0; // the reference falls off the end here (UB, SquareMatrix.h:39-46); equal keys multiply a zero vector
 }
 
+// coarseSolver 7 (top level only).  The reference hands the top-level matrix to Eigen::IncompleteCholesky (SquareMatrix.h:35,224-256;
+// IC_smooth MultigridPreconditioner.h:320-323: u = ICSolver.solve(r), once): Eigen's left-looking IC with AMD ordering, row / column
+// scaling and a shift-and-retry loop.  Eigen is absent here and its AMD tie-breaking cannot be restated, so this is NOT that
+// factorisation but one of the same family, shared bit for bit by the HIP library (hot_amd/csrc/mg_ic.hip): incomplete Cholesky with zero
+// fill by 3x3 BLOCKS on the 125-stencil pattern, rows in the smoother's order (colour, first-touch 4^3 block, node: the order gs_smooth
+// sweeps in), Eigen's shift strategy (factor A + shift * diag(A), shift 0 first, then 1e-3 doubled until every 3x3 pivot is positive
+// definite).  Parity with the reference can therefore only be claimed on the converged solution of the outer solve.
+template <class T>
+void Sim<T>::setup_ic(EllMat<T>& m, const std::vector<std::array<int, 3>>& coords)
+{
+    using ULL = unsigned long long;
+    const int n = m.nrows;
+    std::unordered_map<ULL, int> id;
+    id.reserve((size_t)n * 2);
+    auto key = [](int x, int y, int z) { return ((ULL)(unsigned)x << 42) | ((ULL)(unsigned)y << 21) | (ULL)(unsigned)z; };
+    for (int i = 0; i < n; ++i) id[key(coords[i][0], coords[i][1], coords[i][2])] = i;
+    m.icNbr.assign((size_t)n * 125, -1);
+    std::vector<TM> A((size_t)n * 125, TM::zero()); // the matrix by stencil slot: slot (dx+2)*25 + (dy+2)*5 + dz+2 holds column coord_i - d
+    for (int i = 0; i < n; ++i) {
+        for (int s = 0; s < 125; ++s) {
+            const int x = coords[i][0] - (s / 25 - 2), y = coords[i][1] - ((s / 5) % 5 - 2), z = coords[i][2] - (s % 5 - 2);
+            if ((x | y | z) < 0) continue;
+            auto it = id.find(key(x, y, z));
+            if (it != id.end()) m.icNbr[(size_t)i * 125 + s] = it->second;
+        }
+        for (size_t e = (size_t)i * m.colsize; e < (size_t)(i + 1) * m.colsize; ++e) {
+            const int j = m.entryCol[e];
+            const int dx = coords[i][0] - coords[j][0], dy = coords[i][1] - coords[j][1], dz = coords[i][2] - coords[j][2];
+            if (std::abs(dx) > 2 || std::abs(dy) > 2 || std::abs(dz) > 2) continue; // padding slot (aliases column 0 / 1 with a zero block)
+            A[(size_t)i * 125 + (dx + 2) * 25 + (dy + 2) * 5 + dz + 2] += m.entryVal[e];
+        }
+    }
+    // factorisation order = the smoother's: (colour, block, index in block)
+    m.icOrder.resize(n);
+    for (int i = 0; i < n; ++i) m.icOrder[i] = i;
+    std::sort(m.icOrder.begin(), m.icOrder.end(), [&](int a, int b) { return m.colorOrder[a] < m.colorOrder[b]; });
+    std::vector<int> rank(n);
+    for (int p = 0; p < n; ++p) rank[m.icOrder[p]] = p;
+    auto chol3 = [](const TM& D, TM& L) { // lower Cholesky factor of a symmetric 3x3; false if a pivot is not positive
+        L = TM::zero();
+        T l00 = D(0, 0);
+        if (!(l00 > 0)) return false;
+        l00 = std::sqrt(l00);
+        const T l10 = D(1, 0) / l00, l20 = D(2, 0) / l00;
+        T l11 = D(1, 1) - l10 * l10;
+        if (!(l11 > 0)) return false;
+        l11 = std::sqrt(l11);
+        const T l21 = (D(2, 1) - l20 * l10) / l11;
+        T l22 = D(2, 2) - l20 * l20 - l21 * l21;
+        if (!(l22 > 0)) return false;
+        l22 = std::sqrt(l22);
+        L(0, 0) = l00, L(1, 0) = l10, L(2, 0) = l20, L(1, 1) = l11, L(2, 1) = l21, L(2, 2) = l22;
+        return true;
+    };
+    T shift = 0;
+    for (int attempt = 0; attempt < 60; ++attempt) {
+        m.icL.assign((size_t)n * 125, TM::zero());
+        m.icD.assign(n, TM::zero()), m.icDinv.assign(n, TM::zero());
+        bool ok = true;
+        for (int p = 0; p < n && ok; ++p) {
+            const int i = m.icOrder[p];
+            // the row's lower neighbours in factorisation order
+            std::vector<std::pair<int, int>> lower; // (rank, slot)
+            for (int s = 0; s < 125; ++s) {
+                const int j = m.icNbr[(size_t)i * 125 + s];
+                if (j >= 0 && rank[j] < p) lower.emplace_back(rank[j], s);
+            }
+            std::sort(lower.begin(), lower.end());
+            for (auto& ls : lower) {
+                const int s = ls.second, j = m.icNbr[(size_t)i * 125 + s];
+                TM S = A[(size_t)i * 125 + s];
+                for (int t = 0; t < 125; ++t) { // common earlier neighbours k of i and j (slot order: the order the device's lanes hold them in)
+                    const int k = m.icNbr[(size_t)j * 125 + t];
+                    if (k < 0 || rank[k] >= rank[j]) continue;
+                    const int dx = coords[i][0] - coords[k][0], dy = coords[i][1] - coords[k][1], dz = coords[i][2] - coords[k][2];
+                    if (std::abs(dx) > 2 || std::abs(dy) > 2 || std::abs(dz) > 2) continue;
+                    S = S - m.icL[(size_t)i * 125 + (dx + 2) * 25 + (dy + 2) * 5 + dz + 2] * m.icL[(size_t)j * 125 + t].transpose();
+                }
+                m.icL[(size_t)i * 125 + s] = S * m.icDinv[j].transpose(); // L_ij L_jj^T = S
+            }
+            TM D = A[(size_t)i * 125 + 62] * ((T)1 + shift);
+            for (auto& ls : lower) D = D - m.icL[(size_t)i * 125 + ls.second] * m.icL[(size_t)i * 125 + ls.second].transpose();
+            TM L;
+            if (!chol3(D, L)) {
+                ok = false;
+                break;
+            }
+            m.icD[i] = L, m.icDinv[i] = inverse(L);
+        }
+        if (ok) {
+            m.icShift = shift;
+            return;
+        }
+        shift = shift == 0 ? (T)1e-3 : shift * 2;
+    }
+    throw std::runtime_error("incomplete Cholesky: no positive definite factorisation found");
+}
+template <class T>
+void Sim<T>::solve_ic(const EllMat<T>& m, const std::vector<TV>& r, std::vector<TV>& u) const
+{
+    const int n = m.nrows;
+    std::vector<int> rank(n);
+    for (int p = 0; p < n; ++p) rank[m.icOrder[p]] = p;
+    std::vector<TV> y(n);
+    for (int p = 0; p < n; ++p) { // L y = r
+        const int i = m.icOrder[p];
+        TV s = r[i];
+        for (int t = 0; t < 125; ++t) {
+            const int j = m.icNbr[(size_t)i * 125 + t];
+            if (j >= 0 && rank[j] < p) s = s - m.icL[(size_t)i * 125 + t] * y[j];
+        }
+        y[i] = m.icDinv[i] * s;
+    }
+    u.resize(n);
+    for (int p = n - 1; p >= 0; --p) { // L^T u = y
+        const int i = m.icOrder[p];
+        TV s = y[i];
+        for (int t = 0; t < 125; ++t) { // rows j after i that hold i in their lower part: L_ji sits in row j at the mirrored slot
+            const int j = m.icNbr[(size_t)i * 125 + t];
+            if (j >= 0 && rank[j] > p) s = s - m.icL[(size_t)j * 125 + (124 - t)].transpose() * u[j];
+        }
+        u[i] = m.icDinv[i].transpose() * s;
+    }
+}
+
 // smoothers: reference MultigridPreconditioner.h:160-173 (jacobi), :174-189 (optimal jacobi), :190-226 (cg),
 // :227-264 (chebyshev), :266-318 (gs)
 template <class T>
@@ -513,6 +640,10 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
     auto Aproject = [&](std::vector<TV>& v) {
         if (level == 0 && !cfg.systemBCProject) project(v);
     };
+    if (kind == 7) { // IC_smooth (MultigridPreconditioner.h:320-323): u = IC^-1 r, once; r is left alone
+        solve_ic(A, r, u);
+        return;
+    }
     if (kind == 0) {
         for (; iterations--;) {
             scaler(r, du, A);

@@ -62,6 +62,8 @@ def run_case(lib, cloud, comm, cfgkw, steps, dt=1.0 / 24):
         sts = [ctx.advance(dt) for _ in range(steps)]
         out["stats"] = sts[-1]
         out["iterations"] = [s["iterations"] for s in sts]
+    if cfgkw.get("profile"):
+        out["profile"] = ctx.profile()
     out["particles"] = ctx.get_particles()
     out["ids"] = ctx.particle_ids() if comm is not None else np.arange(len(out["particles"]["X"]), dtype=np.int32)
     return out

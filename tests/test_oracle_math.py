@@ -145,3 +145,20 @@ def test_plasticity_known_answers():
     assert s3.max() <= 1 + snow[2] + 1e-12 and s3.min() >= 1 - snow[1] - 1e-12
     assert np.allclose(Jp3, np.clip(np.linalg.det(F) / np.linalg.det(from_cm(F3)), snow[3], snow[4]))
     assert np.allclose(mu3, MU * np.exp(snow[0] * (1 - Jp3)))
+
+
+def test_oracle_incomplete_cholesky_top_solver(oracle):
+    """-coarseSolver 7 in the oracle (block IC(0) in the smoother's order, Eigen's shift strategy: oracle/sim_matrix.hpp setup_ic): the V-cycle
+    with the IC top solve is a symmetric positive operator on 1, 2 and 3 levels, and the L-BFGS solve behind it converges."""
+    from tests import pipeline_checks as pc
+    for levelCnt in (1, 2, 3):
+        ctx, c = pc.make_ctx(oracle, n=6, levelCnt=levelCnt, coarseSolver=7, cneps=1e-7, max_iterations=300)
+        pc.prepare(ctx)
+        e0 = ctx.update_state(ctx.get_dv())
+        st = ctx.solve()
+        assert st["converged"] == 1 and st["energy"] < e0
+        rng = np.random.default_rng(1)
+        x, y = ctx.project(rng.standard_normal((ctx.Nn, 3))), ctx.project(rng.standard_normal((ctx.Nn, 3)))
+        Mx, My = ctx.vcycle(x), ctx.vcycle(y)
+        assert abs((y * Mx).sum() - (x * My).sum()) < 1e-10 * abs((y * Mx).sum())
+        assert (x * Mx).sum() > 0 and (y * My).sum() > 0
