@@ -14,12 +14,13 @@ def main():
     for rep in (0, 1):
         kw = dict(lsolver=3, levelCnt=3, cneps=1e-7, shard_gs=gs, shard_replicated=rep, profile=1)
         r = mw.launch(world, "hip", n, 1, kw, steps=1, partition_min_rows=minrows, timeout=1800)
-        st = r[0]["stats"]
-        print("%d^3 cells over %d ranks, %s, shard_gs %d, min rows %d: %d iterations, %d collective calls, data %.1f MB, index %.2f MB per step (rank 0)"
-              % (n, world, "replicated vectors" if rep else "halo mode", gs, minrows, st["iterations"], st["comm_calls"], st["comm_bytes_data"] / 1e6, st["comm_bytes_index"] / 1e6))
-        for k, v in sorted(r[0]["profile"].items()):
-            if k.startswith("commMB_"):
-                print("    %-28s %6d calls %10.2f MB" % (k[7:], v["calls"], v["total_ms"]))
+        for rk in range(world):
+            st = r[rk]["stats"]
+            print("%d^3 cells over %d ranks, %s, shard_gs %d, min rows %d: %d iterations, rank %d: %d collective calls, data %.1f MB, index %.2f MB per step"
+                  % (n, world, "replicated vectors" if rep else "halo mode", gs, minrows, st["iterations"], rk, st["comm_calls"], st["comm_bytes_data"] / 1e6, st["comm_bytes_index"] / 1e6))
+            for k, v in sorted(r[rk]["profile"].items()):
+                if k.startswith("commMB_") and v["total_ms"] >= 0.005:
+                    print("    %-28s %6d calls %10.2f MB" % (k[7:], v["calls"], v["total_ms"]))
 
 
 if __name__ == "__main__":
