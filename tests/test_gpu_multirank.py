@@ -142,9 +142,11 @@ def test_c2_size_body_over_two_ranks_hip(hotlib, shard_gs):
     assert mw.rel(ranks[0]["spmv"], ref["spmv"]) < 1e-10 and mw.rel(ranks[0]["r0"], ref["r0"]) < 1e-10
     assert ranks[0]["stats"]["iterations"] == 3 and ranks[0]["stats"]["energy"] < ranks[0]["e0"]
     assert mw.rel(ranks[0]["dv"], ref["dv"]) < 1e-2, mw.rel(ranks[0]["dv"], ref["dv"])
-    st = ranks[0]["stats"]
-    print("C2-size body, 2 ranks, 3 iterations: data bytes %.1f MB, index bytes %.1f MB, %d collective calls" % (st["comm_bytes_data"] / 1e6, st["comm_bytes_index"] / 1e6, st["comm_calls"]))
-    assert st["comm_bytes_data"] + st["comm_bytes_index"] < 100e6, st  # 1.1 GB per step with replicated vectors
+    for r, o in enumerate(ranks):
+        st = o["stats"]
+        print("C2-size body, 2 ranks, 3 iterations, rank %d: data bytes %.1f MB, index bytes %.1f MB, %d collective calls" % (r, st["comm_bytes_data"] / 1e6, st["comm_bytes_index"] / 1e6, st["comm_calls"]))
+    # rank 0 (owns every block both ranks touch: first-touch rule) sends no partial matrix rows, rank 1 sends ~19 k rows of 9 KB once per build
+    assert ranks[0]["stats"]["comm_bytes_data"] < 100e6 and max(o["stats"]["comm_bytes_data"] for o in ranks) < 300e6, [o["stats"] for o in ranks]
 
 
 def test_whole_steps_over_two_ranks_hip(hotlib):
