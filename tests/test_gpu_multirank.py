@@ -67,6 +67,17 @@ def test_rank_local_gs_over_ranks_hip_against_oracle(world, n, kw, minrows):
     assert hip[0]["comm_calls"]["alltoallv"] < 0.6 * exact[0]["comm_calls"]["alltoallv"], (hip[0]["comm_calls"], exact[0]["comm_calls"])  # halo gathers are personalised exchanges
 
 
+def test_one_body_over_six_ranks_hip(hotlib):
+    """Six ranks on one body (blocks shared by up to four ranks at the corners of the Morton-order shards, several peers per halo list,
+    every level partitioned): the single-rank numbering, L-BFGS iterates to round-off with equal counters, replicated decisions identical."""
+    kw = dict(lsolver=3, levelCnt=3, max_iterations=4, cneps=1e-7)
+    ranks = mw.launch(6, "hip", 16, 1, kw, partition_min_rows=1, timeout=1800)
+    ref = mw.single(hotlib, 16, 1, kw)
+    mw.compare(ranks, ref, 1e-11)
+    sizes = [len(o["ids"]) for o in ranks]
+    assert min(sizes) > 0.5 * sum(sizes) / 6, sizes
+
+
 def test_halo_bytes_scale_with_the_cut_surface():
     """Halo mode: what a rank hands to the collectives during a fixed amount of solver work grows with the cut surface (edge^2), not with
     the body (edge^3): a 24^3 and a 48^3 cube over two ranks, three L-BFGS iterations each.  The first-generation decomposition
@@ -145,8 +156,9 @@ def test_c2_size_body_over_two_ranks_hip(hotlib, shard_gs):
     for r, o in enumerate(ranks):
         st = o["stats"]
         print("C2-size body, 2 ranks, 3 iterations, rank %d: data bytes %.1f MB, index bytes %.1f MB, %d collective calls" % (r, st["comm_bytes_data"] / 1e6, st["comm_bytes_index"] / 1e6, st["comm_calls"]))
-    # rank 0 (owns every block both ranks touch: first-touch rule) sends no partial matrix rows, rank 1 sends ~19 k rows of 9 KB once per build
-    assert ranks[0]["stats"]["comm_bytes_data"] < 100e6 and max(o["stats"]["comm_bytes_data"] for o in ranks) < 300e6, [o["stats"] for o in ranks]
+    # rank 0 (owns every block both ranks touch: first-touch rule) sends no partial matrix rows, rank 1 sends ~19 k rows of 9 KB once per build;
+    # the worker's diagnostic getters (complete grid arrays, residual, SpMV and V-cycle results: all-gathers of whole vectors) are in the count
+    assert ranks[0]["stats"]["comm_bytes_data"] < 100e6 and max(o["stats"]["comm_bytes_data"] for o in ranks) < 450e6, [o["stats"] for o in ranks]
 
 
 def test_whole_steps_over_two_ranks_hip(hotlib):
