@@ -23,6 +23,7 @@ void Ctx<T>::set_comm(const hot_comm* c)
         need(c->rank >= 0 && c->rank < c->size && c->size <= 64, "hot_set_comm: 0 <= rank < size <= 64");
         need(!cfg.useBaselineMultigrid, "hot_set_comm: the --baseline geometric multigrid is single-rank only");
         comm = *c;
+        gs_no_chain = true; // a chained coarse-level sweep that timed out would make ONE rank redo its solve and desynchronise the collectives: launch-per-pass sweeps only
     }
     else
         comm = hot_comm{};

@@ -11,7 +11,7 @@ import hot_amd
 from hot_amd import synth, parallel
 lib = hot_amd.HotLib(hot_amd.AB_LIB_PATH)
 cfg = synth.CONFIGS[sys.argv[1]]
-cloud = parallel.shard_cloud(cfg, 0, 1, n=cfg["n"])
+cloud = parallel.shard_cloud(cfg, 0, 1, n=int(os.environ.get("GS_CELLS", cfg["n"])))
 ctx = lib.context(dtype=1 if cfg["dtype"] == np.float64 else 0, dx=cloud["dx"], gravity=(0, -9.8, 0), levelCnt=cfg["levelCnt"], profile=1)
 ctx.set_particles(cloud["X"], cloud["V"], cloud["mass"], cloud["vol"], cloud["mu"], cloud["lam"])
 o, nrm = synth.sticky_floor(cloud["corner"][1], cloud["dx"])
@@ -25,7 +25,8 @@ ctx.profile_reset()
 for _ in range(6):
     ctx.vcycle(x)
 t = ctx.profile()
-print(json.dumps({k: v["total_ms"] / v["calls"] for k, v in t.items() if k.startswith("gs_")}))
+L0 = ctx.level(0, coords=False)["nrows"]
+print(json.dumps(dict({k: v["total_ms"] / v["calls"] for k, v in t.items() if k.startswith("gs_")}, nodes=L0 * 1e-3)))
 ''' % ROOT
 for cname in sys.argv[1:] or ["C2"]:
     for flags in ([int(f) for f in os.environ["GS_FLAGS"].split(",")] if os.environ.get("GS_FLAGS") else (0, 1, 2, 4, 6, 7, 8, 9)):
