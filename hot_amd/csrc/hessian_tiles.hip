@@ -374,9 +374,24 @@ template <class T>
 struct TileLds2 {
     static constexpr int CH = sizeof(T) == 8 ? 40 : 64; // particles per chunk
     static constexpr int KMAX = sizeof(T) == 8 ? 136 : 224; // (particle, row) entries per chunk
-    static constexpr int NINT = 64 * 3 + 8 + 64 * 3 + 2 * CH + KMAX + 512 + 8; // cstart, ccnt, cmask, rdof, segs, soff, sbase, pidx, pseg, entinfo, items, ctl
+    static constexpr int NINT = 64 * 3 + 8 + 2 * (64 * 4 + 2 * CH) + KMAX + 512 + 16 + 48; // cstart, ccnt, cmask, rdof, 2 x (segs, soff, sbase, ibase, pidx, pseg), entinfo, items, 2 x ctl, symtab
     static constexpr size_t bytes = (size_t)8 * 1125 * sizeof(AccT<T>) + ((size_t)CH * (81 + 81 + 12) + (size_t)KMAX * 27) * sizeof(T) + (size_t)NINT * sizeof(int32_t);
 };
+
+// Development aid (-DHOT_HT_CLOCKS, tools/hess_phases.sh): shader clocks thread 0 of every workgroup spends between the barriers
+// of k_hessian_tiles2, summed per phase: 0 prologue, 1 - 4 phases A - D of the chunk loop, 5 write-out.
+#ifdef HOT_HT_CLOCKS
+__device__ unsigned long long ht_clk[8];
+#define HT_CLK(i) \
+    do { \
+        if (tid == 0) { \
+            const unsigned long long t_ = clock64(); \
+            clk_[i] += t_ - t0_, t0_ = t_; \
+        } \
+    } while (0)
+#else
+#define HT_CLK(i)
+#endif
 
 template <class T, bool USE_MFMA>
 __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ dp, int64_t Np, const uint64_t* __restrict__ blocks,
@@ -397,15 +412,21 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
     int32_t* ccnt = cstart + 64; // [64] its particle count
     int32_t* cmask = ccnt + 64; // [64] tile rows inside its 3x3x3 support (and active)
     int32_t* rdof = cmask + 64; // [8]
-    int32_t* segs = rdof + 8; // [64] cell | first << 8 | end << 16 (chunk-relative)
-    int32_t* soff = segs + 64; // [64] offset of the segment inside its cell
-    int32_t* sbase = soff + 64; // [64] first K entry of the segment
-    int32_t* pidx = sbase + 64; // [CH] global particle index
-    int32_t* pseg = pidx + CH; // [CH] segment of the chunk member
-    int32_t* entinfo = pseg + CH; // [KMAX] chunk member | node index of the row inside the member's kernel << 8
+    // chunk tables, two sets (the next chunk is packed while the current one is in its K phase):
+    int32_t* segs = rdof + 8; // [2][64] cell | first << 8 | end << 16 (chunk-relative)
+    int32_t* soff = segs + 2 * 64; // [2][64] offset of the segment inside its cell
+    int32_t* sbase = soff + 2 * 64; // [2][64] first K entry of the segment
+    int32_t* ibase = sbase + 2 * 64; // [2][64] first pair-phase item of the segment
+    int32_t* pidx = ibase + 2 * 64; // [2][CH] global particle index
+    int32_t* pseg = pidx + 2 * CH; // [2][CH] segment of the chunk member
+    int32_t* entinfo = pseg + 2 * CH; // [KMAX] chunk member | node index of the row inside the member's kernel << 8
     int32_t* items = entinfo + KMAX; // [512] segment << 3 | row
-    int32_t* ctl = items + 512; // nitems, nseg, cnt, nent, next cell, next offset
+    int32_t* ctl = items + 512; // [2][8] nitems, nseg, cnt, nent, floor(2^20 / cnt) + 1
+    int32_t* symtab = ctl + 16; // [45] row | column << 4 of the packed upper triangle of a 9 x 9 matrix
     const int tid = threadIdx.x;
+#ifdef HOT_HT_CLOCKS
+    unsigned long long clk_[6] = { 0, 0, 0, 0, 0, 0 }, t0_ = clock64();
+#endif
     const int id = blockIdx.x, run = (id & 7) + 8 * (id >> 8), tile_id = run * 32 + ((id >> 3) & 31); // runs of 32 tiles per XCD, as above
     if (tile_id >= ntiles) return;
     const int b = tile_id / TPB, tt = tile_id % TPB;
@@ -416,12 +437,15 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
         int ex = (tx0 - bx) + (tid >> 2), ey = (ty0 - by) + ((tid >> 1) & 1), ez = (tz0 - bz) + (tid & 1);
         rdof[tid] = gIdx[(int64_t)b * G::EPB + ((ex << (G::yb + G::zb)) | (ey << G::zb) | ez)];
     }
+    if (tid < 45) symtab[tid] = kSymRow[tid] | (kSymCol[tid] << 4);
     for (int e = tid; e < 8 * 1125; e += HT_THREADS) tile[e] = (AT)0;
     __syncthreads();
     bool any = false;
     for (int r = 0; r < 8; ++r) any = any || rdof[r] >= 0;
     if (!any) return;
-    int my_first = 0, my_n = 0, my_w = 0; // lanes of wavefront 0: first particle, particle count (0 if no row is touched), rows touched of cell `tid`
+    // The chunk packer is the LAST wavefront (it has the fewest K-phase tasks): lane pl = cell
+    const int pl = tid - (HT_THREADS - 64);
+    int my_first = 0, my_n = 0, my_w = 0; // its lanes: first particle, particle count (0 if no row is touched), rows touched of cell `pl`
     if (tid < 64) {
         const int ox = (tid >> 4) - 2, oy = ((tid >> 2) & 3) - 2, oz = (tid & 3) - 2; // base cell = tile origin + (-2..1)^3
         const int cx = tx0 + ox, cy = ty0 + oy, cz = tz0 + oz;
@@ -435,10 +459,10 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
             if ((unsigned)ax < 3u && (unsigned)ay < 3u && (unsigned)az < 3u && rdof[r] >= 0) mask |= 1 << r;
         }
         cstart[tid] = first, ccnt[tid] = cnt, cmask[tid] = mask;
-        my_first = first, my_w = __popc(mask), my_n = my_w ? cnt : 0;
     }
-    int pk_c = 0, pk_off = 0; // packing cursor (wavefront 0): cell, offset inside it
+    int pk_c = 0, pk_off = 0; // packing cursor: cell, offset inside it
     __syncthreads();
+    if (pl >= 0) my_first = cstart[pl], my_w = __popc(cmask[pl]), my_n = my_w ? ccnt[pl] : 0;
     if (own) { // sharded: a tile none of whose rows this rank owns and none of whose cells hold particles of its shard is not its business
         bool mine = false;
         for (int r = 0; r < 8; ++r) mine = mine || (rdof[r] >= 0 && own[rdof[r]]);
@@ -446,82 +470,105 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
         for (int c = 0; c < 64; ++c) any_particles = any_particles || (ccnt[c] > 0 && cmask[c] != 0);
         if (!mine && !any_particles) return; // workgroup-uniform (LDS tables)
     }
-    for (;;) {
-        // ---- pack the next chunk: whole or partial cells until CH particles or KMAX entries.  Wavefront 0, lane = cell:
-        // the particles (and K entries) from the chunk start to the end of each cell by two prefix sums, the first cell
-        // that does not fit whole is split.
-        if (tid < 64) {
-            const int rem = tid < pk_c ? 0 : (tid == pk_c ? my_n - pk_off : my_n);
-            const int pin = wave_scan_incl(rem), ein = wave_scan_incl(rem * my_w);
-            const unsigned long long notfull = __ballot(pin > CH || ein > KMAX);
-            const int f = notfull ? __ffsll((long long)notfull) - 1 : 64;
-            const int pbef = pin - rem, ebef = ein - rem * my_w;
-            int take = tid < f ? rem : 0;
-            if (tid == f) take = min(min(rem, CH - pbef), (KMAX - ebef) / my_w); // my_w > 0 here: rem > 0
-            const unsigned long long inc = __ballot(take > 0);
-            const int k = __popcll(inc & ((1ull << tid) - 1ull));
-            if (take > 0) {
-                const int off = tid == pk_c ? pk_off : 0;
-                segs[k] = tid | (pbef << 8) | ((pbef + take) << 16), soff[k] = off, sbase[k] = ebef;
-                for (int t = 0; t < take; ++t) pseg[pbef + t] = k, pidx[pbef + t] = my_first + off + t;
-            }
-            const int last = f < 64 ? f : 63;
-            const int cnt_all = __shfl(pbef + take, last), ent_all = __shfl(ebef + take * my_w, last);
-            const int take_f = __shfl(take, last);
-            if (tid == 0) ctl[0] = 0, ctl[1] = __popcll(inc), ctl[2] = cnt_all, ctl[3] = ent_all;
-            if (f < 64) {
-                pk_off = (f == pk_c ? pk_off : 0) + take_f;
-                pk_c = f;
-            }
-            else
-                pk_c = 64, pk_off = 0;
+    // ---- pack a chunk into table set `nb`: whole or partial cells until CH particles or KMAX entries.  One wavefront, lane =
+    // cell: the particles (and K entries) from the chunk start to the end of each cell by two prefix sums, the first cell that
+    // does not fit whole is split.
+    auto pack = [&](int nb) {
+        const int rem = pl < pk_c ? 0 : (pl == pk_c ? my_n - pk_off : my_n);
+        const int pin = wave_scan_incl(rem), ein = wave_scan_incl(rem * my_w);
+        const unsigned long long notfull = __ballot(pin > CH || ein > KMAX);
+        const int f = notfull ? __ffsll((long long)notfull) - 1 : 64;
+        const int pbef = pin - rem, ebef = ein - rem * my_w;
+        int take = pl < f ? rem : 0;
+        if (pl == f) take = min(min(rem, CH - pbef), (KMAX - ebef) / my_w); // my_w > 0 here: rem > 0
+        const unsigned long long inc = __ballot(take > 0);
+        const int k = __popcll(inc & ((1ull << pl) - 1ull));
+        const int iin = wave_scan_incl(take > 0 ? my_w : 0); // pair-phase items (segment, row) up to and including this cell
+        if (take > 0) {
+            const int off = pl == pk_c ? pk_off : 0;
+            segs[nb * 64 + k] = pl | (pbef << 8) | ((pbef + take) << 16), soff[nb * 64 + k] = off, sbase[nb * 64 + k] = ebef, ibase[nb * 64 + k] = iin - my_w;
+            for (int t = 0; t < take; ++t) pseg[nb * CH + pbef + t] = k, pidx[nb * CH + pbef + t] = my_first + off + t;
         }
-        __syncthreads();
-        const int nseg = ctl[1], cnt = ctl[2], nent = ctl[3];
-        if (cnt == 0) break;
-        // ---- stage dP (45 -> full 9x9), X and Fn: the loads are issued first and land in LDS after the entry / item tables
-        // below are built.  Lanes run over the chunk members first (neighbours in every SoA component).
-        constexpr int NS = (CH * 45 + HT_THREADS - 1) / HT_THREADS;
-        static_assert(CH * 12 <= HT_THREADS, "one X / Fn slot per thread");
-        T ld[NS], ldx = (T)0;
+        const int last = f < 64 ? f : 63;
+        const int cnt_all = __shfl(pbef + take, last), ent_all = __shfl(ebef + take * my_w, last);
+        const int take_f = __shfl(take, last);
+        const int items_all = __shfl(iin, 63);
+        if (pl == 0) ctl[nb * 8 + 0] = items_all, ctl[nb * 8 + 1] = __popcll(inc), ctl[nb * 8 + 2] = cnt_all, ctl[nb * 8 + 3] = ent_all, ctl[nb * 8 + 4] = cnt_all ? (1 << 20) / cnt_all + 1 : 0;
+        if (f < 64) {
+            pk_off = (f == pk_c ? pk_off : 0) + take_f;
+            pk_c = f;
+        }
+        else
+            pk_c = 64, pk_off = 0;
+    };
+    // ---- the chunk's dP (45 scalars), X and Fn go from global memory into registers one chunk ahead (issued before the
+    // previous chunk's pair phase) and land in LDS at the top of the chunk.  Lanes run over the chunk members first
+    // (neighbours in every SoA component).
+    constexpr int NS = (CH * 45 + HT_THREADS - 1) / HT_THREADS;
+    static_assert(CH * 12 <= HT_THREADS, "one X / Fn slot per thread");
+    T ld[NS], ldx = (T)0;
+    auto fetch = [&](int nb) {
+        const int cnt = ctl[nb * 8 + 2];
+        const unsigned magic = (unsigned)ctl[nb * 8 + 4]; // e / cnt = e * magic >> 20, exact for e * cnt < 2^20 (e < 45 * 64, cnt <= 64)
+        const int32_t* pi = pidx + nb * CH;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            const int e = tid + k * HT_THREADS;
-            ld[k] = e < cnt * 45 ? dp[(int64_t)(e / cnt) * Np + pidx[e % cnt]] : (T)0;
+            const int e = tid + k * HT_THREADS, q = (int)(((unsigned)e * magic) >> 20);
+            ld[k] = e < cnt * 45 ? dp[(int64_t)q * Np + pi[e - q * cnt]] : (T)0;
         }
         if (tid < cnt * 12) {
-            const int q = tid / cnt, p = pidx[tid % cnt];
+            const int q = (int)(((unsigned)tid * magic) >> 20), p = pi[tid - q * cnt];
             ldx = q < 3 ? X[(int64_t)q * Np + p] : Fn[(int64_t)(q - 3) * Np + p];
         }
+    };
+    if (pl >= 0) pack(0);
+    __syncthreads();
+    fetch(0);
+    HT_CLK(0);
+    for (int cur = 0;; cur ^= 1) {
+        const int nseg = ctl[cur * 8 + 1], cnt = ctl[cur * 8 + 2], nent = ctl[cur * 8 + 3];
+        if (cnt == 0) break;
+        const unsigned magic = (unsigned)ctl[cur * 8 + 4];
+        const int32_t* ibase_c = ibase + cur * 64;
+        const int32_t* segs_c = segs + cur * 64;
+        const int32_t* sbase_c = sbase + cur * 64;
+        const int32_t* pseg_c = pseg + cur * CH;
+        // ---- phase A: entry / item tables, the staged values to LDS (dP 45 -> full 9x9), spline weights of the chunk's
+        // (particle, axis) pairs straight from the X register
         for (int e = tid; e < cnt * 8; e += HT_THREADS) {
-            const int l = e >> 3, r = e & 7, sp = pseg[l], sd = segs[sp], cell = sd & 255, mask = cmask[cell];
+            const int l = e >> 3, r = e & 7, sp = pseg_c[l], sd = segs_c[sp], cell = sd & 255, mask = cmask[cell];
             if ((mask >> r) & 1) {
                 const int ax = (r >> 2) - ((cell >> 4) - 2), ay = ((r >> 1) & 1) - (((cell >> 2) & 3) - 2), az = (r & 1) - ((cell & 3) - 2);
-                entinfo[sbase[sp] + (l - ((sd >> 8) & 255)) * __popc(mask) + __popc(mask & ((1 << r) - 1))] = l | ((ax * 9 + ay * 3 + az) << 8);
+                entinfo[sbase_c[sp] + (l - ((sd >> 8) & 255)) * __popc(mask) + __popc(mask & ((1 << r) - 1))] = l | ((ax * 9 + ay * 3 + az) << 8);
             }
         }
-        for (int e = tid; e < nseg * 8; e += HT_THREADS)
-            if ((cmask[segs[e >> 3] & 255] >> (e & 7)) & 1) items[atomicAdd(ctl, 1)] = e;
+        for (int e = tid; e < nseg * 8; e += HT_THREADS) {
+            const int mask = cmask[segs_c[e >> 3] & 255];
+            if ((mask >> (e & 7)) & 1) items[ibase_c[e >> 3] + __popc(mask & ((1 << (e & 7)) - 1))] = e;
+        }
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const int e = tid + k * HT_THREADS;
             if (e < cnt * 45) {
-                const int q = e / cnt, l = e - q * cnt, ra = kSymRow[q], cb = kSymCol[q];
+                const int q = (int)(((unsigned)e * magic) >> 20), l = e - q * cnt, rc = symtab[q], ra = rc & 15, cb = rc >> 4;
                 sdp[l * 81 + ra * 9 + cb] = ld[k], sdp[l * 81 + cb * 9 + ra] = ld[k];
             }
         }
-        if (tid < cnt * 12) sxf[(tid % cnt) * 12 + tid / cnt] = ldx;
-        __syncthreads();
-        // ---- spline weights once per (particle, axis), then g = Fn^T grad w for the 27 nodes
         T* sw = sk; // [CH][3][6]: w[3], dw[3] / dx
-        for (int e = tid; e < cnt * 3; e += HT_THREADS) {
-            int base;
-            T w[3], dw[3];
-            bspline<T>(one_over_dx, sxf[(e / 3) * 12 + e % 3], base, w, dw);
+        if (tid < cnt * 12) {
+            const int q = (int)(((unsigned)tid * magic) >> 20), l = tid - q * cnt;
+            sxf[l * 12 + q] = ldx;
+            if (q < 3) {
+                int base;
+                T w[3], dw[3];
+                bspline<T>(one_over_dx, ldx, base, w, dw);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) sw[e * 6 + k] = w[k], sw[e * 6 + 3 + k] = one_over_dx * dw[k];
+                for (int k = 0; k < 3; ++k) sw[(l * 3 + q) * 6 + k] = w[k], sw[(l * 3 + q) * 6 + 3 + k] = one_over_dx * dw[k];
+            }
         }
         __syncthreads();
+        HT_CLK(1);
+        // ---- phase B: g = Fn^T grad w for the 27 nodes
         for (int e = tid; e < cnt * 27; e += HT_THREADS) {
             const int l = e / 27, nd = e - l * 27;
             const int i = nd / 9, j = (nd / 3) % 3, k = nd % 3;
@@ -533,7 +580,10 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
             for (int cc = 0; cc < 3; ++cc) sg[e * 3 + cc] = xf[3 + cc * 3] * g0 + xf[3 + cc * 3 + 1] * g1 + xf[3 + cc * 3 + 2] * g2;
         }
         __syncthreads();
-        // ---- K phase: lane = (entry, (a, b)) -> the 3 values over q
+        HT_CLK(2);
+        // ---- phase C: the last wavefront packs the next chunk into the other table set; K phase: lane = (entry, (a, b)) -> the 3
+        // values over q
+        if (pl >= 0) pack(cur ^ 1);
         for (int e = tid; e < nent * 9; e += HT_THREADS) {
             const int entry = e / 9, ab = e - entry * 9, a = ab % 3, bb = ab / 3;
             const int info = entinfo[entry], l = info & 255;
@@ -544,6 +594,9 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
             for (int q = 0; q < 3; ++q) sk[e * 3 + q] = D[a * 9 + 3 * q] * g0 + D[(a + 3) * 9 + 3 * q] * g1 + D[(a + 6) * 9 + 3 * q] * g2;
         }
         __syncthreads();
+        HT_CLK(3);
+        // ---- phase D: the next chunk's loads go out, then the pair phase of this one
+        fetch(cur ^ 1);
         // ---- pair phase on the matrix cores (A/B build only — measured SLOWER than the scalar version below on MI355X: C2 fp64
         // 19.9 vs 14.4 ms, C3 fp32 64 vs 37 ms.  The chip's FP64 matrix rate equals its FP64 vector rate (78.6 TFLOP/s), and with
         // M = 3 x rows (10 on average) padded to 16 and N = 27 padded to 32 half of every MFMA is padding; what is left is index
@@ -558,14 +611,14 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
             const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
             int g0 = 0;
             for (int s = 0; s < nseg; ++s) {
-                const int sd = segs[s], cell = sd & 255, l0 = (sd >> 8) & 255, l1 = sd >> 16, mask = cmask[cell];
+                const int sd = segs_c[s], cell = sd & 255, l0 = (sd >> 8) & 255, l1 = sd >> 16, mask = cmask[cell];
                 const int nrows = __popc(mask), np = l1 - l0, m3 = nrows * 3;
                 const int cntu = ((m3 + 15) >> 4) * 6;
                 for (int sub = ((w - g0) % 16 + 16) % 16; sub < cntu; sub += 16) {
                     const int mt = sub / 6, rem = sub - mt * 6, bb = rem >> 1, nt = rem & 1;
                     const int mA = li + 16 * mt, rpA = mA / 3, aA = mA - rpA * 3;
                     const bool va = mA < m3;
-                    const T* Ap = sk + (sbase[s] + (va ? rpA : 0)) * 27 + (aA + 3 * bb) * 3;
+                    const T* Ap = sk + (sbase_c[s] + (va ? rpA : 0)) * 27 + (aA + 3 * bb) * 3;
                     const int jB = li + 16 * nt;
                     const bool vb = jB < 27;
                     const T* Bp = sg + (l0 * 27 + (vb ? jB : 0)) * 3;
@@ -604,10 +657,22 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
         }
         else {
             // ---- pair phase (production: scalar multiply-adds)
-            const int ni = ctl[0] * 27;
-            for (int it = tid; it < ni; it += HT_THREADS) {
+            // An item = (segment, row, column triple jg, a) walks its segment's particles with the 3 (column z) x 3 (b) sums in
+            // registers; a chunk holds KMAX / (particles per cell) x 27 ~ 460 of them (fp64), so the walk is split over 2 or 4
+            // lanes per item while that still fits one pass.  (Tried: all three `a` in one item, 27 K + 9 g values per 81
+            // multiply-adds instead of 18 per 27 — 128 registers, spills, C2 15.4 vs 13.6 ms.)
+            const int ni = ctl[cur * 8] * 27;
+            const int split = 4 * ni <= HT_THREADS ? 4 : (2 * ni <= HT_THREADS ? 2 : 1);
+            for (int it0 = tid; it0 < ni * split; it0 += HT_THREADS) {
+                const int part = (it0 >= ni) + (it0 >= 2 * ni) + (it0 >= 3 * ni), it = it0 - part * ni;
                 const int e = items[it / 27], rem = it % 27, jg = rem / 3, a = rem % 3, s = e >> 3, r = e & 7;
-                const int sd = segs[s], cell = sd & 255, l0 = (sd >> 8) & 255, l1 = sd >> 16, mask = cmask[cell];
+                const int sd = segs_c[s], cell = sd & 255, mask = cmask[cell];
+                int l0 = (sd >> 8) & 255, l1 = sd >> 16;
+                if (split > 1) {
+                    const int per = (l1 - l0 + split - 1) / split;
+                    l0 += part * per, l1 = min(l1, l0 + per);
+                    if (l0 >= l1) continue;
+                }
                 const int nrows = __popc(mask), rowpos = __popc(mask & ((1 << r) - 1));
                 const int ax = (r >> 2) - ((cell >> 4) - 2), ay = ((r >> 1) & 1) - (((cell >> 2) & 3) - 2), az = (r & 1) - ((cell & 3) - 2);
                 const int jx = jg / 3, jy = jg % 3;
@@ -616,7 +681,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
                 for (int z = 0; z < 3; ++z)
     #pragma unroll
                     for (int q = 0; q < 3; ++q) acc[z][q] = (T)0;
-                const T* Kp = sk + (sbase[s] + rowpos) * 27 + a * 3;
+                const T* Kp = sk + (sbase_c[s] + (l0 - ((sd >> 8) & 255)) * nrows + rowpos) * 27 + a * 3;
                 const T* gp = sg + (l0 * 27 + jg * 3) * 3;
     #pragma unroll 2
                 for (int l = l0; l < l1; ++l, Kp += nrows * 27, gp += 81) {
@@ -640,6 +705,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
             }
         }
         __syncthreads();
+        HT_CLK(4);
     }
     for (int e = tid; e < 8 * 1125; e += HT_THREADS) {
         int r = e / 1125, q = e - r * 1125;
@@ -650,6 +716,11 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles2(const T* __restri
         val[(int64_t)dof * 1125 + q] = v;
         if (written && q == 0) written[dof] = 1;
     }
+#ifdef HOT_HT_CLOCKS
+    HT_CLK(5);
+    if (tid == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&ht_clk[i], clk_[i]);
+#endif
 }
 
 template <class T>
@@ -687,6 +758,15 @@ void Ctx<T>::assemble_tiles(Level<T>& L)
 #endif
     HOT_LAUNCH(this, "hessian_assemble", (k_hessian_tiles2<T, false>), 256 * div_up(Nb * TPB, 256), HT_THREADS, TileLds2<T>::bytes, pX.p, pFn.p, pDP.p, Np, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, (T)1 / dx, Nb * TPB,
         L.mask(), L.part ? written.p : (uint8_t*)nullptr);
+#ifdef HOT_HT_CLOCKS
+    unsigned long long h[8] = {};
+    HOT_HIP(hipStreamSynchronize(stream));
+    HOT_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(ht_clk), sizeof(h)));
+    const double tiles = (double)Nb * TPB;
+    fprintf(stderr, "hessian tile clocks per workgroup: prologue %.0f A %.0f B %.0f C %.0f D %.0f write-out %.0f\n", h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[5] / tiles);
+    memset(h, 0, sizeof(h));
+    HOT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ht_clk), h, sizeof(h)));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ matrix-free diagonal
