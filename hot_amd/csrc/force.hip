@@ -573,6 +573,88 @@ __global__ __launch_bounds__(256) void k_inertia_energy(const T* __restrict__ dv
     grid_sum_store(k, gg, 2, gr, out, out + 1, red);
 }
 
+// Second production force scatter: items (cell segment, node row j, half of the segment) -> the 9 nodes (i, k) of that row with their
+// 27 sums in registers, the 1-D weights and derivatives recomputed from x per (item, particle) — 12 staged scalars per particle (stress,
+// x) read from LDS once per 9 nodes, where k_force_cells reads 19 of its 27 staged ones per 3 nodes (the item phase of these kernels is
+// bound by LDS reads + VALU issue, profiles/r03_sq_counters_C2.json).  25 KB of LDS per 256 fp64 particles: 256-thread workgroups,
+// six per CU.
+template <class T>
+__global__ __launch_bounds__(256) void k_force_cells2(const T* __restrict__ X, const T* __restrict__ stress, int64_t Np, const int32_t* __restrict__ group_first,
+    const int32_t* __restrict__ group_origin, const int32_t* __restrict__ group_cell0, const int32_t* __restrict__ cell_first, T* __restrict__ part, T one_over_dx, T scale)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ, THREADS = 256;
+    constexpr int CH = sizeof(T) == 4 ? 512 : 256;
+    using AT = AccT<T>; // double tile also in fp32 (see k_force_cells)
+    __shared__ AT acc[3][TILE];
+    __shared__ T sp[12][CH]; // scale * S(9), x(3)
+    __shared__ int32_t segs[G::EPB + 2];
+    __shared__ int32_t nseg;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    for (int t = tid; t < 3 * TILE; t += THREADS) (&acc[0][0])[t] = (AT)0;
+    const int first = group_first[g], last = group_first[g + 1];
+    const int c0 = group_cell0[g], c1 = group_cell0[g + 1];
+    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
+    for (int ch = first; ch < last; ch += CH) {
+        if (tid == 0) nseg = 0;
+        __syncthreads(); // also orders the previous chunk's reads of sp / segs before they are overwritten
+        for (int l = tid; l < CH && ch + l < last; l += THREADS) {
+            const int p = ch + l;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sp[c][l] = scale * stress[(int64_t)c * Np + p];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) sp[9 + d][l] = X[(int64_t)d * Np + p];
+        }
+        for (int c = c0 + tid; c < c1; c += THREADS) {
+            const int s0 = max(cell_first[c], ch), s1 = min(cell_first[c + 1], min(ch + CH, last));
+            if (s1 > s0) segs[atomicAdd(&nseg, 1)] = (s0 - ch) | ((s1 - ch) << 16);
+        }
+        __syncthreads();
+        const int ni = nseg * 6;
+        for (int it = tid; it < ni; it += THREADS) {
+            const int sd = segs[it / 6], j = (it % 6) >> 1, hf = it & 1, s0 = sd & 0xffff, s1 = sd >> 16;
+            const int mid = (s0 + s1 + 1) >> 1, l0 = hf ? mid : s0, l1 = hf ? s1 : mid;
+            if (l0 >= l1) continue;
+            T a[3][3][3]; // [i][k][component]
+#pragma unroll
+            for (int e = 0; e < 27; ++e) (&a[0][0][0])[e] = (T)0;
+            int b0 = 0, b1 = 0, b2 = 0; // the same for every particle of the cell
+            for (int l = l0; l < l1; ++l) {
+                T wx[3], dwx[3], wy3[3], dwy3[3], wz[3], dwz[3];
+                bspline<T>(one_over_dx, sp[9][l], b0, wx, dwx);
+                bspline<T>(one_over_dx, sp[10][l], b1, wy3, dwy3);
+                bspline<T>(one_over_dx, sp[11][l], b2, wz, dwz);
+                const T wy = j == 0 ? wy3[0] : (j == 1 ? wy3[1] : wy3[2]), dwy = j == 0 ? dwy3[0] : (j == 1 ? dwy3[1] : dwy3[2]);
+                T S[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) S[c] = sp[c][l];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const T wi = wx[i], dwi = one_over_dx * dwx[i];
+                    const T wij = wi * wy, dwij_i = dwi * wy, dwij_j = wi * one_over_dx * dwy;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const T g0 = dwij_i * wz[k], g1 = dwij_j * wz[k], g2 = wij * one_over_dx * dwz[k];
+                        a[i][k][0] += -(S[0] * g0 + S[3] * g1 + S[6] * g2);
+                        a[i][k][1] += -(S[1] * g0 + S[4] * g1 + S[7] * g2);
+                        a[i][k][2] += -(S[2] * g0 + S[5] * g1 + S[8] * g2);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int t = ((b0 - ox + i) * TY + (b1 - oy + j)) * TZ + (b2 - oz + k);
+                    lds_atomic_add(&acc[0][t], (AT)a[i][k][0]), lds_atomic_add(&acc[1][t], (AT)a[i][k][1]), lds_atomic_add(&acc[2][t], (AT)a[i][k][2]);
+                }
+        }
+    }
+    __syncthreads();
+    T* out = part + (int64_t)g * 3 * TILE; // partial tile, summed per node by k_tile_reduce
+    for (int t = tid; t < 3 * TILE; t += THREADS) out[t] = (T)(&acc[0][0])[t];
+}
+
 // rasterizeForceToTVStack from the stresses the last k_state left behind (the line search needs it once, at the accepted
 // point: lineSearch evaluates only the energy per trial, ImplicitSolver.h:312-333)
 template <class T>
@@ -584,7 +666,10 @@ void Ctx<T>::force_pass()
         HOT_LAUNCH(this, "force_scatter", k_force_scatter<T>, Ng, 256, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, (T)1 / dx, dt);
     else
 #endif
+    if (ab_flag("HOT_FORCE_CELLS1")) // A/B build only: 27 staged scalars, 3-node items
         HOT_LAUNCH(this, "force_scatter", k_force_cells<T>, Ng, FORCE_THREADS, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, (T)1 / dx, dt);
+    else
+        HOT_LAUNCH(this, "force_scatter", k_force_cells2<T>, Ng, 256, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, (T)1 / dx, dt);
     reduce_tiles(3, gF.p, gF.p + slots, gF.p + 2 * slots, nullptr, nullptr, "force_reduce");
     if (halo_mode()) {
         T* arr[3] = { gF.p, gF.p + slots, gF.p + 2 * slots };

@@ -199,7 +199,25 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
 // CN quantity) per-particle scalars x, m, m v, m C are staged — the nine 1-D weights are recomputed per item from x (a few
 // multiply-adds against nine LDS reads) and the base cell comes from the segment's first particle.  35 KB instead of 56 KB per
 // 256-particle chunk: four 256-thread workgroups per CU instead of two 512-thread ones, i.e. twice as many independent
-// header -> staging -> items chains in flight per CU.
+// header -> staging -> items chains in flight per CU.  (Tried in round 3: persistent workgroups walking the groups with the next
+// unit's 16 scalars requested into registers before the item phase of the current one — C2 0.156 vs 0.132 ms, C3 0.405 vs 0.375:
+// with four workgroups per CU the staging latency is already covered by the other three, what is left is the item phase itself,
+// VALU 44 % + LDS 56 % of the kernel's cycles (profiles/r03_sq_counters_C2.json).)
+// Development aid (-DHOT_HT_CLOCKS, tools/hess_phases.sh): shader clocks of thread 0 between the barriers of k_p2g_cells2, summed
+// over the workgroups: 0 header + zeroing, 1 staging, 2 items, 3 write-out.
+#ifdef HOT_HT_CLOCKS
+__device__ unsigned long long p2g_clk[8];
+#define P2G_CLK(i) \
+    do { \
+        if (tid == 0) { \
+            const unsigned long long t_ = clock64(); \
+            clk_[i] += t_ - t0_, t0_ = t_; \
+        } \
+    } while (0)
+#else
+#define P2G_CLK(i)
+#endif
+
 template <class T, bool WITH_CN>
 __global__ __launch_bounds__(256) void k_p2g_cells2(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C,
     const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
@@ -214,6 +232,9 @@ __global__ __launch_bounds__(256) void k_p2g_cells2(const T* __restrict__ X, con
     __shared__ int32_t segs[G::EPB + 2];
     __shared__ int32_t nseg;
     const int g = blockIdx.x, tid = threadIdx.x;
+#ifdef HOT_HT_CLOCKS
+    unsigned long long clk_[4] = { 0, 0, 0, 0 }, t0_ = clock64();
+#endif
     for (int t = tid; t < NQ * TILE; t += THREADS) (&acc[0][0])[t] = (AT)0;
     const int first = group_first[g], last = group_first[g + 1];
     const int c0 = group_cell0[g], c1 = group_cell0[g + 1];
@@ -221,6 +242,7 @@ __global__ __launch_bounds__(256) void k_p2g_cells2(const T* __restrict__ X, con
     for (int ch = first; ch < last; ch += CH) {
         if (tid == 0) nseg = 0;
         __syncthreads();
+        P2G_CLK(0);
         for (int l = tid; l < CH && ch + l < last; l += THREADS) {
             const int p = ch + l;
             const T m = M[p];
@@ -239,7 +261,70 @@ __global__ __launch_bounds__(256) void k_p2g_cells2(const T* __restrict__ X, con
             if (s1 > s0) segs[atomicAdd(&nseg, 1)] = (s0 - ch) | ((s1 - ch) << 16);
         }
         __syncthreads();
-        const int ni = nseg * 18;
+        P2G_CLK(1);
+        // items, fp32: (cell segment, node row j, half of the segment) -> the 9 nodes (i, k) of that row, 9 x NQ sums in registers:
+        // the 16 scalars of a particle are read from LDS once per 9 nodes instead of once per 3 (the item phase is LDS 56 % + VALU 44 %
+        // of the kernel's cycles): C3 0.302 from 0.375 ms.  In fp64 the 45 sums need 216 registers (two workgroups per CU instead of
+        // four; capped at 168 they spill): C2 0.141 - 0.145 against 0.132 ms, so fp64 keeps the 3-node items below.
+        if constexpr (sizeof(T) == 4) {
+        const int ni = nseg * 6;
+        for (int it = tid; it < ni; it += THREADS) {
+            const int sd = segs[it / 6], j = (it % 6) >> 1, hf = it & 1, s0 = sd & 0xffff, s1 = sd >> 16;
+            const int mid = (s0 + s1 + 1) >> 1, l0 = hf ? mid : s0, l1 = hf ? s1 : mid;
+            if (l0 >= l1) continue;
+            T a[3][3][NQ]; // [i][k][quantity]
+#pragma unroll
+            for (int e = 0; e < 9 * NQ; ++e) (&a[0][0][0])[e] = (T)0;
+            // the base cell is the same for every particle of the segment
+            const int b0 = base_node<T>(one_over_dx * sp[0][l0]), b1 = base_node<T>(one_over_dx * sp[1][l0]), b2 = base_node<T>(one_over_dx * sp[2][l0]);
+            const T fb0 = (T)b0, fb1 = (T)b1, fb2 = (T)b2;
+            for (int l = l0; l < l1; ++l) {
+                const T x0 = sp[0][l], x1 = sp[1][l], x2 = sp[2][l];
+                // 1-D quadratic B-spline weights, the arithmetic of bspline() (BSplines.h:55-81)
+                auto w3 = [&](T x, T fb, T(&w)[3]) {
+                    const T d0 = fma(one_over_dx, x, -fb); // exact product, like the fused multiply-add a -O3 -march=native host build makes of it (hot_common.h bspline)
+                    const T z = (T)1.5 - d0, d1 = d0 - (T)1, zz = (T)1.5 - ((T)1 - d1);
+                    w[0] = (T)0.5 * z * z, w[1] = (T)0.75 - d1 * d1, w[2] = (T)0.5 * zz * zz;
+                };
+                T wi[3], wj3[3], wk[3];
+                w3(x0, fb0, wi), w3(x1, fb1, wj3), w3(x2, fb2, wk);
+                const T wj = j == 0 ? wj3[0] : (j == 1 ? wj3[1] : wj3[2]);
+                const T d1 = (T)(b1 + j) * dx - x1;
+                const T m = sp[3][l];
+                const T u0 = sp[10][l] * d1 + sp[4][l], u1 = sp[11][l] * d1 + sp[5][l], u2 = sp[12][l] * d1 + sp[6][l];
+                const T c0_ = sp[7][l], c1_ = sp[8][l], c2_ = sp[9][l], e0 = sp[13][l], e1 = sp[14][l], e2 = sp[15][l];
+                T cn = (T)0;
+                if (WITH_CN) cn = sp[NS - 1][l];
+                T d0[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) d0[i] = (T)(b0 + i) * dx - x0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T d2 = (T)(b2 + k) * dx - x2, wjk = wj * wk[k];
+                    const T t0 = e0 * d2 + u0, t1 = e1 * d2 + u1, t2 = e2 * d2 + u2;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const T wijk = wi[i] * wjk;
+                        a[i][k][0] += m * wijk;
+                        a[i][k][1] += (c0_ * d0[i] + t0) * wijk;
+                        a[i][k][2] += (c1_ * d0[i] + t1) * wijk;
+                        a[i][k][3] += (c2_ * d0[i] + t2) * wijk;
+                        if (WITH_CN) a[i][k][NQ - 1] += cn * wijk;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int t = ((b0 - ox + i) * TY + (b1 - oy + j)) * TZ + (b2 - oz + k);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) lds_atomic_add(&acc[q][t], (AT)a[i][k][q]);
+                }
+        }
+        }
+        else {
+        const int ni = nseg * 18; // (cell segment, node column (j, k), half of the segment) -> 3 nodes
         for (int it = tid; it < ni; it += THREADS) {
             const int sd = segs[it / 18], jk = (it % 18) >> 1, hf = it & 1, s0 = sd & 0xffff, s1 = sd >> 16;
             const int mid = (s0 + s1 + 1) >> 1, l0 = hf ? mid : s0, l1 = hf ? s1 : mid;
@@ -250,14 +335,12 @@ __global__ __launch_bounds__(256) void k_p2g_cells2(const T* __restrict__ X, con
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) a[i][q] = (T)0;
-            // the base cell is the same for every particle of the segment
             const int b0 = base_node<T>(one_over_dx * sp[0][l0]), b1 = base_node<T>(one_over_dx * sp[1][l0]), b2 = base_node<T>(one_over_dx * sp[2][l0]);
             const T fb0 = (T)b0, fb1 = (T)b1, fb2 = (T)b2;
             for (int l = l0; l < l1; ++l) {
                 const T x0 = sp[0][l], x1 = sp[1][l], x2 = sp[2][l];
-                // 1-D quadratic B-spline weights, the arithmetic of bspline() (BSplines.h:55-81) for the needed components
                 auto w1 = [&](T x, T fb, int q) {
-                    const T d0 = fma(one_over_dx, x, -fb); // exact product, like the fused multiply-add a -O3 -march=native host build makes of it (hot_common.h bspline)
+                    const T d0 = fma(one_over_dx, x, -fb);
                     if (q == 0) {
                         const T z = (T)1.5 - d0;
                         return (T)0.5 * z * z;
@@ -292,10 +375,17 @@ __global__ __launch_bounds__(256) void k_p2g_cells2(const T* __restrict__ X, con
                 for (int q = 0; q < NQ; ++q) lds_atomic_add(&acc[q][t], (AT)a[i][q]);
             }
         }
+        }
     }
     __syncthreads();
+    P2G_CLK(2);
     T* out = part + (int64_t)g * NQ * TILE;
     for (int t = tid; t < NQ * TILE; t += THREADS) out[t] = (T)(&acc[0][0])[t];
+#ifdef HOT_HT_CLOCKS
+    P2G_CLK(3);
+    if (tid == 0)
+        for (int i = 0; i < 4; ++i) atomicAdd(&p2g_clk[i], clk_[i]);
+#endif
 }
 
 template <class T>
@@ -381,6 +471,16 @@ void Ctx<T>::p2g()
         HOT_LAUNCH(this, "p2g", (k_p2g_cells2<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
     else
         HOT_LAUNCH(this, "p2g", (k_p2g_cells2<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
+#ifdef HOT_HT_CLOCKS
+    {
+        unsigned long long h[8] = {};
+        HOT_HIP(hipStreamSynchronize(stream));
+        HOT_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(p2g_clk), sizeof(h)));
+        fprintf(stderr, "p2g clocks per workgroup (%d groups): header %.0f staging %.0f items %.0f write-out %.0f\n", Ng, h[0] / (double)Ng, h[1] / (double)Ng, h[2] / (double)Ng, h[3] / (double)Ng);
+        memset(h, 0, sizeof(h));
+        HOT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(p2g_clk), h, sizeof(h)));
+    }
+#endif
     reduce_tiles(nq, gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p, "p2g_reduce");
     if (halo_mode()) { // the ranks that share a block add their partial sums: complete on every block this rank covers, zero on the others
         T* arr[5] = { gM.p, gMV.p, gMV.p + slots, gMV.p + 2 * slots, gCN.p };

@@ -1,0 +1,28 @@
+"""P2G / G2P / force-pass time (HIP events from the context profile) at C2 / C3 size; HOT_LIB selects another build of the library
+(e.g. the per-phase clock build of tools/hess_phases.sh)."""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import hot_amd
+from hot_amd import parallel, synth
+
+for which in (sys.argv[1:] or ["C2", "C3"]):
+    cfg = dict(synth.CONFIGS[which])
+    cloud = parallel.shard_cloud(cfg, 0, 1, n=cfg["n"])
+    lib = hot_amd.HotLib(os.environ["HOT_LIB"]) if os.environ.get("HOT_LIB") else hot_amd.load()
+    ctx = lib.context(dtype=1 if cfg["dtype"] == np.float64 else 0, dx=cloud["dx"], gravity=(0, -9.8, 0), levelCnt=3, profile=1)
+    ctx.set_particles(cloud["X"], cloud["V"], cloud["mass"], cloud["vol"], cloud["mu"], cloud["lam"])
+    ctx.sort(), ctx.p2g(), ctx.begin_step(cfg["dt"])
+    ctx.profile_reset()
+    for _ in range(6):
+        ctx.p2g()
+    ctx.begin_step(cfg["dt"])
+    dv = ctx.get_dv()
+    for _ in range(6):
+        ctx.update_state(dv)
+        ctx.residual()
+    for _ in range(6):
+        ctx.g2p(0.0)
+    t = ctx.profile()
+    print(which, {k: round(v["total_ms"] / v["calls"], 4) for k, v in t.items() if any(x in k for x in ("p2g", "g2p", "force", "state", "reduce"))})
+    del ctx
