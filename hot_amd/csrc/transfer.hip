@@ -219,7 +219,7 @@ __device__ unsigned long long p2g_clk[8];
 #endif
 
 template <class T, bool WITH_CN>
-__global__ __launch_bounds__(256) void k_p2g_cells2(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_p2g_cells2(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C,
     const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
     const int32_t* __restrict__ group_cell0, const int32_t* __restrict__ cell_first, T* __restrict__ part, T dx, T one_over_dx)
 {
@@ -262,16 +262,16 @@ __global__ __launch_bounds__(256) void k_p2g_cells2(const T* __restrict__ X, con
         }
         __syncthreads();
         P2G_CLK(1);
-        // items, fp32: (cell segment, node row j, half of the segment) -> the 9 nodes (i, k) of that row, 9 x NQ sums in registers:
-        // the 16 scalars of a particle are read from LDS once per 9 nodes instead of once per 3 (the item phase is LDS 56 % + VALU 44 %
-        // of the kernel's cycles): C3 0.302 from 0.375 ms.  In fp64 the 45 sums need 216 registers (two workgroups per CU instead of
-        // four; capped at 168 they spill): C2 0.141 - 0.145 against 0.132 ms, so fp64 keeps the 3-node items below.
-        if constexpr (sizeof(T) == 4) {
-        const int ni = nseg * 6;
-        for (int it = tid; it < ni; it += THREADS) {
+        // items: (cell segment, node row j, half of the segment) -> the 9 nodes (i, k) of that row with their sums in registers: the
+        // scalars of a particle are read from LDS once per 9 nodes instead of once per 3 (the item phase is LDS 56 % + VALU 44 % of the
+        // round-2 kernel's cycles).  fp32: all NQ quantities in one item (C3 0.302 from 0.375 ms).  fp64: 45 sums need 216 registers
+        // (two workgroups per CU instead of four: 0.141 ms against the 3-node items' 0.132), so the quantities are dealt to two items,
+        // {m, m v0, cn} and {m v1, m v2}.
+        auto run9 = [&](auto mask_c, int it) {
+            constexpr int MASK = decltype(mask_c)::value;
             const int sd = segs[it / 6], j = (it % 6) >> 1, hf = it & 1, s0 = sd & 0xffff, s1 = sd >> 16;
             const int mid = (s0 + s1 + 1) >> 1, l0 = hf ? mid : s0, l1 = hf ? s1 : mid;
-            if (l0 >= l1) continue;
+            if (l0 >= l1) return;
             T a[3][3][NQ]; // [i][k][quantity]
 #pragma unroll
             for (int e = 0; e < 9 * NQ; ++e) (&a[0][0][0])[e] = (T)0;
@@ -290,26 +290,30 @@ __global__ __launch_bounds__(256) void k_p2g_cells2(const T* __restrict__ X, con
                 w3(x0, fb0, wi), w3(x1, fb1, wj3), w3(x2, fb2, wk);
                 const T wj = j == 0 ? wj3[0] : (j == 1 ? wj3[1] : wj3[2]);
                 const T d1 = (T)(b1 + j) * dx - x1;
-                const T m = sp[3][l];
-                const T u0 = sp[10][l] * d1 + sp[4][l], u1 = sp[11][l] * d1 + sp[5][l], u2 = sp[12][l] * d1 + sp[6][l];
-                const T c0_ = sp[7][l], c1_ = sp[8][l], c2_ = sp[9][l], e0 = sp[13][l], e1 = sp[14][l], e2 = sp[15][l];
-                T cn = (T)0;
-                if (WITH_CN) cn = sp[NS - 1][l];
+                T m = (T)0, cn = (T)0, u[3], cc[3], ee[3];
+                if constexpr ((MASK & 1) != 0) m = sp[3][l];
+                if constexpr (WITH_CN && (MASK & (1 << (NQ - 1))) != 0) cn = sp[NS - 1][l];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (MASK & (2 << q)) u[q] = sp[10 + q][l] * d1 + sp[4 + q][l], cc[q] = sp[7 + q][l], ee[q] = sp[13 + q][l];
                 T d0[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) d0[i] = (T)(b0 + i) * dx - x0;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const T d2 = (T)(b2 + k) * dx - x2, wjk = wj * wk[k];
-                    const T t0 = e0 * d2 + u0, t1 = e1 * d2 + u1, t2 = e2 * d2 + u2;
+                    T t[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        if (MASK & (2 << q)) t[q] = ee[q] * d2 + u[q];
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const T wijk = wi[i] * wjk;
-                        a[i][k][0] += m * wijk;
-                        a[i][k][1] += (c0_ * d0[i] + t0) * wijk;
-                        a[i][k][2] += (c1_ * d0[i] + t1) * wijk;
-                        a[i][k][3] += (c2_ * d0[i] + t2) * wijk;
-                        if (WITH_CN) a[i][k][NQ - 1] += cn * wijk;
+                        if constexpr ((MASK & 1) != 0) a[i][k][0] += m * wijk;
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            if (MASK & (2 << q)) a[i][k][1 + q] += (cc[q] * d0[i] + t[q]) * wijk;
+                        if constexpr (WITH_CN && (MASK & (1 << (NQ - 1))) != 0) a[i][k][NQ - 1] += cn * wijk;
                     }
                 }
             }
@@ -319,62 +323,21 @@ __global__ __launch_bounds__(256) void k_p2g_cells2(const T* __restrict__ X, con
                 for (int k = 0; k < 3; ++k) {
                     const int t = ((b0 - ox + i) * TY + (b1 - oy + j)) * TZ + (b2 - oz + k);
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) lds_atomic_add(&acc[q][t], (AT)a[i][k][q]);
+                    for (int q = 0; q < NQ; ++q)
+                        if (MASK & (1 << q)) lds_atomic_add(&acc[q][t], (AT)a[i][k][q]);
                 }
-        }
+        };
+        const int n6 = nseg * 6;
+        if constexpr (sizeof(T) == 4) {
+            for (int it = tid; it < n6; it += THREADS) run9(std::integral_constant<int, (1 << NQ) - 1>{}, it);
         }
         else {
-        const int ni = nseg * 18; // (cell segment, node column (j, k), half of the segment) -> 3 nodes
-        for (int it = tid; it < ni; it += THREADS) {
-            const int sd = segs[it / 18], jk = (it % 18) >> 1, hf = it & 1, s0 = sd & 0xffff, s1 = sd >> 16;
-            const int mid = (s0 + s1 + 1) >> 1, l0 = hf ? mid : s0, l1 = hf ? s1 : mid;
-            if (l0 >= l1) continue;
-            const int j = jk / 3, k = jk - 3 * j;
-            T a[3][NQ];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) a[i][q] = (T)0;
-            const int b0 = base_node<T>(one_over_dx * sp[0][l0]), b1 = base_node<T>(one_over_dx * sp[1][l0]), b2 = base_node<T>(one_over_dx * sp[2][l0]);
-            const T fb0 = (T)b0, fb1 = (T)b1, fb2 = (T)b2;
-            for (int l = l0; l < l1; ++l) {
-                const T x0 = sp[0][l], x1 = sp[1][l], x2 = sp[2][l];
-                auto w1 = [&](T x, T fb, int q) {
-                    const T d0 = fma(one_over_dx, x, -fb);
-                    if (q == 0) {
-                        const T z = (T)1.5 - d0;
-                        return (T)0.5 * z * z;
-                    }
-                    const T d1 = d0 - (T)1;
-                    if (q == 1) return (T)0.75 - d1 * d1;
-                    const T zz = (T)1.5 - ((T)1 - d1);
-                    return (T)0.5 * zz * zz;
-                };
-                const T wjk = w1(x1, fb1, j) * w1(x2, fb2, k);
-                const T d1 = (T)(b1 + j) * dx - x1, d2 = (T)(b2 + k) * dx - x2;
-                const T m = sp[3][l];
-                const T t0 = sp[10][l] * d1 + sp[13][l] * d2 + sp[4][l], t1 = sp[11][l] * d1 + sp[14][l] * d2 + sp[5][l], t2 = sp[12][l] * d1 + sp[15][l] * d2 + sp[6][l];
-                const T c0_ = sp[7][l], c1_ = sp[8][l], c2_ = sp[9][l];
-                T cn = (T)0;
-                if (WITH_CN) cn = sp[NS - 1][l];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const T wijk = w1(x0, fb0, i) * wjk;
-                    const T d0 = (T)(b0 + i) * dx - x0;
-                    a[i][0] += m * wijk;
-                    a[i][1] += (c0_ * d0 + t0) * wijk;
-                    a[i][2] += (c1_ * d0 + t1) * wijk;
-                    a[i][3] += (c2_ * d0 + t2) * wijk;
-                    if (WITH_CN) a[i][NQ - 1] += cn * wijk;
-                }
+            for (int it = tid; it < 2 * n6; it += THREADS) {
+                if (it < n6)
+                    run9(std::integral_constant<int, 1 | 2 | (WITH_CN ? 16 : 0)>{}, it);
+                else
+                    run9(std::integral_constant<int, 4 | 8>{}, it - n6);
             }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int t = ((b0 - ox + i) * TY + (b1 - oy + j)) * TZ + (b2 - oz + k);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) lds_atomic_add(&acc[q][t], (AT)a[i][q]);
-            }
-        }
         }
     }
     __syncthreads();
@@ -585,7 +548,7 @@ void Ctx<T>::get_grid(int32_t* ic, void* m, void* v)
 
 // ------------------------------------------------------------------------------------------------ G2P
 template <class T, int PLASTIC>
-__global__ __launch_bounds__(256) void k_g2p(T* __restrict__ X, T* __restrict__ V, T* __restrict__ C, T* __restrict__ F, const T* __restrict__ Fn, T* __restrict__ gradV_out,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_g2p(T* __restrict__ X, T* __restrict__ V, T* __restrict__ C, T* __restrict__ F, const T* __restrict__ Fn, T* __restrict__ gradV_out,
     T* __restrict__ Mu, T* __restrict__ Lam, T* __restrict__ Jp, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
     const int32_t* __restrict__ group_nb, const int32_t* __restrict__ gIdx, const T* __restrict__ nodeV, const T* __restrict__ dv, T dx, T one_over_dx, T dt, T apic_r,
     T cfl, T yield_stress, T sn0, T sn1, T sn2, T sn3, T sn4, int32_t* flags_out)
@@ -595,18 +558,15 @@ __global__ __launch_bounds__(256) void k_g2p(T* __restrict__ X, T* __restrict__ 
     __shared__ T nv[3][TILE];
     const int g = blockIdx.x;
     const int first = group_first[g], last = group_first[g + 1];
-    // position and Fn of this thread's first particle are requested before the tile gather, and the tile's DOF ids come from the
-    // per-group table (tileDof) instead of the nb8 -> gIdx chain: the workgroup's dependent round trips (indices -> nodal values, particle
-    // data) run side by side (the same prologue as k_state)
+    // the position of this thread's first particle is requested before the tile gather, and the tile's DOF ids come from the per-group
+    // table (tileDof) instead of the nb8 -> gIdx chain: the workgroup's dependent round trips (indices -> nodal values, particle data)
+    // run side by side.  Fn is NOT held across the 27-node loop (round 3: with it the fp64 kernel needed 214 registers, two wavefronts
+    // per SIMD; it is read after the loop, when only the 21 sums are live, and the other wavefronts cover that round trip).
     const int p0 = first + threadIdx.x;
-    T xpre[3] = { 0, 0, 0 }, fpre[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) fpre[c] = (T)0;
+    T xpre[3] = { 0, 0, 0 };
     if (p0 < last) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) xpre[d] = X[(int64_t)d * Np + p0];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) fpre[c] = Fn[(int64_t)c * Np + p0];
     }
     for (int t = threadIdx.x; t < TILE; t += 256) {
         int idx = gIdx[(int64_t)g * TILE + t]; // gIdx here = tileDof
@@ -622,18 +582,13 @@ __global__ __launch_bounds__(256) void k_g2p(T* __restrict__ X, T* __restrict__ 
     int myflags = 0;
     for (int p = first + threadIdx.x; p < last; p += 256) {
         T xp[3];
-        Mat3<T> Fo;
         if (p == p0) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) xp[d] = xpre[d];
-#pragma unroll
-            for (int c = 0; c < 9; ++c) Fo.a[c] = fpre[c];
         }
         else { // groups of more than 256 particles
 #pragma unroll
             for (int d = 0; d < 3; ++d) xp[d] = X[(int64_t)d * Np + p];
-#pragma unroll
-            for (int c = 0; c < 9; ++c) Fo.a[c] = Fn[(int64_t)c * Np + p];
         }
         int base[3];
         T w[3][3], dw[3][3];
@@ -671,6 +626,9 @@ __global__ __launch_bounds__(256) void k_g2p(T* __restrict__ X, T* __restrict__ 
                 }
             }
         }
+        Mat3<T> Fo;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Fo.a[c] = Fn[(int64_t)c * Np + p];
         V[p] = pic[0], V[Np + p] = pic[1], V[2 * Np + p] = pic[2];
         T ra = (apic_r + (T)1) * (T)0.5, rb = (apic_r - (T)1) * (T)0.5;
 #pragma unroll

@@ -1,4 +1,9 @@
-mkdir -p gpurun_out/r03
-timeout 600 python tools/p2g_time.py C2 C3 2>&1 | grep -v amdgpu.ids | tail -2
-HOT_AMD_AB=1 HOT_FORCE_CELLS1=1 timeout 600 python tools/p2g_time.py C2 C3 2>&1 | grep -v amdgpu.ids | tail -2
-timeout 1200 python -m pytest tests/test_gpu_transfer.py tests/test_gpu_golden.py tests/test_gpu_force.py tests/test_gpu_solver.py -q -x 2>&1 | grep -v amdgpu.ids | tail -4
+for i in 1 2; do
+timeout 600 python bench.py --no-cpu 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('ms/iter', round(d['value'],3), 'ms/step', round(d['ms_per_step'],1), 'it/step', d['iterations_per_step'])
+t=d['transfers']; print(' xfer', round(t['p2g_ms'],3), round(t['g2p_ms'],3), round(t['mparticles_per_s']), round(t['frac_of_hbm_peak'],3))
+"
+done
+timeout 600 python tools/p2g_time.py C2 2>&1 | grep -v amdgpu.ids | tail -1
