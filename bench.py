@@ -216,9 +216,17 @@ def main():
         pctx = make_ctx(lib, cloud, cfg, device=local, profile=1)
         pctx.advance(dt)
         pctx.profile_reset()
-        nprof = max(1, min(2, args.steps))
-        pst = [pctx.advance(dt) for _ in range(nprof)]
-        table = pctx.profile()
+        nprof = max(1, min(4, args.steps))
+        pst, table, xfer_steps = [], {}, []
+        for _ in range(nprof):  # one table per step: the transfer kernels run once a step, their time is reported as the median over the steps
+            pctx.profile_reset()
+            pst.append(pctx.advance(dt))
+            t1 = pctx.profile()
+            for k, v in t1.items():
+                r = table.setdefault(k, dict(calls=0, total_ms=0.0))
+                r["calls"] += v["calls"]
+                r["total_ms"] += v["total_ms"]
+            xfer_steps.append({k: t1[k]["total_ms"] / t1[k]["calls"] for k in ("p2g", "p2g_reduce", "g2p") if k in t1})
         levels = [(pctx.level(l, coords=False)["nrows"], pctx.level_nnzb(l)) for l in range(pst[-1]["num_levels"])]
         total_ms = sum(v["total_ms"] for v in table.values())
         groups = {}
@@ -246,12 +254,12 @@ def main():
                 "traffic_source": traffic_src,
                 "avg_launch_ms": avg_ms, "launches": g["calls"], "algorithmic_bytes_per_launch": g["bytes"] / g["calls"], "share_of_kernel_time": g["ms"] / total_ms,
                 "per_level": g["records"]}
-        tp, tr, tg = table.get("p2g"), table.get("p2g_reduce"), table.get("g2p")
-        t_p2g = tp["total_ms"] / tp["calls"] + (tr["total_ms"] / tr["calls"] if tr else 0.0)
-        t_g2p = tg["total_ms"] / tg["calls"]
+        med = lambda xs: sorted(xs)[len(xs) // 2] if len(xs) % 2 else 0.5 * (sorted(xs)[len(xs) // 2 - 1] + sorted(xs)[len(xs) // 2])
+        t_p2g = med([x["p2g"] + x.get("p2g_reduce", 0.0) for x in xfer_steps])
+        t_g2p = med([x["g2p"] for x in xfer_steps])
         Nn = levels[0][0]
         tb = 43 * s * Np + 7 * s * Nn
-        transfers = {"p2g_ms": t_p2g, "g2p_ms": t_g2p, "mparticles_per_s": Np / ((t_p2g + t_g2p) * 1e-3) / 1e6, "algorithmic_bytes": tb,
+        transfers = {"p2g_ms": t_p2g, "g2p_ms": t_g2p, "mparticles_per_s": Np / ((t_p2g + t_g2p) * 1e-3) / 1e6, "algorithmic_bytes": tb, "per_step_ms": [{k: round(v, 4) for k, v in x.items()} for x in xfer_steps], "statistic": "median over %d profiled steps" % nprof,
                      "achieved_GBps": tb / ((t_p2g + t_g2p) * 1e-3) / 1e9, "frac_of_hbm_peak": tb / ((t_p2g + t_g2p) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         prof_top = sorted(((k, round(v["ms"] / nprof, 3), v["calls"] // nprof) for k, v in groups.items()), key=lambda x: -x[1])[:14]
         del pctx

@@ -36,6 +36,7 @@ CASES = [
     ({"HOT_P2G_V1": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),
     ({"HOT_P2G_CELLS1": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),
     ({"HOT_FORCE_V1": "1"}, "tests/test_gpu_force.py", "objective_pieces"),
+    ({"HOT_FORCE_CELLS1": "1"}, "tests/test_gpu_force.py", "objective_pieces"),  # round 2's 3-node items with 27 staged scalars
 ]
 
 
