@@ -463,7 +463,8 @@ __global__ __launch_bounds__(256) void k_force_scatter(const T* __restrict__ X, 
 
 #endif
 
-// Production force scatter: same (cell, node column) work items as k_p2g_cells (transfer.hip) — the particles of a
+#ifdef HOT_AB_KERNELS
+// Round-2 production force scatter (A/B build only now): same (cell, node column) work items as k_p2g_cells (transfer.hip) — the particles of a
 // base cell share their 27 nodes, so the three nodes of a column are summed in registers over the cell and added to the
 // LDS tile once.  The 1-D weights and their derivatives are computed once per particle while staging (the first
 // version, k_force_scatter above, recomputed them per node through rotated tables that ended up in scratch memory).
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(FORCE_THREADS) void k_force_cells(const T* __restri
     T* out = part + (int64_t)g * 3 * TILE; // partial tile, summed per node by k_tile_reduce
     for (int t = tid; t < 3 * TILE; t += FORCE_THREADS) out[t] = (T)(&acc[0][0])[t];
 }
+#endif
 
 template <class T>
 __global__ __launch_bounds__(256) void k_inertia_energy(const T* __restrict__ dv, const T* __restrict__ mass, int nn, T g0, T g1, T g2, double* out, GridRed gr, const uint8_t* __restrict__ mask)
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(256) void k_inertia_energy(const T* __restrict__ dv
     grid_sum_store(k, gg, 2, gr, out, out + 1, red);
 }
 
-// Second production force scatter: items (cell segment, node row j, half of the segment) -> the 9 nodes (i, k) of that row with their
+// Production force scatter: items (cell segment, node row j, half of the segment) -> the 9 nodes (i, k) of that row with their
 // 27 sums in registers, the 1-D weights and derivatives recomputed from x per (item, particle) — 12 staged scalars per particle (stress,
 // x) read from LDS once per 9 nodes, where k_force_cells reads 19 of its 27 staged ones per 3 nodes (the item phase of these kernels is
 // bound by LDS reads + VALU issue, profiles/r03_sq_counters_C2.json).  25 KB of LDS per 256 fp64 particles: 256-thread workgroups,
@@ -664,11 +666,10 @@ void Ctx<T>::force_pass()
 #ifdef HOT_AB_KERNELS
     if (ab_flag("HOT_FORCE_V1")) // one LDS atomic per particle, node and component
         HOT_LAUNCH(this, "force_scatter", k_force_scatter<T>, Ng, 256, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, (T)1 / dx, dt);
-    else
-#endif
-    if (ab_flag("HOT_FORCE_CELLS1")) // A/B build only: 27 staged scalars, 3-node items
+    else if (ab_flag("HOT_FORCE_CELLS1")) // 27 staged scalars, 3-node items
         HOT_LAUNCH(this, "force_scatter", k_force_cells<T>, Ng, FORCE_THREADS, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, (T)1 / dx, dt);
     else
+#endif
         HOT_LAUNCH(this, "force_scatter", k_force_cells2<T>, Ng, 256, 0, pX.p, pStress.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, (T)1 / dx, dt);
     reduce_tiles(3, gF.p, gF.p + slots, gF.p + 2 * slots, nullptr, nullptr, "force_reduce");
     if (halo_mode()) {

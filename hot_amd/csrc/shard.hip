@@ -419,22 +419,6 @@ __global__ void k_mark_stencil(HashMap h, const int32_t* __restrict__ coord, con
     const int32_t j = hash_find_id(h, coord_key(x, y, z));
     if (j >= 0 && !own[j]) need[j] = 1;
 }
-__global__ void k_mark_list(const int32_t* __restrict__ ids, int64_t n, const uint8_t* __restrict__ own, uint8_t* __restrict__ need)
-{
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const int32_t j = ids[e];
-    if (j >= 0 && !own[j]) need[j] = 1;
-}
-// ids[row * width + k] for the rows this rank owns only
-__global__ void k_mark_rows(const int32_t* __restrict__ ids, int width, int nrows, const uint8_t* __restrict__ row_own, const uint8_t* __restrict__ own, uint8_t* __restrict__ need)
-{
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (int64_t)nrows * width) return;
-    if (row_own && !row_own[e / width]) return;
-    const int32_t j = ids[e];
-    if (j >= 0 && !own[j]) need[j] = 1;
-}
 // flags over the POSITIONS of gs_order (colour-major): the halo entries owned by rank q
 __global__ void k_need_flags(const int32_t* __restrict__ gs_order, const uint8_t* __restrict__ need, const uint8_t* __restrict__ owner, int q, int32_t* __restrict__ flags, int n)
 {

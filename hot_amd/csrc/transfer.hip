@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void k_p2g(const T* __restrict__ X, const T* _
 
 #endif
 
-// Production P2G.  The particles of one base cell share their 27 support nodes, so a (cell, node column) work item sums
+#ifdef HOT_AB_KERNELS
+// Round-1 production P2G (A/B build only now).  The particles of one base cell share their 27 support nodes, so a (cell, node column) work item sums
 // the contributions of the whole cell to its 3 nodes in registers and touches the LDS accumulator once per node and
 // quantity: ~8x fewer ds_add_f64 than one-add-per-particle (k_p2g above, kept for A/B).  Particle data and the per-
 // particle 1-D weights are staged in LDS (coalesced loads, weights computed once per particle instead of once per
@@ -194,8 +195,9 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
     T* out = part + (int64_t)g * NQ * TILE;
     for (int t = tid; t < NQ * TILE; t += P2G_THREADS) out[t] = (T)(&acc[0][0])[t];
 }
+#endif
 
-// Second production P2G: the same (cell segment, node column, half) work items as k_p2g_cells, but only the 16 (17 with the
+// Production P2G: the (cell segment, node row, half) work items of k_p2g_cells (above, A/B build), but only the 16 (17 with the
 // CN quantity) per-particle scalars x, m, m v, m C are staged — the nine 1-D weights are recomputed per item from x (a few
 // multiply-adds against nine LDS reads) and the base cell comes from the segment's first particle.  35 KB instead of 56 KB per
 // 256-particle chunk: four 256-thread workgroups per CU instead of two 512-thread ones, i.e. twice as many independent
@@ -422,15 +424,15 @@ void Ctx<T>::p2g()
         else
             HOT_LAUNCH(this, "p2g", (k_p2g<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gPart.p, dx, one_over_dx);
     }
-    else
-#endif
-    if (ab_flag("HOT_P2G_CELLS1")) { // A/B build only: the 25-scalar staging version
+    else if (ab_flag("HOT_P2G_CELLS1")) { // the 25-scalar staging version
         if (cfg.useCN)
             HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, true>), Ng, P2G_THREADS, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
         else
             HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, false>), Ng, P2G_THREADS, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
     }
-    else if (cfg.useCN)
+    else
+#endif
+    if (cfg.useCN)
         HOT_LAUNCH(this, "p2g", (k_p2g_cells2<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
     else
         HOT_LAUNCH(this, "p2g", (k_p2g_cells2<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
