@@ -79,11 +79,18 @@ def make_ctx(lib, cloud, cfg, device=0, profile=0, comm=None, **over):
     ctx = lib.context(**kw)
     if isinstance(comm, str):  # "rccl": the library's native communicator on the context's own stream (hot_amd/csrc/rccl_comm.hip)
         from hot_amd import dist as hdist
+        import torch
+        import torch.distributed as tdist
+        ok, why = 1, None
         try:
             hdist.attach_rccl(ctx)
-        except Exception as e:  # RCCL not loadable / not attachable: torch.distributed collectives instead
-            import torch
-            print("bench: native RCCL communicator unavailable (%r), using TorchComm" % (e,), file=sys.stderr)
+            ctx.rccl_selftest()  # every callback once with known data across the group (device and host payloads, ring exchange)
+        except Exception as e:  # RCCL not loadable / not attachable / a collective returned a wrong result
+            ok, why = 0, e
+        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", device))
+        tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)  # the choice of communicator is the group's, not a rank's
+        if int(flag.item()) == 0:  # torch.distributed collectives instead, on every rank
+            print("bench: native RCCL communicator not used (%r on this rank), using TorchComm" % (why,), file=sys.stderr)
             ctx._fallback_comm = hdist.TorchComm(device=torch.device("cuda", device))
             ctx.set_comm(ctx._fallback_comm)
     elif comm is not None:
