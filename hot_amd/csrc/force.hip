@@ -8,9 +8,10 @@
 //                   (Lib/MPM/Force/MpmForceBase.cpp:213-248), restoreStrain/evolveStrain (FBasedMpmForceHelper.cpp:35-43,
 //                   99-114), updateImplicitState (:70-97), FBased totalEnergy (:116-135).  The reference runs these as
 //                   separate particle sweeps with two SVDs per particle; here: one launch, one SVD, LDS-staged node tile.
-//   k_force_cells   rasterizeForceToTVStack<false> (MpmForceBase.cpp:100-153): (cell, node column) items summed in
+//   k_force_cells2  rasterizeForceToTVStack<false> (MpmForceBase.cpp:100-153): (cell half, node row) items summed in
 //                   registers, one partial tile per particle group, ordered reduce (no colour passes, no global
-//                   atomics).  k_force_scatter is the first version (one LDS atomic per particle and node), kept for A/B.
+//                   atomics).  k_force_scatter (one LDS atomic per particle and node) and k_force_cells (3-node items,
+//                   27 staged scalars) are the earlier versions, kept in the A/B build.
 //   k_residual      computeResidual (Projects/multigrid/ImplicitSolver.h:128-155) incl. MassLumpedInertia::addScaledForces
 //                   (Lib/Ziran/Physics/LagrangianForce/Inertia.cpp:33-41), transformResidual (:117-125), project.
 //   k_matfree       matrix-free Hessian product (ImplicitSolver.h:741-758, MpmForceBase.cpp:262-306,
