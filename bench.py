@@ -163,6 +163,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu and args.backend == "nccl":
+        args.backend = "gloo"  # RCCL refuses two ranks on one device
     cores = host_cores()
     os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(cores, 32))))
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
