@@ -225,7 +225,8 @@ def main():
         pctx = make_ctx(lib, cloud, cfg, device=local, profile=1)
         pctx.advance(dt)
         pctx.profile_reset()
-        nprof = max(1, min(4, args.steps))
+        # the transfer kernels run once per step and show an occasional 2 x outlier under event timing: five steps where a step is short (C1 - C3)
+        nprof = 5 if elapsed / max(args.steps, 1) < 1.5 else max(1, min(2, args.steps))
         pst, table, xfer_steps = [], {}, []
         for _ in range(nprof):  # one table per step: the transfer kernels run once a step, their time is reported as the median over the steps
             pctx.profile_reset()
