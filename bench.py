@@ -142,6 +142,7 @@ def parse_args():
                     "cannot be attached) or hot_amd.dist.TorchComm (torch.distributed collectives, host-synchronous)")
     ap.add_argument("--shard-gs", type=int, default=1, choices=[0, 1], help="N > 1, coloured GS across ranks: 1 = processor-block (one exchange per symmetric sweep; default), "
                     "0 = colour-synchronous (the single-rank iterates, sixteen exchanges per symmetric sweep)")
+    ap.add_argument("--watchdog-s", type=float, default=1500.0, help="N > 1: abort the rank (exit code 3) if the run has not finished after this many seconds (a peer that died or a wedged collective would otherwise hang the job); 0 = off")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on device 0 (functional check of the N > 1 path on a one-GPU box, not a measurement)")
     return ap.parse_args()
 
@@ -177,6 +178,16 @@ def main():
     torch.cuda.set_device(local)
     dist = None
     comm = None
+    if world > 1 and args.watchdog_s > 0:
+        import threading
+
+        def _abort():
+            print("bench: rank %d still running after %.0f s, aborting" % (rank, args.watchdog_s), file=sys.stderr, flush=True)
+            os._exit(3)
+
+        wd = threading.Timer(args.watchdog_s, _abort)
+        wd.daemon = True
+        wd.start()
     if world > 1:
         import torch.distributed as dist_
         from hot_amd import dist as hdist
