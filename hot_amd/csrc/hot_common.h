@@ -214,6 +214,27 @@ __device__ inline T block_sum_256(T v, T* sm4)
     return r;
 }
 
+// NV block-wide sums at once (blockDim.x == 256): the same additions in the same order as NV calls of block_sum_256, with one barrier
+// pair instead of NV; results valid in thread 0.  use(k): whether sum k is wanted (workgroup-uniform).  smn: NV * 4 doubles of LDS.
+template <int NV, class Use>
+__device__ inline void block_sum_256_n(double (&v)[NV], Use use, double* smn)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        if (use(k)) {
+            v[k] = wave_sum(v[k]);
+            if (lane == 0) smn[4 * k + w] = v[k];
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (use(k)) v[k] = smn[4 * k] + smn[4 * k + 1] + smn[4 * k + 2] + smn[4 * k + 3];
+    }
+    __syncthreads();
+}
+
 // Order-deterministic grid-wide sum (blockDim.x == 256), one launch: every workgroup deposits its total, the one that
 // arrives last adds the deposits in index order and STORES the result (no same-address floating-point atomics, whose
 // arrival order changes the rounding from run to run and, between ranks of a sharded solve, from rank to rank).
@@ -269,33 +290,43 @@ __device__ inline void grid_sum_store(double t0, double t1, int nv, GridRed gr, 
     }
 }
 
-// The same for up to NVMAX sums per launch (the L-BFGS dot batches): deposits are laid out [k][workgroup]; `tot` holds the block
-// totals in thread 0.  gr.part must hold nv * gridDim.x doubles (Ctx::gred_n).
-template <int NVMAX>
-__device__ inline void grid_sum_store_n(const double (&tot)[NVMAX], int nv, GridRed gr, double* out, double* sm4)
+// The same for up to NVMAX sums per launch (the L-BFGS dot batches): `tot` holds the block totals in thread 0, slot(k) is the deposit
+// row of total k (-1: not used; the used ones fill rows 0 .. nv - 1), deposits are laid out [row][workgroup].  gr.part must hold
+// nv * gridDim.x doubles (Ctx::gred_n), smn NVMAX * 4 doubles of LDS.  The last workgroup adds all nv rows in one pass (loads of every
+// row in flight together, one barrier pair).
+template <int NVMAX, class Slot>
+__device__ inline void grid_sum_store_n(const double (&tot)[NVMAX], Slot slot, int nv, GridRed gr, double* out, double* smn)
 {
     __shared__ int s_last_n;
     const unsigned nb = gridDim.x;
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < NVMAX; ++k)
-            if (k < nv) __hip_atomic_store(gr.part + (size_t)k * nb + blockIdx.x, tot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < NVMAX; ++k) {
+            const int row = slot(k);
+            if (row >= 0) __hip_atomic_store(gr.part + (size_t)row * nb + blockIdx.x, tot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned prev = __hip_atomic_fetch_add(gr.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last_n = prev == nb - 1u;
     }
     __syncthreads();
     if (!s_last_n) return; // workgroup-uniform
-    for (int k = 0; k < nv; ++k) {
-        double a = 0;
-        for (unsigned i = threadIdx.x; i < nb; i += 256) a += __hip_atomic_load(gr.part + (size_t)k * nb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a = block_sum_256<double>(a, sm4);
-        if (threadIdx.x == 0) {
-            out[k] = a;
-            if (gr.mirror) gr.mirror[k] = a;
-        }
+    double a[NVMAX];
+#pragma unroll
+    for (int k = 0; k < NVMAX; ++k) a[k] = 0;
+    for (unsigned i = threadIdx.x; i < nb; i += 256) {
+#pragma unroll
+        for (int k = 0; k < NVMAX; ++k)
+            if (k < nv) a[k] += __hip_atomic_load(gr.part + (size_t)k * nb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    block_sum_256_n<NVMAX>(a, [nv](int k) { return k < nv; }, smn);
     if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NVMAX; ++k)
+            if (k < nv) {
+                out[k] = a[k];
+                if (gr.mirror) gr.mirror[k] = a[k];
+            }
         if (gr.mirror && gr.ticket) host_ticket_store(gr.ticket, gr.ticket_val);
         __hip_atomic_store(gr.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -102,7 +102,7 @@ struct LbVecs {
 template <class T>
 __global__ __launch_bounds__(256) void k_lbfgs_dots(size_t n, LbVecs<T> hv, int use_dg, const T* __restrict__ y, double* out, GridRed gr, const uint8_t* __restrict__ mask)
 {
-    __shared__ double red[4];
+    __shared__ double red[4 * 8];
     double acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0;
@@ -114,10 +114,9 @@ __global__ __launch_bounds__(256) void k_lbfgs_dots(size_t n, LbVecs<T> hv, int 
         for (int k = 0; k < 8; ++k)
             if (k < hv.m) acc[k] += (double)((use_dg ? hv.dg[k][i] : hv.dx[k][i]) * yv);
     }
-    double tot[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) tot[k] = k < hv.m ? block_sum_256<double>(acc[k], red) : 0.0;
-    grid_sum_store_n<8>(tot, hv.m, gr, out, red);
+    const int m = hv.m;
+    block_sum_256_n<8>(acc, [m](int k) { return k < m; }, red);
+    grid_sum_store_n<8>(acc, [m](int k) { return k < m ? k : -1; }, m, gr, out, red);
 }
 // mode 0: q = r - sum ksi_i dg_i (newest pair first), ksi stored at s[50 + ph]; optional keep[i] = r[i] (the working pair's dg starts as
 // the old residual).  mode 1: z = z0 + sum c_i dx_i (oldest first).  Every workgroup runs the scalar recursion itself (m <= 8).
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(256) void k_lbfgs_apply(size_t n, double* s, LbVecs
 template <class T>
 __global__ __launch_bounds__(256) void k_lbfgs_pair(size_t n, LbVecs<T> hv, const T* __restrict__ dxw, T* __restrict__ dgw, const T* __restrict__ rnew, double* out, GridRed gr, const uint8_t* __restrict__ mask)
 {
-    __shared__ double red[4];
+    __shared__ double red[4 * LB_MAXV];
     double acc[LB_MAXV];
 #pragma unroll
     for (int k = 0; k < LB_MAXV; ++k) acc[k] = 0;
@@ -186,19 +185,10 @@ __global__ __launch_bounds__(256) void k_lbfgs_pair(size_t n, LbVecs<T> hv, cons
         for (int k = 0; k < 8; ++k)
             if (k < hv.m) acc[9 + k] += (double)(hv.dx[k][i] * g);
     }
-    // compact order of the deposits: [0] | [1, m] | [m + 1, 2 m]
-    double tot[LB_MAXV];
+    // acc: [0] | [1, 8] | [9, 16], of which m each are in use; compact order of the deposits: [0] | [1, m] | [m + 1, 2 m]
     const int m = hv.m;
-#pragma unroll
-    for (int k = 0; k < LB_MAXV; ++k) tot[k] = 0;
-    tot[0] = block_sum_256<double>(acc[0], red);
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-        if (k < m) {
-            const double a = block_sum_256<double>(acc[1 + k], red), b = block_sum_256<double>(acc[9 + k], red);
-            if (threadIdx.x == 0) tot[1 + k] = a, tot[1 + m + k] = b;
-        }
-    grid_sum_store_n<LB_MAXV>(tot, 2 * m + 1, gr, out, red);
+    block_sum_256_n<LB_MAXV>(acc, [m](int k) { return k == 0 || ((k - 1) & 7) < m; }, red);
+    grid_sum_store_n<LB_MAXV>(acc, [m](int k) { return k == 0 ? 0 : (((k - 1) & 7) < m ? (k <= 8 ? k : k - 8 + m) : -1); }, 2 * m + 1, gr, out, red);
 }
 // files the (all-reduced, when sharded) dots of k_lbfgs_pair: curvature -> s[71] and the pinned host slot, rho -> s[60 + wk] in the
 // arithmetic of the host code it replaces ((T)1 / (T)d, LBFGS.h:424-434), Gram rows / columns of slot wk
