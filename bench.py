@@ -34,7 +34,8 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
 
 SYMBOL = {  # profile-record prefix -> device symbol as rocprofv3 names it
-    "gs_forward": "hot::k_gs_block<T,true,32>", "gs_backward": "hot::k_gs_block<T,false,32>", "spmv": "hot::k_spmv<T>",
+    "gs_forward": "hot::k_gs_subst<T,true,8>", "gs_backward": "hot::k_gs_subst<T,false,8>", "spmv": "hot::k_spmv<T>",
+    "gs_forward_off": "hot::k_gs_offblock<T,true>", "gs_backward_off": "hot::k_gs_offblock<T,false>",
     "gs_forward_chained": "hot::k_gs_sweep<T,true,64>", "gs_backward_chained": "hot::k_gs_sweep<T,false,64>",
     "gs_residual": "hot::k_gs_residual<T>", "hessian_assemble": "hot::k_hessian_tiles2<T,false>", "state_update": "hot::k_state<T>",
     "force_scatter": "hot::k_force_cells2<T>", "p2g": "hot::k_p2g_cells2<T,true>", "g2p": "hot::k_g2p<T,0>",
@@ -51,6 +52,9 @@ def pmc_traffic(symbol, dtype_name):
     files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_summary.json")))
     if not files:
         return None, None
+    newest_src = max((os.path.getmtime(f) for f in glob.glob(os.path.join(here, "hot_amd", "csrc", "*.hip"))), default=0.0)
+    if newest_src > os.path.getmtime(files[-1]):
+        print("bench: %s is older than hot_amd/csrc/*.hip: roofline.traffic is a RECORDED value of an earlier build (re-run profiles/run_profiles.sh)" % os.path.basename(files[-1]), file=sys.stderr)
     want = symbol.replace("<T", "<" + dtype_name).replace(" ", "")
     with open(files[-1]) as fh:
         table = json.load(fh)
@@ -104,8 +108,16 @@ def make_ctx(lib, cloud, cfg, device=0, profile=0, comm=None, **over):
 def algorithmic_bytes(name, s, Np, levels, launches_per_half_sweep=8.0):
     """SURVEY.md §8(d) per-launch algorithmic (compulsory) bytes of one profile record; None if not modelled."""
     base, _, lv = name.rpartition("_L")
+    if base in ("gs_forward_off", "gs_backward_off", "gs_forward", "gs_backward") and lv.isdigit() and len(levels[int(lv)]) > 2 and levels[int(lv)][2] is not None:
+        # the finest level's colour pass is two kernels (one launch each per colour): k_gs_offblock streams the off-block half rows
+        # (values + tagged column ids, the gathered x is cache traffic), reads rhs and the 32-byte row record, writes rhs - sum;
+        # k_gs_subst reads the premultiplied in-block couplings (no column ids), D^-1 (forward also D) and p1, writes x and hD
+        N, nnzb, inb = levels[int(lv)]
+        if base.endswith("_off"):
+            return ((nnzb - N - inb) / 2.0 * (9 * s + 4) + N * (6 * s + 32)) / launches_per_half_sweep
+        return (inb / 2.0 * 9 * s + N * ((18 if base == "gs_forward" else 9) * s + 3 * s + 6 * s + 4)) / launches_per_half_sweep
     if base in ("spmv", "gs_forward", "gs_backward", "gs_residual") and lv.isdigit():
-        N, nnzb = levels[int(lv)]
+        N, nnzb = levels[int(lv)][:2]
         off = max(nnzb - N, 0) / 2.0  # blocks strictly preceding (or following) the row in the sweep order
         if base == "spmv":
             return nnzb * (9 * s + 4) + N * 6 * s
@@ -248,13 +260,13 @@ def main():
                 r["calls"] += v["calls"]
                 r["total_ms"] += v["total_ms"]
             xfer_steps.append({k: t1[k]["total_ms"] / t1[k]["calls"] for k in ("p2g", "p2g_reduce", "g2p") if k in t1})
-        levels = [(pctx.level(l, coords=False)["nrows"], pctx.level_nnzb(l)) for l in range(pst[-1]["num_levels"])]
+        levels = [(pctx.level(l, coords=False)["nrows"], pctx.level_nnzb(l), pctx.level_inblock_nnzb(l) if ("gs_forward_off_L%d" % l) in table else None) for l in range(pst[-1]["num_levels"])]
         total_ms = sum(v["total_ms"] for v in table.values())
         groups = {}
         for name, rec in table.items():
             base = name.rpartition("_L")[0] if name.rpartition("_L")[2].isdigit() else name
             sweeps = table.get("gs_symsweeps_L" + name.rpartition("_L")[2])
-            lph = rec["calls"] / sweeps["calls"] if sweeps and base in ("gs_forward", "gs_backward") else 8.0  # launches per half sweep
+            lph = rec["calls"] / sweeps["calls"] if sweeps and base in ("gs_forward", "gs_backward", "gs_forward_off", "gs_backward_off") else 8.0  # launches per half sweep
             if base in ("gs_forward", "gs_backward") and lph < 1.5:
                 base += "_chained"  # coarse levels: the whole half sweep is one k_gs_sweep launch (a different device symbol)
             g = groups.setdefault(base, dict(ms=0.0, calls=0, bytes=0.0, modelled=True, records={}))

@@ -25,7 +25,7 @@ class hot_config(C.Structure):
         ("useCN", C.c_int32), ("project", C.c_int32), ("systemBCProject", C.c_int32), ("linesearch", C.c_int32),
         ("matrixFree", C.c_int32), ("boundaryType", C.c_int32), ("useAdaptiveHessian", C.c_int32),
         ("topDownMGS", C.c_int32), ("max_iterations", C.c_int32), ("plasticity", C.c_int32),
-        ("yield_stress", C.c_double), ("snow", C.c_double * 5), ("profile", C.c_int32), ("debug_store", C.c_int32), ("useBaselineMultigrid", C.c_int32), ("gs_chain", C.c_int32), ("gs_sub_block", C.c_int32), ("shard_gs", C.c_int32), ("shard_replicated", C.c_int32), ("reserved", C.c_int32 * 1),
+        ("yield_stress", C.c_double), ("snow", C.c_double * 5), ("profile", C.c_int32), ("debug_store", C.c_int32), ("useBaselineMultigrid", C.c_int32), ("gs_chain", C.c_int32), ("gs_sub_block", C.c_int32), ("shard_gs", C.c_int32), ("shard_replicated", C.c_int32), ("ls_energy_only", C.c_int32), ("reserved", C.c_int32 * 7),
     ]
 
 
@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
 
 
 # declared by the header for the HIP product only (device-runtime services a host-memory implementation of the ABI has no use for)
-PRODUCT_ONLY_SYMBOLS = ["rccl_unique_id", "rccl_attach", "rccl_selftest"]
+PRODUCT_ONLY_SYMBOLS = ["rccl_unique_id", "rccl_attach", "rccl_selftest", "get_level_inblock_nnzb"]
 
 
 class HotError(RuntimeError):
@@ -385,6 +385,16 @@ class Context:
     def level_nnzb(self, level):
         v = C.c_int64()
         self._call("get_level_nnzb", C.c_int32(level), C.byref(v))
+        return v.value
+
+    def level_inblock_nnzb(self, level):
+        """off-diagonal blocks whose column lies in the row's own colour block (HIP product only)"""
+        f = getattr(self.lib.lib, self.lib.prefix + "get_level_inblock_nnzb")
+        f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+        v = C.c_int64()
+        rc = f(self.h, C.c_int32(level), C.byref(v))
+        if rc != 0:
+            raise HotError(f"get_level_inblock_nnzb -> {rc}")
         return v.value
 
     def prolongation(self, level):

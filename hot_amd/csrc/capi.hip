@@ -244,6 +244,12 @@ int hot_get_level_nnzb(hot_ctx* ctx, int32_t level, int64_t* nnzb)
     *nnzb = ctx->impl->get_level_nnzb(level);
     HOT_API_END
 }
+int hot_get_level_inblock_nnzb(hot_ctx* ctx, int32_t level, int64_t* nnzb)
+{
+    HOT_API_BEGIN
+    *nnzb = ctx->impl->get_level_inblock_nnzb(level);
+    HOT_API_END
+}
 int hot_get_prolongation(hot_ctx* ctx, int32_t level, int32_t* entryCol, void* weight)
 {
     HOT_API_BEGIN

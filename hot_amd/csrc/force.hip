@@ -279,7 +279,7 @@ void Ctx<T>::begin_step(double dt_)
     if (Nc > 0) HOT_LAUNCH(this, "bc_index", k_bc_index, div_up(Nc, 256), 256, 0, bcNode.p, bcIdx.p, Nc);
     HOT_LAUNCH(this, "begin_step", k_begin<T>, div_up(Nn, 256), 256, 0, nodeV.p, bcIdx.p, bcDv.p, bcHasDv.p, dv.p, vn.p, dv0.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dt);
     HOT_HIP(hipMemcpyAsync(pFn.p, pF.p, 9 * (size_t)Np * sizeof(T), hipMemcpyDeviceToDevice, stream));
-    updated = false;
+    updated = false, ls_prev_trials = 1;
     release_levels(halo_mode() ? 1 : 0); // halo mode: level 0 (coordinates, row ownership, exchange lists) was set up by hot_p2g and lasts for the step
     stats.ms_begin = wall_ms() - t0;
 }
@@ -312,7 +312,11 @@ __device__ __forceinline__ void rot3(const T (&in)[3], int r, T (&out)[3])
 }
 
 // pass A: gather grad(vn+dv) from the LDS node tile -> trial F -> one SVD -> psi, P -> stress = V_p P Fn^T, energy
-template <class T>
+// ENERGY_ONLY (a line-search trial that may be rejected, ImplicitSolver.h:312-333 reads nothing but the energy): no trial-F / stress
+// stores, singular values only — the rotations that would accumulate U and V are dead code, the bidiagonal sees the same ones, so sigma is
+// bit-identical — and psi from sigma: mu sum (sigma_i - 1)^2 = mu |F - R|_F^2 up to round-off (CorotatedIsotropic.h:151-155).  The accepted
+// point is always re-evaluated by the full pass, whose energy is the one the solver keeps.
+template <class T, bool ENERGY_ONLY = false>
 __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ Vol, const T* __restrict__ Mu, const T* __restrict__ Lam,
     T* __restrict__ Ft, T* __restrict__ stress_out, T* __restrict__ gradV_out, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
     const int32_t* __restrict__ group_nb, const int32_t* __restrict__ gIdx, const T* __restrict__ vn, const T* __restrict__ dv, T dx, T one_over_dx, T dt, double* energy, GridRed gr)
@@ -385,13 +389,17 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
             for (int c = 0; c < 9; ++c) A.a[c] = dt * gv[c] + ((c % 4 == 0) ? (T)1 : (T)0), Fo.a[c] = p == p0 ? fpre[c] : Fn[(int64_t)c * Np + p];
             Fnew = m3_mul(A, Fo);
         }
+        T mu = Mu[p], la = Lam[p];
+        T vol = Vol[p];
+        if constexpr (ENERGY_ONLY) {
+            e += (double)(vol * corotated_psi_sigma(Fnew, mu, la));
+            continue;
+        }
 #pragma unroll
         for (int c = 0; c < 9; ++c) Ft[(int64_t)c * Np + p] = Fnew.a[c];
-        T mu = Mu[p], la = Lam[p];
         T psi;
         Mat3<T> P;
         corotated_state(Fnew, mu, la, psi, P);
-        T vol = Vol[p];
         e += (double)(vol * psi);
         // stress = V_p P Fn^T  (Fn re-read after the SVD instead of being kept live across it)
         asm volatile("" ::: "memory");
@@ -682,11 +690,15 @@ void Ctx<T>::force_pass()
 }
 
 template <class T>
-double Ctx<T>::state_pass(const T* dv_in, bool want_force)
+double Ctx<T>::state_pass(const T* dv_in, bool want_force, bool energy_only)
 {
     if (halo_mode()) halo_gather(*levels[0], const_cast<T*>(dv_in)); // dv at the nodes of this rank's particle tiles that other ranks own
-    HOT_LAUNCH(this, "state_update", k_state<T>, Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, pFt.p, pStress.p, keep_debug ? pGradV.p : (T*)nullptr, Np, group_first.p, group_origin.p,
-        group_nb.p, tileDof.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p, gred(Ng, hscal)); // the sums land in the pinned host slots too: one stream sync, no copy
+    if (energy_only) // a line-search trial: nothing but the energy leaves the kernel (trial F and stresses keep those of the last full pass)
+        HOT_LAUNCH(this, "state_energy", (k_state<T, true>), Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, (T*)nullptr, (T*)nullptr, (T*)nullptr, Np, group_first.p, group_origin.p,
+            group_nb.p, tileDof.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p, gred(Ng, hscal));
+    else
+        HOT_LAUNCH(this, "state_update", (k_state<T, false>), Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, pFt.p, pStress.p, keep_debug ? pGradV.p : (T*)nullptr, Np, group_first.p, group_origin.p,
+            group_nb.p, tileDof.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p, gred(Ng, hscal)); // the sums land in the pinned host slots too: one stream sync, no copy
     if (want_force) force_pass();
     {
         const int grid = std::min(div_up(Nn, 1024), 1024);

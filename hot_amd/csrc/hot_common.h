@@ -137,21 +137,21 @@ __host__ __device__ inline int int_floor(T x)
 template <class T>
 __host__ __device__ inline int base_node(T x_index_space) { return int_floor<T>(x_index_space - (T)0.5); }
 
-// The index-space coordinate X / dx: the reference stores the rounded product one_over_dx * X, takes its floor for the base node and
-// subtracts the floor from it (BSplineWeights::compute, BSplines.h:16-29, MpmGrid.h:55-78).  Built as the reference is (-O3 -march=native,
-// CMakeLists.txt:28) a host compiler contracts that subtraction with the multiply into one fma — g++ does for the CPU restatement this
-// repository's tests compare with: measured against an fp64 run of the same inputs, the fp32 trial F of that build is 40x closer to the
-// truth than a rounded-product evaluation (6.5e-7 against 2.6e-5: at X / dx ~ 500 a rounded float product has lost 3e-5 of a cell).  hipcc does not fuse here (the
-// product has a second use), so the two roundings are spelled out: the BASE NODE comes from the rounded product (bit-exact indexing,
-// SURVEY §8c), the FRACTION from the exact one.
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+// The index-space coordinate X / dx: the reference stores the rounded product one_over_dx * X, takes floor(. - 0.5) for the base node and
+// subtracts the base node from it (BSplineWeights::compute, BSplines.h:16-29, MpmGrid.h:55-78).  Built as the reference is (-O3
+// -march=native, CMakeLists.txt:28; GCC's default -ffp-contract=fast) both the subtraction of 0.5 and the subtraction of the base node are
+// contracted with the multiply, i.e. both see the EXACT product — which is also 40x closer to the truth in fp32 (measured against an fp64
+// run of the same inputs: 6.5e-7 against 2.6e-5 in the trial F; at X / dx ~ 500 a rounded float product has lost 3e-5 of a cell).  Whether
+// a compiler fuses here is its choice, so both roundings are spelled out as fma on the device (sort keys, transfers, state pass; the CPU
+// restatement the tests compare with does the same): base = floor(fma(1/dx, X, -0.5)), fraction = fma(1/dx, X, -base).
+template <class T>
+__host__ __device__ inline int base_node_of(T one_over_dx, T x) { return int_floor<T>(fma(one_over_dx, x, -(T)0.5)); }
 
 // quadratic B-spline weights and derivatives of one axis: reference BSplines.h:55-81
 template <class T>
 __device__ inline void bspline(T one_over_dx, T xw, int& base, T (&w)[3], T (&dw)[3])
 {
-    base = base_node<T>(mul_rn(one_over_dx, xw));
+    base = base_node_of<T>(one_over_dx, xw);
     T d0 = fma(one_over_dx, xw, -(T)base);
     T z = ((T)1.5 - d0);
     w[0] = (T)0.5 * z * z;

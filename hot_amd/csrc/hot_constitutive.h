@@ -41,6 +41,20 @@ __device__ inline void corotated_state(const Mat3<T>& F, T mu, T lambda, T& psi,
     psi = mu * fr + (T)0.5 * lambda * Jm1 * Jm1;
 }
 
+// psi alone, from the singular values: |F - R|_F^2 = sum (sigma_i - 1)^2.  U and V are never used, so their rotations are dead code after
+// inlining; the bidiagonal and with it sigma are bit-identical to corotated_state's.
+template <class T>
+__device__ inline T corotated_psi_sigma(const Mat3<T>& F, T mu, T lambda)
+{
+    Mat3<T> U, V;
+    T sg[3];
+    svd3(F, U, sg, V);
+    T J = sg[0] * sg[1] * sg[2];
+    T d0 = sg[0] - (T)1, d1 = sg[1] - (T)1, d2 = sg[2] - (T)1;
+    T Jm1 = J - (T)1;
+    return mu * (d0 * d0 + d1 * d1 + d2 * d2) + (T)0.5 * lambda * Jm1 * Jm1;
+}
+
 // dP/dF in the SVD frame: symmetric 3x3 A (diagonal-diagonal couplings) and three symmetric 2x2 blocks
 template <class T>
 struct HessBlocks {

@@ -97,6 +97,7 @@ struct CtxBase {
     virtual void build_mg() = 0;
     virtual void get_level(int32_t level, int32_t* nrows, int32_t* colsize, int32_t* id2coord) = 0;
     virtual long long get_level_nnzb(int32_t level) = 0;
+    virtual long long get_level_inblock_nnzb(int32_t level) = 0;
     virtual void get_matrix(int32_t level, int32_t* entryCol, void* entryVal) = 0;
     virtual void get_prolongation(int32_t level, int32_t* entryCol, void* weight) = 0;
     virtual void spmv(int32_t level, const void* x, void* y) = 0;

@@ -7,6 +7,19 @@
 
 namespace hot {
 
+// In-block image of one colour block (k_gs_images -> k_gs_subst): everything the block's 64-row triangular solve reads of the matrix,
+// premultiplied and packed in the order the substitution consumes it.  Per block: D[64][9] | D^-1[64][9] by position; per direction
+// (0 forward: strictly lower in-block couplings, 1 backward: strictly upper) the entries -(D_r^-1 A_rc) column by column (column = position c
+// of the block, in the direction's sweep order), inside a column by ascending row position, 9 scalars each, behind an all-zero entry 0.
+// ints (as uint64): per direction mask[64], bit r of mask[c] = row r has an entry in column c.
+template <class T>
+struct GsImg {
+    static constexpr size_t hdr_elems = 2 * 64 * 9;
+    static constexpr size_t cap_entries = 64 * 63 / 2 + 1; // + the all-zero entry 0
+    static constexpr size_t per_dir = cap_entries * 9, per_block = hdr_elems + 2 * per_dir;
+    static constexpr size_t masks_per_block = 2 * 64;
+};
+
 // one multigrid level: system matrix in 125-slot stencil ELL + transfer tables to the next coarser level
 template <class T>
 struct Level {
@@ -31,6 +44,11 @@ struct Level {
     DBuf<int32_t> gs_nbr; // nblocks*26: the adjacent colour blocks (global block id | colour << 28, or -1): whose unknowns a block's rows read
     DBuf<int> gs_flag; // 4*nblocks: sweep number in which the (block, sub-block) was last finished (k_gs_sweep's point-to-point hand-off)
     DBuf<int32_t> gs_pad; // nblocks*64*8: per (colour block, position) {node or -1, the row's four class counts, pad}: the GS kernels' header in one load
+    DBuf<int32_t> gs_col; // n*125: col after the regrouping with in-block columns replaced by -1 - (position in the colour block): k_gs_block2 tells triangle entries from gathers without fetching ckey[j]
+    DBuf<T> gs_img; // nblocks * GsImg<T>::per_block: premultiplied in-block couplings in the order k_gs_subst consumes them (k_gs_images, mg_build.hip)
+    DBuf<unsigned long long> gs_imgm; // nblocks * GsImg<T>::masks_per_block: which rows have an entry in each column of the images
+    DBuf<T> gs_p1; // nblocks*64*3, by (block, position): rhs minus the off-block part of the row sums (k_gs_offblock -> k_gs_subst)
+    bool gs_img_ready = false;
     DBuf<int32_t> rowcnt; // 4n: (precede-off, precede-in, follow-in, follow-off) slot counts of the regrouped rows
     bool split = false;
     // coarseSolver 7 (mg_ic.hip): block incomplete Cholesky of a top level.  ic_l: the strictly lower blocks by stencil slot; (ic_col, ic_val)
@@ -152,6 +170,7 @@ struct Ctx : CtxBase {
     // ---- objective
     double Ek = 0;
     bool updated = false;
+    int ls_prev_trials = 1; // trials the previous line search of this step took (hot_config.ls_energy_only = 0 starts energy-only after a search that halved)
     T max_cn_tolerance = 0;
     DBuf<T> rhs, work0, work1, work2, work3, solve_keep;
     // ---- sharded solve: one connected body over several ranks (include/hot_mi355x.h hot_comm)
@@ -335,13 +354,13 @@ struct Ctx : CtxBase {
     // launch-per-pass path for good and throws ERR_RETRY, which the operations that can contain such a sweep (solve, vcycle,
     // smooth) catch to redo themselves from their saved inputs — the context is never left poisoned.
     static constexpr int ERR_RETRY = -100; // internal, never crosses the C ABI
-    bool gs_no_chain = false;
+    bool gs_no_chain = false, gs_chain_timed_out = false;
     void sync()
     {
         HOT_HIP(hipStreamSynchronize(stream));
         if (*(volatile int*)(hscal + 250) != 0) {
             *(volatile int*)(hscal + 250) = 0;
-            gs_no_chain = true;
+            gs_no_chain = gs_chain_timed_out = true;
             throw Error{ ERR_RETRY, "k_gs_sweep: wait on a neighbouring block timed out; redoing the operation with one launch per pass" };
         }
     }
@@ -389,6 +408,17 @@ struct Ctx : CtxBase {
         if (levels[level]->nnzb < 0) count_nnzb(*levels[level]); // one pass over the values, only when somebody asks
         return levels[level]->nnzb;
     }
+    long long get_level_inblock_nnzb(int32_t level) override
+    {
+        need(level >= 0 && level < (int)levels.size() && levels[level]->split, "hot_get_level_inblock_nnzb: level out of range or not coloured (hot_build_mg)");
+        Level<T>& L = *levels[level];
+        std::vector<int32_t> rc(4 * (size_t)L.n);
+        HOT_HIP(hipMemcpyAsync(rc.data(), L.rowcnt.p, rc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        sync();
+        long long tot = 0;
+        for (int i = 0; i < L.n; ++i) tot += rc[4 * (size_t)i + 1] + rc[4 * (size_t)i + 2]; // precede-in + follow-in (rows of other ranks hold zeros)
+        return tot;
+    }
     void get_prolongation(int32_t level, int32_t* entryCol, void* weight) override;
     void spmv(int32_t level, const void* x, void* y) override;
     void restrict_(int32_t level, const void* fine, void* coarse) override;
@@ -406,7 +436,7 @@ struct Ctx : CtxBase {
     // ---- device-side building blocks (device pointers)
     void eval_halfspaces();
     void eval_collision_objects();
-    double state_pass(const T* dv_in, bool want_force); // G2P(vn+dv) -> F, energy, force scatter; returns total energy (syncs)
+    double state_pass(const T* dv_in, bool want_force, bool energy_only = false); // G2P(vn+dv) -> F, energy, force scatter; returns total energy (syncs)
     void force_pass(); // force scatter from the stresses of the last state_pass
     void residual_dev(T* r); // from the force tiles of the last state_pass / force_pass
     void project_dev(T* v);

@@ -351,10 +351,11 @@ static void mark_colors(Ctx<T>* ctx, Level<T>& L)
 // per row, the row is staged in LDS and rewritten in place.  rowcnt[4 i ..] = the four off-diagonal class sizes.
 template <class T>
 __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col, T* __restrict__ val, const uint32_t* __restrict__ ckey, int32_t* __restrict__ rowcnt, int n,
-    const uint8_t* __restrict__ own)
+    const uint8_t* __restrict__ own, int32_t* __restrict__ gcol /*may be null: the tagged copy of col (in-block column -> -1 - its position in the colour block) the finest-level GS kernels read*/)
 {
     __shared__ T sval[4][1125];
     __shared__ int32_t scol[4][125];
+    __shared__ int32_t sgcol[4][125];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = blockIdx.x * 4 + w;
     const bool valid = i0 < n && (!own || own[i0]); // sharded: only the rows this rank owns hold a matrix // no early return: the workgroup barrier below must be reached by all four waves
@@ -367,13 +368,13 @@ __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col
     // of the colour just before the row's own in sweep order — sit at the outer ends of the two halves, in the 64 slots the
     // sweep keeps in registers.
     constexpr int NCLS = 8;
-    int cls[2], jj[2];
+    int cls[2], jj[2], tag[2];
     T bv[2][9];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         int k = lane + 64 * r;
         cls[r] = NCLS;
-        jj[r] = 0;
+        jj[r] = 0, tag[r] = 0;
         if (k < 125 && valid) {
             jj[r] = c[k];
             bool nz = false;
@@ -388,7 +389,9 @@ __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col
                 const bool in = (keyj >> 7) == (keyi >> 7);
                 const int cj = (int)(keyj >> 28), ci = (int)(keyi >> 28);
                 cls[r] = keyj < keyi ? (in ? 2 : (cj == ci - 1 ? 0 : 1)) : (in ? 4 : (cj == ci + 1 ? 6 : 5));
+                tag[r] = in ? -(int)(keyj & 127u) : jj[r]; // -1 - (0-based position in the block)
             }
+            if (cls[r] == 7 || cls[r] == 3) tag[r] = jj[r];
         }
     }
     // stable positions: class-major, then round, then lane
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         if (cls[r] < NCLS) {
-            scol[w][pos[r]] = jj[r];
+            scol[w][pos[r]] = jj[r], sgcol[w][pos[r]] = tag[r];
 #pragma unroll
             for (int e = 0; e < 9; ++e) sval[w][pos[r] * 9 + e] = bv[r][e];
         }
@@ -414,6 +417,8 @@ __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col
     if (!valid) return;
     for (int e = lane; e < 1125; e += 64) v[e] = sval[w][e];
     for (int k = lane; k < 125; k += 64) c[k] = scol[w][k];
+    if (gcol)
+        for (int k = lane; k < 125; k += 64) gcol[(int64_t)i * 125 + k] = sgcol[w][k];
     if (lane == 0) rowcnt[4 * i] = cnt[0] + cnt[1], rowcnt[4 * i + 1] = cnt[2], rowcnt[4 * i + 2] = cnt[4], rowcnt[4 * i + 3] = cnt[5] + cnt[6];
 }
 
@@ -432,14 +437,105 @@ __global__ void k_gs_pad(const int32_t* __restrict__ block_start, const int32_t*
     o[5] = o[6] = o[7] = 0;
 }
 
+// In-block images for the finest-level GS kernels (layout: GsImg, hot_impl.h; consumer: k_gs_subst, mg_solve.hip).  One workgroup per
+// colour block: (1) every row marks itself in the masks of the columns it couples to (LDS), (2) column offsets = running popcounts,
+// (3) every entry -(D_r^-1 A_rc) goes to [offset of column c + rank of r among the column's rows].
+template <class T>
+__global__ __launch_bounds__(512) void k_gs_images(const int32_t* __restrict__ gcol, const T* __restrict__ val, const T* __restrict__ diagBlockInv, const T* __restrict__ diagVal,
+    const int32_t* __restrict__ gs_pad, T* __restrict__ img, unsigned long long* __restrict__ imgm, int nblocks)
+{
+    using I = GsImg<T>;
+    __shared__ int32_t nodes[64], rcl[64 * 4];
+    __shared__ unsigned int mlo[2][64], mhi[2][64];
+    __shared__ int32_t coff[2][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x;
+    T* hdr = img + (size_t)b * I::per_block;
+    for (int e = tid; e < 2 * 64 * 9; e += 512) { // header: D and D^-1 by position
+        const int pos = (e % 576) / 9;
+        const int nd = gs_pad[8 * ((int64_t)b * 64 + pos)];
+        hdr[e] = nd < 0 ? (T)0 : (e < 576 ? diagVal : diagBlockInv)[9 * (int64_t)nd + e % 9];
+    }
+    if (tid < 64) {
+        const int32_t* rec = gs_pad + 8 * ((int64_t)b * 64 + tid);
+        nodes[tid] = rec[0];
+        rcl[4 * tid] = rec[1], rcl[4 * tid + 1] = rec[2], rcl[4 * tid + 2] = rec[3], rcl[4 * tid + 3] = rec[4];
+    }
+    if (tid < 128) mlo[tid >> 6][tid & 63] = 0u, mhi[tid >> 6][tid & 63] = 0u;
+    if (tid < 18) hdr[I::hdr_elems + (tid / 9) * I::per_dir + tid % 9] = (T)0;
+    __syncthreads();
+    // this thread's entries: rows r = w + 8 t, both directions; kept for the third pass
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int dir = 0; dir < 2; ++dir) {
+            T* dbase = hdr + I::hdr_elems + dir * I::per_dir;
+            for (int t = 0; t < 8; ++t) {
+                const int r = w + 8 * t;
+                const int i = nodes[r];
+                if (i < 0) continue; // wave-uniform
+                const int po = rcl[4 * r], pi = rcl[4 * r + 1], fi = rcl[4 * r + 2];
+                const int kbeg = dir == 0 ? po : po + pi + 1, kend = dir == 0 ? po + pi : po + pi + 1 + fi; // at most 63 in-block entries
+                const int k = kbeg + lane;
+                if (k >= kend) continue;
+                const int cpos = -1 - gcol[(int64_t)i * 125 + k];
+                if (pass == 0) {
+                    if (r < 32)
+                        atomicOr(&mlo[dir][cpos], 1u << r);
+                    else
+                        atomicOr(&mhi[dir][cpos], 1u << (r - 32));
+                    continue;
+                }
+                T A[9], di[9];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) A[e] = val[((int64_t)i * 125 + k) * 9 + e], di[e] = diagBlockInv[9 * (int64_t)i + e];
+                const unsigned long long m = ((unsigned long long)mhi[dir][cpos] << 32) | mlo[dir][cpos];
+                const int rank = __popcll(m & ((1ULL << r) - 1ULL));
+                T* dst = dbase + (size_t)(coff[dir][cpos] + rank) * 9;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) dst[rr + 3 * c] = -(di[rr] * A[3 * c] + di[rr + 3] * A[3 * c + 1] + di[rr + 6] * A[3 * c + 2]); // gs_store_tri's product
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            if (tid < 2) { // offsets in the order the substitution walks the columns: forward ascending, backward descending
+                int off = 1; // entry 0 of either direction is all zeros: what a lane without an entry in a column reads
+                for (int s = 0; s < 64; ++s) {
+                    const int c = tid == 0 ? s : 63 - s;
+                    coff[tid][c] = off;
+                    off += __popc(mlo[tid][c]) + __popc(mhi[tid][c]);
+                }
+            }
+            if (tid >= 64 && tid < 192) {
+                const int dir = (tid - 64) >> 6, c = tid & 63;
+                imgm[(size_t)b * I::masks_per_block + dir * 64 + c] = ((unsigned long long)mhi[dir][c] << 32) | mlo[dir][c];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <class T>
 static void split_rows(Ctx<T>* ctx, Level<T>& L)
 {
     L.rowcnt.reserve(4 * (size_t)L.n);
-    HOT_LAUNCH(ctx, "gs_split_rows", k_gs_split_rows<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.ckey.p, L.rowcnt.p, L.n, L.mask());
+    if (L.part) HOT_HIP(hipMemsetAsync(L.rowcnt.p, 0, 4 * (size_t)L.n * sizeof(int32_t), ctx->stream)); // rows of other ranks: no matrix, zero counts
+    L.gs_col.reserve(125 * (size_t)L.n);
+    HOT_LAUNCH(ctx, "gs_split_rows", k_gs_split_rows<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.ckey.p, L.rowcnt.p, L.n, L.mask(), L.gs_col.p);
     L.gs_pad.reserve(512 * (size_t)L.nblocks);
     HOT_LAUNCH(ctx, "gs_pad", k_gs_pad, div_up((size_t)L.nblocks * 64, 256), 256, 0, L.gs_block_start.p, L.gs_order.p, L.rowcnt.p, L.gs_pad.p, L.nblocks);
     L.split = true;
+    // levels whose colours hold more blocks than the chip has compute units (smooth_dev's half-block case) run the off-block / substitution kernel
+    // pair, which reads the in-block couplings from premultiplied images
+    int max_nb = 0;
+    for (int c = 0; c < 8; ++c) max_nb = std::max(max_nb, L.color_block_begin[c + 1] - L.color_block_begin[c]);
+    L.gs_img_ready = false;
+    if (!L.part && (max_nb > 256 || ctx->cfg.gs_sub_block == 32)) {
+        L.gs_img.reserve(GsImg<T>::per_block * (size_t)L.nblocks + 16), // + one entry: k_gs_subst's unconditional loads
+        L.gs_imgm.reserve(GsImg<T>::masks_per_block * (size_t)L.nblocks), L.gs_p1.reserve(192 * (size_t)L.nblocks);
+        HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, L.nblocks, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p, L.gs_imgm.p, L.nblocks);
+        L.gs_img_ready = true;
+    }
 }
 
 template <class T>
@@ -719,7 +815,7 @@ void Ctx<T>::build_mg()
         Level<T>& Top = *levels.back();
         build_ic(Top);
         Top.ic_rowcnt.reserve(4 * (size_t)Top.n), Top.ic_pad.reserve(512 * (size_t)Top.nblocks);
-        HOT_LAUNCH(this, "gs_split_rows", k_gs_split_rows<T>, div_up(Top.n, 4), 256, 0, Top.ic_col.p, Top.ic_val.p, Top.ckey.p, Top.ic_rowcnt.p, Top.n, (const uint8_t*)nullptr);
+        HOT_LAUNCH(this, "gs_split_rows", k_gs_split_rows<T>, div_up(Top.n, 4), 256, 0, Top.ic_col.p, Top.ic_val.p, Top.ckey.p, Top.ic_rowcnt.p, Top.n, (const uint8_t*)nullptr, (int32_t*)nullptr);
         HOT_LAUNCH(this, "gs_pad", k_gs_pad, div_up((size_t)Top.nblocks * 64, 256), 256, 0, Top.gs_block_start.p, Top.gs_order.p, Top.ic_rowcnt.p, Top.ic_pad.p, Top.nblocks);
     }
     if (colors) split_rows(this, *levels.back());

@@ -515,7 +515,7 @@ __device__ __forceinline__ void gs_store_rhs(T* sv, int ii, const T* __restrict_
 
 template <class T, bool FWD, int SB, bool WT = false>
 __device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int32_t* nodes, int cnt, int lane, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, T* x, T* hD,
-    const T* ldsD = nullptr);
+    const T* ldsD = nullptr, T* ldsX = nullptr);
 
 // six waves per SIMD (three 512-thread workgroups per CU: a colour of the finest level is resident in one round) = at most 80 VGPRs
 #ifdef HOT_AB_KERNELS
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
 // write-through (sc1) stores so that other workgroups of the same launch can read it with sc1 loads
 template <class T, bool FWD, int SB, bool WT>
 __device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int32_t* nodes, int cnt, int lane, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, T* x, T* hD,
-    const T* ldsD)
+    const T* ldsD, T* ldsX)
 {
     constexpr int TRI = GsLds<T, SB>::TRI;
     const int me = lane;
@@ -674,6 +674,7 @@ __device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int3
 #pragma unroll
         for (int e = 0; e < 9; ++e) dd[e] = i >= 0 ? (ldsD ? ldsD[9 * me + e] : diagVal[9 * (int64_t)i + e]) : (T)0; // ldsD: staged by the caller
     }
+    if (ldsX && i >= 0) ldsX[3 * me] = h0, ldsX[3 * me + 1] = h1, ldsX[3 * me + 2] = h2; // k_gs_block2: the block's other sub-block reads these instead of global memory
     if (i >= 0) {
         if (WT) {
             __hip_atomic_store(x + 3 * (int64_t)i, h0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -690,6 +691,164 @@ __device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int3
         else if (hD) { // backward: hD is the iterate u, which takes the correction here (u += du of gs_smooth) instead of in an axpy launch
             hD[3 * (int64_t)i] += h0, hD[3 * (int64_t)i + 1] += h1, hD[3 * (int64_t)i + 2] += h2;
         }
+    }
+}
+
+// ---------------- the finest-level colour pass as two kernels (levels prepared by k_gs_images, mg_build.hip)
+// Measured on k_gs_block / k_gs_block2 (per-phase timestamps, C2): a colour launch lasts as long as its slowest workgroup, an interior
+// block, which walks a ~45 us chain of dependent round trips (header -> columns -> values -> gathers -> D^-1 -> sums, twice per
+// sub-block) even when it has nothing but its in-block couplings to read (first colour), and up to 45 us more where the off-block
+// half rows are long (last colour) — while half of the workgroups (surface blocks) have long finished and HBM idles.  So:
+//   k_gs_offblock  one wavefront per ROW of the colour: p1_i = rhs_i - sum of the off-block products (lane = slot, wave_sum).  No
+//                  serial part, tens of thousands of independent wavefronts: streams like k_gs_residual, balanced whatever the body;
+//   k_gs_subst     one wavefront per colour block: h = D^-1 p1 + (strict in-block triangle of -(D^-1 A)) h by substitution (below).
+template <class T>
+__device__ __forceinline__ T row16_sum(T v) // sum over each 16-lane DPP row; valid in the row's lane 15
+{
+    v += dpp_move<0xb1, 0xf>(v);
+    v += dpp_move<0x4e, 0xf>(v);
+    v += dpp_move<0x114, 0xf>(v);
+    v += dpp_move<0x118, 0xf>(v);
+    return v;
+}
+template <class T, bool FWD>
+__global__ __launch_bounds__(256) void k_gs_offblock(const int32_t* __restrict__ gcol, const T* __restrict__ val, const int32_t* __restrict__ gs_pad, const T* __restrict__ rhs,
+    const T* __restrict__ x, T* __restrict__ p1, int64_t pos0, int64_t npos)
+{
+    // two rows (adjacent positions of a block) per wavefront, side by side: a wavefront spends two thirds of its life waiting for something
+    // other than matrix values (header record, then the gathers), so one row per wavefront leaves HBM half idle even at eight per SIMD
+    const int lane = threadIdx.x & 63;
+    const int64_t e0 = 2 * ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (e0 >= npos) return;
+    int row[2], kb[2], ke[2], j[2];
+    T bv[2][9], rh[2][3];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int64_t e = e0 + q;
+        row[q] = -1, kb[q] = ke[q] = 0, j[q] = -1;
+        if (e < npos) {
+            const int4 rec0 = *(const int4*)(gs_pad + 8 * (pos0 + e));
+            const int fo = gs_pad[8 * (pos0 + e) + 4];
+            row[q] = rec0.x;
+            const int po = rec0.y, pi = rec0.z, fi = rec0.w;
+            kb[q] = FWD ? 0 : po + pi + 1 + fi, ke[q] = FWD ? po : po + pi + 1 + fi + fo;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) bv[q][t] = (T)0;
+        rh[q][0] = rh[q][1] = rh[q][2] = (T)0;
+        if (row[q] >= 0) { // wave-uniform
+            const int64_t i = row[q];
+            const int k = kb[q] + lane;
+            if (k < ke[q]) {
+                j[q] = gcol[i * 125 + k];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) bv[q][t] = val[(i * 125 + k) * 9 + t];
+            }
+            rh[q][0] = rhs[3 * i], rh[q][1] = rhs[3 * i + 1], rh[q][2] = rhs[3 * i + 2];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (row[q] < 0) continue; // wave-uniform
+        const int64_t i = row[q];
+        T s0 = 0, s1 = 0, s2 = 0;
+        if (j[q] >= 0) {
+            const int64_t jj = j[q];
+            const T x0 = x[3 * jj], x1 = x[3 * jj + 1], x2 = x[3 * jj + 2];
+            s0 = bv[q][0] * x0 + bv[q][3] * x1 + bv[q][6] * x2;
+            s1 = bv[q][1] * x0 + bv[q][4] * x1 + bv[q][7] * x2;
+            s2 = bv[q][2] * x0 + bv[q][5] * x1 + bv[q][8] * x2;
+        }
+        const int k1 = kb[q] + 64 + lane; // more than 64 off-block slots: the last colours of a sweep
+        if (k1 < ke[q]) {
+            const int64_t jj = gcol[i * 125 + k1];
+            const T* bb = val + (i * 125 + k1) * 9;
+            const T x0 = x[3 * jj], x1 = x[3 * jj + 1], x2 = x[3 * jj + 2];
+            s0 += bb[0] * x0 + bb[3] * x1 + bb[6] * x2;
+            s1 += bb[1] * x0 + bb[4] * x1 + bb[7] * x2;
+            s2 += bb[2] * x0 + bb[5] * x1 + bb[8] * x2;
+        }
+        s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
+        if (lane == 0) p1[3 * (pos0 + e0 + q)] = rh[q][0] - s0, p1[3 * (pos0 + e0 + q) + 1] = rh[q][1] - s1, p1[3 * (pos0 + e0 + q) + 2] = rh[q][2] - s2; // by (block, position)
+    }
+}
+
+// The block's 64-row triangular solve, one wavefront per colour block, lane = row, NO LDS: column c of the premultiplied in-block image
+// (GsImg: entries packed column by column in sweep order, rows ascending inside a column) is fetched straight into registers D steps
+// before the substitution reaches it — the loads depend on nothing but the block id and the masks, so the only chain left is the
+// substitution's own (broadcast of the finished row, nine multiply-adds) instead of an LDS round trip per step plus a dependent-load
+// prologue.  One wavefront runs alone on its SIMD, so what a step costs is its instruction count (every dependent instruction pays the
+// full pipeline latency): the loop is kept branch-free and lean — the column masks sit in a register pair (lane c = column c), a lane's
+// entry index is column offset + v_mbcnt of the mask, a lane without an entry in the column reads the image's all-zero entry 0 instead of
+// being masked out of the multiply-adds.  (Measured, C2, per launch: 28 us with the entries stored as nine coalesced planes — more address arithmetic —, 21 us as below; steps
+// 32..64 of a block take 150 ns each whether 8 or 16 columns are in flight: at 4.4 TB/s over the 729 blocks of a colour the kernel is
+// bound by HBM, not by its chain any more.)
+template <class T, bool FWD, int D>
+__global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, const unsigned long long* __restrict__ imgm, const int32_t* __restrict__ gs_pad, const T* __restrict__ p1, T* x,
+    T* hD, int block0)
+{
+    using I = GsImg<T>;
+    const int lane = threadIdx.x;
+    const int b = block0 + blockIdx.x;
+    const T* hdr = img + (size_t)b * I::per_block;
+    const T* ent = hdr + I::hdr_elems + (FWD ? 0 : I::per_dir);
+    const unsigned long long mymask = imgm[(size_t)b * I::masks_per_block + (FWD ? 0 : 64) + lane];
+    const int mylo = (int)(unsigned)(mymask & 0xffffffffULL), myhi = (int)(unsigned)(mymask >> 32);
+    const int64_t pos = (int64_t)b * 64 + lane;
+    const int node = gs_pad[8 * pos];
+    T ring[D][9];
+    unsigned off = 1; // entries consumed so far (wave-uniform); entry 0 is all zeros
+    // Branch-free on purpose: a load under a divergent branch makes the compiler wait for EVERY outstanding load before the next use
+    // (s_waitcnt vmcnt(0) at the join), i.e. one memory round trip per step.
+    auto issue = [&](int s, T (&L)[9]) __attribute__((always_inline)) {
+        const int c = (FWD ? s : 63 - s) & 63; // past the last step: wraps to columns whose slots are never consumed
+        const unsigned mlo = (unsigned)__builtin_amdgcn_readlane(mylo, c), mhi = (unsigned)__builtin_amdgcn_readlane(myhi, c);
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)); // set bits below this lane
+        const bool mine = ((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1u;
+        const T* p = ent + (size_t)(mine ? off + rank : 0u) * 9;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) L[e] = p[e];
+        asm volatile("" ::: "memory"); // the loads stay HERE, D steps ahead of their use (the scheduler otherwise sinks them to the multiply-adds and carries addresses instead of data)
+        off += __popc(mlo) + __popc(mhi);
+    };
+#pragma unroll
+    for (int k = 0; k < D; ++k) issue(k, ring[k]);
+    // a = D^-1 p1 (p1 and D^-1 are stored by position)
+    T a0, a1, a2;
+    {
+        const T q0 = p1[3 * pos], q1 = p1[3 * pos + 1], q2 = p1[3 * pos + 2];
+        const T* di = hdr + 576 + 9 * lane;
+        a0 = di[0] * q0 + di[3] * q1 + di[6] * q2, a1 = di[1] * q0 + di[4] * q1 + di[7] * q2, a2 = di[2] * q0 + di[5] * q1 + di[8] * q2; // gs_store_rhs's product
+    }
+    T dd[9];
+    if (FWD) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) dd[e] = hdr[9 * lane + e];
+    }
+    for (int s0 = 0; s0 < 64; s0 += D) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const int s = s0 + k, c = FWD ? s : 63 - s;
+            const T b0 = lane_bcast(a0, c), b1 = lane_bcast(a1, c), b2 = lane_bcast(a2, c);
+            const T(&L)[9] = ring[k];
+            a0 = fma(L[0], b0, a0), a1 = fma(L[1], b0, a1), a2 = fma(L[2], b0, a2);
+            a0 = fma(L[3], b1, a0), a1 = fma(L[4], b1, a1), a2 = fma(L[5], b1, a2);
+            a0 = fma(L[6], b2, a0), a1 = fma(L[7], b2, a1), a2 = fma(L[8], b2, a2);
+            issue(s + D, ring[k]);
+        }
+    }
+    if (node < 0) return;
+    x[3 * (int64_t)node] = a0, x[3 * (int64_t)node + 1] = a1, x[3 * (int64_t)node + 2] = a2;
+    if (FWD) {
+        hD[3 * (int64_t)node] = dd[0] * a0 + dd[3] * a1 + dd[6] * a2;
+        hD[3 * (int64_t)node + 1] = dd[1] * a0 + dd[4] * a1 + dd[7] * a2;
+        hD[3 * (int64_t)node + 2] = dd[2] * a0 + dd[5] * a1 + dd[8] * a2;
+    }
+    else if (hD) { // backward: hD is the iterate u, which takes the correction here (u += du of gs_smooth)
+        hD[3 * (int64_t)node] += a0, hD[3 * (int64_t)node + 1] += a1, hD[3 * (int64_t)node + 2] += a2;
     }
 }
 
@@ -1280,6 +1439,31 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             }
 #undef HOT_GS_CASE
         };
+        // ---- the finest-level colour passes as kernel pairs: k_gs_offblock (row sums over the off-block columns), then k_gs_subst (the blocks'
+        // substitutions).  (Tried: the part of the next colour's off-block sums that reads only colours finished two passes ago on a second,
+        // low-priority stream beside the substitution — event waits between the streams cost more than the overlap gains: C2 95 vs 84 ms a step.)
+        const bool pair_path = sb == 32 && L.gs_img_ready && nmerge > 1 && !simple_gs && !ab_flag("HOT_GS_V1"); // A/B build: HOT_GS_V1 = one k_gs_block launch per colour
+        auto pair_sweep = [&](bool fwd) {
+            const T* rhs = fwd ? r : dAu;
+            T* xx = fwd ? hdu : du;
+            T* hD = fwd ? dAu : u;
+            const char* nmT = fwd ? "gs_forward" : "gs_backward";
+            const char* nmO = fwd ? "gs_forward_off" : "gs_backward_off";
+            for (int q = 0; q < 8; ++q) {
+                const int c = fwd ? q : 7 - q, b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
+                if (nb <= 0) continue;
+                const int64_t pos0 = (int64_t)b0 * 64, npos = (int64_t)nb * 64;
+                const unsigned grid = (unsigned)div_up(npos, 8);
+                if (fwd) {
+                    HOT_LAUNCH(this, lname(nmO, L.id).c_str(), (k_gs_offblock<T, true>), grid, 256, 0, L.gs_col.p, L.val.p, L.gs_pad.p, rhs, xx, L.gs_p1.p, pos0, npos);
+                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgm.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0);
+                }
+                else {
+                    HOT_LAUNCH(this, lname(nmO, L.id).c_str(), (k_gs_offblock<T, false>), grid, 256, 0, L.gs_col.p, L.val.p, L.gs_pad.p, rhs, xx, L.gs_p1.p, pos0, npos);
+                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgm.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0);
+                }
+            }
+        };
         HOT_CHECK(sb == 16 || sb == 32 || sb == 64, HOT_ERR_INVALID, "hot_config.gs_sub_block must be 0 (auto), 16, 32 or 64");
         HOT_CHECK(cfg.gs_chain >= 0 && cfg.gs_chain <= 2, HOT_ERR_INVALID, "hot_config.gs_chain must be 0 (auto), 1 (one launch per colour) or 2 (one chained launch per half sweep)");
         // one launch per half sweep (k_gs_sweep, passes chained by device-scope counters) unless the A/B switches ask
@@ -1344,12 +1528,16 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             if (rank_local) zero(n3, hdu), zero(n3, du);
             if (dataflow)
                 sweep(true);
+            else if (pair_path)
+                pair_sweep(true);
             else
                 for (int c = 0; c < 8; ++c)
                     for (int h = 0; h < nsub; ++h) pass(true, c, h);
             // dAu now holds D h ; du = backward solve
             if (dataflow)
                 sweep(false);
+            else if (pair_path)
+                pair_sweep(false);
             else
                 for (int c = 7; c >= 0; --c)
                     for (int h = nsub - 1; h >= 0; --h) pass(false, c, h);

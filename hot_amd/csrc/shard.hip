@@ -25,8 +25,10 @@ void Ctx<T>::set_comm(const hot_comm* c)
         comm = *c;
         gs_no_chain = true; // a chained coarse-level sweep that timed out would make ONE rank redo its solve and desynchronise the collectives: launch-per-pass sweeps only
     }
-    else
+    else {
         comm = hot_comm{};
+        gs_no_chain = gs_chain_timed_out; // back to one rank: chained sweeps again, unless one has timed out on this context
+    }
     block_first.clear();
     vmask = nullptr;
 }
@@ -400,11 +402,12 @@ void Ctx<T>::tile_exchange(T* const* arrays, int q)
     PeerSegs seg{};
     std::vector<int64_t> off(R, 0), bytes(R, 0);
     for (int p = 0; p < R; ++p) seg.lbeg[p] = toff[p], seg.cnt[p] = tcnt[p], seg.obeg[p] = tot, off[p] = tot * per * (int64_t)sizeof(T), bytes[p] = tcnt[p] * per * (int64_t)sizeof(T), tot += tcnt[p];
-    if (tot == 0) return; // this rank shares no block (all ranks call the collective only if they share something: the lists are symmetric)
-    xsend.reserve((size_t)tot * per * sizeof(T)), xrecv.reserve((size_t)tot * per * sizeof(T));
-    HOT_LAUNCH(this, "tile_pack", k_tile_pack<T>, div_up((size_t)tot * per, 256), 256, 0, arr, q, tlist.p, tot, (T*)xsend.p);
+    // a rank that shares no block (an isolated body, an interior-only range) still enters the collective, with zero byte counts: "all ranks make
+    // the same sequence of calls" is the hot_comm contract, and a true collective (MPI_Alltoallv, all_to_all_single) would otherwise wait for it
+    xsend.reserve(std::max<size_t>((size_t)tot * per * sizeof(T), 16)), xrecv.reserve(std::max<size_t>((size_t)tot * per * sizeof(T), 16));
+    if (tot > 0) HOT_LAUNCH(this, "tile_pack", k_tile_pack<T>, div_up((size_t)tot * per, 256), 256, 0, arr, q, tlist.p, tot, (T*)xsend.p);
     c_alltoallv(xsend.p, off.data(), bytes.data(), xrecv.p, off.data(), bytes.data()); // symmetric lists: what goes to a peer and what comes from it have the same layout
-    HOT_LAUNCH(this, "tile_sum", k_tile_sum<T>, div_up((size_t)Nb * per, 256), 256, 0, arr, q, sharers.p, tpos.p, (const T*)xrecv.p, seg, R, me, Nb);
+    if (tot > 0) HOT_LAUNCH(this, "tile_sum", k_tile_sum<T>, div_up((size_t)Nb * per, 256), 256, 0, arr, q, sharers.p, tpos.p, (const T*)xrecv.p, seg, R, me, Nb);
 }
 
 // ------------------------------------------------------------------------------------------------ DOF-vector halos
@@ -637,7 +640,7 @@ __global__ void k_page_ids(const T* __restrict__ X, uint64_t* __restrict__ page,
     using G = Geo<T>;
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const int b0 = base_node<T>(X[p] * one_over_dx), b1 = base_node<T>(X[n + p] * one_over_dx), b2 = base_node<T>(X[2 * n + p] * one_over_dx);
+    const int b0 = base_node_of<T>(one_over_dx, X[p]), b1 = base_node_of<T>(one_over_dx, X[n + p]), b2 = base_node_of<T>(one_over_dx, X[2 * n + p]);
     page[p] = G::linear_offset(b0, b1, b2) >> 12;
 }
 __global__ void k_page_sample(const uint64_t* __restrict__ page, int64_t n, uint64_t* __restrict__ out, int S)

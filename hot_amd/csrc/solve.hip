@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_lbfgs_dots(size_t n, LbVecs<T> hv, int 
         const T yv = y[i];
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (k < hv.m) acc[k] += (double)((use_dg ? hv.dg[k][i] : hv.dx[k][i]) * yv);
+            if (k < hv.m) acc[k] += (double)(use_dg ? hv.dg[k][i] : hv.dx[k][i]) * (double)yv; // products in double also in the fp32 build: the Gram recursion subtracts them
     }
     const int m = hv.m;
     block_sum_256_n<8>(acc, [m](int k) { return k < m; }, red);
@@ -177,13 +177,13 @@ __global__ __launch_bounds__(256) void k_lbfgs_pair(size_t n, LbVecs<T> hv, cons
         if (mask && !mask[i / 3]) continue;
         const T g = dgw[i] - rnew[i], x = dxw[i];
         dgw[i] = g;
-        acc[0] += (double)(g * x);
+        acc[0] += (double)g * (double)x;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (k < hv.m) acc[1 + k] += (double)(x * hv.dg[k][i]);
+            if (k < hv.m) acc[1 + k] += (double)x * (double)hv.dg[k][i];
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (k < hv.m) acc[9 + k] += (double)(hv.dx[k][i] * g);
+            if (k < hv.m) acc[9 + k] += (double)hv.dx[k][i] * (double)g;
     }
     // acc: [0] | [1, 8] | [9, 16], of which m each are in use; compact order of the deposits: [0] | [1, m] | [m + 1, 2 m]
     const int m = hv.m;
@@ -237,10 +237,20 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
     transform_dev(ddv, true); // recoverSolution
     double Ek0 = Ek;
     int guard = 0;
+    // Energy-only trials (hot_config.ls_energy_only): a rejected trial pays for singular values and the sum, not for U, V, the stress and
+    // 18 stores per particle; the accepted point then gets the full pass.  0 = adaptive: the first trial is a full pass unless the previous
+    // search had to halve (one trial per iteration, the common case at moderate stiffness, costs what it did), every trial after a rejection
+    // is energy-only; 1 = never; 2 = always.
+    const int eo_mode = cfg.ls_energy_only;
+    bool eo = eo_mode == 2 || (eo_mode == 0 && ls_prev_trials > 1), last_eo = false;
+    int trials = 0;
     do {
         HOT_LAUNCH(this, "linesearch_combine", k_combine<T>, div_up(n3, 256), 256, 0, n3, dv0.p, alpha, ddv, dvnew);
         copy(n3, dvnew, dv.p); // moveNodes
-        Ek = state_pass(dv.p, false); // a trial needs the energy only; the force is rasterised once, at the accepted point
+        Ek = state_pass(dv.p, false, eo); // a trial needs the energy only; the force is rasterised once, at the accepted point
+        last_eo = eo;
+        if (eo_mode != 1) eo = true;
+        ++trials;
         stats.linesearch_trials++;
         alpha *= (T)0.5;
         if (ab_flag("HOT_DEBUG")) fprintf(stderr, "[hot]   linesearch alpha=%g Ek=%.12e Ek0=%.12e\n", (double)alpha * 2, Ek, Ek0);
@@ -256,6 +266,8 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
         HOT_CHECK(false, HOT_ERR_NUMERIC, msg);
     }
     alpha *= 2;
+    ls_prev_trials = trials;
+    if (last_eo) Ek = state_pass(dv.p, false, false); // the accepted point: trial F, stresses and the energy the next search compares with
     HOT_LAUNCH(this, "scal", k_scal<T>, div_up(n3, 256), 256, 0, n3, alpha, ddv);
     transform_dev(ddv, false); // transformResidual
     force_pass(); // the stresses of the last (accepted) trial are still in place

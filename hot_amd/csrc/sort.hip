@@ -60,7 +60,7 @@ __global__ void k_make_keys(const T* __restrict__ X, const int32_t* __restrict__
     using G = Geo<T>;
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    int b0 = base_node<T>(X[p] * one_over_dx), b1 = base_node<T>(X[n + p] * one_over_dx), b2 = base_node<T>(X[2 * n + p] * one_over_dx);
+    int b0 = base_node_of<T>(one_over_dx, X[p]), b1 = base_node_of<T>(one_over_dx, X[n + p]), b2 = base_node_of<T>(one_over_dx, X[2 * n + p]);
     uint64_t offset = G::linear_offset(b0, b1, b2);
     constexpr int index_bits = 32 - G::block_bits;
     keys[p] = ((offset >> G::data_bits) << index_bits) + (uint64_t)(uint32_t)slot2orig[p];
@@ -82,7 +82,7 @@ __global__ void k_make_keys_in_order(const T* __restrict__ X, const uint32_t* __
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int64_t p = visit[k];
-    int b0 = base_node<T>(X[p] * one_over_dx), b1 = base_node<T>(X[n + p] * one_over_dx), b2 = base_node<T>(X[2 * n + p] * one_over_dx);
+    int b0 = base_node_of<T>(one_over_dx, X[p]), b1 = base_node_of<T>(one_over_dx, X[n + p]), b2 = base_node_of<T>(one_over_dx, X[2 * n + p]);
     constexpr int index_bits = 32 - G::block_bits;
     keys[k] = ((G::linear_offset(b0, b1, b2) >> G::data_bits) << index_bits) + (uint64_t)k; // k = the particle's rank by id on this rank (< Np < 2^index_bits)
     vals[k] = (uint32_t)p;
@@ -174,7 +174,7 @@ __global__ void k_base_offsets(const T* __restrict__ X, const int32_t* __restric
     using G = Geo<T>;
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    int b0 = base_node<T>(X[p] * one_over_dx), b1 = base_node<T>(X[n + p] * one_over_dx), b2 = base_node<T>(X[2 * n + p] * one_over_dx);
+    int b0 = base_node_of<T>(one_over_dx, X[p]), b1 = base_node_of<T>(one_over_dx, X[n + p]), b2 = base_node_of<T>(one_over_dx, X[2 * n + p]);
     uint64_t offset = G::linear_offset(b0, b1, b2);
     offset = (offset >> G::data_bits) << G::data_bits;
     int32_t o = slot2orig[p];

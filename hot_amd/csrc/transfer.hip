@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 #pragma unroll
             for (int e = 0; e < 9 * NQ; ++e) (&a[0][0][0])[e] = (T)0;
             // the base cell is the same for every particle of the segment
-            const int b0 = base_node<T>(one_over_dx * sp[0][l0]), b1 = base_node<T>(one_over_dx * sp[1][l0]), b2 = base_node<T>(one_over_dx * sp[2][l0]);
+            const int b0 = base_node_of<T>(one_over_dx, sp[0][l0]), b1 = base_node_of<T>(one_over_dx, sp[1][l0]), b2 = base_node_of<T>(one_over_dx, sp[2][l0]);
             const T fb0 = (T)b0, fb1 = (T)b1, fb2 = (T)b2;
             for (int l = l0; l < l1; ++l) {
                 const T x0 = sp[0][l], x1 = sp[1][l], x2 = sp[2][l];

@@ -2,8 +2,9 @@
 
 The multi-GPU decomposition itself lives in the library (hot_amd/csrc/shard.hip, hot_set_comm) and in hot_amd/dist.py
 (the collectives over torch.distributed, the split of a cloud into page-order shards): ONE connected body is sharded over
-the ranks — particle ranges of the global sort order per rank, node tiles summed with all-reduces, matrix rows owned by
-one rank each, colour-synchronous Gauss-Seidel.  This module only builds the synthetic
+the ranks in "halo mode" — particle runs of the global page order per rank, node tiles summed pairwise between the ranks
+that share a block, matrix rows owned by one rank each, DOF vectors on owned rows plus halos, batched scalar all-reduces,
+colour-synchronous or rank-local Gauss-Seidel.  This module only builds the synthetic
 body of a BASELINE configuration, hands a rank its shard, and provides the bench clock (max over ranks).
 
 Weak scaling: the body grows with the number of ranks so that every GPU keeps the single-GPU configuration's particle

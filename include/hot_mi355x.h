@@ -84,7 +84,10 @@ typedef struct hot_config {
     int32_t shard_replicated; /* sharded runs: 0 (default) = halo mode: DOF vectors live on the rows a rank owns plus the halo it reads, node tiles are summed
                                  between the ranks that share a block, inner products are summed with one small all-reduce per batch; 1 = the first-generation
                                  decomposition: every DOF vector replicated, whole-array all-reduce per scatter and all-gather per operator (kept for A/B) */
-    int32_t reserved[1];
+    int32_t ls_energy_only; /* line-search trials that evaluate nothing but the energy (singular values only, no stress / trial-F stores), full state pass once at the
+                               accepted step: 0 = adaptive (default: from the second trial of a search on, and from the first when the previous search had to halve),
+                               1 = never (every trial is a full pass), 2 = always */
+    int32_t reserved[7];
 } hot_config;
 
 typedef struct hot_stats {
@@ -207,6 +210,10 @@ int hot_get_level(hot_ctx*, int32_t level, int32_t* nrows, int32_t* colsize, int
 int hot_get_matrix(hot_ctx*, int32_t level, int32_t* entryCol, void* entryVal);
 /* structurally non-zero 3x3 blocks of the level's system matrix (used for the roofline's algorithmic bytes) */
 int hot_get_level_nnzb(hot_ctx*, int32_t level, int64_t* nnzb);
+/* of those, the off-diagonal blocks whose column lies in the row's own 4^3 colour block (the coloured-GS kernels split a row into its
+ * off-block part, streamed one wavefront per row, and its in-block part, the block's triangular solve): the roofline's algorithmic bytes
+ * of the two kernels.  Valid after hot_build_mg on levels that were coloured; HIP product only. */
+int hot_get_level_inblock_nnzb(hot_ctx*, int32_t level, int64_t* nnzb);
 int hot_get_prolongation(hot_ctx*, int32_t level, int32_t* entryCol /*8*nrows(level)*/, void* weight /*8*nrows(level)*/);
 
 /* ---- operators */
@@ -240,20 +247,25 @@ int hot_calculate_dt(hot_ctx*, double max_dt, double* dt, double* max_speed, dou
 int hot_advance_frame(hot_ctx*, double frame_dt, double min_dt, double max_dt, int32_t* substeps, int32_t* iterations_total, hot_stats* stats);
 
 /* ---- one connected body over several ranks (one context per rank = per GPU).  The reference is a single process (SURVEY.md
- *      §8e); this is the MI355X-native extension of the path.  Decomposition ("particle shard, replicated grid, row-
- *      partitioned operators"):
- *        particles   every rank holds a contiguous range of the globally sorted particle_group list (its shard); scatters
- *                    (P2G, force, CN tolerance, matrix-free product) are computed from the shard and summed over the ranks
- *                    with one all-reduce of the node tiles; per-particle sums (energy, max speed) with a scalar all-reduce;
- *        grid        block list, node numbering, DOF vectors, collision nodes and the hierarchy's index structure are
- *                    replicated: identical on every rank by construction (bit-identical all-reduce results), so every rank
- *                    takes the same line-search / termination decisions without further communication;
- *        operators   matrix rows (level 0 and every coarse level above `partition_min_rows` rows) are owned by one rank
- *                    each: a 4^3 colour block belongs to the rank whose particles first touch it.  Hessian / Galerkin rows
- *                    that receive contributions from another rank's particles / fine rows are completed by a personalised
- *                    exchange of partial rows; SpMV, the residual updates and each colour of the Gauss-Seidel sweeps are
- *                    computed by the owner and handed to the other ranks right after (colour-synchronous, i.e. the update
- *                    order is the reference's: MultigridPreconditioner.h:266-318); small coarse levels are replicated.
+ *      §8e); this is the MI355X-native extension of the path.  Decomposition ("halo mode", the default):
+ *        particles   every rank holds one of `size` runs of the global SPGrid page order, re-cut by particle-count-weighted splitters at
+ *                    every hot_sort (particles migrate with their global ids); per-particle sums (energy, max speed) are scalar all-reduces;
+ *        index       block list, node numbering and coordinates, colouring, coarse numbering, transfer tables and row ownership are
+ *                    REPLICATED integers: every rank derives them with deterministic kernels from small all-gathered inputs once per step,
+ *                    so every exchange list is computable locally and every numbering equals the single-rank one;
+ *        node tiles  (P2G, force, CN tolerance, matrix-free product) are summed PAIRWISE between the ranks whose particle groups cover a
+ *                    block, in ascending rank order (every sharer ends with the same bits; nobody else receives anything);
+ *        rows        a 4^3 colour block — its Hessian / Galerkin rows, its Gauss-Seidel updates — is owned by the rank whose particles first
+ *                    touch it; rows that also receive contributions of another rank's particles / fine rows are completed by a personalised
+ *                    exchange of partial rows per build;
+ *        vectors     DOF vectors are valid on the rows a rank owns plus the halo it reads (125-stencil, particle tiles, transfer windows),
+ *                    refreshed by one halo gather per operator; vector algebra runs on owned rows, every batch of inner products is one
+ *                    small all-reduce, whose identical results let all ranks take the same line-search / termination decisions;
+ *        smoothing   colour-synchronous Gauss-Seidel (the reference's update order across ranks, MultigridPreconditioner.h:266-318,
+ *                    sixteen halo exchanges per symmetric sweep) or, hot_config.shard_gs = 1, rank-local sweeps with one exchange;
+ *        coarse      levels below `partition_min_rows` rows are replicated (one all-reduce of the level's matrix per build).
+ *      hot_config.shard_replicated = 1 selects the first-generation decomposition instead (replicated DOF vectors, one all-reduce of the
+ *      node tiles per scatter, one all-gather per operator).
  *      The library performs no communication itself: it calls the three collectives below at those points, with DEVICE
  *      pointers (a host-memory implementation of this ABI: host pointers), after synchronising its stream; the callee must have completed the
  *      operation when it returns.  hot_amd/dist.py implements them over torch.distributed (RCCL on GPUs, gloo in the CPU

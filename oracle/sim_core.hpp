@@ -203,10 +203,11 @@ struct Sim {
     {
         s.one_over_dx = 1 / dx;
         for (int d = 0; d < 3; ++d) {
-            T x = s.one_over_dx * Xp(d);
-            int bn = base_node(x);
+            // both roundings spelled out (see hot_common.h "The index-space coordinate"): what g++ -O3 -march=native makes of the
+            // reference's `x = one_over_dx * X; floor(x - 0.5); x - base` anyway, but not left to the compiler here
+            int bn = int_floor(std::fma(s.one_over_dx, Xp(d), -(T)0.5));
             s.base[d] = bn;
-            T d0 = x - bn;
+            T d0 = std::fma(s.one_over_dx, Xp(d), -(T)bn);
             T z = ((T)1.5 - d0);
             T z2 = z * z;
             s.w[d][0] = (T)0.5 * z2;
@@ -318,7 +319,7 @@ struct Sim {
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < Np; ++i) {
             int b[3];
-            for (int d = 0; d < 3; ++d) b[d] = base_node(X[i](d) * one_over_dx);
+            for (int d = 0; d < 3; ++d) b[d] = int_floor(std::fma(one_over_dx, X[i](d), -(T)0.5));
             uint64_t offset = Mask::linear_offset(b[0], b[1], b[2]);
             particle_sorter[i] = ((offset >> Mask::data_bits) << index_bits) + (uint64_t)i;
         }

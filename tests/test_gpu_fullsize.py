@@ -129,28 +129,38 @@ def test_fullsize_invariants(hotlib, name):
     assert np.isfinite(p["X"]).all() and np.isfinite(p["F"]).all()
 
 
-@pytest.mark.parametrize("cname,n", [("C2", 63), ("C3", 100)])
-def test_gs_colour_launch_equals_sub_block_launches(hotlib, cname, n):
-    """The finest-level GS walks both 32-node sub-blocks of a colour block inside one launch; the later sub-block must see what
-    the earlier one stored.  With a launch per sub-block (HOT_GS_SPLIT_LAUNCHES, read per call) the arithmetic is the same,
-    so on one and the same matrix the V-cycle is bitwise identical."""
+@pytest.mark.parametrize("cname,n,tol", [("C2", 63, 1e-12), ("C3", 100, 2e-4)])
+def test_finest_level_gs_kernel_generations_agree(hotlib, cname, n, tol):
+    """Three launch structures of the finest-level coloured GS on one and the same matrix at full size (A/B build, switches read per call):
+    the production pair (k_gs_offblock: off-block row sums, one wavefront per row; k_gs_subst: the block's 64-row substitution from the
+    premultiplied image, one wavefront per block), the first-generation k_gs_block with both 32-node sub-blocks of a colour block walked
+    inside one launch (HOT_GS_V1), and that kernel with a launch per sub-block (+ HOT_GS_SPLIT_LAUNCHES).  The two k_gs_block structures
+    do the same arithmetic: bitwise equal V-cycles.  The pair associates the row sums differently (off-block part, then the in-block
+    columns one by one): equal to rounding.  Every variant is run-to-run deterministic."""
     import os
     import hot_amd
-    ablib = hot_amd.HotLib(hot_amd.AB_LIB_PATH)  # the launch-structure switch exists only in the A/B build of the library
+    ablib = hot_amd.HotLib(hot_amd.AB_LIB_PATH)  # the launch-structure switches exist only in the A/B build of the library
     cfg = synth.CONFIGS[cname]
     ctx, cloud = make(ablib, cfg, n)
     ctx.sort(), ctx.p2g(), ctx.begin_step(cfg["dt"])
     ctx.update_state(ctx.get_dv())
     ctx.build_hessian(), ctx.build_mg()
     x = ctx.project(np.random.default_rng(1).standard_normal((ctx.Nn, 3)))
-    os.environ.pop("HOT_GS_SPLIT_LAUNCHES", None)
-    a = [ctx.vcycle(x) for _ in range(3)]
-    os.environ["HOT_GS_SPLIT_LAUNCHES"] = "1"
+    for k in ("HOT_GS_SPLIT_LAUNCHES", "HOT_GS_V1"):
+        os.environ.pop(k, None)
+    pair = [ctx.vcycle(x) for _ in range(3)]
     try:
-        b = [ctx.vcycle(x) for _ in range(3)]
+        os.environ["HOT_GS_V1"] = "1"
+        a = [ctx.vcycle(x) for _ in range(2)]
+        os.environ["HOT_GS_SPLIT_LAUNCHES"] = "1"
+        b = [ctx.vcycle(x) for _ in range(2)]
     finally:
-        os.environ.pop("HOT_GS_SPLIT_LAUNCHES", None)
+        for k in ("HOT_GS_SPLIT_LAUNCHES", "HOT_GS_V1"):
+            os.environ.pop(k, None)
+    assert all(np.array_equal(pair[0], y) for y in pair[1:])
     assert all(np.array_equal(a[0], y) for y in a[1:] + b)
+    err = np.abs(pair[0].astype(np.float64) - a[0]).max() / np.abs(a[0]).max()
+    assert err < tol, err
 
 
 @pytest.mark.parametrize("name", ["C4_per_gpu", "C5_per_gpu", "C4_full", "C5_full"])

@@ -24,7 +24,8 @@ CASES = [
     ({"HOT_TEST_CFG": "gs_chain=2,gs_sub_block=32", "HOT_GS_PASS_COUNTERS": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_TEST_CFG": "gs_chain=2,gs_sub_block=32", "HOT_GS_BLOCK_FLAGS": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # hand-off through per-block sweep stamps
     ({"HOT_GS_BLOCK_FLAGS": "1"}, SOLVER, "smoothers or vcycle"),
-    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_SPLIT_LAUNCHES": "1"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_V1": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # first-generation k_gs_block instead of the off-block / substitution pair
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_V1": "1", "HOT_GS_SPLIT_LAUNCHES": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_SIMPLE_GS": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_GS_FULL_RESIDUAL": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_MG_FULL_SPMV": "1"}, SOLVER, "vcycle or iterates"),
