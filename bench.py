@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measu
 
 SYMBOL = {  # profile-record prefix -> device symbol as rocprofv3 names it
     "gs_forward": "hot::k_gs_subst<T,true,8>", "gs_backward": "hot::k_gs_subst<T,false,8>", "spmv": "hot::k_spmv<T>",
-    "gs_forward_off": "hot::k_gs_offblock<T,true>", "gs_backward_off": "hot::k_gs_offblock<T,false>",
+    "gs_forward_off": "hot::k_gs_offblock<T>", "gs_backward_off": "hot::k_gs_offblock<T>",
     "gs_forward_chained": "hot::k_gs_sweep<T,true,64>", "gs_backward_chained": "hot::k_gs_sweep<T,false,64>",
     "gs_residual": "hot::k_gs_residual<T>", "hessian_assemble": "hot::k_hessian_tiles2<T,false>", "state_update": "hot::k_state<T>",
     "force_scatter": "hot::k_force_cells2<T>", "p2g": "hot::k_p2g_cells2<T,true>", "g2p": "hot::k_g2p<T,0>",
@@ -269,7 +269,7 @@ def main():
             lph = rec["calls"] / sweeps["calls"] if sweeps and base in ("gs_forward", "gs_backward", "gs_forward_off", "gs_backward_off") else 8.0  # launches per half sweep
             if base in ("gs_forward", "gs_backward") and lph < 1.5:
                 base += "_chained"  # coarse levels: the whole half sweep is one k_gs_sweep launch (a different device symbol)
-            g = groups.setdefault(base, dict(ms=0.0, calls=0, bytes=0.0, modelled=True, records={}))
+            g = groups.setdefault(SYMBOL.get(base, base), dict(ms=0.0, calls=0, bytes=0.0, modelled=True, records={}))  # by device symbol: the forward and backward off-block sums are one kernel
             g["ms"] += rec["total_ms"]
             g["calls"] += rec["calls"]
             ab = algorithmic_bytes(name, s, Np, levels, lph)
@@ -282,8 +282,8 @@ def main():
         g = groups[top]
         avg_ms = g["ms"] / g["calls"]
         achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(SYMBOL.get(top, top), "double" if s == 8 else "float") if args.config == "C2" and not args.cells else (None, None)
-        roof = {"kernel": SYMBOL.get(top, top), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        traffic, traffic_src = pmc_traffic(top, "double" if s == 8 else "float") if args.config == "C2" and not args.cells else (None, None)
+        roof = {"kernel": top, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src,
                 "avg_launch_ms": avg_ms, "launches": g["calls"], "algorithmic_bytes_per_launch": g["bytes"] / g["calls"], "share_of_kernel_time": g["ms"] / total_ms,
                 "per_level": g["records"]}

@@ -711,28 +711,29 @@ __device__ __forceinline__ T row16_sum(T v) // sum over each 16-lane DPP row; va
     v += dpp_move<0x118, 0xf>(v);
     return v;
 }
-template <class T, bool FWD>
-__global__ __launch_bounds__(256) void k_gs_offblock(const int32_t* __restrict__ gcol, const T* __restrict__ val, const int32_t* __restrict__ gs_pad, const T* __restrict__ rhs,
-    const T* __restrict__ x, T* __restrict__ p1, int64_t pos0, int64_t npos)
+template <class T>
+__global__ __launch_bounds__(1024) void k_gs_offblock(const int32_t* __restrict__ gcol, const T* __restrict__ val, const int32_t* __restrict__ gs_pad, const T* __restrict__ rhs,
+    const T* __restrict__ x, T* __restrict__ p1, int64_t pos0, int64_t npos, int FWD /*forward sweep: the off-block columns preceding the row; else those following it*/)
 {
     // two rows (adjacent positions of a block) per wavefront, side by side: a wavefront spends two thirds of its life waiting for something
     // other than matrix values (header record, then the gathers), so one row per wavefront leaves HBM half idle even at eight per SIMD
     const int lane = threadIdx.x & 63;
-    const int64_t e0 = 2 * ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int64_t e0 = 2 * ((int64_t)blockIdx.x * 16 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))); // wave-uniform, and known to be: the two row records come through the scalar cache, both at once
     if (e0 >= npos) return;
     int row[2], kb[2], ke[2], j[2];
     T bv[2][9], rh[2][3];
+    int rec[2][5];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int64_t e = e0 + q;
-        row[q] = -1, kb[q] = ke[q] = 0, j[q] = -1;
-        if (e < npos) {
-            const int4 rec0 = *(const int4*)(gs_pad + 8 * (pos0 + e));
-            const int fo = gs_pad[8 * (pos0 + e) + 4];
-            row[q] = rec0.x;
-            const int po = rec0.y, pi = rec0.z, fi = rec0.w;
-            kb[q] = FWD ? 0 : po + pi + 1 + fi, ke[q] = FWD ? po : po + pi + 1 + fi + fo;
-        }
+        const int32_t* rp = gs_pad + 8 * (pos0 + (e0 + q < npos ? e0 + q : e0));
+#pragma unroll
+        for (int t = 0; t < 5; ++t) rec[q][t] = rp[t];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        row[q] = e0 + q < npos ? rec[q][0] : -1, j[q] = -1;
+        const int po = rec[q][1], pi = rec[q][2], fi = rec[q][3], fo = rec[q][4];
+        kb[q] = FWD ? 0 : po + pi + 1 + fi, ke[q] = FWD ? po : po + pi + 1 + fi + fo;
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(256) void k_gs_offblock(const int32_t* __restrict__
 // bound by HBM, not by its chain any more.)
 template <class T, bool FWD, int D>
 __global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, const unsigned long long* __restrict__ imgm, const int32_t* __restrict__ gs_pad, const T* __restrict__ p1, T* x,
-    T* hD, int block0)
+    T* hD, int block0, const T* __restrict__ rhs /*not null: the first colour of a half sweep, whose rows have no off-block columns to subtract: p1 = rhs, by node*/)
 {
     using I = GsImg<T>;
     const int lane = threadIdx.x;
@@ -819,7 +820,8 @@ __global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, cons
     // a = D^-1 p1 (p1 and D^-1 are stored by position)
     T a0, a1, a2;
     {
-        const T q0 = p1[3 * pos], q1 = p1[3 * pos + 1], q2 = p1[3 * pos + 2];
+        const T* src = rhs ? rhs + 3 * (int64_t)max(node, 0) : p1 + 3 * pos;
+        const T q0 = src[0], q1 = src[1], q2 = src[2];
         const T* di = hdr + 576 + 9 * lane;
         a0 = di[0] * q0 + di[3] * q1 + di[6] * q2, a1 = di[1] * q0 + di[4] * q1 + di[7] * q2, a2 = di[2] * q0 + di[5] * q1 + di[8] * q2; // gs_store_rhs's product
     }
@@ -1449,19 +1451,22 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             T* hD = fwd ? dAu : u;
             const char* nmT = fwd ? "gs_forward" : "gs_backward";
             const char* nmO = fwd ? "gs_forward_off" : "gs_backward_off";
+            bool first = true; // the first colour walked has no off-block columns before it: no off-block launch, the substitution reads rhs itself
             for (int q = 0; q < 8; ++q) {
                 const int c = fwd ? q : 7 - q, b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
                 if (nb <= 0) continue;
                 const int64_t pos0 = (int64_t)b0 * 64, npos = (int64_t)nb * 64;
-                const unsigned grid = (unsigned)div_up(npos, 8);
+                const unsigned grid = (unsigned)div_up(npos, 32);
+                const T* direct = first ? rhs : (const T*)nullptr;
                 if (fwd) {
-                    HOT_LAUNCH(this, lname(nmO, L.id).c_str(), (k_gs_offblock<T, true>), grid, 256, 0, L.gs_col.p, L.val.p, L.gs_pad.p, rhs, xx, L.gs_p1.p, pos0, npos);
-                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgm.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0);
+                    if (!first) HOT_LAUNCH(this, lname(nmO, L.id).c_str(), k_gs_offblock<T>, grid, 1024, 0, L.gs_col.p, L.val.p, L.gs_pad.p, rhs, xx, L.gs_p1.p, pos0, npos, 1);
+                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgm.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, direct);
                 }
                 else {
-                    HOT_LAUNCH(this, lname(nmO, L.id).c_str(), (k_gs_offblock<T, false>), grid, 256, 0, L.gs_col.p, L.val.p, L.gs_pad.p, rhs, xx, L.gs_p1.p, pos0, npos);
-                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgm.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0);
+                    if (!first) HOT_LAUNCH(this, lname(nmO, L.id).c_str(), k_gs_offblock<T>, grid, 1024, 0, L.gs_col.p, L.val.p, L.gs_pad.p, rhs, xx, L.gs_p1.p, pos0, npos, 0);
+                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgm.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, direct);
                 }
+                first = false;
             }
         };
         HOT_CHECK(sb == 16 || sb == 32 || sb == 64, HOT_ERR_INVALID, "hot_config.gs_sub_block must be 0 (auto), 16, 32 or 64");

@@ -146,3 +146,98 @@ def check_p2g(path, prefix, dtype):
     heavy = rm > 1e-3 * rm.max()  # v = mv / m of almost massless nodes is ill-conditioned in any precision
     assert np.abs(gv[got_idx] - rv)[heavy].max() < tol * np.abs(rv[heavy]).max()
     assert np.abs((gm[got_idx, None] * gv[got_idx]) - (rm[:, None] * rv)).max() < tol * np.abs(rm[:, None] * rv).max()
+
+
+def check_step(path, prefix, dtype=1):
+    """One whole tiny time step against tests/golden/np_step.py (numpy only): node masses and velocities, energy, residual, the assembled
+    Hessian with its boundary projection, prolongation and Galerkin coarse matrix, one symmetric coloured GS sweep, the two-level V-cycle
+    and two L-BFGS iterations with their line searches — in the library's own node numbering (an input of the numpy restatement)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import np_step as ns
+    T = np.float64 if dtype == 1 else np.float32
+    c = ns.tiny_cloud()
+    r = Raw(path, prefix)
+    kw = dict(dx=c.dx, levelCnt=2, lsolver=3, smoother=5, coarseSolver=2, max_iterations=2)
+    h = r.create(dtype, **kw)
+    n = c.X.shape[0]
+    cmaj = lambda M: np.ascontiguousarray(np.transpose(M, (0, 2, 1)).reshape(-1, 9), T)
+    X, V, m, vol = (np.ascontiguousarray(a, T) for a in (c.X, c.V, c.mass, c.vol))
+    mu, lam = np.full(n, c.mu, T), np.full(n, c.lam, T)
+    Cm, Fm = cmaj(c.C), cmaj(c.F)
+    r.call("set_particles", h, C.c_int64(n), vp(X), vp(V), vp(m), vp(Cm), vp(Fm), vp(vol), vp(mu), vp(lam), None)
+    org, nrm = np.array([0.0, c.floor_y, 0.0]), np.array([0.0, 1.0, 0.0])
+    r.call("set_sticky_halfspaces", h, C.c_int32(1), vp(org), vp(nrm))
+    r.call("sort", h)
+    r.call("p2g", h)
+    np_, ng, nb, nn = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+    r.call("get_counts", h, C.byref(np_), C.byref(ng), C.byref(nb), C.byref(nn))
+    N = nn.value
+    ic, gm, gv = np.empty((N, 3), np.int32), np.empty(N, T), np.empty((N, 3), T)
+    r.call("get_grid", h, vp(ic), vp(gm), vp(gv))
+    st = ns.Step(c, ic)
+    out = {}
+    out["mass"], out["v"] = relerr(gm, st.m), relerr(gv, st.vn)
+    r.call("begin_step", h, C.c_double(c.dt))
+    dv = np.empty((N, 3), T)
+    r.call("get_dv", h, vp(dv))
+    out["dv0"] = relerr(dv, st.dv0)
+    e = C.c_double()
+    r.call("update_state", h, None, C.byref(e))
+    out["energy"] = abs(e.value - st.energy(st.dv0)) / abs(st.energy(st.dv0))
+    res = np.empty((N, 3), T)
+    r.call("residual", h, vp(res))
+    out["residual"] = relerr(res, st.residual(st.dv0))
+    r.call("build_hessian", h)
+    r.call("build_mg", h)
+
+    def dense(level, nrows):
+        nr, cs = C.c_int32(), C.c_int32()
+        r.call("get_level", h, C.c_int32(level), C.byref(nr), C.byref(cs), None)
+        assert nr.value == nrows
+        col, val = np.empty((nrows, cs.value), np.int32), np.empty((nrows, cs.value, 9), T)
+        r.call("get_matrix", h, C.c_int32(level), vp(col), vp(val))
+        A = np.zeros((3 * nrows, 3 * nrows))
+        for i in range(nrows):
+            for k in range(cs.value):
+                A[3 * i:3 * i + 3, 3 * col[i, k]:3 * col[i, k] + 3] += val[i, k].reshape(3, 3).T  # 3x3 column-major
+        return A
+    H = st.hessian(st.dv0)
+    A0 = dense(0, N)
+    out["hessian"] = np.abs(A0 - H).max() / np.abs(H).max()
+    coord1, P = ns.coarsen(st.coord)
+    nr1 = C.c_int32()
+    r.call("get_level", h, C.c_int32(1), C.byref(nr1), C.byref(C.c_int32()), None)
+    assert nr1.value == len(coord1), (nr1.value, len(coord1))
+    ic1 = np.empty((nr1.value, 3), np.int32)
+    r.call("get_level", h, C.c_int32(1), C.byref(nr1), C.byref(C.c_int32()), vp(ic1))
+    assert [tuple(int(v) for v in q) for q in ic1] == coord1  # first-touch coarse numbering, bit for bit
+    pc, pw = np.empty((N, 8), np.int32), np.empty((N, 8), T)
+    r.call("get_prolongation", h, C.c_int32(0), vp(pc), vp(pw))
+    Pd = np.zeros_like(P)
+    for i in range(N):
+        for k in range(8):
+            Pd[i, pc[i, k]] += pw[i, k]
+    out["prolongation"] = np.abs(Pd - P).max()
+    P3 = ns.expand3(P)
+    A1 = P3.T @ H @ P3
+    out["coarse_matrix"] = np.abs(dense(1, len(coord1)) - A1).max() / np.abs(A1).max()
+    # one symmetric coloured GS sweep on level 0 (iterations = 2 in the reference's counting)
+    b = st.project(np.random.default_rng(7).standard_normal((N, 3)))
+    u, rr = np.zeros((N, 3), T), np.array(b, T)  # (a copy: the call overwrites r)
+    r.call("smooth", h, C.c_int32(0), C.c_int32(5), C.c_int32(2), C.c_double(0.0), vp(u), vp(rr), None)
+    un, rn = ns.gs_smooth(H, st.coord, np.zeros((N, 3)), b, 2)
+    out["gs_u"], out["gs_r"] = relerr(u, un), relerr(rr, rn)
+    mg = ns.Hierarchy(H, st.coord)
+    xin, xout = np.ascontiguousarray(b, T), np.empty((N, 3), T)
+    r.call("vcycle", h, vp(xin), vp(xout))
+    out["vcycle"] = relerr(xout, mg.vcycle(b))
+    # two L-BFGS iterations with their line searches
+    stats = (C.c_byte * 512)()
+    r.call("solve", h, C.byref(stats))
+    r.call("get_dv", h, vp(dv))
+    xn, trials, _ = ns.lbfgs(st, 2)
+    out["lbfgs_dv"] = relerr(dv, xn)
+    out["linesearch_trials"] = (int(np.frombuffer(stats, np.int32, 3)[2]), trials)
+    r.f("destroy", None)(h)
+    return out
