@@ -221,7 +221,8 @@ def check_step(path, prefix, dtype=1):
     out["prolongation"] = np.abs(Pd - P).max()
     P3 = ns.expand3(P)
     A1 = P3.T @ H @ P3
-    out["coarse_matrix"] = np.abs(dense(1, len(coord1)) - A1).max() / np.abs(A1).max()
+    dense1 = dense(1, len(coord1))
+    out["coarse_matrix"] = np.abs(dense1 - A1).max() / np.abs(A1).max()
     # one symmetric coloured GS sweep on level 0 (iterations = 2 in the reference's counting)
     b = st.project(np.random.default_rng(7).standard_normal((N, 3)))
     u, rr = np.zeros((N, 3), T), np.array(b, T)  # (a copy: the call overwrites r)
@@ -240,4 +241,35 @@ def check_step(path, prefix, dtype=1):
     out["lbfgs_dv"] = relerr(dv, xn)
     out["linesearch_trials"] = (int(np.frombuffer(stats, np.int32, 3)[2]), trials)
     r.f("destroy", None)(h)
+    # ---- the stored vectors (tests/golden/step_golden.npz, keyed by coordinates in lexicographic order): the library's numbering mapped onto them
+    g = np.load(os.path.join(ROOT, "tests", "golden", "step_golden.npz"))
+    lex = {tuple(int(v) for v in k): i for i, k in enumerate(g["coord"])}
+    assert len(lex) == N and all(k in lex for k in st.coord)
+    perm = np.array([lex[k] for k in st.coord])  # library id -> lexicographic index
+    p3 = (3 * perm[:, None] + np.arange(3)[None, :]).reshape(-1)
+    out["stored_mass"], out["stored_v"], out["stored_dv0"] = relerr(gm, g["mass"][perm]), relerr(gv, g["v"][perm]), relerr(dv * 0 + st.dv0, g["dv0"][perm])
+    out["stored_energy"] = abs(e.value - float(g["energy"])) / abs(float(g["energy"]))
+    out["stored_residual"] = relerr(res, g["residual"][perm])
+    out["stored_hessian"] = np.abs(A0 - g["hessian"][np.ix_(p3, p3)]).max() / np.abs(g["hessian"]).max()
+    lex1 = {tuple(int(v) for v in k): i for i, k in enumerate(g["coord1"])}
+    perm1 = np.array([lex1[k] for k in coord1])
+    q3 = (3 * perm1[:, None] + np.arange(3)[None, :]).reshape(-1)
+    out["stored_prolongation"] = np.abs(Pd - g["P"][np.ix_(perm, perm1)]).max()
+    out["stored_coarse_matrix"] = np.abs(dense1 - g["A1"][np.ix_(q3, q3)]).max() / np.abs(g["A1"]).max()
     return out
+
+
+def check_step_numpy_regression():
+    """the numpy restatement in lexicographic numbering reproduces the stored numbering-dependent vectors (pins np_step.py itself)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import np_step as ns
+    g = np.load(os.path.join(ROOT, "tests", "golden", "step_golden.npz"))
+    st = ns.Step(ns.tiny_cloud(), g["coord"])
+    H = st.hessian(st.dv0)
+    assert np.abs(H - g["hessian"]).max() < 1e-12 * np.abs(H).max()
+    u, rr = ns.gs_smooth(H, st.coord, np.zeros((st.n, 3)), g["lex_rhs"], 2)
+    assert relerr(u, g["lex_gs_u"]) < 1e-11 and relerr(rr, g["lex_gs_r"]) < 1e-11
+    assert relerr(ns.Hierarchy(H, st.coord).vcycle(g["lex_rhs"]), g["lex_vcycle"]) < 1e-10
+    x2, trials, _ = ns.lbfgs(st, 2)
+    assert relerr(x2, g["lex_lbfgs_dv"]) < 1e-9 and trials == int(g["lex_linesearch_trials"])

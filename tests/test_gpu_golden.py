@@ -1,6 +1,7 @@
-"""The HIP library against the numpy-generated golden vectors (tests/golden/fp_golden.npz) — no oracle, no shared binding:
-the device SVD / fixed-corotated model / PSD-projected dP/dF, the von Mises and snow return mappings and the APIC P2G are
-compared with numpy.linalg-based restatements directly through the C ABI."""
+"""The HIP library against the numpy-generated golden vectors (tests/golden/fp_golden.npz, step_golden.npz) — no oracle, no shared binding:
+the device SVD / fixed-corotated model / PSD-projected dP/dF, the von Mises and snow return mappings, the APIC P2G and one whole tiny time
+step (assembled Hessian, hierarchy, coloured GS sweep, V-cycle, L-BFGS iterates; tests/golden/np_step.py) are compared with numpy
+restatements directly through the C ABI."""
 import pytest
 
 import hot_amd
@@ -22,3 +23,22 @@ def test_hip_plasticity_against_numpy_golden(dtype):
 @pytest.mark.parametrize("dtype", [1, 0])
 def test_hip_p2g_against_numpy_golden(dtype):
     gc.check_p2g(hot_amd.LIB_PATH, "hot_", dtype)
+
+
+def test_hip_whole_tiny_step_against_numpy():
+    from tests.test_oracle_golden import check_step_result
+    out = gc.check_step(hot_amd.LIB_PATH, "hot_", 1)
+    print(out)
+    check_step_result(out)
+
+
+def test_hip_whole_tiny_step_fp32_against_numpy():
+    """the fp32 build against the fp64 numpy restatement: single passes to float round-off, the iterated quantities looser"""
+    out = gc.check_step(hot_amd.LIB_PATH, "hot_", 0)
+    print(out)
+    t0, t1 = out.pop("linesearch_trials")
+    assert abs(t0 - t1) <= 1, (t0, t1)
+    # (positions near 5.0 with dx = 0.01 leave ~1e-5 of a cell in a float's B-spline weights: that is the floor of every quantity below)
+    tol = dict(mass=5e-5, v=1e-3, dv0=5e-4, energy=5e-5, residual=3e-4, hessian=1e-4, prolongation=0.0, coarse_matrix=5e-5, gs_u=1e-2, gs_r=1e-2, vcycle=1e-2, lbfgs_dv=1e-2)  # measured: 1.2e-5, 2.7e-4, 9.5e-5, 9.7e-6, 5.0e-5, 1.2e-5, 0, 2.9e-6, 3.6e-3, 2.0e-3, 3.5e-3, 1.8e-3
+    for k, v in out.items():
+        assert v <= tol[k.replace("stored_", "")], (k, v)

@@ -1,5 +1,3 @@
-for a in "8 1" "17 1"; do
-echo "== prod $a"; timeout 120 python tools/dbg_gs2.py $a 2>&1 | tail -1
+for cfg in "" "gs_chain=1,gs_sub_block=32" "gs_sub_block=64"; do
+echo "== cfg '$cfg'"; HOT_SOAK_CFG=$cfg timeout 600 python tools/soak.py C2 16 2>&1 | grep "^step" | awk '{it+=$4; ms+=$NF; if (NR>4) {it2+=$4; ms2+=$NF}} END {printf "all: %.2f ms/iter  steps 4..: %.3f ms/iter %.1f ms/step\n", ms/it, ms2/it2, ms2/(NR-4)}'
 done
-HOT_PROF_TOP=9 timeout 300 python tools/prof_table.py C2 2>&1 | grep -v "^$" | tail -10
-timeout 300 python tools/soak.py C2 8 2>&1 | tail -3
