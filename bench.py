@@ -100,6 +100,8 @@ def make_ctx(lib, cloud, cfg, device=0, profile=0, comm=None, **over):
     elif comm is not None:
         ctx.set_comm(comm)  # this rank's shard of ONE body (hot_amd/dist.py)
     ctx.set_particles(cloud["X"], cloud["V"], cloud["mass"], cloud["vol"], cloud["mu"], cloud["lam"])
+    if comm is not None and cloud.get("index") is not None:
+        ctx.set_particle_ids(np.asarray(cloud["index"], np.int32))  # positions in the whole body: sort-key tie break, identity of a migrating particle
     o, n = synth.sticky_floor(cloud["corner"][1], cloud["dx"])
     ctx.set_sticky_halfspaces(o, n)
     return ctx
@@ -155,6 +157,8 @@ def parse_args():
     ap.add_argument("--shard-gs", type=int, default=1, choices=[0, 1], help="N > 1, coloured GS across ranks: 1 = processor-block (one exchange per symmetric sweep; default), "
                     "0 = colour-synchronous (the single-rank iterates, sixteen exchanges per symmetric sweep)")
     ap.add_argument("--watchdog-s", type=float, default=1500.0, help="N > 1: abort the rank (exit code 3) if the run has not finished after this many seconds (a peer that died or a wedged collective would otherwise hang the job); 0 = off")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = the body grows so that every GPU keeps the configuration's particle count (default); "
+                    "strong = the configuration's own body (e.g. --config C4 --gpus 4: BASELINE's 16 M particles over four GPUs), every rank generating only its cell planes")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on device 0 (functional check of the N > 1 path on a one-GPU box, not a measurement)")
     return ap.parse_args()
 
@@ -218,8 +222,12 @@ def main():
     lib = hot_amd.load()
     cfg = dict(synth.CONFIGS[args.config])
     n1 = args.cells or cfg["n"]  # per-GPU body edge
-    n = parallel.cells_for_world(n1, world)  # edge of the one body all ranks share
-    cloud = parallel.shard_cloud(cfg, rank, world, n=n)
+    if args.scaling == "strong":
+        n = n1  # the configuration's own body whatever the number of ranks
+        cloud = parallel.slab_cloud(cfg, rank, world, n=n)
+    else:
+        n = parallel.cells_for_world(n1, world)  # edge of the one body all ranks share
+        cloud = parallel.shard_cloud(cfg, rank, world, n=n)
     Np = cloud["X"].shape[0]
     s = 8 if cfg["dtype"] == np.float64 else 4
     dt = cfg["dt"]
@@ -346,13 +354,23 @@ def main():
                "cpu_build_ms": f["ms_hessian"] + f["ms_mg_build"], "cpu_fair_build_ms": fa["ms_hessian"] + fa["ms_mg_build"], "gpu_build_ms": gp["ms_hessian"] + gp["ms_mg_build"],
                "cpu_sort_ms": f["ms_sort"], "cpu_fair_sort_ms": fa["ms_sort"]}
 
+    by_rank = None
+    if world > 1:  # what every rank handed to the collectives and where its step went (a sharded run's balance, not only rank 0's view)
+        import torch
+        last = stats[-1]
+        mine = torch.tensor([float(Np), float(last["comm_calls"]), float(last["comm_bytes_index"]), float(last["comm_bytes_data"]), last["ms_sort"], last["ms_p2g"], last["ms_begin"],
+                             last["ms_hessian"], last["ms_mg_build"], last["ms_solve"], last["ms_g2p"], last["ms_total"]], dtype=torch.float64, device=torch.device("cuda", local) if args.backend == "nccl" else "cpu")
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        keys = ("particles", "collective_calls", "index_bytes", "data_bytes", "ms_sort", "ms_p2g", "ms_begin", "ms_hessian", "ms_mg_build", "ms_solve", "ms_g2p", "ms_total")
+        by_rank = [{k: (int(v) if i < 4 else round(float(v), 2)) for i, (k, v) in enumerate(zip(keys, t.tolist()))} for t in allv]
     if rank == 0:
         out = {
             "metric": "ms per nonlinear (L-BFGS) iteration; P2G+G2P Mparticles/s; achieved HBM GB/s vs roofline",
             "value": ms_per_iter, "unit": "ms/iter", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / max(args.steps, 1), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed * 1e3 / max(args.steps, 1), "higher_is_better": False, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64" if s == 8 else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: one {n}^3-cell cube x {cfg['ppc']} ppc ({n1}^3 cells per GPU), fixed-corotated E={cfg['E']:g} nu={cfg['nu']}, dx=0.01, dt=1/24, "
+            "config": {"workload": f"{args.config}: one {n}^3-cell cube x {cfg['ppc']} ppc ({'the whole body over all GPUs' if args.scaling == 'strong' and world > 1 else str(n1) + '^3 cells per GPU'}), fixed-corotated E={cfg['E']:g} nu={cfg['nu']}, dx=0.01, dt=1/24, "
                                    f"-lsolver 3 -mg_level {cfg['levelCnt']} -smoother 5 -coarseSolver 2 --project --linesearch --bcproject --usecn -cneps 1e-7"
                                    + ({1: f", von Mises return mapping (yield {cfg.get('yield_stress', 0):g})", 2: ", snow plasticity return mapping"}.get(cfg.get("plasticity", 0), "")),
                        "particles_per_gpu": int(total_particles / world), "particles_total": int(total_particles), "nodes_total": stats[-1]["num_nodes"], "levels": stats[-1]["num_levels"],
@@ -365,6 +383,7 @@ def main():
             "communicator": (None if comm is None else ("native RCCL on the context's stream" if isinstance(comm, str) and not hasattr(ctx, "_fallback_comm") else f"torch.distributed ({args.backend})")),
             "comm_calls_per_step": ({k: v / max(args.steps + args.warmup, 1) for k, v in comm.calls.items()} if (comm is not None and not isinstance(comm, str)) else None),
             "comm_per_step_rank0": ({"collective_calls": stats[-1]["comm_calls"], "index_bytes": stats[-1]["comm_bytes_index"], "data_bytes": stats[-1]["comm_bytes_data"]} if world > 1 else None),
+            "last_step_by_rank": by_rank,
             "roofline": roof, "transfers": transfers, "cpu_baseline": cpu, "kernel_ms_per_step_top": prof_top,
         }
         print(json.dumps(out))

@@ -42,6 +42,34 @@ def cube_cloud(n, ppc=8, dx=0.01, corner=(5.0, 5.0, 5.0), E=5e4, nu=0.3, rho=200
                 mu=np.full(Np, mu, T), lam=np.full(Np, lam, T), dx=dx)
 
 
+def cube_slab(n, x0, x1, ppc=8, dx=0.01, corner=(5.0, 5.0, 5.0), E=5e4, nu=0.3, rho=2000.0, dtype=np.float64, seed=123, omega=(0.0, 0.0, 2.0), noise=0.1):
+    """The cell planes x0 <= i < x1 of an n^3-cell block like cube_cloud's, generated plane by plane from per-plane random streams: any
+    partition of the planes among processes yields the same body, and nobody has to hold all of it (bench.py --scaling strong).  "index" =
+    the particles' positions in the whole body (plane-major): their global ids."""
+    fx, fy, fz = _FACT[ppc]
+    cj, ck = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    si, sj, sk = np.meshgrid(np.arange(fx), np.arange(fy), np.arange(fz), indexing="ij")
+    sub = np.stack([si.ravel() / fx, sj.ravel() / fy, sk.ravel() / fz], 1)
+    ext = np.array([1.0 / fx, 1.0 / fy, 1.0 / fz])
+    centre = np.asarray(corner) + 0.5 * dx * n
+    per_plane = n * n * ppc
+    Xs, Vs, ids = [], [], []
+    for i in range(x0, x1):
+        rng = np.random.default_rng([seed, i])
+        cell = np.stack([np.full(n * n, float(i)), cj.ravel().astype(np.float64), ck.ravel().astype(np.float64)], 1)
+        jit = 0.1 + 0.8 * rng.random((n * n, ppc, 3))
+        X = (cell[:, None, :] + sub[None, :, :] + jit * ext[None, None, :]).reshape(-1, 3) * dx + np.asarray(corner)
+        V = np.cross(np.asarray(omega)[None, :], X - centre[None, :]) + noise * rng.standard_normal((per_plane, 3))
+        perm = rng.permutation(per_plane)  # the caller's particle order is not the sorted order
+        Xs.append(X[perm]), Vs.append(V[perm]), ids.append((i * per_plane + perm).astype(np.int64))
+    X, V = (np.concatenate(a) if a else np.zeros((0, 3)) for a in (Xs, Vs))
+    Np = X.shape[0]
+    mu, lam = lame(E, nu)
+    T = dtype
+    return dict(X=X.astype(T), V=V.astype(T), mass=np.full(Np, rho * dx ** 3 / ppc, T), vol=np.full(Np, dx ** 3 / ppc, T), mu=np.full(Np, mu, T), lam=np.full(Np, lam, T), dx=dx,
+                index=(np.concatenate(ids) if ids else np.zeros(0, np.int64)))
+
+
 def sticky_floor(corner_y, dx, layers=2):
     """Half space {y <= corner_y + (layers-0.5)*dx}: the bottom `layers` node layers of a cloud whose lowest
     cell starts at corner_y (node layer k sits at corner_y + k*dx ... the kernel reaches one layer below)."""

@@ -161,6 +161,20 @@ def test_c2_size_body_over_two_ranks_hip(hotlib, shard_gs):
     assert ranks[0]["stats"]["comm_bytes_data"] < 100e6 and max(o["stats"]["comm_bytes_data"] for o in ranks) < 450e6, [o["stats"] for o in ranks]
 
 
+def test_c4_size_body_four_levels_over_two_ranks_hip(hotlib):
+    """BASELINE config 4's body size sharded: a 126^3-cell cube (16.0 M particles, 2.1 M nodes), FOUR levels, over two ranks (8 M
+    particles each).  Colour-synchronous GS: two L-BFGS iterations (Hessian rows completed across the cut, a 4-level hierarchy whose upper
+    levels are replicated, halos on 2.1 M-row vectors, int64 offsets everywhere) reproduce the single-rank run to round-off."""
+    kw = dict(lsolver=3, levelCnt=4, max_iterations=2, cneps=1e-7)
+    ranks = mw.launch(2, "hip", 126, 1, kw, partition_min_rows=0, timeout=3000)
+    ref = mw.single(hotlib, 126, 1, kw)
+    assert ref["stats"]["num_levels"] == 4 and ref["stats"]["num_nodes"] > 2.0e6
+    mw.compare(ranks, ref, 1e-10)
+    for r, o in enumerate(ranks):
+        st = o["stats"]
+        print("C4-size body, 2 ranks, 2 iterations, rank %d: data bytes %.1f MB, index bytes %.1f MB, %d collective calls" % (r, st["comm_bytes_data"] / 1e6, st["comm_bytes_index"] / 1e6, st["comm_calls"]))
+
+
 def test_whole_steps_over_two_ranks_hip(hotlib):
     kw = dict(lsolver=3, levelCnt=3, cneps=1e-6)
     ranks = mw.launch(2, "hip", 8, 1, kw, steps=2, partition_min_rows=1)

@@ -175,7 +175,7 @@ def test_three_time_steps_fp32_against_fp32_oracle(hotlib, oracle):
     after that.  What is comparable: a bounded number of iterations from one and the same state, for as long as the discrete decisions
     agree.  At the start of each of three consecutive time steps (the trajectory itself is advanced by the HIP library's converged fp32
     solve) both sides take k = 1..4 L-BFGS iterations from identical particle data; while their counters (line-search trials, linear
-    iterations, dropped pairs) agree, dv must agree within 1e-4 of max|dv| and the energies within 1e-5 on the first step, 5e-3 (1e-1 at k = 4) / 1e-2 on
+    iterations, dropped pairs) agree, dv must agree within 1e-4 of max|dv| and the energies within 1e-5 on the first step, 3e-3 (6e-2 at k = 4) / 1e-2 on
     the later ones (relative, floor 1e-3).  The
     oracle runs its wide-sums variant (node sums and inner products in double, like the HIP build: tests/oracle_lib.py wide_sums).
     Round 2 needed dt = 0.03 and 5e-3 here: the B-spline fraction was then evaluated from the rounded product X / dx (3e-5 of a cell in
@@ -226,7 +226,7 @@ def test_three_time_steps_fp32_against_fp32_oracle(hotlib, oracle):
             # time step and the float errors are amplified by the solve (measured 3e-6 - 2.3e-3 and 1e-7 - 5e-3)
             # (on the later steps every iteration amplifies the difference 10 - 20 x: measured 2e-6, 1.4e-4, 1.3e-3, 3e-2 for k = 1..4, so the
             # fourth iteration is held to 1e-1 only and judged on the energy)
-            assert err < (1e-4 if step == 0 else (5e-3 if its < 4 else 1e-1)), err
+            assert err < (1e-4 if step == 0 else (3e-3 if its < 4 else 6e-2)), err  # growth 10 - 20 x per iteration on the later steps (cond ~ 1e8): 2e-6, 1.4e-4, 1.3e-3, 3e-2 measured
             assert abs(sg["energy"] - sc["energy"]) < (1e-5 if step == 0 else 1e-2) * max(abs(sc["energy"]), 1e-3)
             compared += 1
         full = ctx_for(hotlib, max_iterations=300, cneps=1e-4)
