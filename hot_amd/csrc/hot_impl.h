@@ -288,6 +288,7 @@ struct Ctx : CtxBase {
             __builtin_ia32_pause();
             if ((spin & 1023u) == 1023u && wall_ms() - t0 > 20.0) {
                 HOT_HIP(hipStreamSynchronize(stream));
+                if (*(volatile int*)(hscal + 250) != 0) sync(); // a spinning kernel (k_gs_sweep, k_cg_persist) gave up: throws ERR_RETRY, the caller redoes the operation with launches
                 HOT_CHECK(*t == want, HOT_ERR_DEVICE, "a reduction launch did not deliver its result");
                 break;
             }
@@ -298,6 +299,8 @@ struct Ctx : CtxBase {
     DBuf<uint64_t> col_hk; // mark_colors scratch (block hash map, colour block heads)
     DBuf<unsigned long long> col_hr;
     DBuf<int32_t> col_hi, col_cb;
+    DBuf<unsigned> cg_bar; // k_cg_persist: barrier arrival counter + exit counter (zero between launches)
+    DBuf<double> cg_dep; // its dot-product deposits, two alternating sets of two per workgroup
     int cg_group = 2; // iterations the last fused top-level PCG took: size of the first group of launches of the next one
     int gs_epoch = 0; // sweep number, never reused inside a context
     bool attr_tiles_set = false, attr_gs_set = false; // dynamic-LDS limits raised on this context's device (hipFuncSetAttribute is per device)

@@ -251,6 +251,159 @@ __global__ void k_cg_direction(size_t n3, const T* __restrict__ z, T* __restrict
         if (ticket) host_ticket_store(ticket, ticket_val); // last launch of a group: the host is waiting for hm (Ctx::wait_ticket)
     }
 }
+// ---- cg_smooth on a SMALL top level as ONE persistent launch (C2 level 2: 5.4 k rows, a 49 MB matrix, ~6 iterations per V-cycle): the
+// three launches per iteration above cost ~20 us each there, an iteration's arithmetic 10 us.  One workgroup per compute unit at most, rows
+// dealt to wavefronts once and for all (a wavefront touches only its own rows of u, r, z, dAu: plain loads / stores); du is the one vector
+// read across workgroups (the SpMV's gathers): published with write-through stores and read with agent-scope loads, like k_gs_sweep's
+// unknowns.  Three grid barriers per iteration (arrival counter + spin, all workgroups are resident); a dot product = every workgroup
+// deposits its partial sum before the barrier and adds ALL deposits in index order after it, so every workgroup holds the same bits and
+// takes the same exit decision.  Same recurrences as k_cg_spmv_dot / k_cg_update / k_cg_direction; only the association of the dot
+// products differs.  count / exitc are zero between launches (the last workgroup to leave resets them).
+template <class T>
+__global__ __launch_bounds__(1024) void k_cg_persist(const int32_t* __restrict__ col, const T* __restrict__ val, const T* __restrict__ Dinv, const T* __restrict__ init, T* __restrict__ u,
+    T* __restrict__ r, T* __restrict__ z, T* du, T* __restrict__ dAu, int n, int max_iters, unsigned* count, double* dep /*[2][2][gridDim.x]*/, double* hm, double* ticket, double ticket_val,
+    int* err /*pinned host word (k_gs_sweep's): a barrier that does not complete — the workgroups are not all resident because something else holds the chip — sets it; the host redoes the solve with launches*/)
+{
+    __shared__ double red[32], sdep[2][256], sres[2];
+    __shared__ int s_bail;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int G = gridDim.x, wg = blockIdx.x;
+    unsigned phase = 0;
+    auto ldu = [&](int64_t j, int c) { return __hip_atomic_load(du + 3 * j + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto sdu = [&](int64_t j, int c, T v) { __hip_atomic_store(du + 3 * j + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // workgroup-wide fixed-order sum of the wavefronts' lane-0 values, deposit, barrier, ordered sum of all deposits -> (o0, o1) everywhere
+    auto all_sum = [&](double v0, double v1, double& o0, double& o1) -> bool {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every thread's write-through stores of du have been performed before its workgroup is counted
+        if (lane == 0) red[w] = v0, red[16 + w] = v1;
+        __syncthreads();
+        double* d = dep + (size_t)(phase & 1u) * 2 * G;
+        if (tid == 0) {
+            double t0 = 0, t1 = 0;
+            for (int k = 0; k < 16; ++k) t0 += red[k], t1 += red[16 + k];
+            __hip_atomic_store(d + wg, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d + G + wg, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // ... and so have the deposits
+            // two-level arrival: 256 read-modify-writes of ONE word serialise at the memory side (~12 us a barrier, measured); eight group
+            // counters in separate lines take 32 each, the last arrival of a group bumps the top word everybody polls
+            const unsigned grp = (unsigned)wg & 7u, ngrp = (unsigned)min(G, 8), gsz = ((unsigned)G - grp + 7u) / 8u;
+            const unsigned prev = __hip_atomic_fetch_add(count + 32 * (1 + grp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev + 1u == (phase + 1u) * gsz) __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (phase + 1u) * ngrp;
+            int spins = 0, bail = 0;
+            while (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22) || ((spins & 255) == 0 && *(volatile int*)err)) {
+                    *(volatile int*)err = 1;
+                    bail = 1;
+                    break;
+                }
+            }
+            s_bail = bail;
+        }
+        __syncthreads();
+        if (s_bail) return false; // workgroup-uniform
+        if (tid < G) sdep[0][tid] = __hip_atomic_load(d + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sdep[1][tid] = __hip_atomic_load(d + G + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tid < 2) {
+            double a = 0;
+            for (int k = 0; k < G; ++k) a += sdep[tid][k];
+            sres[tid] = a;
+        }
+        __syncthreads();
+        o0 = sres[0], o1 = sres[1];
+        ++phase;
+        return true;
+    };
+    auto scale = [&](int64_t i, const T (&v)[3], T (&o)[3]) {
+        const T* d = Dinv + 9 * i;
+        o[0] = d[0] * v[0] + d[3] * v[1] + d[6] * v[2], o[1] = d[1] * v[0] + d[4] * v[1] + d[7] * v[2], o[2] = d[2] * v[0] + d[5] * v[1] + d[8] * v[2];
+    };
+    const int stride = 16 * G;
+    // ---- set-up: z'r of the reference residual (the tolerance) and of r; du = z = Dinv r
+    double p0 = 0, p1 = 0;
+    for (int row = wg * 16 + w; row < n; row += stride) {
+        if (lane == 0) {
+            T a[3] = { init[3 * (int64_t)row], init[3 * (int64_t)row + 1], init[3 * (int64_t)row + 2] }, za[3];
+            scale(row, a, za);
+            p0 += (double)(za[0] * a[0]) + (double)(za[1] * a[1]) + (double)(za[2] * a[2]);
+            T b[3] = { r[3 * (int64_t)row], r[3 * (int64_t)row + 1], r[3 * (int64_t)row + 2] }, zb[3];
+            scale(row, b, zb);
+            for (int c = 0; c < 3; ++c) z[3 * (int64_t)row + c] = zb[c], sdu(row, c, zb[c]);
+            p1 += (double)(zb[0] * b[0]) + (double)(zb[1] * b[1]) + (double)(zb[2] * b[2]);
+        }
+    }
+    double zTr0, zTr;
+    if (!all_sum(p0, p1, zTr0, zTr)) return;
+    const double tol = (double)(T)(zTr0 * 0.25); // cgratio 0.5, squared (MultigridPreconditioner.h:203-209)
+    int cnt = 0;
+    for (; cnt < max_iters && cg_active(zTr, tol); ++cnt) {
+        // dAu = A du on this workgroup's rows, du'dAu
+        double pd = 0;
+        for (int row = wg * 16 + w; row < n; row += stride) {
+            const int32_t* c = col + (int64_t)row * 125;
+            const T* v = val + (int64_t)row * 1125;
+            T s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = lane + 64 * q;
+                if (k < 125) {
+                    const int64_t j = c[k];
+                    const T* b = v + k * 9;
+                    const T x0 = ldu(j, 0), x1 = ldu(j, 1), x2 = ldu(j, 2);
+                    s0 += b[0] * x0 + b[3] * x1 + b[6] * x2;
+                    s1 += b[1] * x0 + b[4] * x1 + b[7] * x2;
+                    s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
+                }
+            }
+            s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
+            if (lane == 0) {
+                dAu[3 * (int64_t)row] = s0, dAu[3 * (int64_t)row + 1] = s1, dAu[3 * (int64_t)row + 2] = s2;
+                pd += (double)(s0 * ldu(row, 0)) + (double)(s1 * ldu(row, 1)) + (double)(s2 * ldu(row, 2));
+            }
+        }
+        double dAd, unused;
+        if (!all_sum(pd, 0.0, dAd, unused)) return;
+        // u += w du ; r -= w A du ; z = Dinv r ; z'r
+        const double omega = zTr / dAd;
+        const T wp = (T)omega, wm = (T)(-omega);
+        double pz = 0;
+        for (int row = wg * 16 + w; row < n; row += stride) {
+            if (lane == 0) {
+                T rr[3], zz[3];
+                for (int c = 0; c < 3; ++c) {
+                    u[3 * (int64_t)row + c] += wp * ldu(row, c);
+                    rr[c] = r[3 * (int64_t)row + c] + wm * dAu[3 * (int64_t)row + c];
+                    r[3 * (int64_t)row + c] = rr[c];
+                }
+                scale(row, rr, zz);
+                for (int c = 0; c < 3; ++c) z[3 * (int64_t)row + c] = zz[c];
+                pz += (double)(zz[0] * rr[0]) + (double)(zz[1] * rr[1]) + (double)(zz[2] * rr[2]);
+            }
+        }
+        double zTrNew;
+        if (!all_sum(pz, 0.0, zTrNew, unused)) return;
+        // du = z + b du, published before the next SpMV gathers it
+        const T beta = (T)(zTrNew / zTr);
+        for (int row = wg * 16 + w; row < n; row += stride)
+            if (lane == 0)
+                for (int c = 0; c < 3; ++c) sdu(row, c, z[3 * (int64_t)row + c] + beta * ldu(row, c));
+        zTr = zTrNew;
+        if (!all_sum(0.0, 0.0, unused, unused)) return;
+    }
+    if (tid == 0) {
+        if (wg == 0) {
+            hm[0] = zTr, hm[1] = (double)cnt, hm[2] = tol;
+            if (ticket) host_ticket_store(ticket, ticket_val);
+        }
+        // the last workgroup to leave re-arms the counters (everybody is past every barrier by then)
+        const unsigned prev = __hip_atomic_fetch_add(count + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == (unsigned)G - 1u) {
+            for (int k = 0; k < 9; ++k) __hip_atomic_store(count + 32 * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 template <class T>
 __global__ void k_scal_v(size_t n, T a, T* x)
 {
@@ -1249,7 +1402,18 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         const bool fused = !cg_unfused && !(level == 0 && !cfg.systemBCProject) && !L.part; // (partitioned level: the generic path below, whose SpMV exchanges)
         int cnt = 0;
         double zTrk = 0, tol = 0;
-        if (fused) {
+        if (fused && L.n <= 65536 && !gs_no_chain && !sharded() && !ab_flag("HOT_CG_LAUNCHES")) { // (not when ranks may share a device, nor after a spinning kernel has timed out on this context) // A/B build: HOT_CG_LAUNCHES = three launches per iteration on small levels too
+            // the whole solve in one persistent launch (k_cg_persist), one host round trip for the iteration count
+            const int G = std::min(256, div_up(L.n, 16));
+            cg_bar.reserve(32 * 9 + 8), cg_dep.reserve(4 * 256);
+            HOT_HIP(hipMemsetAsync(cg_bar.p, 0, (32 * 9 + 8) * sizeof(unsigned), stream));
+            HOT_LAUNCH(this, lname("cg_persistent", L.id).c_str(), k_cg_persist<T>, G, 1024, 0, L.col.p, L.val.p, L.diagInv.p, L.initialResidual.p, u, r, z, du, dAu, L.n, iterations, cg_bar.p, cg_dep.p,
+                hscal + 40, hscal + 251, new_ticket(), (int*)(hscal + 250));
+            wait_ticket(); // a timed-out barrier shows in hscal[250]: sync() inside throws ERR_RETRY and the caller redoes the operation with launches
+            cnt = (int)hscal[41];
+            iterations = 0;
+        }
+        else if (fused) {
             // no host round trip before the first iteration and one per group of iterations afterwards (see k_cg_setup)
             scaler(L.initialResidual.p, z);
             dot_to(n3, z, L.initialResidual.p, s + 7);
