@@ -31,6 +31,7 @@ CASES = [
     ({"HOT_MG_FULL_SPMV": "1"}, SOLVER, "vcycle or iterates"),
     ({"HOT_LBFGS_UNFUSED": "1"}, SOLVER, "iterates"),
     ({"HOT_CG_UNFUSED": "1"}, SOLVER, "smoothers or vcycle or iterates"),
+    ({"HOT_CG_LAUNCHES": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # three launches per PCG iteration instead of the persistent launch on small top levels
     ({"HOT_HESSIAN_V1": "1"}, SOLVER, "hessian_and_hierarchy"),
     ({"HOT_HESSIAN_TILES_V1": "1"}, SOLVER, "hessian_and_hierarchy"),
     ({"HOT_HESSIAN_MFMA": "1"}, SOLVER, "hessian_and_hierarchy"),  # pair phase on v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32
