@@ -525,12 +525,12 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
     L.gs_pad.reserve(512 * (size_t)L.nblocks);
     HOT_LAUNCH(ctx, "gs_pad", k_gs_pad, div_up((size_t)L.nblocks * 64, 256), 256, 0, L.gs_block_start.p, L.gs_order.p, L.rowcnt.p, L.gs_pad.p, L.nblocks);
     L.split = true;
-    // levels whose colours hold more than 64 blocks (smooth_dev: below that the chained single-launch sweep wins) run the off-block / substitution kernel
+    // levels whose colours hold more blocks than the chip has compute units (smooth_dev: below that the chained single-launch sweep is as fast) run the off-block / substitution kernel
     // pair, which reads the in-block couplings from premultiplied images
     int max_nb = 0;
     for (int c = 0; c < 8; ++c) max_nb = std::max(max_nb, L.color_block_begin[c + 1] - L.color_block_begin[c]);
     L.gs_img_ready = false;
-    if (!L.part && (max_nb > 64 || ctx->cfg.gs_sub_block == 32)) {
+    if (!L.part && (max_nb > 256 || ctx->cfg.gs_sub_block == 32)) {
         L.gs_img.reserve(GsImg<T>::per_block * (size_t)L.nblocks + 16), // + one entry: k_gs_subst's unconditional loads
         L.gs_imgm.reserve(GsImg<T>::masks_per_block * (size_t)L.nblocks), L.gs_p1.reserve(192 * (size_t)L.nblocks);
         HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, L.nblocks, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p, L.gs_imgm.p, L.nblocks);

@@ -1546,7 +1546,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         // workgroups per CU, one round per launch); small levels are latency-bound per launch and keep whole blocks
         int max_nb = 0;
         for (int c = 0; c < 8; ++c) max_nb = std::max(max_nb, L.color_block_begin[c + 1] - L.color_block_begin[c]);
-        const int sb = env_sb ? env_sb : (max_nb > 64 ? 32 : 64);
+        const int sb = env_sb ? env_sb : (max_nb > 256 ? 32 : 64);
         const int gs_threads = sb == 64 ? 1024 : 512;
         const int nsub = 64 / sb;
         HOT_CHECK(L.split || simple_gs, HOT_ERR_INVALID, "block GS kernels need the regrouped rows (k_gs_split_rows)");
@@ -1624,7 +1624,9 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 const T* direct = first ? rhs : (const T*)nullptr;
                 if (!first) HOT_LAUNCH(this, lname(nmO, L.id).c_str(), k_gs_offblock<T>, grid, 1024, 0, L.gs_col.p, L.val.p, L.gs_pad.p, rhs, xx, L.gs_p1.p, pos0, npos, fwd ? 1 : 0);
                 // (eight columns in flight per block: sixteen change nothing, neither on the finest level, HBM-bound, nor on C2's level 1 with 91
-                // blocks a colour, where a step costs its ~45 dependent-issue instructions, 190 ns)
+                // blocks a colour, where a step costs its ~45 dependent-issue instructions, 190 ns.  On such a level — colours that fit the chip at
+                // once — the pair equals the chained k_gs_sweep in kernel time, 12.7 vs 12.2 ms per C2 step, and both kernels of a colour in ONE launch,
+                // substitution waves spinning on their block's arrival counter, were slower: 43 vs 24 us per colour.  k_gs_sweep stays there.)
                 if (fwd)
                     HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgm.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, direct);
                 else
@@ -1639,7 +1641,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         const bool multilaunch = cfg.gs_chain == 1, force_dataflow = cfg.gs_chain == 2; // tuning overrides (0 = by level size)
         // measured (C2, fp64): the chained launch wins on levels whose colours fit the chip in one round (latency-bound
         // passes, no launch gaps); on the finest level the waiting workgroups cost more than the kernel boundaries
-        const bool dataflow = !gs_no_chain && !multilaunch && !simple_gs && L.split && !L.part && (force_dataflow || max_nb <= 64); // a chained launch cannot stop for the exchange
+        const bool dataflow = !gs_no_chain && !multilaunch && !simple_gs && L.split && !L.part && (force_dataflow || max_nb <= 256); // a chained launch cannot stop for the exchange
         GsPasses PF{}, PB{};
         if (dataflow) {
             auto add = [&](GsPasses& P, int c, int h) {
