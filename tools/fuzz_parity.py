@@ -67,7 +67,8 @@ def main():
         err = None
         for name, lib in (("gpu", hip), ("cpu", cpu)):
             try:
-                ctx = lib.context(dtype=dtype, dx=c["dx"], gravity=(0, -9.8, 0), **kw)
+                over = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("HOT_FUZZ_CFG", "").split(",") if kv)} if name == "gpu" else {}  # e.g. HOT_FUZZ_CFG=ls_energy_only=1: HIP-only knobs
+                ctx = lib.context(dtype=dtype, dx=c["dx"], gravity=(0, -9.8, 0), **dict(kw, **over))
                 ctx.set_particles(c["X"][keep], c["V"][keep], c["mass"][keep], c["vol"][keep], mu[keep], lam[keep])
                 o, nrm = synth.sticky_floor(float(X[keep][:, 1].min()) - 0.002, c["dx"])
                 ctx.set_sticky_halfspaces(o, nrm)
