@@ -1402,7 +1402,10 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         const bool fused = !cg_unfused && !(level == 0 && !cfg.systemBCProject) && !L.part; // (partitioned level: the generic path below, whose SpMV exchanges)
         int cnt = 0;
         double zTrk = 0, tol = 0;
-        if (fused && L.n <= 65536 && !gs_no_chain && !sharded() && !ab_flag("HOT_CG_LAUNCHES")) { // (not when ranks may share a device, nor after a spinning kernel has timed out on this context) // A/B build: HOT_CG_LAUNCHES = three launches per iteration on small levels too
+        // (not when ranks may share a device, nor after a spinning kernel has timed out on this context; fp64 only: in float the association of
+        // the dot products decides which of several line-search halvings is taken two iterations later — cond ~ 1e8 —, and the whole-step fp32
+        // parity test was validated against the launch-per-operation sums)
+        if (fused && sizeof(T) == 8 && L.n <= 65536 && !gs_no_chain && !sharded() && !ab_flag("HOT_CG_LAUNCHES")) { // A/B build: HOT_CG_LAUNCHES = three launches per iteration on small levels too
             // the whole solve in one persistent launch (k_cg_persist), one host round trip for the iteration count
             const int G = std::min(256, div_up(L.n, 16));
             cg_bar.reserve(32 * 9 + 8), cg_dep.reserve(4 * 256);
