@@ -407,8 +407,10 @@ __host__ __device__ inline uint64_t coord_key(int x, int y, int z) { return ((ui
 // neither the kernels nor any getenv.
 #ifdef HOT_AB_KERNELS
 inline bool ab_flag(const char* name) { return getenv(name) != nullptr; }
+inline int ab_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 #else
 constexpr bool ab_flag(const char*) { return false; }
+constexpr int ab_int(const char*, int dflt) { return dflt; }
 #endif
 
 inline double wall_ms()

@@ -43,11 +43,13 @@ struct Level {
     DBuf<int32_t> apc; // n*64: coarse column of every window slot (0 where the coarse node does not exist; its block is 0)
     DBuf<int32_t> gs_nbr; // nblocks*26: the adjacent colour blocks (global block id | colour << 28, or -1): whose unknowns a block's rows read
     DBuf<int> gs_flag; // 4*nblocks: sweep number in which the (block, sub-block) was last finished (k_gs_sweep's point-to-point hand-off)
-    DBuf<int32_t> gs_pad; // nblocks*64*8: per (colour block, position) {node or -1, the row's four class counts, pad}: the GS kernels' header in one load
+    DBuf<int32_t> gs_pad; // nblocks*64*8 (+ one sentinel record): per (colour block, position) {node or -1, the row's four class counts, first forward slot, first backward slot, pad}: the GS kernels' header in one load
     DBuf<int32_t> gs_col; // n*125: col after the regrouping with in-block columns replaced by -1 - (position in the colour block): k_gs_block2 tells triangle entries from gathers without fetching ckey[j]
     DBuf<T> gs_img; // nblocks * GsImg<T>::per_block: premultiplied in-block couplings in the order k_gs_subst consumes them (k_gs_images, mg_build.hip)
     DBuf<unsigned long long> gs_imgm; // nblocks * GsImg<T>::masks_per_block: which rows have an entry in each column of the images
-    DBuf<T> gs_p1; // nblocks*64*3, by (block, position): rhs minus the off-block part of the row sums (k_gs_offblock -> k_gs_subst)
+    DBuf<T> gs_p1; // 3 per slot: the off-block products summed over the slot's (up to 16) entries (k_gs_offblock -> k_gs_subst, which subtracts a row's slots from its rhs in order)
+    DBuf<int2> gs_slot; // {first stored entry (row * 125 + k), entries} per slot (k_gs_slot_fill); gs_pad[8 pos + 5 / 6]: the position's first forward / backward slot
+    int gs_nslot = 0;
     bool gs_img_ready = false;
     DBuf<int32_t> rowcnt; // 4n: (precede-off, precede-in, follow-in, follow-off) slot counts of the regrouped rows
     bool split = false;

@@ -437,6 +437,40 @@ __global__ void k_gs_pad(const int32_t* __restrict__ block_start, const int32_t*
     o[5] = o[6] = o[7] = 0;
 }
 
+// Off-block slots for k_gs_offblock (mg_solve.hip): a row's preceding (forward sweep) / following (backward sweep) off-block columns are cut
+// into runs of up to 16 stored entries, numbered over the level in (colour block, position) order — all forward slots first, then all
+// backward ones — so that every colour's slots of a direction are one contiguous range and 16-lane groups of a wavefront take one slot
+// each whatever the row lengths (3 to 98 entries a row on C2: one wavefront per row leaves more than half of its lanes without an entry).
+//   count: flags[pos] = forward slots of the position, flags[npos + pos] = backward slots
+//   fill : gs_pad[8 pos + 5 / 6] = first forward / backward slot of the position (record npos: the end sentinels), slot[s] = {first entry, count}
+__global__ void k_gs_slot_count(const int32_t* __restrict__ pad, int32_t* __restrict__ flags, int npos)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npos) return;
+    const int32_t* o = pad + 8 * (int64_t)e;
+    const bool node = o[0] >= 0;
+    flags[e] = node ? (o[1] + 15) >> 4 : 0, flags[npos + e] = node ? (o[4] + 15) >> 4 : 0;
+}
+__global__ void k_gs_slot_fill(int32_t* __restrict__ pad, const int32_t* __restrict__ scan, int2* __restrict__ slot, int npos, int total)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > npos) return;
+    int32_t* o = pad + 8 * (int64_t)e;
+    if (e == npos) { // sentinel record: where the last colour's ranges end
+        o[0] = -1, o[1] = o[2] = o[3] = o[4] = 0, o[5] = scan[npos], o[6] = total, o[7] = 0;
+        return;
+    }
+    const int sf = scan[e], sb = scan[npos + e];
+    o[5] = sf, o[6] = sb;
+    const int node = o[0];
+    if (node < 0) return;
+    const int po = o[1], pi = o[2], fi = o[3], fo = o[4];
+    const int base = node * 125; // entry index (< 2^31: 125 slots a row, up to 17 M rows)
+    for (int q = 0; 16 * q < po; ++q) slot[sf + q] = make_int2(base + 16 * q, min(16, po - 16 * q));
+    const int kb = po + pi + 1 + fi;
+    for (int q = 0; 16 * q < fo; ++q) slot[sb + q] = make_int2(base + kb + 16 * q, min(16, fo - 16 * q));
+}
+
 // In-block images for the finest-level GS kernels (layout: GsImg, hot_impl.h; consumer: k_gs_subst, mg_solve.hip).  One workgroup per
 // colour block: (1) every row marks itself in the masks of the columns it couples to (LDS), (2) column offsets = running popcounts,
 // (3) every entry -(D_r^-1 A_rc) goes to [offset of column c + rank of r among the column's rows].
@@ -522,7 +556,7 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
     if (L.part) HOT_HIP(hipMemsetAsync(L.rowcnt.p, 0, 4 * (size_t)L.n * sizeof(int32_t), ctx->stream)); // rows of other ranks: no matrix, zero counts
     L.gs_col.reserve(125 * (size_t)L.n);
     HOT_LAUNCH(ctx, "gs_split_rows", k_gs_split_rows<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.ckey.p, L.rowcnt.p, L.n, L.mask(), L.gs_col.p);
-    L.gs_pad.reserve(512 * (size_t)L.nblocks);
+    L.gs_pad.reserve(512 * (size_t)L.nblocks + 8); // + the sentinel record of k_gs_slot_fill
     HOT_LAUNCH(ctx, "gs_pad", k_gs_pad, div_up((size_t)L.nblocks * 64, 256), 256, 0, L.gs_block_start.p, L.gs_order.p, L.rowcnt.p, L.gs_pad.p, L.nblocks);
     L.split = true;
     // levels whose colours hold more blocks than the chip has compute units (smooth_dev: below that the chained single-launch sweep is as fast) run the off-block / substitution kernel
@@ -532,7 +566,13 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
     L.gs_img_ready = false;
     if (!L.part && (max_nb > 256 || ctx->cfg.gs_sub_block == 32)) {
         L.gs_img.reserve(GsImg<T>::per_block * (size_t)L.nblocks + 16), // + one entry: k_gs_subst's unconditional loads
-        L.gs_imgm.reserve(GsImg<T>::masks_per_block * (size_t)L.nblocks), L.gs_p1.reserve(192 * (size_t)L.nblocks);
+        L.gs_imgm.reserve(GsImg<T>::masks_per_block * (size_t)L.nblocks);
+        const int npos = 64 * L.nblocks;
+        ctx->flags.reserve(2 * (size_t)npos), ctx->scan.reserve(2 * (size_t)npos);
+        HOT_LAUNCH(ctx, "gs_slot_count", k_gs_slot_count, div_up((size_t)npos, 256), 256, 0, L.gs_pad.p, ctx->flags.p, npos);
+        L.gs_nslot = ctx->exclusive_scan_i32(ctx->flags.p, ctx->scan.p, 2 * (size_t)npos);
+        L.gs_slot.reserve((size_t)L.gs_nslot + 8), L.gs_p1.reserve(3 * ((size_t)L.gs_nslot + 8)); // + what the kernels' unconditional (clamped, dropped) loads may touch
+        HOT_LAUNCH(ctx, "gs_slot_fill", k_gs_slot_fill, div_up((size_t)npos + 1, 256), 256, 0, L.gs_pad.p, ctx->scan.p, L.gs_slot.p, npos, L.gs_nslot);
         HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, L.nblocks, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p, L.gs_imgm.p, L.nblocks);
         L.gs_img_ready = true;
     }

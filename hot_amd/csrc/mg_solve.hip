@@ -865,68 +865,67 @@ __device__ __forceinline__ T row16_sum(T v) // sum over each 16-lane DPP row; va
     return v;
 }
 template <class T>
-__global__ __launch_bounds__(1024) void k_gs_offblock(const int32_t* __restrict__ gcol, const T* __restrict__ val, const int32_t* __restrict__ gs_pad, const T* __restrict__ rhs,
-    const T* __restrict__ x, T* __restrict__ p1, int64_t pos0, int64_t npos, int FWD /*forward sweep: the off-block columns preceding the row; else those following it*/)
+struct GsOffItem { // what a 16-lane group has in flight for its slot between the value loads and the sums
+    int j;
+    bool valid;
+    T bv[9];
+};
+// Four slots (runs of up to 16 stored off-block entries of one row, k_gs_slot_fill) per wavefront and step, one per 16-lane group, as a
+// software pipeline: the slot descriptors of step n+2 (scalar cache), the column ids + values of step n+1 and the gathers of step n are
+// in flight together — the descriptor -> values -> gathers chain of dependent round trips is paid once per wavefront, not per row.
+// Why slots: with one wavefront per row (rows of 3..98 entries) more than half of the lanes of every load carry nothing, and the kernel
+// is bound by the load instructions a compute unit can retire (measured: the same time with 4096 or 16384 wavefronts resident), not by HBM.
+// Branch-free on purpose (see k_gs_subst): a lane past the slot's end reads the slot's first entry and its product is dropped by a
+// select — a load under a branch, even a wave-uniform one, is a join at which the compiler waits for ALL loads in flight.
+// Sums: fixed-order DPP tree over the group's 16 lanes (wave_sum's first four additions); the group's lane 15 stores the slot's three sums,
+// k_gs_subst subtracts a row's slots from its right-hand side in slot order.
+template <class T>
+__global__ __launch_bounds__(256) void k_gs_offblock(const int2* __restrict__ slot, const int32_t* __restrict__ gcol, const T* __restrict__ val, const int32_t* __restrict__ gs_pad,
+    const T* __restrict__ x, T* __restrict__ part, int64_t pos0, int npos, int FWD /*forward sweep: the off-block columns preceding the row; else those following it*/)
 {
-    // two rows (adjacent positions of a block) per wavefront, side by side: a wavefront spends two thirds of its life waiting for something
-    // other than matrix values (header record, then the gathers), so one row per wavefront leaves HBM half idle even at eight per SIMD
-    const int lane = threadIdx.x & 63;
-    const int64_t e0 = 2 * ((int64_t)blockIdx.x * 16 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))); // wave-uniform, and known to be: the two row records come through the scalar cache, both at once
-    if (e0 >= npos) return;
-    int row[2], kb[2], ke[2], j[2];
-    T bv[2][9], rh[2][3];
-    int rec[2][5];
+    const int lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
+    const int s_begin = gs_pad[8 * pos0 + (FWD ? 5 : 6)], s_end = gs_pad[8 * (pos0 + npos) + (FWD ? 5 : 6)];
+    const int nstep = (s_end - s_begin + 3) >> 2, W = gridDim.x * 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))); // wave-uniform, and known to be: descriptors come through the scalar cache
+    if (w >= nstep) return;
+    auto descriptor = [&](int n) __attribute__((always_inline)) { // of this lane's group (past the colour's last slot: the last slot's again)
+        return slot[min(s_begin + 4 * min(n, nstep - 1) + g, s_end - 1)];
+    };
+    auto values = [&](int n, const int2 d, GsOffItem<T>& R) __attribute__((always_inline)) {
+        R.valid = n < nstep && s_begin + 4 * n + g < s_end && l16 < d.y;
+        const int64_t e = (int64_t)d.x + (R.valid ? l16 : 0);
+        R.j = gcol[e];
+        const T* bb = val + e * 9;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int32_t* rp = gs_pad + 8 * (pos0 + (e0 + q < npos ? e0 + q : e0));
+        for (int t = 0; t < 9; ++t) R.bv[t] = bb[t];
+    };
+    auto finish = [&](int n, const GsOffItem<T>& R, int nn, const int2 dn, GsOffItem<T>& N, int nd, int2& dd) __attribute__((always_inline)) {
+        const int64_t jj = R.j; // (a dropped lane: the column of the slot's first entry)
+        const T x0 = x[3 * jj], x1 = x[3 * jj + 1], x2 = x[3 * jj + 2];
+        asm volatile("" ::: "memory"); // gathers first, then the next step's values and the descriptor after that: the sums below wait for the former only
+        values(nn, dn, N);
+        dd = descriptor(nd);
+        asm volatile("" ::: "memory"); // issued HERE, a step (two steps) ahead of their use
+        const T(&b)[9] = R.bv;
+        T s[3] = { b[0] * x0 + b[3] * x1 + b[6] * x2, b[1] * x0 + b[4] * x1 + b[7] * x2, b[2] * x0 + b[5] * x1 + b[8] * x2 };
 #pragma unroll
-        for (int t = 0; t < 5; ++t) rec[q][t] = rp[t];
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        row[q] = e0 + q < npos ? rec[q][0] : -1, j[q] = -1;
-        const int po = rec[q][1], pi = rec[q][2], fi = rec[q][3], fo = rec[q][4];
-        kb[q] = FWD ? 0 : po + pi + 1 + fi, ke[q] = FWD ? po : po + pi + 1 + fi + fo;
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) bv[q][t] = (T)0;
-        rh[q][0] = rh[q][1] = rh[q][2] = (T)0;
-        if (row[q] >= 0) { // wave-uniform
-            const int64_t i = row[q];
-            const int k = kb[q] + lane;
-            if (k < ke[q]) {
-                j[q] = gcol[i * 125 + k];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) bv[q][t] = val[(i * 125 + k) * 9 + t];
-            }
-            rh[q][0] = rhs[3 * i], rh[q][1] = rhs[3 * i + 1], rh[q][2] = rhs[3 * i + 2];
+        for (int d = 0; d < 3; ++d) s[d] = row16_sum(R.valid ? s[d] : (T)0);
+        const int sl = s_begin + 4 * n + g;
+        if (l16 == 15 && n < nstep && sl < s_end) {
+            T* o = part + 3 * (int64_t)sl;
+            o[0] = s[0], o[1] = s[1], o[2] = s[2];
         }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        if (row[q] < 0) continue; // wave-uniform
-        const int64_t i = row[q];
-        T s0 = 0, s1 = 0, s2 = 0;
-        if (j[q] >= 0) {
-            const int64_t jj = j[q];
-            const T x0 = x[3 * jj], x1 = x[3 * jj + 1], x2 = x[3 * jj + 2];
-            s0 = bv[q][0] * x0 + bv[q][3] * x1 + bv[q][6] * x2;
-            s1 = bv[q][1] * x0 + bv[q][4] * x1 + bv[q][7] * x2;
-            s2 = bv[q][2] * x0 + bv[q][5] * x1 + bv[q][8] * x2;
-        }
-        const int k1 = kb[q] + 64 + lane; // more than 64 off-block slots: the last colours of a sweep
-        if (k1 < ke[q]) {
-            const int64_t jj = gcol[i * 125 + k1];
-            const T* bb = val + (i * 125 + k1) * 9;
-            const T x0 = x[3 * jj], x1 = x[3 * jj + 1], x2 = x[3 * jj + 2];
-            s0 += bb[0] * x0 + bb[3] * x1 + bb[6] * x2;
-            s1 += bb[1] * x0 + bb[4] * x1 + bb[7] * x2;
-            s2 += bb[2] * x0 + bb[5] * x1 + bb[8] * x2;
-        }
-        s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
-        if (lane == 0) p1[3 * (pos0 + e0 + q)] = rh[q][0] - s0, p1[3 * (pos0 + e0 + q) + 1] = rh[q][1] - s1, p1[3 * (pos0 + e0 + q) + 2] = rh[q][2] - s2; // by (block, position)
+    };
+    GsOffItem<T> A, B;
+    int2 d1 = descriptor(w + W), d2;
+    values(w, descriptor(w), A);
+    d2 = descriptor(w + 2 * W);
+    asm volatile("" ::: "memory");
+    for (int n = w; n < nstep; n += 2 * W) {
+        int2 d3, d4;
+        finish(n, A, n + W, d1, B, n + 3 * W, d3);
+        finish(n + W, B, n + 2 * W, d2, A, n + 4 * W, d4); // (an odd number of steps: one step past the end, computed from the last step's descriptor and not stored)
+        d1 = d3, d2 = d4;
     }
 }
 
@@ -941,8 +940,8 @@ __global__ __launch_bounds__(1024) void k_gs_offblock(const int32_t* __restrict_
 // 32..64 of a block take 150 ns each whether 8 or 16 columns are in flight: at 4.4 TB/s over the 729 blocks of a colour the kernel is
 // bound by HBM, not by its chain any more.)
 template <class T, bool FWD, int D>
-__global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, const unsigned long long* __restrict__ imgm, const int32_t* __restrict__ gs_pad, const T* __restrict__ p1, T* x,
-    T* hD, int block0, const T* __restrict__ rhs /*not null: the first colour of a half sweep, whose rows have no off-block columns to subtract: p1 = rhs, by node*/)
+__global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, const unsigned long long* __restrict__ imgm, const int32_t* __restrict__ gs_pad, const T* __restrict__ part, T* x,
+    T* hD, int block0, const T* __restrict__ rhs)
 {
     using I = GsImg<T>;
     const int lane = threadIdx.x;
@@ -952,7 +951,8 @@ __global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, cons
     const unsigned long long mymask = imgm[(size_t)b * I::masks_per_block + (FWD ? 0 : 64) + lane];
     const int mylo = (int)(unsigned)(mymask & 0xffffffffULL), myhi = (int)(unsigned)(mymask >> 32);
     const int64_t pos = (int64_t)b * 64 + lane;
-    const int node = gs_pad[8 * pos];
+    const int32_t* rec = gs_pad + 8 * pos;
+    const int node = rec[0], nslot = ((FWD ? rec[1] : rec[4]) + 15) >> 4, slot0 = rec[FWD ? 5 : 6]; // the row's off-block slots of this direction (none in the first colour of a half sweep)
     T ring[D][9];
     unsigned off = 1; // entries consumed so far (wave-uniform); entry 0 is all zeros
     // Branch-free on purpose: a load under a divergent branch makes the compiler wait for EVERY outstanding load before the next use
@@ -970,11 +970,21 @@ __global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, cons
     };
 #pragma unroll
     for (int k = 0; k < D; ++k) issue(k, ring[k]);
-    // a = D^-1 p1 (p1 and D^-1 are stored by position)
+    // a = D^-1 p1, p1 = rhs - the row's off-block products: the sums of its slots (k_gs_offblock) in slot order; D^-1 is stored by position
     T a0, a1, a2;
     {
-        const T* src = rhs ? rhs + 3 * (int64_t)max(node, 0) : p1 + 3 * pos;
-        const T q0 = src[0], q1 = src[1], q2 = src[2];
+        const T* src = rhs + 3 * (int64_t)max(node, 0);
+        T q0 = src[0], q1 = src[1], q2 = src[2];
+        T ps[8][3]; // (a row has at most 124 off-block columns: eight slots; branch-free: past the row's last slot its first one — or the padding — is read and dropped)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const T* pp = part + 3 * (int64_t)(slot0 + (q < nslot ? q : 0));
+            ps[q][0] = pp[0], ps[q][1] = pp[1], ps[q][2] = pp[2];
+        }
+        T s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s0 += q < nslot ? ps[q][0] : (T)0, s1 += q < nslot ? ps[q][1] : (T)0, s2 += q < nslot ? ps[q][2] : (T)0;
+        q0 -= s0, q1 -= s1, q2 -= s2;
         const T* di = hdr + 576 + 9 * lane;
         a0 = di[0] * q0 + di[3] * q1 + di[6] * q2, a1 = di[1] * q0 + di[4] * q1 + di[7] * q2, a2 = di[2] * q0 + di[5] * q1 + di[8] * q2; // gs_store_rhs's product
     }
@@ -1623,17 +1633,17 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 const int c = fwd ? q : 7 - q, b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
                 if (nb <= 0) continue;
                 const int64_t pos0 = (int64_t)b0 * 64, npos = (int64_t)nb * 64;
-                const unsigned grid = (unsigned)div_up(npos, 32);
-                const T* direct = first ? rhs : (const T*)nullptr;
-                if (!first) HOT_LAUNCH(this, lname(nmO, L.id).c_str(), k_gs_offblock<T>, grid, 1024, 0, L.gs_col.p, L.val.p, L.gs_pad.p, rhs, xx, L.gs_p1.p, pos0, npos, fwd ? 1 : 0);
+                // (the first colour walked has no off-block columns before it: no slots, no launch)
+                const int grid = std::max(1, ab_int("HOT_GS_OFF_WAVES", 4096) / 4);
+                if (!first) HOT_LAUNCH(this, lname(nmO, L.id).c_str(), k_gs_offblock<T>, grid, 256, 0, L.gs_slot.p, L.gs_col.p, L.val.p, L.gs_pad.p, xx, L.gs_p1.p, pos0, (int)npos, fwd ? 1 : 0);
                 // (eight columns in flight per block: sixteen change nothing, neither on the finest level, HBM-bound, nor on C2's level 1 with 91
                 // blocks a colour, where a step costs its ~45 dependent-issue instructions, 190 ns.  On such a level — colours that fit the chip at
                 // once — the pair equals the chained k_gs_sweep in kernel time, 12.7 vs 12.2 ms per C2 step, and both kernels of a colour in ONE launch,
                 // substitution waves spinning on their block's arrival counter, were slower: 43 vs 24 us per colour.  k_gs_sweep stays there.)
                 if (fwd)
-                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgm.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, direct);
+                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgm.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
                 else
-                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgm.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, direct);
+                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgm.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
                 first = false;
             }
         };
