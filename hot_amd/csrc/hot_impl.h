@@ -360,6 +360,7 @@ struct Ctx : CtxBase {
     // smooth) catch to redo themselves from their saved inputs — the context is never left poisoned.
     static constexpr int ERR_RETRY = -100; // internal, never crosses the C ABI
     bool gs_no_chain = false, gs_chain_timed_out = false;
+    int unset_level = -1; // the level whose GS forward target (Level::tmp) carries "not written yet" marks from the kernel launched last on it (restrict_dev / vcycle_dev -> smooth_dev)
     void sync()
     {
         HOT_HIP(hipStreamSynchronize(stream));
@@ -457,6 +458,7 @@ struct Ctx : CtxBase {
     void estimate_2norm(Level<T>& L, double tol);
     int minres_dev(const std::function<void(const T*, T*)>& Amul, const std::function<void(const T*, T*)>& prec, T* x, const T* b, T relative_tolerance, T tolerance, int max_iterations);
     void scal(size_t n, T a, T* x); // x *= a
+    bool gs_marks_wanted(int level) const; // the level's next smoother is the chained GS sweep that takes its forward target's "not written yet" marks from the kernel before it
     void restrict_dev(int level, const T* fine, T* coarse);
     void prolong_dev(int level, const T* coarse, T* fine);
     void smooth_dev(int level, int kind, int iterations, T tol, T* u, T* r, T* du, T* dAu, bool final_residual = true);

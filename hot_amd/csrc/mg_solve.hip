@@ -137,15 +137,39 @@ __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ col, c
     s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
     if (lane == 0) y[3 * (int64_t)row] = s0, y[3 * (int64_t)row + 1] = s1, y[3 * (int64_t)row + 2] = s2;
 }
+// "not written yet" marks of the chained GS sweeps (k_gs_sweep): signalling-NaN payloads that no arithmetic result carries
+template <class T>
+struct GsUnset;
+template <>
+struct GsUnset<double> {
+    static constexpr unsigned long long bits = 0x7ff4dead0badf00dull;
+    static __device__ __forceinline__ bool is(double v) { return (unsigned long long)__double_as_longlong(v) == bits; }
+};
+template <>
+struct GsUnset<float> {
+    static constexpr unsigned bits = 0x7fa0f00du;
+    static __device__ __forceinline__ bool is(float v) { return (unsigned)__float_as_int(v) == bits; }
+};
+template <class T>
+__device__ __forceinline__ void gs_store_unset(T* p)
+{
+    if constexpr (sizeof(T) == 8)
+        *(unsigned long long*)p = GsUnset<double>::bits;
+    else
+        *(unsigned*)p = GsUnset<float>::bits;
+}
 // r_i -= sum_J AP[i][J] e_J : the residual update after the coarse-grid correction.  A (P e) and (A P) e are the same
 // vector; A P is a by-product of the Galerkin build with 64 window slots per row instead of the 125 of A, i.e. half
 // the bytes of the SpMV the reference performs here (MultigridPreconditioner.h:362-421).
 template <class T>
-__global__ __launch_bounds__(256) void k_apmv_sub(const int32_t* __restrict__ apc, const T* __restrict__ apv, const T* __restrict__ e, T* __restrict__ r, int n, const uint8_t* __restrict__ own)
+__global__ __launch_bounds__(256) void k_apmv_sub(const int32_t* __restrict__ apc, const T* __restrict__ apv, const T* __restrict__ e, T* __restrict__ r, int n, const uint8_t* __restrict__ own,
+    T* unset /*not null: the level's GS forward target, marked "not written yet" here (see smooth_dev)*/)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n || (own && !own[row])) return;
+    if (row >= n) return;
+    if (unset && lane < 3) gs_store_unset(unset + 3 * (int64_t)row + lane);
+    if (own && !own[row]) return;
     const int j = apc[(int64_t)row * 64 + lane];
     const T* b = apv + ((int64_t)row * 64 + lane) * 9;
     const T x0 = e[3 * (int64_t)j], x1 = e[3 * (int64_t)j + 1], x2 = e[3 * (int64_t)j + 2];
@@ -425,10 +449,12 @@ void Ctx<T>::spmv_dev(Level<T>& L, const T* x, T* y)
 
 // ------------------------------------------------------------------------------------------------ transfers
 template <class T>
-__global__ void k_restrict(const int32_t* __restrict__ child, const T* __restrict__ fine, T* coarse, int nc, const uint8_t* __restrict__ coarse_own, const uint8_t* __restrict__ fine_own)
+__global__ void k_restrict(const int32_t* __restrict__ child, const T* __restrict__ fine, T* coarse, int nc, const uint8_t* __restrict__ coarse_own, const uint8_t* __restrict__ fine_own,
+    T* unset /*not null: the coarse level's GS forward target, marked "not written yet" here (see smooth_dev)*/)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 3 * nc) return;
+    if (unset) gs_store_unset(unset + e);
     int I = e / 3, d = e - 3 * I;
     if (coarse_own && !coarse_own[I]) return; // sharded, both levels partitioned: the coarse rows this rank owns (their children are in the fine halo)
     // all 27 child ids first, then all 27 values (clamped index, dropped by the select): two rounds of independent loads instead of
@@ -458,6 +484,20 @@ __global__ void k_prolong(const int32_t* __restrict__ pcol, const T* __restrict_
     for (int l = 0; l < 8; ++l) s += pw[8 * (int64_t)i + l] * coarse[3 * (int64_t)pcol[8 * (int64_t)i + l] + d];
     fine[e] = s;
 }
+// Same decision as smooth_dev / vcycle_dev take (kind 5, chained launch, unknowns as their own flags).
+template <class T>
+bool Ctx<T>::gs_marks_wanted(int level) const
+{
+    const Level<T>& L = *levels[level];
+    const bool baseline = cfg.useBaselineMultigrid != 0;
+    const int splitLevel = cfg.topDownMGS ? 1 : cfg.levelCnt - 1;
+    const int kind = level < splitLevel ? (baseline ? 5 : cfg.smoother) : (baseline ? 2 : cfg.coarseSolver);
+    if (kind != 5 || gs_no_chain || !L.split || L.part || !L.tmp.p || cfg.gs_chain == 1) return false;
+    if (ab_flag("HOT_SIMPLE_GS") || ab_flag("HOT_GS_PASS_COUNTERS") || ab_flag("HOT_GS_BLOCK_FLAGS")) return false;
+    int max_nb = 0;
+    for (int c = 0; c < 8; ++c) max_nb = std::max(max_nb, L.color_block_begin[c + 1] - L.color_block_begin[c]);
+    return cfg.gs_chain == 2 || max_nb <= 256;
+}
 template <class T>
 void Ctx<T>::restrict_dev(int level, const T* fine, T* coarse)
 {
@@ -466,16 +506,19 @@ void Ctx<T>::restrict_dev(int level, const T* fine, T* coarse)
     if (F.part && halo_mode()) {
         if (C.part) { // owner of a coarse row sums its 27 children: those owned elsewhere come with the fine level's halo
             halo_gather(F, const_cast<T*>(fine));
-            HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n, C.own.p, (const uint8_t*)nullptr);
+            HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n, C.own.p, (const uint8_t*)nullptr, (T*)nullptr);
         }
         else { // replicated coarse level: every rank sums the children it owns, one all-reduce of the (small) coarse vector completes the rows
-            HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n, (const uint8_t*)nullptr, F.own.p);
+            HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n, (const uint8_t*)nullptr, F.own.p, (T*)nullptr);
             CommTag tag(this, "coarse_vector_allreduce");
             c_allreduce(coarse, 3 * (int64_t)C.n, REAL, HOT_COMM_SUM, true);
         }
         return;
     }
-    HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n, (const uint8_t*)nullptr, (const uint8_t*)nullptr);
+    // (every smoother on the coarse level is preceded by a restriction into it: its GS forward target gets its marks here)
+    T* mark = gs_marks_wanted(level + 1) ? C.tmp.p : (T*)nullptr;
+    HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n, (const uint8_t*)nullptr, (const uint8_t*)nullptr, mark);
+    unset_level = mark ? level + 1 : -1;
 }
 template <class T>
 void Ctx<T>::prolong_dev(int level, const T* coarse, T* fine)
@@ -1029,18 +1072,6 @@ __global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, cons
 // dispatched before it and waits on nothing itself that is not; the spin is bounded anyway and reports through `err`.
 // "not written yet in this half sweep": signalling-NaN payloads that no arithmetic result carries (a computed NaN is the canonical quiet one)
 template <class T>
-struct GsUnset;
-template <>
-struct GsUnset<double> {
-    static constexpr unsigned long long bits = 0x7ff4dead0badf00dull;
-    static __device__ __forceinline__ bool is(double v) { return (unsigned long long)__double_as_longlong(v) == bits; }
-};
-template <>
-struct GsUnset<float> {
-    static constexpr unsigned bits = 0x7fa0f00du;
-    static __device__ __forceinline__ bool is(float v) { return (unsigned)__float_as_int(v) == bits; }
-};
-template <class T>
 __global__ void k_gs_fill_unset(size_t n, T* x)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1061,7 +1092,8 @@ struct GsPasses {
 template <class T, bool FWD, int SB>
 __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
     const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, GsPasses P,
-    const int32_t* __restrict__ rowcnt, int* done, int* err, const int32_t* __restrict__ nbr, int* flag, int epoch, int dataflag)
+    const int32_t* __restrict__ rowcnt, int* done, int* err, const int32_t* __restrict__ nbr, int* flag, int epoch, int dataflag,
+    T* unset_next /*not null: the target of the NEXT half sweep (nobody reads it during this one): every workgroup marks its rows' unknowns there "not written yet", instead of a fill launch between the sweeps*/)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     constexpr int TRI = GsLds<T, SB>::TRI;
@@ -1106,6 +1138,8 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
         if (FWD) sD[e] = diagVal[9 * i + e % 9];
     }
     for (int e = tid; e < 3 * cnt; e += 64 * NW) srhs[e] = rhs[3 * (int64_t)nodes[e / 3] + e % 3];
+    if (unset_next)
+        for (int e = tid; e < 3 * cnt; e += 64 * NW) gs_store_unset(unset_next + 3 * (int64_t)nodes[e / 3] + e % 3);
     // ---- 1. stream the half rows (lane = slot), keep what couples to nodes outside the sub-block
     T bv[RQ][9];
     int jj[RQ], node[RQ], kb2[RQ], ke[RQ];
@@ -1377,6 +1411,8 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
     size_t n3 = 3 * (size_t)L.n;
     MaskScope mscope(this, halo_mode() ? L.mask() : nullptr); // halo mode: this level's vectors live on the rows the rank owns (replicated level: everywhere)
     const bool hm = L.part && halo_mode();
+    bool tmp_marked = unset_level == level; // L.tmp carries the chained GS sweep's "not written yet" marks (restrict_dev / vcycle_dev ran just before)
+    unset_level = -1; // whatever this call does with L.tmp, the marks are spent
     auto Aproject = [&](T* v) {
         if (level == 0 && !cfg.systemBCProject) project_dev(v);
     };
@@ -1655,6 +1691,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         // measured (C2, fp64): the chained launch wins on levels whose colours fit the chip in one round (latency-bound
         // passes, no launch gaps); on the finest level the waiting workgroups cost more than the kernel boundaries
         const bool dataflow = !gs_no_chain && !multilaunch && !simple_gs && L.split && !L.part && (force_dataflow || max_nb <= 256); // a chained launch cannot stop for the exchange
+        if (tmp_marked && !(dataflow && !ab_flag("HOT_GS_PASS_COUNTERS") && !ab_flag("HOT_GS_BLOCK_FLAGS"))) zero(n3, hdu), tmp_marked = false; // (cannot happen: gs_marks_wanted takes the same decision)
         GsPasses PF{}, PB{};
         if (dataflow) {
             auto add = [&](GsPasses& P, int c, int h) {
@@ -1669,6 +1706,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 for (int h = nsub - 1; h >= 0; --h) add(PB, c, h);
             gs_done.reserve(64);
         }
+        bool du_marked = false;
         auto sweep = [&](bool fwd) {
             const GsPasses& P = fwd ? PF : PB;
             if (P.npass == 0) return;
@@ -1681,8 +1719,14 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             const bool block_flags = ab_flag("HOT_GS_BLOCK_FLAGS"); // A/B build only: per-block sweep stamps instead of the unknowns being their own flags
             const bool p2p = !pass_counters;
             const int dataflag = (pass_counters || block_flags) ? 0 : 1;
-            if (dataflag)
+            // "not written yet" marks of the sweep's target: the forward target (L.tmp) by the kernel that ran just before this smoother on the level
+            // (restrict_dev / the k_apmv_sub of the way up: unset_level), the backward target by the forward sweep itself; a fill launch otherwise
+            const bool marked = fwd ? tmp_marked : du_marked;
+            if (fwd) tmp_marked = false;
+            if (dataflag && !marked)
                 HOT_LAUNCH(this, "gs_fill_unset", k_gs_fill_unset<T>, div_up(n3, 256), 256, 0, n3, xx);
+            else if (dataflag)
+                ;
             else if (p2p)
                 ++gs_epoch;
             else
@@ -1690,7 +1734,9 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             const int grid = P.wg_begin[P.npass];
 #define HOT_GS_CASE(F, S)                                                                                                                                              \
     HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_sweep<T, F, S>), grid, 16 * S, (GsLds<T, S>::bytes + 21 * S * sizeof(T)), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
-        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, P, rc, gs_done.p, (int*)(hscal + 250), p2p ? L.gs_nbr.p : (const int32_t*)nullptr, L.gs_flag.p, gs_epoch, dataflag)
+        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, P, rc, gs_done.p, (int*)(hscal + 250), p2p ? L.gs_nbr.p : (const int32_t*)nullptr, L.gs_flag.p, gs_epoch, dataflag, \
+        (fwd && dataflag) ? du : (T*)nullptr)
+            du_marked = fwd && dataflag;
             if (fwd) {
                 if (sb == 64) HOT_GS_CASE(true, 64);
                 else if (sb == 32) HOT_GS_CASE(true, 32);
@@ -1796,7 +1842,11 @@ void Ctx<T>::vcycle_dev(const T* in, T* out)
             axpy(n3, (T)-1, L.dAu.p, L.residual.p);
         }
         else
-            HOT_LAUNCH(this, lname("apmv", L.id).c_str(), k_apmv_sub<T>, div_up(L.n, 4), 256, 0, L.apc.p, L.apv.p, levels[level + 1]->sol.p, L.residual.p, L.n, L.mask());
+        {
+            T* mark = gs_marks_wanted(level) ? L.tmp.p : (T*)nullptr;
+            HOT_LAUNCH(this, lname("apmv", L.id).c_str(), k_apmv_sub<T>, div_up(L.n, 4), 256, 0, L.apc.p, L.apv.p, levels[level + 1]->sol.p, L.residual.p, L.n, L.mask(), mark);
+            unset_level = mark ? level : -1;
+        }
         if (L.part && !halo_mode() && (level < splitLevel ? (baseline ? 5 : cfg.smoother) : (baseline ? 2 : cfg.coarseSolver)) != 5)
             exchange(L, L.residual.p, -1); // a GS post-smoother reads only the rows it owns; every other smoother runs replicated vector algebra on all of r
         run(level < splitLevel, level, sol, level < splitLevel ? downIter(level) : topIter(level), false);
