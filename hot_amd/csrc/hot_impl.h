@@ -11,13 +11,13 @@ namespace hot {
 // premultiplied and packed in the order the substitution consumes it.  Per block: D[64][9] | D^-1[64][9] by position; per direction
 // (0 forward: strictly lower in-block couplings, 1 backward: strictly upper) the entries -(D_r^-1 A_rc) column by column (column = position c
 // of the block, in the direction's sweep order), inside a column by ascending row position, 9 scalars each, behind an all-zero entry 0.
-// ints (as uint64): per direction mask[64], bit r of mask[c] = row r has an entry in column c.
+// index table (16 bits): per direction idx[row][step] = the row's entry in the column walked at that step, 0 if none.
 template <class T>
 struct GsImg {
     static constexpr size_t hdr_elems = 2 * 64 * 9;
     static constexpr size_t cap_entries = 64 * 63 / 2 + 1; // + the all-zero entry 0
     static constexpr size_t per_dir = cap_entries * 9, per_block = hdr_elems + 2 * per_dir;
-    static constexpr size_t masks_per_block = 2 * 64;
+    static constexpr size_t idx_per_dir = 64 * 64; // 16-bit entry indices [row][step of the direction's walk] (0 = no entry in that column: the all-zero entry)
 };
 
 // one multigrid level: system matrix in 125-slot stencil ELL + transfer tables to the next coarser level
@@ -46,7 +46,7 @@ struct Level {
     DBuf<int32_t> gs_pad; // nblocks*64*8 (+ one sentinel record): per (colour block, position) {node or -1, the row's four class counts, first forward slot, first backward slot, pad}: the GS kernels' header in one load
     DBuf<int32_t> gs_col; // n*125: col after the regrouping with in-block columns replaced by -1 - (position in the colour block): k_gs_block2 tells triangle entries from gathers without fetching ckey[j]
     DBuf<T> gs_img; // nblocks * GsImg<T>::per_block: premultiplied in-block couplings in the order k_gs_subst consumes them (k_gs_images, mg_build.hip)
-    DBuf<unsigned long long> gs_imgm; // nblocks * GsImg<T>::masks_per_block: which rows have an entry in each column of the images
+    DBuf<uint16_t> gs_imgi; // nblocks * 2 * GsImg<T>::idx_per_dir: the images' entry index of every (row, step)
     DBuf<T> gs_p1; // 3 per slot: the off-block products summed over the slot's (up to 16) entries (k_gs_offblock -> k_gs_subst, which subtracts a row's slots from its rhs in order)
     DBuf<int2> gs_slot; // {first stored entry (row * 125 + k), entries} per slot (k_gs_slot_fill); gs_pad[8 pos + 5 / 6]: the position's first forward / backward slot
     int gs_nslot = 0;

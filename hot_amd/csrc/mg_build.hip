@@ -473,10 +473,10 @@ __global__ void k_gs_slot_fill(int32_t* __restrict__ pad, const int32_t* __restr
 
 // In-block images for the finest-level GS kernels (layout: GsImg, hot_impl.h; consumer: k_gs_subst, mg_solve.hip).  One workgroup per
 // colour block: (1) every row marks itself in the masks of the columns it couples to (LDS), (2) column offsets = running popcounts,
-// (3) every entry -(D_r^-1 A_rc) goes to [offset of column c + rank of r among the column's rows].
+// (3) every entry -(D_r^-1 A_rc) goes to [offset of column c + rank of r among the column's rows]; the same index, per row and step of the walk, goes to the index table.
 template <class T>
 __global__ __launch_bounds__(512) void k_gs_images(const int32_t* __restrict__ gcol, const T* __restrict__ val, const T* __restrict__ diagBlockInv, const T* __restrict__ diagVal,
-    const int32_t* __restrict__ gs_pad, T* __restrict__ img, unsigned long long* __restrict__ imgm, int nblocks)
+    const int32_t* __restrict__ gs_pad, T* __restrict__ img, uint16_t* __restrict__ imgi, int nblocks)
 {
     using I = GsImg<T>;
     __shared__ int32_t nodes[64], rcl[64 * 4];
@@ -540,11 +540,21 @@ __global__ __launch_bounds__(512) void k_gs_images(const int32_t* __restrict__ g
                     off += __popc(mlo[tid][c]) + __popc(mhi[tid][c]);
                 }
             }
-            if (tid >= 64 && tid < 192) {
-                const int dir = (tid - 64) >> 6, c = tid & 63;
-                imgm[(size_t)b * I::masks_per_block + dir * 64 + c] = ((unsigned long long)mhi[dir][c] << 32) | mlo[dir][c];
-            }
             __syncthreads();
+            if (tid >= 64 && tid < 192) { // the row's entry index at every step of the direction's walk (0: none, the all-zero entry): 64 x 16 bits = the 128 bytes a lane of k_gs_subst loads
+                const int dir = (tid - 64) >> 6, r = tid & 63;
+                uint32_t* o = (uint32_t*)(imgi + ((size_t)b * 2 + dir) * I::idx_per_dir + r * 64);
+                for (int s2 = 0; s2 < 32; ++s2) {
+                    uint32_t pair = 0;
+                    for (int h = 0; h < 2; ++h) {
+                        const int c = dir == 0 ? 2 * s2 + h : 63 - (2 * s2 + h);
+                        const unsigned long long m = ((unsigned long long)mhi[dir][c] << 32) | mlo[dir][c];
+                        const uint32_t idx = ((m >> r) & 1ULL) ? (uint32_t)(coff[dir][c] + __popcll(m & ((1ULL << r) - 1ULL))) : 0u;
+                        pair |= idx << (16 * h);
+                    }
+                    o[s2] = pair;
+                }
+            }
         }
     }
 }
@@ -566,14 +576,14 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
     L.gs_img_ready = false;
     if (!L.part && (max_nb > 256 || ctx->cfg.gs_sub_block == 32)) {
         L.gs_img.reserve(GsImg<T>::per_block * (size_t)L.nblocks + 16), // + one entry: k_gs_subst's unconditional loads
-        L.gs_imgm.reserve(GsImg<T>::masks_per_block * (size_t)L.nblocks);
+        L.gs_imgi.reserve(2 * GsImg<T>::idx_per_dir * (size_t)L.nblocks);
         const int npos = 64 * L.nblocks;
         ctx->flags.reserve(2 * (size_t)npos), ctx->scan.reserve(2 * (size_t)npos);
         HOT_LAUNCH(ctx, "gs_slot_count", k_gs_slot_count, div_up((size_t)npos, 256), 256, 0, L.gs_pad.p, ctx->flags.p, npos);
         L.gs_nslot = ctx->exclusive_scan_i32(ctx->flags.p, ctx->scan.p, 2 * (size_t)npos);
         L.gs_slot.reserve((size_t)L.gs_nslot + 8), L.gs_p1.reserve(3 * ((size_t)L.gs_nslot + 8)); // + what the kernels' unconditional (clamped, dropped) loads may touch
         HOT_LAUNCH(ctx, "gs_slot_fill", k_gs_slot_fill, div_up((size_t)npos + 1, 256), 256, 0, L.gs_pad.p, ctx->scan.p, L.gs_slot.p, npos, L.gs_nslot);
-        HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, L.nblocks, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p, L.gs_imgm.p, L.nblocks);
+        HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, L.nblocks, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p, L.gs_imgi.p, L.nblocks);
         L.gs_img_ready = true;
     }
 }

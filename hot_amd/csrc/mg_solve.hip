@@ -983,7 +983,7 @@ __global__ __launch_bounds__(256) void k_gs_offblock(const int2* __restrict__ sl
 // 32..64 of a block take 150 ns each whether 8 or 16 columns are in flight: at 4.4 TB/s over the 729 blocks of a colour the kernel is
 // bound by HBM, not by its chain any more.)
 template <class T, bool FWD, int D>
-__global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, const unsigned long long* __restrict__ imgm, const int32_t* __restrict__ gs_pad, const T* __restrict__ part, T* x,
+__global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, const uint16_t* __restrict__ imgi, const int32_t* __restrict__ gs_pad, const T* __restrict__ part, T* x,
     T* hD, int block0, const T* __restrict__ rhs)
 {
     using I = GsImg<T>;
@@ -991,28 +991,33 @@ __global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, cons
     const int b = block0 + blockIdx.x;
     const T* hdr = img + (size_t)b * I::per_block;
     const T* ent = hdr + I::hdr_elems + (FWD ? 0 : I::per_dir);
-    const unsigned long long mymask = imgm[(size_t)b * I::masks_per_block + (FWD ? 0 : 64) + lane];
-    const int mylo = (int)(unsigned)(mymask & 0xffffffffULL), myhi = (int)(unsigned)(mymask >> 32);
     const int64_t pos = (int64_t)b * 64 + lane;
     const int32_t* rec = gs_pad + 8 * pos;
     const int node = rec[0], nslot = ((FWD ? rec[1] : rec[4]) + 15) >> 4, slot0 = rec[FWD ? 5 : 6]; // the row's off-block slots of this direction (none in the first colour of a half sweep)
+    // this row's entry index at each of the 64 steps, 16 bits each: 128 bytes per lane, one round trip before the first entry load
+    uint32_t iw[32];
+    {
+        const uint4* ip = (const uint4*)(imgi + ((size_t)b * 2 + (FWD ? 0 : 1)) * I::idx_per_dir + lane * 64);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint4 v = ip[q];
+            iw[4 * q] = v.x, iw[4 * q + 1] = v.y, iw[4 * q + 2] = v.z, iw[4 * q + 3] = v.w;
+        }
+    }
     T ring[D][9];
-    unsigned off = 1; // entries consumed so far (wave-uniform); entry 0 is all zeros
-    // Branch-free on purpose: a load under a divergent branch makes the compiler wait for EVERY outstanding load before the next use
-    // (s_waitcnt vmcnt(0) at the join), i.e. one memory round trip per step.
-    auto issue = [&](int s, T (&L)[9]) __attribute__((always_inline)) {
-        const int c = (FWD ? s : 63 - s) & 63; // past the last step: wraps to columns whose slots are never consumed
-        const unsigned mlo = (unsigned)__builtin_amdgcn_readlane(mylo, c), mhi = (unsigned)__builtin_amdgcn_readlane(myhi, c);
-        const unsigned rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)); // set bits below this lane
-        const bool mine = ((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1u;
-        const T* p = ent + (size_t)(mine ? off + rank : 0u) * 9;
+    // The 64 steps are unrolled, so a step's index is a fixed half of a fixed register and its loads are a multiply and five loads off one
+    // base (24 instructions a step; 50 with the column masks + v_mbcnt ranks of the first version).  A lane without an entry in the column
+    // reads the all-zero entry 0 instead of being masked out (a load under a divergent branch makes the compiler wait for EVERY outstanding
+    // load at the join).
+#define HOT_GS_ISSUE(s, L)                                                                   \
+    do {                                                                                      \
+        const uint32_t idx_ = (iw[(s) >> 1] >> (16 * ((s)&1))) & 0xffffu;                     \
+        const T* p_ = ent + (size_t)idx_ * 9;                                                 \
+        _Pragma("unroll") for (int e_ = 0; e_ < 9; ++e_) L[e_] = p_[e_];                      \
+        asm volatile("" ::: "memory"); /* the loads stay HERE, D steps ahead of their use */ \
+    } while (0)
 #pragma unroll
-        for (int e = 0; e < 9; ++e) L[e] = p[e];
-        asm volatile("" ::: "memory"); // the loads stay HERE, D steps ahead of their use (the scheduler otherwise sinks them to the multiply-adds and carries addresses instead of data)
-        off += __popc(mlo) + __popc(mhi);
-    };
-#pragma unroll
-    for (int k = 0; k < D; ++k) issue(k, ring[k]);
+    for (int k = 0; k < D; ++k) HOT_GS_ISSUE(k, ring[k]);
     // a = D^-1 p1, p1 = rhs - the row's off-block products: the sums of its slots (k_gs_offblock) in slot order; D^-1 is stored by position
     T a0, a1, a2;
     {
@@ -1036,18 +1041,17 @@ __global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, cons
 #pragma unroll
         for (int e = 0; e < 9; ++e) dd[e] = hdr[9 * lane + e];
     }
-    for (int s0 = 0; s0 < 64; s0 += D) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const int s = s0 + k, c = FWD ? s : 63 - s;
-            const T b0 = lane_bcast(a0, c), b1 = lane_bcast(a1, c), b2 = lane_bcast(a2, c);
-            const T(&L)[9] = ring[k];
-            a0 = fma(L[0], b0, a0), a1 = fma(L[1], b0, a1), a2 = fma(L[2], b0, a2);
-            a0 = fma(L[3], b1, a0), a1 = fma(L[4], b1, a1), a2 = fma(L[5], b1, a2);
-            a0 = fma(L[6], b2, a0), a1 = fma(L[7], b2, a1), a2 = fma(L[8], b2, a2);
-            issue(s + D, ring[k]);
-        }
+    for (int s = 0; s < 64; ++s) {
+        const int c = FWD ? s : 63 - s;
+        const T b0 = lane_bcast(a0, c), b1 = lane_bcast(a1, c), b2 = lane_bcast(a2, c);
+        T(&L)[9] = ring[s % D];
+        a0 = fma(L[0], b0, a0), a1 = fma(L[1], b0, a1), a2 = fma(L[2], b0, a2);
+        a0 = fma(L[3], b1, a0), a1 = fma(L[4], b1, a1), a2 = fma(L[5], b1, a2);
+        a0 = fma(L[6], b2, a0), a1 = fma(L[7], b2, a1), a2 = fma(L[8], b2, a2);
+        if (s + D < 64) HOT_GS_ISSUE(s + D, L);
     }
+#undef HOT_GS_ISSUE
     if (node < 0) return;
     x[3 * (int64_t)node] = a0, x[3 * (int64_t)node + 1] = a1, x[3 * (int64_t)node + 2] = a2;
     if (FWD) {
@@ -1677,9 +1681,9 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 // once — the pair equals the chained k_gs_sweep in kernel time, 12.7 vs 12.2 ms per C2 step, and both kernels of a colour in ONE launch,
                 // substitution waves spinning on their block's arrival counter, were slower: 43 vs 24 us per colour.  k_gs_sweep stays there.)
                 if (fwd)
-                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgm.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
+                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
                 else
-                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgm.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
+                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
                 first = false;
             }
         };
