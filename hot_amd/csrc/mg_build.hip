@@ -541,15 +541,16 @@ __global__ __launch_bounds__(512) void k_gs_images(const int32_t* __restrict__ g
                 }
             }
             __syncthreads();
-            if (tid >= 64 && tid < 192) { // the row's entry index at every step of the direction's walk (0: none, the all-zero entry): 64 x 16 bits = the 128 bytes a lane of k_gs_subst loads
-                const int dir = (tid - 64) >> 6, r = tid & 63;
-                uint32_t* o = (uint32_t*)(imgi + ((size_t)b * 2 + dir) * I::idx_per_dir + r * 64);
-                for (int s2 = 0; s2 < 32; ++s2) {
+            { // the row's entry index at every step of the direction's walk (0: none, the all-zero entry): 64 x 16 bits = the 128 bytes a lane of k_gs_subst loads; a thread writes a quarter of a row's
+                const int dir = tid >> 8, r = (tid >> 2) & 63, q4 = tid & 3;
+                uint32_t* o = (uint32_t*)(imgi + ((size_t)b * 2 + dir) * I::idx_per_dir + r * 64) + 8 * q4;
+                const unsigned long long below = (1ULL << r) - 1ULL;
+                for (int s2 = 0; s2 < 8; ++s2) {
                     uint32_t pair = 0;
                     for (int h = 0; h < 2; ++h) {
-                        const int c = dir == 0 ? 2 * s2 + h : 63 - (2 * s2 + h);
+                        const int st = 16 * q4 + 2 * s2 + h, c = dir == 0 ? st : 63 - st;
                         const unsigned long long m = ((unsigned long long)mhi[dir][c] << 32) | mlo[dir][c];
-                        const uint32_t idx = ((m >> r) & 1ULL) ? (uint32_t)(coff[dir][c] + __popcll(m & ((1ULL << r) - 1ULL))) : 0u;
+                        const uint32_t idx = ((m >> r) & 1ULL) ? (uint32_t)(coff[dir][c] + __popcll(m & below)) : 0u;
                         pair |= idx << (16 * h);
                     }
                     o[s2] = pair;
