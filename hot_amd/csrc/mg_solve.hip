@@ -113,11 +113,18 @@ double Ctx<T>::dot_host(size_t n, const T* x, const T* y)
 }
 
 // ------------------------------------------------------------------------------------------------ SpMV
+// Row-per-wavefront kernels deal their workgroups to the XCDs in eight contiguous runs of rows (workgroup b runs on XCD b % 8: observed
+// placement, used for speed only — any placement computes the same rows): DOF ids follow the blocks in first-touch (page) order, so an
+// XCD's rows gather x from one region of the grid and that part of x stays in ITS 4 MB L2, instead of every XCD pulling all of x
+// through its own L2 (k_gs_offblock: 46 MB of 155 MB per launch were those eight copies, profiles/r04_pmc_summary.json).  Launch with
+// xcd_grid(number of workgroups).
+__device__ __forceinline__ int xcd_block() { return (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)); }
+static inline int xcd_grid(int nwg) { return 8 * div_up(nwg, 8); }
 template <class T>
 __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ col, const T* __restrict__ val, const T* __restrict__ x, T* __restrict__ y, int n, const uint8_t* __restrict__ own)
 {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = xcd_block() * 4 + (threadIdx.x >> 6);
     if (row >= n || (own && !own[row])) return; // sharded: rows of other ranks (wave-uniform)
     const int32_t* c = col + (int64_t)row * 125;
     const T* v = val + (int64_t)row * 1125;
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256) void k_apmv_sub(const int32_t* __restrict__ ap
     T* unset /*not null: the level's GS forward target, marked "not written yet" here (see smooth_dev)*/)
 {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = xcd_block() * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     if (unset && lane < 3) gs_store_unset(unset + 3 * (int64_t)row + lane);
     if (own && !own[row]) return;
@@ -443,7 +450,7 @@ template <class T>
 void Ctx<T>::spmv_dev(Level<T>& L, const T* x, T* y)
 {
     if (L.part && halo_mode()) halo_gather(L, const_cast<T*>(x)); // the entries of x the owned rows couple to
-    HOT_LAUNCH(this, lname("spmv", L.id).c_str(), k_spmv<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, x, y, L.n, L.mask());
+    HOT_LAUNCH(this, lname("spmv", L.id).c_str(), k_spmv<T>, xcd_grid(div_up(L.n, 4)), 256, 0, L.col.p, L.val.p, x, y, L.n, L.mask());
     if (!halo_mode()) exchange(L, y, -1); // first-generation sharding: every rank computed the rows it owns; all of y is needed by the replicated vector algebra
 }
 
@@ -928,8 +935,17 @@ __global__ __launch_bounds__(256) void k_gs_offblock(const int2* __restrict__ sl
 {
     const int lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
     const int s_begin = gs_pad[8 * pos0 + (FWD ? 5 : 6)], s_end = gs_pad[8 * (pos0 + npos) + (FWD ? 5 : 6)];
-    const int nstep = (s_end - s_begin + 3) >> 2, W = gridDim.x * 4;
-    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))); // wave-uniform, and known to be: descriptors come through the scalar cache
+    // Steps are dealt to the XCDs in eight contiguous runs (workgroup b runs on XCD b % 8 — observed placement, used for speed only; any
+    // placement gives the same sums): slots follow the colour's blocks in first-touch (page) order, so an XCD's run gathers x from one
+    // region of the grid and that part of x stays in ITS L2.  Dealt round robin, every XCD pulled all of x through its own L2 in every
+    // launch: measured 155 MB of fabric reads per launch against 109 MB algorithmic (profiles/r04_pmc_summary.json), the difference being
+    // eight copies of x (C2: 6.5 MB each).
+    const int nstep_all = (s_end - s_begin + 3) >> 2;
+    const bool by_xcd = (gridDim.x & 7) == 0;
+    const int chunk = by_xcd ? (nstep_all + 7) >> 3 : nstep_all, xcd = by_xcd ? (int)(blockIdx.x & 7) : 0;
+    const int W = by_xcd ? (int)(gridDim.x >> 3) * 4 : (int)gridDim.x * 4;
+    const int nstep = min(nstep_all, (xcd + 1) * chunk); // end of this XCD's run of steps
+    const int w = __builtin_amdgcn_readfirstlane(xcd * chunk + (int)((by_xcd ? blockIdx.x >> 3 : blockIdx.x) * 4 + (threadIdx.x >> 6))); // wave-uniform, and known to be: descriptors come through the scalar cache
     if (w >= nstep) return;
     auto descriptor = [&](int n) __attribute__((always_inline)) { // of this lane's group (past the colour's last slot: the last slot's again)
         return slot[min(s_begin + 4 * min(n, nstep - 1) + g, s_end - 1)];
@@ -1363,7 +1379,7 @@ __global__ __launch_bounds__(256) void k_gs_residual(const int32_t* __restrict__
     int me)
 {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = xcd_block() * 4 + (threadIdx.x >> 6);
     if (row >= n || (own && !own[row])) return;
     const int nl = rowcnt[4 * row] + rowcnt[4 * row + 1];
     const int32_t* c = col + (int64_t)row * 125;
@@ -1599,7 +1615,15 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         // workgroups per CU, one round per launch); small levels are latency-bound per launch and keep whole blocks
         int max_nb = 0;
         for (int c = 0; c < 8; ++c) max_nb = std::max(max_nb, L.color_block_begin[c + 1] - L.color_block_begin[c]);
-        const int sb = env_sb ? env_sb : (max_nb > 256 ? 32 : 64);
+        // one launch per half sweep (k_gs_sweep, passes chained by device-scope counters) unless the A/B switches ask
+        // for one launch per pass
+        const bool multilaunch = cfg.gs_chain == 1, force_dataflow = cfg.gs_chain == 2; // tuning overrides (0 = by level size)
+        // measured (C2, fp64): the chained launch wins on levels whose colours fit the chip in one round (latency-bound
+        // passes, no launch gaps); on the finest level the waiting workgroups cost more than the kernel boundaries
+        const bool dataflow = !gs_no_chain && !multilaunch && !simple_gs && L.split && !L.part && (force_dataflow || max_nb <= 256); // a chained launch cannot stop for the exchange
+        // (chained levels of more than 32 blocks a colour run half blocks too: twice the workgroups stream a colour's off-block rows — C2
+        // level 1, 91 blocks a colour: 159 against 178 us per half sweep, 10.9 against 12.2 ms per step)
+        const int sb = env_sb ? env_sb : ((max_nb > 256 || (dataflow && max_nb > 32)) ? 32 : 64);
         const int gs_threads = sb == 64 ? 1024 : 512;
         const int nsub = 64 / sb;
         HOT_CHECK(L.split || simple_gs, HOT_ERR_INVALID, "block GS kernels need the regrouped rows (k_gs_split_rows)");
@@ -1689,12 +1713,6 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         };
         HOT_CHECK(sb == 16 || sb == 32 || sb == 64, HOT_ERR_INVALID, "hot_config.gs_sub_block must be 0 (auto), 16, 32 or 64");
         HOT_CHECK(cfg.gs_chain >= 0 && cfg.gs_chain <= 2, HOT_ERR_INVALID, "hot_config.gs_chain must be 0 (auto), 1 (one launch per colour) or 2 (one chained launch per half sweep)");
-        // one launch per half sweep (k_gs_sweep, passes chained by device-scope counters) unless the A/B switches ask
-        // for one launch per pass
-        const bool multilaunch = cfg.gs_chain == 1, force_dataflow = cfg.gs_chain == 2; // tuning overrides (0 = by level size)
-        // measured (C2, fp64): the chained launch wins on levels whose colours fit the chip in one round (latency-bound
-        // passes, no launch gaps); on the finest level the waiting workgroups cost more than the kernel boundaries
-        const bool dataflow = !gs_no_chain && !multilaunch && !simple_gs && L.split && !L.part && (force_dataflow || max_nb <= 256); // a chained launch cannot stop for the exchange
         if (tmp_marked && !(dataflow && !ab_flag("HOT_GS_PASS_COUNTERS") && !ab_flag("HOT_GS_BLOCK_FLAGS"))) zero(n3, hdu), tmp_marked = false; // (cannot happen: gs_marks_wanted takes the same decision)
         GsPasses PF{}, PB{};
         if (dataflow) {
@@ -1780,7 +1798,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             if (L.split && !simple_gs && !(level == 0 && !cfg.systemBCProject) && !no_lres) {
                 // r - A du = L (h - du): with (D+L) h = r and (D+U) du = D h the full product A du collapses to the
                 // strictly-preceding half of the matrix applied to (h - du) (same value, half the bytes of an SpMV)
-                HOT_LAUNCH(this, lname("gs_residual", L.id).c_str(), k_gs_residual<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.rowcnt.p, hdu, du, r, L.n, L.mask(),
+                HOT_LAUNCH(this, lname("gs_residual", L.id).c_str(), k_gs_residual<T>, xcd_grid(div_up(L.n, 4)), 256, 0, L.col.p, L.val.p, L.rowcnt.p, hdu, du, r, L.n, L.mask(),
                     rank_local ? L.owner.p : (const uint8_t*)nullptr, comm.rank);
                 if (!hm) exchange(L, r, -1); // first-generation sharding: the restriction / the next smoother read all of r (halo mode: r is needed on owned rows only; restrict_dev fetches what it reads)
             }
@@ -1848,7 +1866,7 @@ void Ctx<T>::vcycle_dev(const T* in, T* out)
         else
         {
             T* mark = gs_marks_wanted(level) ? L.tmp.p : (T*)nullptr;
-            HOT_LAUNCH(this, lname("apmv", L.id).c_str(), k_apmv_sub<T>, div_up(L.n, 4), 256, 0, L.apc.p, L.apv.p, levels[level + 1]->sol.p, L.residual.p, L.n, L.mask(), mark);
+            HOT_LAUNCH(this, lname("apmv", L.id).c_str(), k_apmv_sub<T>, xcd_grid(div_up(L.n, 4)), 256, 0, L.apc.p, L.apv.p, levels[level + 1]->sol.p, L.residual.p, L.n, L.mask(), mark);
             unset_level = mark ? level : -1;
         }
         if (L.part && !halo_mode() && (level < splitLevel ? (baseline ? 5 : cfg.smoother) : (baseline ? 2 : cfg.coarseSolver)) != 5)

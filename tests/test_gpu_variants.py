@@ -37,6 +37,7 @@ CASES = [
     ({"HOT_HESSIAN_MFMA": "1"}, SOLVER, "hessian_and_hierarchy"),  # pair phase on v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32
     ({"HOT_P2G_V1": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),
     ({"HOT_P2G_CELLS1": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),
+    ({"HOT_G2P_V1": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),  # node-by-node sums instead of the sum-factorised ones
     ({"HOT_FORCE_V1": "1"}, "tests/test_gpu_force.py", "objective_pieces"),
     ({"HOT_FORCE_CELLS1": "1"}, "tests/test_gpu_force.py", "objective_pieces"),  # round 2's 3-node items with 27 staged scalars
 ]
