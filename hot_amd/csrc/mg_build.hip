@@ -474,6 +474,16 @@ __global__ void k_gs_slot_count(const int32_t* __restrict__ pad, int32_t* __rest
     const bool node = o[0] >= 0;
     flags[e] = node ? (o[1] + 15) >> 4 : 0, flags[npos + e] = node ? (o[4] + 15) >> 4 : 0;
 }
+struct GsColourStarts {
+    int pos[9];
+};
+__global__ void k_gs_slot_starts(const int32_t* __restrict__ scan, GsColourStarts cs, int npos, int total, int32_t* __restrict__ out)
+{
+    const int c = threadIdx.x;
+    if (c > 8) return;
+    out[c] = scan[cs.pos[c]]; // forward ranges (scan[npos]: the first backward slot = the forward total)
+    out[9 + c] = cs.pos[c] < npos ? scan[npos + cs.pos[c]] : total;
+}
 __global__ void k_gs_slot_fill(int32_t* __restrict__ pad, const int32_t* __restrict__ scan, int2* __restrict__ slot, int npos, int total)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -607,6 +617,14 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
         L.gs_nslot = ctx->exclusive_scan_i32(ctx->flags.p, ctx->scan.p, 2 * (size_t)npos);
         L.gs_slot.reserve((size_t)L.gs_nslot + 8), L.gs_p1.reserve(3 * ((size_t)L.gs_nslot + 8)); // + what the kernels' unconditional (clamped, dropped) loads may touch
         HOT_LAUNCH(ctx, "gs_slot_fill", k_gs_slot_fill, div_up((size_t)npos + 1, 256), 256, 0, L.gs_pad.p, ctx->scan.p, L.gs_slot.p, npos, L.gs_nslot);
+        { // where each colour's slots begin, per direction, for the host: k_gs_offblock gets its range as launch arguments instead of starting with a dependent load
+            GsColourStarts cs;
+            for (int c = 0; c <= 8; ++c) cs.pos[c] = 64 * L.color_block_begin[c];
+            int32_t* d = (int32_t*)(ctx->flags.p); // (flags: consumed by the scan above)
+            HOT_LAUNCH(ctx, "gs_slot_starts", k_gs_slot_starts, 1, 32, 0, ctx->scan.p, cs, npos, L.gs_nslot, d);
+            HOT_HIP(hipMemcpyAsync(&L.gs_slot_start[0][0], d, 18 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            ctx->sync();
+        }
         HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, L.nblocks, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p, L.gs_imgi.p, L.nblocks);
         L.gs_img_ready = true;
     }

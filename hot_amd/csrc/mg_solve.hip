@@ -931,10 +931,9 @@ struct GsOffItem { // what a 16-lane group has in flight for its slot between th
 // k_gs_subst subtracts a row's slots from its right-hand side in slot order.
 template <class T>
 __global__ __launch_bounds__(256) void k_gs_offblock(const int2* __restrict__ slot, const int32_t* __restrict__ gcol, const T* __restrict__ val, const int32_t* __restrict__ gs_pad,
-    const T* __restrict__ x, T* __restrict__ part, int64_t pos0, int npos, int FWD /*forward sweep: the off-block columns preceding the row; else those following it*/)
+    const T* __restrict__ x, T* __restrict__ part, int s_begin, int s_end /*the colour's slots of this sweep direction (Level::gs_slot_start: known to the host since the build)*/)
 {
     const int lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
-    const int s_begin = gs_pad[8 * pos0 + (FWD ? 5 : 6)], s_end = gs_pad[8 * (pos0 + npos) + (FWD ? 5 : 6)];
     // Steps are dealt to the XCDs in eight contiguous runs (workgroup b runs on XCD b % 8 — observed placement, used for speed only; any
     // placement gives the same sums): slots follow the colour's blocks in first-touch (page) order, so an XCD's run gathers x from one
     // region of the grid and that part of x stays in ITS L2.  Dealt round robin, every XCD pulled all of x through its own L2 in every
@@ -1696,10 +1695,9 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             for (int q = 0; q < 8; ++q) {
                 const int c = fwd ? q : 7 - q, b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
                 if (nb <= 0) continue;
-                const int64_t pos0 = (int64_t)b0 * 64, npos = (int64_t)nb * 64;
                 // (the first colour walked has no off-block columns before it: no slots, no launch)
                 const int grid = std::max(1, ab_int("HOT_GS_OFF_WAVES", 4096) / 4);
-                if (!first) HOT_LAUNCH(this, lname(nmO, L.id).c_str(), k_gs_offblock<T>, grid, 256, 0, L.gs_slot.p, L.gs_col.p, L.val.p, L.gs_pad.p, xx, L.gs_p1.p, pos0, (int)npos, fwd ? 1 : 0);
+                if (!first) HOT_LAUNCH(this, lname(nmO, L.id).c_str(), k_gs_offblock<T>, grid, 256, 0, L.gs_slot.p, L.gs_col.p, L.val.p, L.gs_pad.p, xx, L.gs_p1.p, L.gs_slot_start[fwd ? 0 : 1][c], L.gs_slot_start[fwd ? 0 : 1][c + 1]);
                 // (eight columns in flight per block: sixteen change nothing, neither on the finest level, HBM-bound, nor on C2's level 1 with 91
                 // blocks a colour, where a step costs its ~45 dependent-issue instructions, 190 ns.  On such a level — colours that fit the chip at
                 // once — the pair equals the chained k_gs_sweep in kernel time, 12.7 vs 12.2 ms per C2 step, and both kernels of a colour in ONE launch,
