@@ -100,6 +100,48 @@ __device__ __forceinline__ double hsqrt<double>(double x) { return sqrt(x); }
 template <class T>
 __device__ __forceinline__ T habs(T x) { return x < 0 ? -x : x; }
 
+// sqrt(d) and 1 / sqrt(d) together, for the rotations (c, s) = (a, b) / sqrt(a^2 + b^2).  Written as sqrt followed by a division, the
+// compiler emits its correctly rounded sequences for both (range scaling, v_rsq + Goldschmidt, v_div_scale / v_rcp / v_div_fmas /
+// v_div_fixup): ~28 of the per-particle kernels' instructions per rotation, and FP64 instructions issue at half rate — k_state is bound
+// by them (SQ counters: 21 M of 36 M VALU instructions are FP64 FMAs at C2).  Here: one v_rsq, two coupled Newton (Goldschmidt) steps
+// for both values and a last correction of the root: 11 instructions, both results within 1-2 ulp.  Outside [1e-280, 1e280] (and for 0)
+// the plain forms are used.
+template <class T>
+__device__ __forceinline__ void hrsqrt2(T d, T& sq, T& inv);
+template <>
+__device__ __forceinline__ void hrsqrt2<double>(double d, double& sq, double& inv)
+{
+    if (d > 1e-280 && d < 1e280) {
+        const double y = __builtin_amdgcn_rsq(d);
+        double g = d * y, h = 0.5 * y;
+        double r = fma(-h, g, 0.5);
+        g = fma(g, r, g), h = fma(h, r, h);
+        r = fma(-h, g, 0.5);
+        g = fma(g, r, g), h = fma(h, r, h);
+        g = fma(fma(-g, g, d), h, g);
+        sq = g, inv = h + h;
+    }
+    else {
+        sq = sqrt(d);
+        inv = sq != 0.0 ? 1.0 / sq : 0.0;
+    }
+}
+template <>
+__device__ __forceinline__ void hrsqrt2<float>(float d, float& sq, float& inv)
+{
+    if (d > 1e-30f && d < 1e30f) {
+        float y = __builtin_amdgcn_rsqf(d); // 1 ulp
+        y = fmaf(y * 0.5f, fmaf(-d * y, y, 1.0f), y); // one Newton step
+        inv = y;
+        const float g = d * y;
+        sq = fmaf(fmaf(-g, g, d), 0.5f * y, g);
+    }
+    else {
+        sq = sqrtf(d);
+        inv = sq != 0.0f ? 1.0f / sq : 0.0f;
+    }
+}
+
 // Givens pair (c,s): [c -s; s c] applied to rows (I,K) / columns (I,K)
 template <class T>
 struct Giv {
@@ -110,9 +152,9 @@ __device__ __forceinline__ Giv<T> giv_compute(T a, T b) // (c -s; s c)(a;b) = (*
 {
     Giv<T> g{ (T)1, (T)0 };
     T d = a * a + b * b;
-    T sq = hsqrt(d);
+    T sq, t;
+    hrsqrt2(d, sq, t);
     if (sq != (T)0) {
-        T t = (T)1 / sq;
         g.c = a * t;
         g.s = -b * t;
     }
@@ -123,9 +165,9 @@ __device__ __forceinline__ Giv<T> giv_unconventional(T a, T b) // (c -s; s c)(a;
 {
     Giv<T> g{ (T)0, (T)1 };
     T d = a * a + b * b;
-    T sq = hsqrt(d);
+    T sq, t;
+    hrsqrt2(d, sq, t);
     if (sq != (T)0) {
-        T t = (T)1 / sq;
         g.s = a * t;
         g.c = b * t;
     }
@@ -175,11 +217,12 @@ template <class T>
 __device__ __forceinline__ void svd2(T a00, T a01, T a10, T a11, Giv<T>& U, T& s0, T& s1, Giv<T>& V)
 {
     T x0 = a00 + a11, x1 = a10 - a01;
-    T den = hsqrt(x0 * x0 + x1 * x1);
+    T den, iden;
+    hrsqrt2(x0 * x0 + x1 * x1, den, iden);
     U.c = (T)1, U.s = (T)0;
     if (den != (T)0) {
-        U.c = x0 / den;
-        U.s = -x1 / den;
+        U.c = x0 * iden;
+        U.s = -x1 * iden;
     }
     T x = U.c * a00 - U.s * a10, y = U.c * a01 - U.s * a11, z = U.s * a01 + U.c * a11;
     T cosine, sine;
@@ -192,7 +235,8 @@ __device__ __forceinline__ void svd2(T a00, T a01, T a10, T a11, Giv<T>& U, T& s
         T tau = (T)0.5 * (x - z);
         T w = hsqrt(tau * tau + y2);
         T t = (tau > (T)0) ? y / (tau + w) : y / (tau - w);
-        cosine = (T)1 / hsqrt(t * t + (T)1);
+        T sq1;
+        hrsqrt2(t * t + (T)1, sq1, cosine);
         sine = -t * cosine;
         T c2 = cosine * cosine, csy = (T)2 * cosine * sine * y, s2 = sine * sine;
         s0 = c2 * x - csy + s2 * z;
@@ -374,7 +418,8 @@ __device__ inline void make_pd3(Mat3<T>& S)
             T theta = (A(Q_, Q_) - A(P_, P_)) / ((T)2 * apq);                           \
             T t = (theta >= (T)0 ? (T)1 : (T)-1) / (habs(theta) + hsqrt(theta * theta + (T)1)); \
             Giv<T> g;                                                                   \
-            g.c = (T)1 / hsqrt(t * t + (T)1);                                           \
+            T sq1_;                                                                     \
+            hrsqrt2(t * t + (T)1, sq1_, g.c);                                           \
             g.s = t * g.c;                                                              \
             giv_cols<P_, Q_>(g, A);                                                     \
             giv_rows<P_, Q_>(g, A);                                                     \
@@ -403,7 +448,9 @@ __device__ __forceinline__ void make_pd2(T& a, T& b, T& d)
     }
     T theta = (d - a) / ((T)2 * b);
     T t = (theta >= (T)0 ? (T)1 : (T)-1) / (habs(theta) + hsqrt(theta * theta + (T)1));
-    T c = (T)1 / hsqrt(t * t + (T)1), s = t * c;
+    T sq1, c;
+    hrsqrt2(t * t + (T)1, sq1, c);
+    T s = t * c;
     T l0 = a - t * b, l1 = d + t * b;
     if (l0 < (T)0) l0 = (T)0;
     if (l1 < (T)0) l1 = (T)0;
