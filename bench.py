@@ -38,7 +38,7 @@ SYMBOL = {  # profile-record prefix -> device symbol as rocprofv3 names it
     "gs_forward_off": "hot::k_gs_offblock<T>", "gs_backward_off": "hot::k_gs_offblock<T>",
     "gs_forward_chained": "hot::k_gs_sweep<T,true,64>", "gs_backward_chained": "hot::k_gs_sweep<T,false,64>",
     "gs_residual": "hot::k_gs_residual<T>", "hessian_assemble": "hot::k_hessian_tiles2<T,false>", "state_update": "hot::k_state<T>",
-    "force_scatter": "hot::k_force_cells2<T>", "p2g": "hot::k_p2g_cells2<T,true>", "g2p": "hot::k_g2p<T,0>",
+    "force_scatter": "hot::k_force_cells2<T>", "p2g": "hot::k_p2g_cells2<T,true>", "g2p": "hot::k_g2p<T,0,true>",
 }
 
 
@@ -302,6 +302,14 @@ def main():
         tb = 43 * s * Np + 7 * s * Nn
         transfers = {"p2g_ms": t_p2g, "g2p_ms": t_g2p, "mparticles_per_s": Np / ((t_p2g + t_g2p) * 1e-3) / 1e6, "algorithmic_bytes": tb, "per_step_ms": [{k: round(v, 4) for k, v in x.items()} for x in xfer_steps], "statistic": "median over %d profiled steps" % nprof,
                      "achieved_GBps": tb / ((t_p2g + t_g2p) * 1e-3) / 1e9, "frac_of_hbm_peak": tb / ((t_p2g + t_g2p) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # what the two kernels actually move (recorded PMC counters, see pmc_traffic): G2P also carries the fused strain update (Fn in, F out:
+        # 18 s per particle that SURVEY 8(d)'s transfer-only figure does not count) and is bound by THAT traffic; P2G is bound by its FP64 issue
+        if args.config == "C2" and not args.cells:
+            tp, src = pmc_traffic(SYMBOL["p2g"], "double" if s == 8 else "float")
+            tg, _ = pmc_traffic(SYMBOL["g2p"], "double" if s == 8 else "float")
+            if tp and tg:
+                transfers.update({"pmc_bytes_p2g_kernel": tp, "pmc_bytes_g2p_kernel": tg, "pmc_source": src,
+                                  "g2p_traffic_GBps": tg / (t_g2p * 1e-3) / 1e9, "g2p_traffic_frac_of_hbm_peak": tg / (t_g2p * 1e-3) / 1e9 / HBM_PEAK_GBS})
         prof_top = sorted(((k, round(v["ms"] / nprof, 3), v["calls"] // nprof) for k, v in groups.items()), key=lambda x: -x[1])[:14]
         del pctx
 
