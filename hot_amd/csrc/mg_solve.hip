@@ -1391,20 +1391,7 @@ __global__ __launch_bounds__(256) void k_gs_residual(const int32_t* __restrict__
         s1 += b[1] * x0 + b[4] * x1 + b[7] * x2;
         s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
     };
-    { // the first 64 slots are requested before the counts are known (every slot of a row holds a valid column id; a lane past the
-      // preceding part drops its product): the row's chain of dependent round trips is column ids -> gathers, not counts -> column ids -> gathers
-        const int j = c[lane];
-        const T* b = v + lane * 9;
-        T bb[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) bb[t] = b[t];
-        const T x0 = h[3 * (int64_t)j] - du[3 * (int64_t)j], x1 = h[3 * (int64_t)j + 1] - du[3 * (int64_t)j + 1], x2 = h[3 * (int64_t)j + 2] - du[3 * (int64_t)j + 2];
-        const bool in = lane < nl;
-        s0 = in ? bb[0] * x0 + bb[3] * x1 + bb[6] * x2 : (T)0;
-        s1 = in ? bb[1] * x0 + bb[4] * x1 + bb[7] * x2 : (T)0;
-        s2 = in ? bb[2] * x0 + bb[5] * x1 + bb[8] * x2 : (T)0;
-    }
-    for (int k = lane + 64; k < nl; k += 64) add(k, c[k]);
+    for (int k = lane; k < nl; k += 64) add(k, c[k]);
     if (owner) {
         // rank-local sweeps: the identity r - A du = L (h - du) holds for the rank's own diagonal block of A.  What is left of A du are the
         // couplings to other ranks' rows: those preceding the row are in the loop above already (h is zero there: never computed here, never
