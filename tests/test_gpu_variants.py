@@ -24,6 +24,8 @@ CASES = [
     ({"HOT_TEST_CFG": "gs_chain=2,gs_sub_block=32", "HOT_GS_PASS_COUNTERS": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_TEST_CFG": "gs_chain=2,gs_sub_block=32", "HOT_GS_BLOCK_FLAGS": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # hand-off through per-block sweep stamps
     ({"HOT_GS_BLOCK_FLAGS": "1"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_OFF_WAVES": "4100"}, SOLVER, "smoothers or vcycle"),  # a grid that is no multiple of 8: off-block steps dealt round robin instead of in per-XCD runs
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_OFF_WAVES": "64"}, SOLVER, "smoothers or vcycle"),  # few wavefronts: many steps per wavefront, odd and even step counts
     ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_V1": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # first-generation k_gs_block instead of the off-block / substitution pair
     ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_V1": "1", "HOT_GS_SPLIT_LAUNCHES": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_SIMPLE_GS": "1"}, SOLVER, "smoothers or vcycle"),
