@@ -549,7 +549,7 @@ void Ctx<T>::compute_step_dev(const T* residual, T* step)
         T residual_norm = (T)std::sqrt(dot_host(n3, residual, residual));
         T newton_tol = cfg.useCN ? max_cn_tolerance : (T)cfg.cneps;
         T rel = std::min((T)0.5, (T)std::sqrt(std::max(residual_norm, newton_tol)));
-        stats.linear_iterations += minres_dev(Amul, prec, step, residual, rel, cg_tolerance, 10000);
+        stats.linear_iterations += minres_dev(Amul, prec, step, residual, rel, cg_tolerance, cfg.linear_iteration_cap > 0 ? cfg.linear_iteration_cap : 10000);
         return;
     }
     // b = residual (+ dRhs == 0)
@@ -563,7 +563,7 @@ void Ctx<T>::compute_step_dev(const T* residual, T* step)
     T forcing = std::min((T)0.5, (T)std::sqrt(std::max(rpn, cg_tolerance)));
     T local_tol = forcing * rpn;
     int cnt = 0;
-    for (; cnt < 10000; ++cnt) {
+    for (; cnt < (cfg.linear_iteration_cap > 0 ? cfg.linear_iteration_cap : 10000); ++cnt) {
         if (rpn < local_tol) break;
         Amul(p.p, temp.p);
         project_dev(temp.p);

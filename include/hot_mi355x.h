@@ -87,7 +87,9 @@ typedef struct hot_config {
     int32_t ls_energy_only; /* line-search trials that evaluate nothing but the energy (singular values only, no stress / trial-F stores), full state pass once at the
                                accepted step: 0 = adaptive (default: from the second trial of a search on, and from the first when the previous search had to halve),
                                1 = never (every trial is a full pass), 2 = always */
-    int32_t reserved[7];
+    int32_t linear_iteration_cap; /* lsolver 1 / 2: iterations of one MINRES / PCG solve at most; 0 = the reference's 10000 (ImplicitSolver.h: the solvers' max_iterations).  A fixed
+                                     small count makes two implementations stop at the same Lanczos step, whatever round-off does to the stopping test (parity tests) */
+    int32_t reserved[6];
 } hot_config;
 
 typedef struct hot_stats {

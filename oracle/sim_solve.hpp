@@ -340,7 +340,7 @@ void Sim<T>::compute_step(const std::vector<TV>& residual, std::vector<TV>& step
         T residual_norm = std::sqrt(dot_product(residual, residual));
         T newton_tol = cfg.useCN ? max_cn_tolerance : (T)cfg.cneps;
         T rel = std::min((T)0.5, std::sqrt(std::max(residual_norm, newton_tol)));
-        stats.linear_iterations += minres_solve(Amul, prec, step, b, rel, cg_tolerance, 10000);
+        stats.linear_iterations += minres_solve(Amul, prec, step, b, rel, cg_tolerance, cfg.linear_iteration_cap > 0 ? cfg.linear_iteration_cap : 10000);
     }
     else
     // inexact PCG
@@ -357,7 +357,7 @@ void Sim<T>::compute_step(const std::vector<TV>& residual, std::vector<TV>& step
         T forcing = std::min((T)0.5, std::sqrt(std::max(rpn, cg_tolerance)));
         T local_tol = forcing * rpn;
         int cnt = 0;
-        for (; cnt < 10000; ++cnt) {
+        for (; cnt < (cfg.linear_iteration_cap > 0 ? cfg.linear_iteration_cap : 10000); ++cnt) {
             if (rpn < local_tol) break;
             Amul(p, temp);
             project(temp);
