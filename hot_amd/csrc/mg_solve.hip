@@ -1702,6 +1702,24 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 // blocks a colour, where a step costs its ~45 dependent-issue instructions, 190 ns.  On such a level — colours that fit the chip at
                 // once — the pair equals the chained k_gs_sweep in kernel time, 12.7 vs 12.2 ms per C2 step, and both kernels of a colour in ONE launch,
                 // substitution waves spinning on their block's arrival counter, were slower: 43 vs 24 us per colour.  k_gs_sweep stays there.)
+#ifdef HOT_AB_KERNELS
+                const int depth = ab_int("HOT_GS_SUBST_D", 8); // A/B build: image columns in flight per block (4 / 6 / 10 / 12 / 16 instead of 8)
+#define HOT_SUBST_D(DD)                                                                                                                                                       \
+    if (depth == DD) {                                                                                                                                                        \
+        if (fwd)                                                                                                                                                              \
+            HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, DD>), nb, 64, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);                 \
+        else                                                                                                                                                                  \
+            HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, DD>), nb, 64, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);                \
+        first = false;                                                                                                                                                        \
+        continue;                                                                                                                                                             \
+    }
+                HOT_SUBST_D(4)
+                HOT_SUBST_D(6)
+                HOT_SUBST_D(10)
+                HOT_SUBST_D(12)
+                HOT_SUBST_D(16)
+#undef HOT_SUBST_D
+#endif
                 if (fwd)
                     HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
                 else
