@@ -7,7 +7,7 @@ from hot_amd import parallel, synth
 which = sys.argv[1] if len(sys.argv) > 1 else "C2"
 cfg = dict(synth.CONFIGS[which])
 cloud = parallel.shard_cloud(cfg, 0, 1, n=cfg["n"])
-lib = hot_amd.load()
+lib = hot_amd.HotLib(os.environ["HOT_LIB"]) if os.environ.get("HOT_LIB") else hot_amd.load()  # HOT_LIB: another build of the library
 over = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("HOT_SOAK_CFG", "").split(",") if kv)}  # e.g. HOT_SOAK_CFG=gs_chain=2
 ctx = bench.make_ctx(lib, cloud, cfg, profile=1, **over)
 for _ in range(3):
