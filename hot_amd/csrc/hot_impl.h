@@ -50,7 +50,7 @@ struct Level {
     DBuf<T> gs_p1; // 3 per slot: the off-block products summed over the slot's (up to 16) entries (k_gs_offblock -> k_gs_subst, which subtracts a row's slots from its rhs in order)
     DBuf<int2> gs_slot; // {first stored entry (row * 125 + k), entries} per slot (k_gs_slot_fill); gs_pad[8 pos + 5 / 6]: the position's first forward / backward slot
     int gs_nslot = 0;
-    int32_t gs_slot_start[2][9] = {}; // [forward / backward][colour .. 8]: first slot of the colour's off-block runs (8: the end)
+    int32_t gs_slot_rng[2][2][8] = {}; // [forward / backward][first / end][colour]: the off-block slots of the colour's blocks — on a row-partitioned level of the blocks THIS rank owns
     bool gs_img_ready = false;
     DBuf<int32_t> rowcnt; // 4n: (precede-off, precede-in, follow-in, follow-off) slot counts of the regrouped rows
     bool split = false;

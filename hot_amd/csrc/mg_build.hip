@@ -475,14 +475,15 @@ __global__ void k_gs_slot_count(const int32_t* __restrict__ pad, int32_t* __rest
     flags[e] = node ? (o[1] + 15) >> 4 : 0, flags[npos + e] = node ? (o[4] + 15) >> 4 : 0;
 }
 struct GsColourStarts {
-    int pos[9];
+    int pos[2][8]; // [first / end][colour]: positions (64 per colour block) of the blocks whose rows are swept
 };
 __global__ void k_gs_slot_starts(const int32_t* __restrict__ scan, GsColourStarts cs, int npos, int total, int32_t* __restrict__ out)
 {
-    const int c = threadIdx.x;
-    if (c > 8) return;
-    out[c] = scan[cs.pos[c]]; // forward ranges (scan[npos]: the first backward slot = the forward total)
-    out[9 + c] = cs.pos[c] < npos ? scan[npos + cs.pos[c]] : total;
+    const int e = threadIdx.x;
+    if (e >= 16) return;
+    const int p = cs.pos[e >> 3][e & 7];
+    out[e] = scan[p]; // forward ranges (scan[npos]: the first backward slot = the forward total)
+    out[16 + e] = p < npos ? scan[npos + p] : total;
 }
 __global__ void k_gs_slot_fill(int32_t* __restrict__ pad, const int32_t* __restrict__ scan, int2* __restrict__ slot, int npos, int total)
 {
@@ -608,7 +609,7 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
     int max_nb = 0;
     for (int c = 0; c < 8; ++c) max_nb = std::max(max_nb, L.color_block_begin[c + 1] - L.color_block_begin[c]);
     L.gs_img_ready = false;
-    if (!L.part && (max_nb > 256 || ctx->cfg.gs_sub_block == 32)) {
+    if (max_nb > 256 || ctx->cfg.gs_sub_block == 32) { // (row-partitioned levels too: the rows of other ranks have zero counts, hence no slots and empty images)
         L.gs_img.reserve(GsImg<T>::per_block * (size_t)L.nblocks + 16), // + one entry: k_gs_subst's unconditional loads
         L.gs_imgi.reserve(2 * GsImg<T>::idx_per_dir * (size_t)L.nblocks);
         const int npos = 64 * L.nblocks;
@@ -619,11 +620,20 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
         HOT_LAUNCH(ctx, "gs_slot_fill", k_gs_slot_fill, div_up((size_t)npos + 1, 256), 256, 0, L.gs_pad.p, ctx->scan.p, L.gs_slot.p, npos, L.gs_nslot);
         { // where each colour's slots begin, per direction, for the host: k_gs_offblock gets its range as launch arguments instead of starting with a dependent load
             GsColourStarts cs;
-            for (int c = 0; c <= 8; ++c) cs.pos[c] = 64 * L.color_block_begin[c];
+            const int R1 = ctx->comm.size + 1, me = ctx->comm.rank;
+            for (int c = 0; c < 8; ++c) {
+                const int b0 = L.color_block_begin[c], b1 = L.color_block_begin[c + 1];
+                // a row-partitioned level: the run of the colour's block list this rank owns (Level::csplit, level_ownership)
+                cs.pos[0][c] = 64 * (L.part ? b0 + L.csplit[c * R1 + me] : b0), cs.pos[1][c] = 64 * (L.part ? b0 + L.csplit[c * R1 + me + 1] : b1);
+            }
             int32_t* d = (int32_t*)(ctx->flags.p); // (flags: consumed by the scan above)
             HOT_LAUNCH(ctx, "gs_slot_starts", k_gs_slot_starts, 1, 32, 0, ctx->scan.p, cs, npos, L.gs_nslot, d);
-            HOT_HIP(hipMemcpyAsync(&L.gs_slot_start[0][0], d, 18 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            int32_t h[32];
+            HOT_HIP(hipMemcpyAsync(h, d, 32 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
             ctx->sync();
+            for (int dir = 0; dir < 2; ++dir)
+                for (int fe = 0; fe < 2; ++fe)
+                    for (int c = 0; c < 8; ++c) L.gs_slot_rng[dir][fe][c] = h[16 * dir + 8 * fe + c];
         }
         HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, L.nblocks, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p, L.gs_imgi.p, L.nblocks);
         L.gs_img_ready = true;

@@ -1691,17 +1691,34 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             T* hD = fwd ? dAu : u;
             const char* nmT = fwd ? "gs_forward" : "gs_backward";
             const char* nmO = fwd ? "gs_forward_off" : "gs_backward_off";
-            bool first = true; // the first colour walked has no off-block columns before it: no off-block launch, the substitution reads rhs itself
+            if (L.part) hD = fwd ? dAu : (T*)nullptr; // partitioned level: u takes the correction in one axpy after the colour exchanges (only the owner's rows would get it here)
             for (int q = 0; q < 8; ++q) {
-                const int c = fwd ? q : 7 - q, b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
+                const int c = fwd ? q : 7 - q;
+                int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0;
                 if (nb <= 0) continue;
-                // (the first colour walked has no off-block columns before it: no slots, no launch)
+                // sharded: this rank sums and substitutes the colour blocks it owns (a contiguous run of the colour's list), then every rank receives
+                // the colour's new values before the next colour starts (rank-local sweeps: no hand-off inside the sweep) — as the k_gs_block path does
+                struct AfterColour {
+                    Ctx<T>* ctx;
+                    Level<T>& L;
+                    T* x;
+                    int c;
+                    bool on;
+                    ~AfterColour()
+                    {
+                        if (on) ctx->exchange(L, x, c);
+                    }
+                } after{ this, L, xx, c, L.part && !rank_local };
+                if (L.part) {
+                    const int R1 = comm.size + 1;
+                    b0 += L.csplit[c * R1 + comm.rank], nb = L.csplit[c * R1 + comm.rank + 1] - L.csplit[c * R1 + comm.rank];
+                    if (nb <= 0) continue;
+                }
+                // (the first colour walked has no off-block columns before it — an empty slot range, like a rank without rows of the colour: no launch)
+                const int s0 = L.gs_slot_rng[fwd ? 0 : 1][0][c], s1 = L.gs_slot_rng[fwd ? 0 : 1][1][c];
                 const int grid = std::max(1, ab_int("HOT_GS_OFF_WAVES", 4096) / 4);
-                if (!first) HOT_LAUNCH(this, lname(nmO, L.id).c_str(), k_gs_offblock<T>, grid, 256, 0, L.gs_slot.p, L.gs_col.p, L.val.p, L.gs_pad.p, xx, L.gs_p1.p, L.gs_slot_start[fwd ? 0 : 1][c], L.gs_slot_start[fwd ? 0 : 1][c + 1]);
-                // (eight columns in flight per block: sixteen change nothing, neither on the finest level, HBM-bound, nor on C2's level 1 with 91
-                // blocks a colour, where a step costs its ~45 dependent-issue instructions, 190 ns.  On such a level — colours that fit the chip at
-                // once — the pair equals the chained k_gs_sweep in kernel time, 12.7 vs 12.2 ms per C2 step, and both kernels of a colour in ONE launch,
-                // substitution waves spinning on their block's arrival counter, were slower: 43 vs 24 us per colour.  k_gs_sweep stays there.)
+                if (s1 > s0) HOT_LAUNCH(this, lname(nmO, L.id).c_str(), k_gs_offblock<T>, grid, 256, 0, L.gs_slot.p, L.gs_col.p, L.val.p, L.gs_pad.p, xx, L.gs_p1.p, s0, s1);
+                // (eight columns in flight per block: 4 .. 16 change nothing, §6 of DESIGN.md)
 #ifdef HOT_AB_KERNELS
                 const int depth = ab_int("HOT_GS_SUBST_D", 8); // A/B build: image columns in flight per block (4 / 6 / 10 / 12 / 16 instead of 8)
 #define HOT_SUBST_D(DD)                                                                                                                                                       \
@@ -1710,7 +1727,6 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, DD>), nb, 64, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);                 \
         else                                                                                                                                                                  \
             HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, DD>), nb, 64, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);                \
-        first = false;                                                                                                                                                        \
         continue;                                                                                                                                                             \
     }
                 HOT_SUBST_D(4)
@@ -1724,7 +1740,6 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                     HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
                 else
                     HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
-                first = false;
             }
         };
         HOT_CHECK(sb == 16 || sb == 32 || sb == 64, HOT_ERR_INVALID, "hot_config.gs_sub_block must be 0 (auto), 16, 32 or 64");
