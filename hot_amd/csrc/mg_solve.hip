@@ -902,8 +902,9 @@ __device__ __forceinline__ void gs_phase_b(const T* tri, const T* sv, const int3
 // block, which walks a ~45 us chain of dependent round trips (header -> columns -> values -> gathers -> D^-1 -> sums, twice per
 // sub-block) even when it has nothing but its in-block couplings to read (first colour), and up to 45 us more where the off-block
 // half rows are long (last colour) — while half of the workgroups (surface blocks) have long finished and HBM idles.  So:
-//   k_gs_offblock  one wavefront per ROW of the colour: p1_i = rhs_i - sum of the off-block products (lane = slot, wave_sum).  No
-//                  serial part, tens of thousands of independent wavefronts: streams like k_gs_residual, balanced whatever the body;
+//   k_gs_offblock  the off-block products of the colour's rows, summed per SLOT (a run of up to 16 stored entries of one row; four slots per
+//                  wavefront step, below): no serial part, streams like k_gs_residual, balanced whatever the body; k_gs_subst subtracts a
+//                  row's slot sums from its right-hand side;
 //   k_gs_subst     one wavefront per colour block: h = D^-1 p1 + (strict in-block triangle of -(D^-1 A)) h by substitution (below).
 template <class T>
 __device__ __forceinline__ T row16_sum(T v) // sum over each 16-lane DPP row; valid in the row's lane 15
