@@ -371,9 +371,11 @@ void Ctx<T>::build_hessian()
     if (v1)
         HOT_LAUNCH(this, "hessian_assemble_v1", k_hessian<T>, Ng, 256, 0, pX.p, pFn.p, pFt.p, pVol.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gIdx.p, L->val.p, dx, (T)1 / dx,
             dt, cfg.project);
+    else if (ab_flag("HOT_HESSIAN_TILES"))
+        assemble_tiles(*L); // rounds 2 - 4: particle chunks staged in LDS
     else
 #endif
-        assemble_tiles(*L);
+        assemble_rows(*L);
     if (L->part) exchange_rows(*L, written.p); // rows near the shard boundary: the other side's particles contribute as well
     if (cfg.systemBCProject && Nc > 0)
         HOT_LAUNCH(this, "hessian_bc_project", k_bc_project_matrix<T>, div_up(ne, 256), 256, 0, L->col.p, L->val.p, bcIdx.p, bcR.p, bcRinv.p, bcSlip.p, Nn, L->mask());

@@ -1,0 +1,429 @@
+// libhotmi355x — Hessian assembly, production kernel of round 5: output-stationary row tiles, barrier-free wavefront tasks,
+// the contraction on broadcast FMAs (v_fmac_*_dpp row_newbcast), no staging of particle data in LDS.
+//
+// Mathematics (reference Projects/multigrid/ImplicitSolver.h:498-552): every ordered node pair (i, j) of every particle adds
+//   H(i, j)[a][b] = V_p dt^2 sum_{v,q} dP_{(a,v),(b,q)} g_i[v] g_j[q],   g_i = Fn^T grad w_i
+// to row dof_i, slot linearOffset(node_i - node_j).  With  E[(a,r),(b,s)] = V_p dt^2 sum_{v,q} Fn(r,v) Fn(s,q) dP_{(a,v),(b,q)}
+// (symmetric 9 x 9, 45 scalars, formed once per particle by k_dpdf_rec) the deformation gradient leaves the inner loops:
+//   H(i, j)[a][b] = sum_{r,s} E[(a,r),(b,s)] gw_i[r] gw_j[s],   gw_i = grad w_i(x_p)
+// and is evaluated as  K_i[a][b][s] = sum_r E[(a,r),(b,s)] gw_i[r]  (27 values per (particle, row node)), then
+// H(i, j)[a][b] = sum_s K_i[a][b][s] gw_j[s]  (27 multiply-adds per block).
+//
+// k_hessian_tiles2 (round 2 - 4, hessian_tiles.hip, now A/B build only) staged dP, g and K of 40-particle chunks in LDS behind four
+// barriers per chunk and paid 18 LDS reads per 27 multiply-adds in its pair phase: 13.7 ms at C2, 62 % of the wave cycles parked on
+// barriers, 10 % of the FP64 rate.  Here:
+//   * one workgroup (8 wavefronts) per aligned 2x2x2 tile of grid nodes, its 8 rows x 125 slots x 9 values in LDS (72 KB, two
+//     workgroups per CU); nothing else of the workgroup is shared, there is no barrier between the prologue and the write-out;
+//   * a TASK = (base cell among the 4x4x4 cells around the tile, x-plane of the tile): the <= 4 tile rows of that plane inside the
+//     cell's 3x3x3 support.  Wavefronts draw tasks, heaviest first, from an LDS counter.  A wavefront walks the cell's particles
+//     (contiguous records, the next one requested while the current one is worked on) with lane = (half h, column node j): the 27
+//     column nodes of the cell twice, half 0 owning the (a, b) entries 0..4 of every 3x3 block, half 1 the entries 4..8;
+//   * per particle a lane loads its three E values and six 1-D weights straight from the particle record (global memory, L2),
+//     forms gw_j, parks it in a 768-byte wavefront-private LDS strip (the only LDS traffic of the inner loop: 3 stores per
+//     particle, 3 wave-uniform loads per row);
+//   * per (particle, row): lanes 0..14 of every 16-lane DPP row form the 15 K values of their half (3 FMAs), then every lane runs
+//     15 broadcast FMAs  acc[ab] += K[lane 3 ab + s of my DPP row] * gw_j[s]  — the K operand never leaves the register file —
+//     into 5 accumulators per row (40 VGPRs for the task's 4 rows);
+//   * after the cell's last particle the accumulators go to the LDS tile with 5 (4) ds_add_f64 per lane and row.
+// 18 VALU instructions per (particle, row) for 27 x 27 multiply-adds on 64 lanes: 70 % of them useful, no LDS atomics or index
+// decoding inside the particle loop.
+#include "hot_impl.h"
+#include "hot_constitutive.h"
+
+namespace hot {
+
+__host__ __device__ constexpr int sym45i(int a, int b) { return a <= b ? (a * 9 - (a * (a - 1)) / 2 + (b - a)) : (b * 9 - (b * (b - 1)) / 2 + (a - b)); }
+
+constexpr int REC = 64; // scalars per particle record: E (45), per axis w[3] and dw[3] / dx (18), pad
+
+// ---- pass 1: the particle record
+template <class T>
+__global__ __launch_bounds__(256) void k_dpdf_rec(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ Ft, const T* __restrict__ Vol, const T* __restrict__ Mu,
+    const T* __restrict__ Lam, T* __restrict__ rec, int64_t Np, T dt, T one_over_dx, int project)
+{
+    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= Np) return;
+    Mat3<T> Fc;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Fc.a[c] = Ft[(int64_t)c * Np + p];
+    HessBlocks<T> h;
+    corotated_hessian(Fc, Mu[p], Lam[p], project != 0, h);
+    const T sc = Vol[p] * dt * dt;
+    const Mat3<T>& U = h.U;
+    const Mat3<T>& V = h.V;
+    auto Kval = [&](int a, int b, int c, int d) -> T { // non-zero only for (aa,cc) [A], (ab,ab) and (ab,ba) [B blocks]
+        if (a == b && c == d) return h.A(a, c);
+        if (a != b && ((a == c && b == d) || (a == d && b == c))) {
+            int lo = a < b ? a : b, hi = a < b ? b : a;
+            const T* B = (lo == 0 && hi == 1) ? h.B01 : ((lo == 1 && hi == 2) ? h.B12 : h.B20);
+            int ia, ic;
+            if (lo == 0 && hi == 2) {
+                ia = (a == 2) ? 0 : 1, ic = (c == 2) ? 0 : 1;
+            }
+            else {
+                ia = (a == lo) ? 0 : 1, ic = (c == lo) ? 0 : 1;
+            }
+            return B[ia + ic];
+        }
+        return (T)0;
+    };
+    // D[(a,v),(b,q)] = V_p dt^2 dP/dF in the rotated-back frame, index (a + 3 v, b + 3 q), full symmetric 9 x 9 in registers
+    T D[81];
+#pragma unroll
+    for (int ij = 0; ij < 9; ++ij) {
+        const int jj = ij / 3, ii = ij - jj * 3;
+#pragma unroll
+        for (int rs = ij; rs < 9; ++rs) {
+            const int ss = rs / 3, rr = rs - ss * 3;
+            T v = (T)0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    T ub = U(ii, a) * V(jj, b);
+                    if (a == b) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) v += Kval(a, a, c, c) * ub * U(rr, c) * V(ss, c);
+                    }
+                    else {
+                        v += Kval(a, b, a, b) * ub * U(rr, a) * V(ss, b) + Kval(a, b, b, a) * ub * U(rr, b) * V(ss, a);
+                    }
+                }
+            D[ij * 9 + rs] = D[rs * 9 + ij] = v * sc;
+        }
+    }
+    // E[(a,r),(b,s)] = sum_{v,q} Fn(r,v) Fn(s,q) D[(a,v),(b,q)],  Fn(r,c) at component r + 3 c
+    T F9[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) F9[c] = Fn[(int64_t)c * Np + p];
+    T Th[81]; // Th[(a,r),(b,q)] = sum_v Fn(r,v) D[(a,v),(b,q)]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int n = 0; n < 9; ++n) Th[(a + 3 * r) * 9 + n] = F9[r] * D[a * 9 + n] + F9[r + 3] * D[(a + 3) * 9 + n] + F9[r + 6] * D[(a + 6) * 9 + n];
+    T* o = rec + p * REC;
+#pragma unroll
+    for (int m = 0; m < 9; ++m)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int n = b + 3 * s;
+                if (n >= m) o[sym45i(m, n)] = F9[s] * Th[m * 9 + b] + F9[s + 3] * Th[m * 9 + b + 3] + F9[s + 6] * Th[m * 9 + b + 6];
+            }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int base;
+        T w[3], dw[3];
+        bspline<T>(one_over_dx, X[(int64_t)d * Np + p], base, w, dw);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[45 + 6 * d + k] = w[k], o[48 + 6 * d + k] = one_over_dx * dw[k];
+    }
+    o[63] = (T)0;
+}
+
+// ---- the 15 broadcast FMAs of a (particle, row): acc[ab] += K(lane 3 ab + s of this lane's 16-lane row) * g[s].  The s_nop covers
+// the VALU-write -> DPP-read distance of K that the compiler's hazard recogniser does not see inside an asm statement.
+__device__ __forceinline__ void dpp_row_fma(double (&acc)[5], double K, double g0, double g1, double g2)
+{
+#define HOT_DPPF(i, g, n) "v_fmac_f64_dpp %" #i ", %5, %" #g " row_newbcast:" #n " row_mask:0xf bank_mask:0xf\n"
+    asm("s_nop 1\n" HOT_DPPF(0, 6, 0) HOT_DPPF(1, 6, 3) HOT_DPPF(2, 6, 6) HOT_DPPF(3, 6, 9) HOT_DPPF(4, 6, 12) HOT_DPPF(0, 7, 1) HOT_DPPF(1, 7, 4) HOT_DPPF(2, 7, 7) HOT_DPPF(3, 7, 10)
+            HOT_DPPF(4, 7, 13) HOT_DPPF(0, 8, 2) HOT_DPPF(1, 8, 5) HOT_DPPF(2, 8, 8) HOT_DPPF(3, 8, 11) HOT_DPPF(4, 8, 14)
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4])
+        : "v"(K), "v"(g0), "v"(g1), "v"(g2));
+#undef HOT_DPPF
+}
+__device__ __forceinline__ void dpp_row_fma(float (&acc)[5], float K, float g0, float g1, float g2)
+{
+#define HOT_DPPF(i, g, n) "v_fmac_f32_dpp %" #i ", %5, %" #g " row_newbcast:" #n " row_mask:0xf bank_mask:0xf\n"
+    asm("s_nop 1\n" HOT_DPPF(0, 6, 0) HOT_DPPF(1, 6, 3) HOT_DPPF(2, 6, 6) HOT_DPPF(3, 6, 9) HOT_DPPF(4, 6, 12) HOT_DPPF(0, 7, 1) HOT_DPPF(1, 7, 4) HOT_DPPF(2, 7, 7) HOT_DPPF(3, 7, 10)
+            HOT_DPPF(4, 7, 13) HOT_DPPF(0, 8, 2) HOT_DPPF(1, 8, 5) HOT_DPPF(2, 8, 8) HOT_DPPF(3, 8, 11) HOT_DPPF(4, 8, 14)
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4])
+        : "v"(K), "v"(g0), "v"(g1), "v"(g2));
+#undef HOT_DPPF
+}
+
+// ---- lane roles of a task wavefront: half h = lane >> 5 owns the block entries 4 h .. 4 h + 4; its lane jl = lane & 31 (< 27) the column node
+// (j0, j1, j2) of the cell's kernel; lane n = lane & 15 (< 15) of every 16-lane DPP row forms K[(a, b) = 4 h + n / 3][s = n % 3]
+struct RowsLane {
+    int h, jl, j0, j1, j2;
+    unsigned eo0, eo1, eo2; // record offsets of E[(a, r), (b, s)], r = 0, 1, 2
+    unsigned wo0, wo1, wo2; // record offsets of w_x[j0], w_y[j1], w_z[j2] (dw / dx three scalars further)
+};
+__device__ __forceinline__ RowsLane rows_lane(int lane)
+{
+    RowsLane L;
+    L.h = lane >> 5, L.jl = min(lane & 31, 26);
+    L.j0 = L.jl / 9, L.j1 = (L.jl / 3) % 3, L.j2 = L.jl % 3;
+    const int n = min(lane & 15, 14), ab = 4 * L.h + n / 3, ks = n % 3, ka = ab % 3, kb = ab / 3;
+    L.eo0 = sym45i(ka, kb + 3 * ks), L.eo1 = sym45i(ka + 3, kb + 3 * ks), L.eo2 = sym45i(ka + 6, kb + 3 * ks);
+    L.wo0 = 45 + L.j0, L.wo1 = 51 + L.j1, L.wo2 = 57 + L.j2;
+    return L;
+}
+struct RowsTask { // wave-uniform
+    int px; // x-plane of the tile
+    int lx, ly0, lz0; // kernel index of the plane's row (0, 0) inside the cell: row (ry, rz) sits at (lx, ly0 + ry, lz0 + rz)
+    int m4; // rows (ry << 1 | rz) of the plane inside the cell's support (and active)
+};
+
+// One task: the particles [rp, rp + cnt records) of a cell against NR rows of a tile plane.  Records are requested one particle ahead into
+// two alternating register sets (no copies); the NR x 3 wave-uniform strip loads of a particle are issued together.
+template <class T, int NR>
+__device__ __forceinline__ void hr_walk(const T* __restrict__ rp /*wave-uniform*/, int cnt, const RowsTask& tk, T* __restrict__ strip, AccT<T>* __restrict__ tile, int lane, const RowsLane& ld)
+{
+    using AT = AccT<T>;
+    int qs[NR], so[NR]; // rows of the task in ascending order (ordinals beyond the row count repeat row 0: computed, not stored), their strip offsets
+    {
+        int m = tk.m4;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            qs[r] = m ? __builtin_ctz(m) : __builtin_ctz(tk.m4);
+            m &= m - 1;
+            so[r] = tk.lx * 9 + (tk.ly0 + (qs[r] >> 1)) * 3 + (tk.lz0 + (qs[r] & 1));
+        }
+    }
+    T acc[NR][5];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 5; ++e) acc[r][e] = (T)0;
+    // The record of a particle (64 scalars) comes with ONE coalesced load per wavefront, one particle ahead, is parked in the wavefront's LDS
+    // stage and picked apart from there: a lane's three E values and six 1-D weights sit at lane-specific offsets, and as nine gathering
+    // global loads per particle they made the kernel wait for the texture addresser (16 clocks per vector memory instruction whatever its
+    // width: 8.2 ms at C2 with 48 % of the VALU cycles used).
+    T* stage = strip + 96;
+    auto work = [&](T rec_lane) {
+        stage[lane] = rec_lane;
+        __builtin_amdgcn_wave_barrier();
+        const T e0 = stage[ld.eo0], e1 = stage[ld.eo1], e2 = stage[ld.eo2];
+        const T wx = stage[ld.wo0], dwx = stage[ld.wo0 + 3], wy = stage[ld.wo1], dwy = stage[ld.wo1 + 3], wz = stage[ld.wo2], dwz = stage[ld.wo2 + 3];
+        const T g0 = dwx * (wy * wz), g1 = (wx * wz) * dwy, g2 = (wx * wy) * dwz;
+        strip[ld.jl] = g0, strip[32 + ld.jl] = g1, strip[64 + ld.jl] = g2;
+        __builtin_amdgcn_wave_barrier();
+        T gw[NR][3];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gw[r][k] = strip[so[r] + 32 * k];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const T K = e0 * gw[r][0] + e1 * gw[r][1] + e2 * gw[r][2];
+            dpp_row_fma(acc[r], K, g0, g1, g2);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    T A = rp[lane], B;
+    for (int l = 0; l < cnt; l += 2) {
+        B = rp[(l + 1 < cnt ? l + 1 : l) * REC + lane];
+        work(A);
+        if (l + 1 >= cnt) break;
+        A = rp[(l + 2 < cnt ? l + 2 : l + 1) * REC + lane];
+        work(B);
+    }
+    // ---- accumulators -> LDS tile: half 0 holds the block entries 0..4, half 1 the entries 4..8 (its entry 4 is the duplicate)
+    if ((lane & 31) < 27) {
+        const int nrow = __popc(tk.m4);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r < nrow) { // wave-uniform
+                const int q = qs[r], row = 4 * tk.px + q;
+                AT* o = tile + row * 1125 + ((tk.lx - ld.j0 + 2) * 25 + (tk.ly0 + (q >> 1) - ld.j1 + 2) * 5 + (tk.lz0 + (q & 1) - ld.j2 + 2)) * 9 + 4 * ld.h;
+                if (ld.h == 0) lds_atomic_add(o, (AT)acc[r][0]);
+#pragma unroll
+                for (int e = 1; e < 5; ++e) lds_atomic_add(o + e, (AT)acc[r][e]);
+            }
+        }
+    }
+}
+
+
+// LDS of a workgroup: the tile (72 000 bytes in either build), per wavefront a strip (96 scalars) and a record stage (64 scalars), the
+// integer tables.  Two workgroups per CU: 6 wavefronts each in fp64 (81 536 bytes), 8 in fp32.
+#ifndef HOT_HR_WAVES64
+#define HOT_HR_WAVES64 6
+#endif
+template <class T>
+struct RowsLds {
+    static constexpr int WAVES = sizeof(T) == 8 ? HOT_HR_WAVES64 : 8, THREADS = WAVES * 64;
+    static constexpr int NINT = 64 * 3 + 8 + 128 + 128 + 8; // cstart, ccnt, cmask | rdof | work | tasks | ctl
+    static constexpr size_t bytes = (size_t)8 * 1125 * sizeof(AccT<T>) + (size_t)WAVES * 160 * sizeof(T) + (size_t)NINT * sizeof(int32_t);
+};
+
+// Development aid (-DHOT_HT_CLOCKS, tools/hess_phases.sh): shader clocks of every wavefront (lane 0), summed per phase: 0 prologue, 1 task fetch
+// and set-up, 2 particle loop and accumulators -> tile, 4 wait at the final barrier, 5 write-out; 6 particle visits, 7 (particle, row) steps.
+#ifdef HOT_HT_CLOCKS
+__device__ unsigned long long hr_clk[8];
+#define HR_CLK(i) \
+    do { \
+        const unsigned long long t_ = clock64(); /* wave-uniform: the sums stay in SGPRs */ \
+        clk_[i] += t_ - t0_, t0_ = t_; \
+    } while (0)
+#define HR_CNT(i, n) clk_[i] += (n)
+#else
+#define HR_CLK(i)
+#define HR_CNT(i, n)
+#endif
+
+template <class T>
+__global__ __launch_bounds__(RowsLds<T>::THREADS) void k_hessian_rows(const T* __restrict__ rec, const uint64_t* __restrict__ blocks, const int32_t* __restrict__ gIdx,
+    const int32_t* __restrict__ cell_first, HashMap cmap, const T* __restrict__ mass, T* __restrict__ val, int ntiles, const uint8_t* __restrict__ own /*sharded: rows this rank owns, else null*/,
+    uint8_t* __restrict__ written /*sharded: rows this launch wrote*/)
+{
+    using G = Geo<T>;
+    using AT = AccT<T>;
+    constexpr int HR_WAVES = RowsLds<T>::WAVES, HR_THREADS = RowsLds<T>::THREADS;
+    constexpr int TPBY = G::BY / 2, TPBZ = G::BZ / 2, TPB = (G::BX / 2) * TPBY * TPBZ;
+    extern __shared__ __attribute__((aligned(16))) char hr_smem[];
+    AT* tile = (AT*)hr_smem; // [8][1125]
+    T* strips = (T*)(tile + 8 * 1125); // [HR_WAVES][160]: gw_j[r] of the wavefront's current particle [3][32], its record [64]
+    int32_t* cstart = (int32_t*)(strips + HR_WAVES * 160); // [64] first particle of each contributing cell
+    int32_t* ccnt = cstart + 64; // [64] its particle count
+    int32_t* cmask = ccnt + 64; // [64] tile rows inside its 3x3x3 support (and active)
+    int32_t* rdof = cmask + 64; // [8]
+    int32_t* work = rdof + 8; // [128] rows x particles of task candidate (cell, x-plane)
+    int32_t* tasks = work + 128; // [128] candidates with work, heaviest first: cell | plane << 6 | row mask << 8
+    int32_t* ctl = tasks + 128; // [0] task cursor, [1] number of tasks
+    const int tid = threadIdx.x;
+#ifdef HOT_HT_CLOCKS
+    unsigned long long clk_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t0_ = clock64();
+#endif
+    // workgroup i runs on XCD i % 8: runs of 32 consecutive tiles (4 - 8 SPGrid blocks) share most of their particle records; a run goes to
+    // one XCD so that its L2 serves the re-reads
+    const int id = blockIdx.x, run = (id & 7) + 8 * (id >> 8), tile_id = run * 32 + ((id >> 3) & 31);
+    if (tile_id >= ntiles) return;
+    const int b = tile_id / TPB, tt = tile_id % TPB;
+    int bx, by, bz;
+    G::linear_to_coord(blocks[b], bx, by, bz);
+    const int tx0 = bx + 2 * (tt / (TPBY * TPBZ)), ty0 = by + 2 * ((tt / TPBZ) % TPBY), tz0 = bz + 2 * (tt % TPBZ);
+    if (tid < 8) {
+        int ex = (tx0 - bx) + (tid >> 2), ey = (ty0 - by) + ((tid >> 1) & 1), ez = (tz0 - bz) + (tid & 1);
+        rdof[tid] = gIdx[(int64_t)b * G::EPB + ((ex << (G::yb + G::zb)) | (ey << G::zb) | ez)];
+    }
+    if (tid == 0) ctl[0] = 0, ctl[1] = 0;
+    for (int e = tid; e < 8 * 1125; e += HR_THREADS) tile[e] = (AT)0;
+    __syncthreads();
+    bool any = false;
+    for (int r = 0; r < 8; ++r) any = any || rdof[r] >= 0;
+    if (!any) return;
+    if (tid < 64) {
+        const int ox = (tid >> 4) - 2, oy = ((tid >> 2) & 3) - 2, oz = (tid & 3) - 2; // base cell = tile origin + (-2..1)^3
+        const int cx = tx0 + ox, cy = ty0 + oy, cz = tz0 + oz;
+        int first = 0, cnt = 0, mask = 0;
+        if ((cx | cy | cz) >= 0) {
+            int32_t c = hash_find_id(cmap, G::linear_offset(cx, cy, cz) >> G::data_bits);
+            if (c >= 0) first = cell_first[c], cnt = cell_first[c + 1] - first;
+        }
+        for (int r = 0; r < 8; ++r) {
+            const int ax = (r >> 2) - ox, ay = ((r >> 1) & 1) - oy, az = (r & 1) - oz; // row node inside the cell's kernel
+            if ((unsigned)ax < 3u && (unsigned)ay < 3u && (unsigned)az < 3u && rdof[r] >= 0) mask |= 1 << r;
+        }
+        cstart[tid] = first, ccnt[tid] = cnt, cmask[tid] = mask;
+    }
+    __syncthreads();
+    if (own) { // sharded: a tile none of whose rows this rank owns and none of whose cells hold particles of its shard is not its business
+        bool mine = false;
+        for (int r = 0; r < 8; ++r) mine = mine || (rdof[r] >= 0 && own[rdof[r]]);
+        bool any_particles = false;
+        for (int c = 0; c < 64; ++c) any_particles = any_particles || (ccnt[c] > 0 && cmask[c] != 0);
+        if (!mine && !any_particles) return; // workgroup-uniform (LDS tables)
+    }
+    // ---- task list: candidate t = (cell, x-plane), its work = rows x particles; rank sort, heaviest first
+    int my_work = 0, my_m4 = 0;
+    if (tid < 128) {
+        const int cell = tid >> 1, px = tid & 1;
+        my_m4 = (cmask[cell] >> (4 * px)) & 15;
+        my_work = __popc(my_m4) * ccnt[cell];
+        work[tid] = my_work;
+    }
+    __syncthreads();
+    if (tid < 128 && my_work > 0) {
+        int rank = 0;
+        for (int u = 0; u < 128; ++u) {
+            const int wu = work[u];
+            rank += (wu > my_work) || (wu == my_work && u < tid);
+        }
+        tasks[rank] = (tid >> 1) | ((tid & 1) << 6) | (my_m4 << 8);
+        atomicAdd(ctl + 1, 1);
+    }
+    __syncthreads();
+    const int ntask = ctl[1];
+    HR_CLK(0);
+    // ---- lane roles
+    const int lane = tid & 63, wv = tid >> 6;
+    const RowsLane ld = rows_lane(lane);
+    T* strip = strips + wv * 160;
+    while (true) {
+        int k = 0;
+        if (lane == 0) k = atomicAdd(ctl, 1);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (k >= ntask) break;
+        const int task = __builtin_amdgcn_readfirstlane(tasks[k]), cell = task & 63, px = (task >> 6) & 1, m4 = task >> 8;
+        const int first = __builtin_amdgcn_readfirstlane(cstart[cell]), cnt = __builtin_amdgcn_readfirstlane(ccnt[cell]);
+        HR_CNT(6, cnt);
+        HR_CNT(7, cnt * __popc(m4));
+        const int nr = __popc(m4);
+        const RowsTask tk = { px, px - ((cell >> 4) - 2), -(((cell >> 2) & 3) - 2), -((cell & 3) - 2), m4 };
+        const T* rp = rec + (int64_t)first * REC;
+        // the particle walk is compiled for 1, 2 and 4 rows (3 rows — an inactive node in the plane — run as 4 with a row computed and dropped)
+        if (nr == 1)
+            hr_walk<T, 1>(rp, cnt, tk, strip, tile, lane, ld);
+        else if (nr == 2)
+            hr_walk<T, 2>(rp, cnt, tk, strip, tile, lane, ld);
+        else
+            hr_walk<T, 4>(rp, cnt, tk, strip, tile, lane, ld);
+        HR_CLK(2);
+    }
+    HR_CLK(1);
+    __syncthreads();
+    HR_CLK(4);
+    for (int e = tid; e < 8 * 1125; e += HR_THREADS) {
+        int r = e / 1125, q = e - r * 1125;
+        int dof = rdof[r];
+        if (dof < 0) continue;
+        T v = (T)tile[e];
+        if (q >= 62 * 9 && q < 63 * 9 && ((q - 62 * 9) % 4 == 0) && (!own || own[dof])) v += mass[dof]; // inertia term on the diagonal slot (ImplicitSolver.h:486-496)
+        val[(int64_t)dof * 1125 + q] = v;
+        if (written && q == 0) written[dof] = 1;
+    }
+#ifdef HOT_HT_CLOCKS
+    HR_CLK(5);
+    if ((tid & 63) == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&hr_clk[i], clk_[i]);
+#endif
+}
+
+template <class T>
+void Ctx<T>::assemble_rows(Level<T>& L)
+{
+    pDP.reserve((size_t)REC * (size_t)Np);
+    HOT_LAUNCH(this, "hessian_dpdf", k_dpdf_rec<T>, div_up(Np, 256), 256, 0, pX.p, pFn.p, pFt.p, pVol.p, pMu.p, pLam.p, pDP.p, Np, dt, (T)1 / dx, cfg.project);
+    if (!attr_rows_set) {
+        HOT_HIP(hipFuncSetAttribute((const void*)k_hessian_rows<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowsLds<T>::bytes));
+        attr_rows_set = true;
+    }
+    constexpr int TPB = (G::BX / 2) * (G::BY / 2) * (G::BZ / 2);
+    if (L.part) {
+        written.reserve(Nn);
+        HOT_HIP(hipMemsetAsync(written.p, 0, Nn, stream));
+    }
+    HOT_LAUNCH(this, "hessian_assemble", k_hessian_rows<T>, 256 * div_up(Nb * TPB, 256), RowsLds<T>::THREADS, RowsLds<T>::bytes, pDP.p, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, Nb * TPB, L.mask(),
+        L.part ? written.p : (uint8_t*)nullptr);
+#ifdef HOT_HT_CLOCKS
+    unsigned long long hc[8] = {};
+    HOT_HIP(hipStreamSynchronize(stream));
+    HOT_HIP(hipMemcpyFromSymbol(hc, HIP_SYMBOL(hr_clk), sizeof(hc)));
+    const double tiles = (double)Nb * TPB;
+    const double wv = tiles * RowsLds<T>::WAVES;
+    fprintf(stderr, "hessian row tiles, clocks per wavefront: prologue %.0f fetch %.0f particle loop + flush %.0f (%.0f) barrier %.0f write-out %.0f; per workgroup %.0f visits, %.0f row steps; %.0f clocks per visit\n", hc[0] / wv, hc[1] / wv,
+        hc[2] / wv, hc[3] / wv, hc[4] / wv, hc[5] / wv, hc[6] / tiles, hc[7] / tiles, (double)hc[2] / (double)(hc[6] ? hc[6] : 1));
+    memset(hc, 0, sizeof(hc));
+    HOT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(hr_clk), hc, sizeof(hc)));
+#endif
+}
+
+template void Ctx<float>::assemble_rows(Level<float>&);
+template void Ctx<double>::assemble_rows(Level<double>&);
+
+} // namespace hot

@@ -142,10 +142,11 @@ struct Ctx : CtxBase {
     DBuf<unsigned long long> ch_rank;
     DBuf<int32_t> ch_id;
     HashMap cell_map; // (Linear_Offset(base cell) >> data_bits) -> cell id
-    DBuf<T> pDP; // 45*Np: symmetric 9x9 V_p dt^2 dP/dF per particle (Hessian assembly)
+    DBuf<T> pDP; // Hessian assembly: 64*Np particle records (k_dpdf_rec, hessian_rows.hip); matrix-free diagonal: 45*Np symmetric 9x9 V_p dt^2 dP/dF
     void build_cell_table();
     void matfree_diagonal(T* dinv); // 9 Nn: inverse (Ainv) of the block diagonal of the matrix-free operator
-    void assemble_tiles(Level<T>& L);
+    void assemble_tiles(Level<T>& L); // A/B build: the LDS-staged kernels of rounds 1 - 4
+    void assemble_rows(Level<T>& L); // production (hessian_rows.hip)
     // ---- atomic-free scatter: every particle group writes its (BX+2)(BY+2)(BZ+2) partial tile, then each node sums
     //      the <= 8 partial tiles that cover it in a fixed order (deterministic; global fp64 atomics top out at ~2e10/s)
     DBuf<int32_t> block_group; // Nb: group whose page is this block, or -1
@@ -306,7 +307,7 @@ struct Ctx : CtxBase {
     DBuf<double> cg_dep; // its dot-product deposits, two alternating sets of two per workgroup
     int cg_group = 2; // iterations the last fused top-level PCG took: size of the first group of launches of the next one
     int gs_epoch = 0; // sweep number, never reused inside a context
-    bool attr_tiles_set = false, attr_gs_set = false; // dynamic-LDS limits raised on this context's device (hipFuncSetAttribute is per device)
+    bool attr_tiles_set = false, attr_rows_set = false, attr_gs_set = false; // dynamic-LDS limits raised on this context's device (hipFuncSetAttribute is per device)
     DBuf<int> gs_done; // [0,40) pass counters of k_gs_sweep (the sticky wait-timeout flag lives in pinned host memory, hscal[250])
     double* hscal = nullptr; // pinned host mirror
     // ---- L-BFGS history
