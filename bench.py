@@ -37,7 +37,7 @@ SYMBOL = {  # profile-record prefix -> device symbol as rocprofv3 names it
     "gs_forward": "hot::k_gs_subst<T,true,8>", "gs_backward": "hot::k_gs_subst<T,false,8>", "spmv": "hot::k_spmv<T>",
     "gs_forward_off": "hot::k_gs_offblock<T>", "gs_backward_off": "hot::k_gs_offblock<T>",
     "gs_forward_chained": "hot::k_gs_sweep<T,true,SB>", "gs_backward_chained": "hot::k_gs_sweep<T,false,SB>",
-    "gs_residual": "hot::k_gs_residual<T>", "hessian_assemble": "hot::k_hessian_tiles2<T,false>", "state_update": "hot::k_state<T>",
+    "gs_residual": "hot::k_gs_residual<T>", "hessian_assemble": "hot::k_hessian_rows<T>", "state_update": "hot::k_state<T>",
     "force_scatter": "hot::k_force_cells2<T>", "p2g": "hot::k_p2g_cells2<T,true>", "g2p": "hot::k_g2p<T,0,true>",
 }
 

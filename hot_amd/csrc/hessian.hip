@@ -371,7 +371,7 @@ void Ctx<T>::build_hessian()
     if (v1)
         HOT_LAUNCH(this, "hessian_assemble_v1", k_hessian<T>, Ng, 256, 0, pX.p, pFn.p, pFt.p, pVol.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_nb.p, gIdx.p, L->val.p, dx, (T)1 / dx,
             dt, cfg.project);
-    else if (ab_flag("HOT_HESSIAN_TILES"))
+    else if (ab_flag("HOT_HESSIAN_TILES") || ab_flag("HOT_HESSIAN_TILES_V1") || ab_flag("HOT_HESSIAN_MFMA"))
         assemble_tiles(*L); // rounds 2 - 4: particle chunks staged in LDS
     else
 #endif

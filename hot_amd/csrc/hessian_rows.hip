@@ -34,7 +34,7 @@ namespace hot {
 
 __host__ __device__ constexpr int sym45i(int a, int b) { return a <= b ? (a * 9 - (a * (a - 1)) / 2 + (b - a)) : (b * 9 - (b * (b - 1)) / 2 + (a - b)); }
 
-constexpr int REC = 64; // scalars per particle record: E (45), per axis w[3] and dw[3] / dx (18), pad
+constexpr int REC = 128; // scalars per particle record: E (45), grad w of the 27 kernel nodes (81), pad
 
 // ---- pass 1: the particle record
 template <class T>
@@ -113,15 +113,20 @@ __global__ __launch_bounds__(256) void k_dpdf_rec(const T* __restrict__ X, const
                 const int n = b + 3 * s;
                 if (n >= m) o[sym45i(m, n)] = F9[s] * Th[m * 9 + b] + F9[s + 3] * Th[m * 9 + b + 3] + F9[s + 6] * Th[m * 9 + b + 6];
             }
+    T w[3][3], dw[3][3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         int base;
-        T w[3], dw[3];
-        bspline<T>(one_over_dx, X[(int64_t)d * Np + p], base, w, dw);
+        bspline<T>(one_over_dx, X[(int64_t)d * Np + p], base, w[d], dw[d]);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) o[45 + 6 * d + k] = w[k], o[48 + 6 * d + k] = one_over_dx * dw[k];
+        for (int k = 0; k < 3; ++k) dw[d][k] *= one_over_dx;
     }
-    o[63] = (T)0;
+#pragma unroll
+    for (int j = 0; j < 27; ++j) {
+        const int j0 = j / 9, j1 = (j / 3) % 3, j2 = j % 3;
+        o[45 + 3 * j] = dw[0][j0] * (w[1][j1] * w[2][j2]), o[46 + 3 * j] = (w[0][j0] * w[2][j2]) * dw[1][j1], o[47 + 3 * j] = (w[0][j0] * w[1][j1]) * dw[2][j2];
+    }
+    o[126] = o[127] = (T)0;
 }
 
 // ---- the 15 broadcast FMAs of a (particle, row): acc[ab] += K(lane 3 ab + s of this lane's 16-lane row) * g[s].  The s_nop covers
@@ -145,12 +150,41 @@ __device__ __forceinline__ void dpp_row_fma(float (&acc)[5], float K, float g0, 
 #undef HOT_DPPF
 }
 
+// ---- pass 1b: per tile the first particle and the particle count of the 4x4x4 base cells around it and the DOF of its 8 rows, so that a
+// tile workgroup starts from ONE coalesced load instead of a chain of five dependent ones (block offset -> hash probe -> cell id -> cell
+// range; ~10 us per workgroup beside a busy neighbour, a sixth of the kernel).  TileTab: [tile][64] {first, count} then [tile][8] DOF.
+template <class T>
+__global__ __launch_bounds__(256) void k_tile_cells(const uint64_t* __restrict__ blocks, const int32_t* __restrict__ gIdx, const int32_t* __restrict__ cell_first, HashMap cmap, int2* __restrict__ tcell,
+    int32_t* __restrict__ trow, int ntiles)
+{
+    using G = Geo<T>;
+    constexpr int TPBY = G::BY / 2, TPBZ = G::BZ / 2, TPB = (G::BX / 2) * TPBY * TPBZ;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int tile_id = (int)(e >> 6), c64 = (int)(e & 63);
+    if (tile_id >= ntiles) return;
+    const int b = tile_id / TPB, tt = tile_id % TPB;
+    int bx, by, bz;
+    G::linear_to_coord(blocks[b], bx, by, bz);
+    const int tx0 = bx + 2 * (tt / (TPBY * TPBZ)), ty0 = by + 2 * ((tt / TPBZ) % TPBY), tz0 = bz + 2 * (tt % TPBZ);
+    const int cx = tx0 + (c64 >> 4) - 2, cy = ty0 + ((c64 >> 2) & 3) - 2, cz = tz0 + (c64 & 3) - 2; // base cell = tile origin + (-2..1)^3
+    int first = 0, cnt = 0;
+    if ((cx | cy | cz) >= 0) {
+        int32_t c = hash_find_id(cmap, G::linear_offset(cx, cy, cz) >> G::data_bits);
+        if (c >= 0) first = cell_first[c], cnt = cell_first[c + 1] - first;
+    }
+    tcell[e] = make_int2(first, cnt);
+    if (c64 < 8) {
+        int ex = (tx0 - bx) + (c64 >> 2), ey = (ty0 - by) + ((c64 >> 1) & 1), ez = (tz0 - bz) + (c64 & 1);
+        trow[(int64_t)tile_id * 8 + c64] = gIdx[(int64_t)b * G::EPB + ((ex << (G::yb + G::zb)) | (ey << G::zb) | ez)];
+    }
+}
+
 // ---- lane roles of a task wavefront: half h = lane >> 5 owns the block entries 4 h .. 4 h + 4; its lane jl = lane & 31 (< 27) the column node
 // (j0, j1, j2) of the cell's kernel; lane n = lane & 15 (< 15) of every 16-lane DPP row forms K[(a, b) = 4 h + n / 3][s = n % 3]
 struct RowsLane {
     int h, jl, j0, j1, j2;
     unsigned eo0, eo1, eo2; // record offsets of E[(a, r), (b, s)], r = 0, 1, 2
-    unsigned wo0, wo1, wo2; // record offsets of w_x[j0], w_y[j1], w_z[j2] (dw / dx three scalars further)
+    unsigned go; // record offset of grad w of the lane's column node
 };
 __device__ __forceinline__ RowsLane rows_lane(int lane)
 {
@@ -159,7 +193,7 @@ __device__ __forceinline__ RowsLane rows_lane(int lane)
     L.j0 = L.jl / 9, L.j1 = (L.jl / 3) % 3, L.j2 = L.jl % 3;
     const int n = min(lane & 15, 14), ab = 4 * L.h + n / 3, ks = n % 3, ka = ab % 3, kb = ab / 3;
     L.eo0 = sym45i(ka, kb + 3 * ks), L.eo1 = sym45i(ka + 3, kb + 3 * ks), L.eo2 = sym45i(ka + 6, kb + 3 * ks);
-    L.wo0 = 45 + L.j0, L.wo1 = 51 + L.j1, L.wo2 = 57 + L.j2;
+    L.go = 45 + 3 * L.jl;
     return L;
 }
 struct RowsTask { // wave-uniform
@@ -171,17 +205,17 @@ struct RowsTask { // wave-uniform
 // One task: the particles [rp, rp + cnt records) of a cell against NR rows of a tile plane.  Records are requested one particle ahead into
 // two alternating register sets (no copies); the NR x 3 wave-uniform strip loads of a particle are issued together.
 template <class T, int NR>
-__device__ __forceinline__ void hr_walk(const T* __restrict__ rp /*wave-uniform*/, int cnt, const RowsTask& tk, T* __restrict__ strip, AccT<T>* __restrict__ tile, int lane, const RowsLane& ld)
+__device__ __forceinline__ void hr_walk(const T* __restrict__ rp /*wave-uniform*/, int cnt, const RowsTask& tk, T* __restrict__ stage, AccT<T>* __restrict__ tile, int lane, const RowsLane& ld)
 {
     using AT = AccT<T>;
-    int qs[NR], so[NR]; // rows of the task in ascending order (ordinals beyond the row count repeat row 0: computed, not stored), their strip offsets
+    int qs[NR], so[NR]; // rows of the task in ascending order (ordinals beyond the row count repeat row 0: computed, not stored), record offsets of their grad w
     {
         int m = tk.m4;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             qs[r] = m ? __builtin_ctz(m) : __builtin_ctz(tk.m4);
             m &= m - 1;
-            so[r] = tk.lx * 9 + (tk.ly0 + (qs[r] >> 1)) * 3 + (tk.lz0 + (qs[r] & 1));
+            so[r] = 45 + 3 * (tk.lx * 9 + (tk.ly0 + (qs[r] >> 1)) * 3 + (tk.lz0 + (qs[r] & 1)));
         }
     }
     T acc[NR][5];
@@ -189,24 +223,21 @@ __device__ __forceinline__ void hr_walk(const T* __restrict__ rp /*wave-uniform*
     for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int e = 0; e < 5; ++e) acc[r][e] = (T)0;
-    // The record of a particle (64 scalars) comes with ONE coalesced load per wavefront, one particle ahead, is parked in the wavefront's LDS
-    // stage and picked apart from there: a lane's three E values and six 1-D weights sit at lane-specific offsets, and as nine gathering
-    // global loads per particle they made the kernel wait for the texture addresser (16 clocks per vector memory instruction whatever its
-    // width: 8.2 ms at C2 with 48 % of the VALU cycles used).
-    T* stage = strip + 96;
-    auto work = [&](T rec_lane) {
-        stage[lane] = rec_lane;
+    // The record of a particle (128 scalars) comes with TWO coalesced loads per wavefront, one particle ahead, is parked in the wavefront's
+    // LDS stage and picked apart from there — a lane's three E values, grad w of its column node, grad w of the task's row nodes (wave-uniform
+    // addresses) — in ONE round trip.  (As nine gathering global loads per particle the kernel waited for the texture addresser, 16 clocks per
+    // vector memory instruction whatever its width: 8.2 ms at C2 with 48 % of the VALU cycles used; with the 1-D weights in the record and
+    // grad w formed and exchanged through a second LDS strip, three dependent LDS round trips per particle: 6.25 ms.)
+    auto work = [&](T rec0, T rec1) {
+        stage[lane] = rec0, stage[64 + lane] = rec1;
         __builtin_amdgcn_wave_barrier();
         const T e0 = stage[ld.eo0], e1 = stage[ld.eo1], e2 = stage[ld.eo2];
-        const T wx = stage[ld.wo0], dwx = stage[ld.wo0 + 3], wy = stage[ld.wo1], dwy = stage[ld.wo1 + 3], wz = stage[ld.wo2], dwz = stage[ld.wo2 + 3];
-        const T g0 = dwx * (wy * wz), g1 = (wx * wz) * dwy, g2 = (wx * wy) * dwz;
-        strip[ld.jl] = g0, strip[32 + ld.jl] = g1, strip[64 + ld.jl] = g2;
-        __builtin_amdgcn_wave_barrier();
+        const T g0 = stage[ld.go], g1 = stage[ld.go + 1], g2 = stage[ld.go + 2];
         T gw[NR][3];
 #pragma unroll
         for (int r = 0; r < NR; ++r)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) gw[r][k] = strip[so[r] + 32 * k];
+            for (int k = 0; k < 3; ++k) gw[r][k] = stage[so[r] + k];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const T K = e0 * gw[r][0] + e1 * gw[r][1] + e2 * gw[r][2];
@@ -214,13 +245,15 @@ __device__ __forceinline__ void hr_walk(const T* __restrict__ rp /*wave-uniform*
         }
         __builtin_amdgcn_wave_barrier();
     };
-    T A = rp[lane], B;
+    T A0 = rp[lane], A1 = rp[64 + lane], B0, B1;
     for (int l = 0; l < cnt; l += 2) {
-        B = rp[(l + 1 < cnt ? l + 1 : l) * REC + lane];
-        work(A);
+        const T* rb = rp + (l + 1 < cnt ? l + 1 : l) * REC;
+        B0 = rb[lane], B1 = rb[64 + lane];
+        work(A0, A1);
         if (l + 1 >= cnt) break;
-        A = rp[(l + 2 < cnt ? l + 2 : l + 1) * REC + lane];
-        work(B);
+        const T* ra = rp + (l + 2 < cnt ? l + 2 : l + 1) * REC;
+        A0 = ra[lane], A1 = ra[64 + lane];
+        work(B0, B1);
     }
     // ---- accumulators -> LDS tile: half 0 holds the block entries 0..4, half 1 the entries 4..8 (its entry 4 is the duplicate)
     if ((lane & 31) < 27) {
@@ -239,22 +272,43 @@ __device__ __forceinline__ void hr_walk(const T* __restrict__ rp /*wave-uniform*
 }
 
 
-// LDS of a workgroup: the tile (72 000 bytes in either build), per wavefront a strip (96 scalars) and a record stage (64 scalars), the
-// integer tables.  Two workgroups per CU: 6 wavefronts each in fp64 (81 536 bytes), 8 in fp32.
+// task candidates (cell << 1 | x-plane) ordered by the number of tile rows the plane has inside the cell's support: 4, then 2, then 1, then none
+struct HrOrder {
+    uint8_t v[128];
+};
+constexpr HrOrder hr_order()
+{
+    HrOrder o{};
+    int n = 0;
+    for (int want = 4; want >= 0; want = want == 4 ? 2 : (want == 2 ? 1 : (want == 1 ? 0 : -1))) {
+        for (int t = 0; t < 128; ++t) {
+            const int cell = t >> 1, px = t & 1, ox = (cell >> 4) - 2, oy = ((cell >> 2) & 3) - 2, oz = (cell & 3) - 2;
+            const int rows = (px - ox >= 0 && px - ox < 3) ? ((oy == -1 || oy == 0) ? 2 : 1) * ((oz == -1 || oz == 0) ? 2 : 1) : 0;
+            if (rows == want) o.v[n++] = (uint8_t)t;
+        }
+        if (want == 0) break;
+    }
+    return o;
+}
+__constant__ HrOrder kHrOrderTab = hr_order();
+#define kHrOrder kHrOrderTab.v
+
+// LDS of a workgroup: the tile (72 000 bytes in either build), per wavefront a record stage (128 scalars), the integer tables.  Two
+// workgroups per CU: 7 wavefronts each in fp64 (81 024 bytes), 8 in fp32.
 #ifndef HOT_HR_WAVES64
-#define HOT_HR_WAVES64 6
+#define HOT_HR_WAVES64 7
 #endif
 template <class T>
 struct RowsLds {
     static constexpr int WAVES = sizeof(T) == 8 ? HOT_HR_WAVES64 : 8, THREADS = WAVES * 64;
-    static constexpr int NINT = 64 * 3 + 8 + 128 + 128 + 8; // cstart, ccnt, cmask | rdof | work | tasks | ctl
-    static constexpr size_t bytes = (size_t)8 * 1125 * sizeof(AccT<T>) + (size_t)WAVES * 160 * sizeof(T) + (size_t)NINT * sizeof(int32_t);
+    static constexpr int NINT = 64 * 2 + 8 + 128 + 8; // cstart, ccnt | rdof | tasks | ctl
+    static constexpr size_t bytes = (size_t)8 * 1125 * sizeof(AccT<T>) + (size_t)WAVES * REC * sizeof(T) + (size_t)NINT * sizeof(int32_t);
 };
 
 // Development aid (-DHOT_HT_CLOCKS, tools/hess_phases.sh): shader clocks of every wavefront (lane 0), summed per phase: 0 prologue, 1 task fetch
 // and set-up, 2 particle loop and accumulators -> tile, 4 wait at the final barrier, 5 write-out; 6 particle visits, 7 (particle, row) steps.
 #ifdef HOT_HT_CLOCKS
-__device__ unsigned long long hr_clk[8];
+__device__ unsigned long long hr_clk[65536 * 8]; // per tile (mod 65536): same-address atomics of 3e5 wavefronts would cost more than the kernel
 #define HR_CLK(i) \
     do { \
         const unsigned long long t_ = clock64(); /* wave-uniform: the sums stay in SGPRs */ \
@@ -267,23 +321,19 @@ __device__ unsigned long long hr_clk[8];
 #endif
 
 template <class T>
-__global__ __launch_bounds__(RowsLds<T>::THREADS) void k_hessian_rows(const T* __restrict__ rec, const uint64_t* __restrict__ blocks, const int32_t* __restrict__ gIdx,
-    const int32_t* __restrict__ cell_first, HashMap cmap, const T* __restrict__ mass, T* __restrict__ val, int ntiles, const uint8_t* __restrict__ own /*sharded: rows this rank owns, else null*/,
+__global__ __launch_bounds__(RowsLds<T>::THREADS) void k_hessian_rows(const T* __restrict__ rec, const int2* __restrict__ tcell, const int32_t* __restrict__ trow, const T* __restrict__ mass, T* __restrict__ val, int ntiles, const uint8_t* __restrict__ own /*sharded: rows this rank owns, else null*/,
     uint8_t* __restrict__ written /*sharded: rows this launch wrote*/)
 {
     using G = Geo<T>;
     using AT = AccT<T>;
     constexpr int HR_WAVES = RowsLds<T>::WAVES, HR_THREADS = RowsLds<T>::THREADS;
-    constexpr int TPBY = G::BY / 2, TPBZ = G::BZ / 2, TPB = (G::BX / 2) * TPBY * TPBZ;
     extern __shared__ __attribute__((aligned(16))) char hr_smem[];
     AT* tile = (AT*)hr_smem; // [8][1125]
-    T* strips = (T*)(tile + 8 * 1125); // [HR_WAVES][160]: gw_j[r] of the wavefront's current particle [3][32], its record [64]
-    int32_t* cstart = (int32_t*)(strips + HR_WAVES * 160); // [64] first particle of each contributing cell
+    T* stages = (T*)(tile + 8 * 1125); // [HR_WAVES][REC]: the record of the wavefront's current particle
+    int32_t* cstart = (int32_t*)(stages + HR_WAVES * REC); // [64] first particle of each contributing cell
     int32_t* ccnt = cstart + 64; // [64] its particle count
-    int32_t* cmask = ccnt + 64; // [64] tile rows inside its 3x3x3 support (and active)
-    int32_t* rdof = cmask + 64; // [8]
-    int32_t* work = rdof + 8; // [128] rows x particles of task candidate (cell, x-plane)
-    int32_t* tasks = work + 128; // [128] candidates with work, heaviest first: cell | plane << 6 | row mask << 8
+    int32_t* rdof = ccnt + 64; // [8]
+    int32_t* tasks = rdof + 8; // [128] candidates with rows and particles, planes of four rows first: cell | plane << 6 | row mask << 8
     int32_t* ctl = tasks + 128; // [0] task cursor, [1] number of tasks
     const int tid = threadIdx.x;
 #ifdef HOT_HT_CLOCKS
@@ -293,67 +343,51 @@ __global__ __launch_bounds__(RowsLds<T>::THREADS) void k_hessian_rows(const T* _
     // one XCD so that its L2 serves the re-reads
     const int id = blockIdx.x, run = (id & 7) + 8 * (id >> 8), tile_id = run * 32 + ((id >> 3) & 31);
     if (tile_id >= ntiles) return;
-    const int b = tile_id / TPB, tt = tile_id % TPB;
-    int bx, by, bz;
-    G::linear_to_coord(blocks[b], bx, by, bz);
-    const int tx0 = bx + 2 * (tt / (TPBY * TPBZ)), ty0 = by + 2 * ((tt / TPBZ) % TPBY), tz0 = bz + 2 * (tt % TPBZ);
-    if (tid < 8) {
-        int ex = (tx0 - bx) + (tid >> 2), ey = (ty0 - by) + ((tid >> 1) & 1), ez = (tz0 - bz) + (tid & 1);
-        rdof[tid] = gIdx[(int64_t)b * G::EPB + ((ex << (G::yb + G::zb)) | (ey << G::zb) | ez)];
-    }
+    if (tid < 8) rdof[tid] = trow[(int64_t)tile_id * 8 + tid];
     if (tid == 0) ctl[0] = 0, ctl[1] = 0;
+    if (tid >= 64 && tid < 128) {
+        const int2 fc = tcell[(int64_t)tile_id * 64 + (tid - 64)];
+        cstart[tid - 64] = fc.x, ccnt[tid - 64] = fc.y;
+    }
     for (int e = tid; e < 8 * 1125; e += HR_THREADS) tile[e] = (AT)0;
     __syncthreads();
     bool any = false;
     for (int r = 0; r < 8; ++r) any = any || rdof[r] >= 0;
     if (!any) return;
+    // ---- task list: candidates (cell, x-plane) in the static order kHrOrder — four-row planes first, then two, then one — with the rows that
+    // are inside the cell's 3x3x3 support AND active; those with rows and particles are compacted by the first wavefront (two candidates per
+    // lane).  (A rank sort by rows x particles took a seventh of the kernel: 770 VALU instructions on two wavefronts beside a busy neighbour.)
     if (tid < 64) {
-        const int ox = (tid >> 4) - 2, oy = ((tid >> 2) & 3) - 2, oz = (tid & 3) - 2; // base cell = tile origin + (-2..1)^3
-        const int cx = tx0 + ox, cy = ty0 + oy, cz = tz0 + oz;
-        int first = 0, cnt = 0, mask = 0;
-        if ((cx | cy | cz) >= 0) {
-            int32_t c = hash_find_id(cmap, G::linear_offset(cx, cy, cz) >> G::data_bits);
-            if (c >= 0) first = cell_first[c], cnt = cell_first[c + 1] - first;
+        int tk[2], nz[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int t = kHrOrder[64 * k + tid], cell = t >> 1, px = t & 1, ox = (cell >> 4) - 2, oy = ((cell >> 2) & 3) - 2, oz = (cell & 3) - 2;
+            int m4 = 0;
+            if ((unsigned)(px - ox) < 3u) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((unsigned)((q >> 1) - oy) < 3u && (unsigned)((q & 1) - oz) < 3u && rdof[4 * px + q] >= 0) m4 |= 1 << q;
+            }
+            tk[k] = cell | (px << 6) | (m4 << 8), nz[k] = m4 != 0 && ccnt[cell] > 0;
         }
-        for (int r = 0; r < 8; ++r) {
-            const int ax = (r >> 2) - ox, ay = ((r >> 1) & 1) - oy, az = (r & 1) - oz; // row node inside the cell's kernel
-            if ((unsigned)ax < 3u && (unsigned)ay < 3u && (unsigned)az < 3u && rdof[r] >= 0) mask |= 1 << r;
-        }
-        cstart[tid] = first, ccnt[tid] = cnt, cmask[tid] = mask;
+        const unsigned long long b0 = __ballot(nz[0]), b1 = __ballot(nz[1]), below = (1ull << tid) - 1ull;
+        const int n0 = __popcll(b0);
+        if (nz[0]) tasks[__popcll(b0 & below)] = tk[0];
+        if (nz[1]) tasks[n0 + __popcll(b1 & below)] = tk[1];
+        if (tid == 0) ctl[1] = n0 + __popcll(b1);
     }
     __syncthreads();
     if (own) { // sharded: a tile none of whose rows this rank owns and none of whose cells hold particles of its shard is not its business
         bool mine = false;
         for (int r = 0; r < 8; ++r) mine = mine || (rdof[r] >= 0 && own[rdof[r]]);
-        bool any_particles = false;
-        for (int c = 0; c < 64; ++c) any_particles = any_particles || (ccnt[c] > 0 && cmask[c] != 0);
-        if (!mine && !any_particles) return; // workgroup-uniform (LDS tables)
+        if (!mine && ctl[1] == 0) return; // workgroup-uniform (LDS tables)
     }
-    // ---- task list: candidate t = (cell, x-plane), its work = rows x particles; rank sort, heaviest first
-    int my_work = 0, my_m4 = 0;
-    if (tid < 128) {
-        const int cell = tid >> 1, px = tid & 1;
-        my_m4 = (cmask[cell] >> (4 * px)) & 15;
-        my_work = __popc(my_m4) * ccnt[cell];
-        work[tid] = my_work;
-    }
-    __syncthreads();
-    if (tid < 128 && my_work > 0) {
-        int rank = 0;
-        for (int u = 0; u < 128; ++u) {
-            const int wu = work[u];
-            rank += (wu > my_work) || (wu == my_work && u < tid);
-        }
-        tasks[rank] = (tid >> 1) | ((tid & 1) << 6) | (my_m4 << 8);
-        atomicAdd(ctl + 1, 1);
-    }
-    __syncthreads();
     const int ntask = ctl[1];
     HR_CLK(0);
     // ---- lane roles
     const int lane = tid & 63, wv = tid >> 6;
     const RowsLane ld = rows_lane(lane);
-    T* strip = strips + wv * 160;
+    T* stage = stages + wv * REC;
     while (true) {
         int k = 0;
         if (lane == 0) k = atomicAdd(ctl, 1);
@@ -368,14 +402,13 @@ __global__ __launch_bounds__(RowsLds<T>::THREADS) void k_hessian_rows(const T* _
         const T* rp = rec + (int64_t)first * REC;
         // the particle walk is compiled for 1, 2 and 4 rows (3 rows — an inactive node in the plane — run as 4 with a row computed and dropped)
         if (nr == 1)
-            hr_walk<T, 1>(rp, cnt, tk, strip, tile, lane, ld);
+            hr_walk<T, 1>(rp, cnt, tk, stage, tile, lane, ld);
         else if (nr == 2)
-            hr_walk<T, 2>(rp, cnt, tk, strip, tile, lane, ld);
+            hr_walk<T, 2>(rp, cnt, tk, stage, tile, lane, ld);
         else
-            hr_walk<T, 4>(rp, cnt, tk, strip, tile, lane, ld);
-        HR_CLK(2);
+            hr_walk<T, 4>(rp, cnt, tk, stage, tile, lane, ld);
     }
-    HR_CLK(1);
+    HR_CLK(2);
     __syncthreads();
     HR_CLK(4);
     for (int e = tid; e < 8 * 1125; e += HR_THREADS) {
@@ -390,7 +423,7 @@ __global__ __launch_bounds__(RowsLds<T>::THREADS) void k_hessian_rows(const T* _
 #ifdef HOT_HT_CLOCKS
     HR_CLK(5);
     if ((tid & 63) == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&hr_clk[i], clk_[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(&hr_clk[(tile_id & 65535) * 8 + i], clk_[i]);
 #endif
 }
 
@@ -408,18 +441,25 @@ void Ctx<T>::assemble_rows(Level<T>& L)
         written.reserve(Nn);
         HOT_HIP(hipMemsetAsync(written.p, 0, Nn, stream));
     }
-    HOT_LAUNCH(this, "hessian_assemble", k_hessian_rows<T>, 256 * div_up(Nb * TPB, 256), RowsLds<T>::THREADS, RowsLds<T>::bytes, pDP.p, blocks.p, gIdx.p, cell_first.p, cell_map, mass.p, L.val.p, Nb * TPB, L.mask(),
+    const int ntiles = Nb * TPB;
+    tile_tab.reserve((size_t)ntiles * (2 * 64 + 8));
+    int2* tcell = (int2*)tile_tab.p;
+    int32_t* trow = tile_tab.p + (size_t)ntiles * 128;
+    HOT_LAUNCH(this, "hessian_tile_cells", k_tile_cells<T>, div_up((int64_t)ntiles * 64, 256), 256, 0, blocks.p, gIdx.p, cell_first.p, cell_map, tcell, trow, ntiles);
+    HOT_LAUNCH(this, "hessian_assemble", k_hessian_rows<T>, 256 * div_up(ntiles, 256), RowsLds<T>::THREADS, RowsLds<T>::bytes, pDP.p, tcell, trow, mass.p, L.val.p, ntiles, L.mask(),
         L.part ? written.p : (uint8_t*)nullptr);
 #ifdef HOT_HT_CLOCKS
+    std::vector<unsigned long long> hall(65536 * 8);
     unsigned long long hc[8] = {};
     HOT_HIP(hipStreamSynchronize(stream));
-    HOT_HIP(hipMemcpyFromSymbol(hc, HIP_SYMBOL(hr_clk), sizeof(hc)));
+    HOT_HIP(hipMemcpyFromSymbol(hall.data(), HIP_SYMBOL(hr_clk), hall.size() * 8));
+    for (size_t i = 0; i < hall.size(); ++i) hc[i & 7] += hall[i];
     const double tiles = (double)Nb * TPB;
     const double wv = tiles * RowsLds<T>::WAVES;
     fprintf(stderr, "hessian row tiles, clocks per wavefront: prologue %.0f fetch %.0f particle loop + flush %.0f (%.0f) barrier %.0f write-out %.0f; per workgroup %.0f visits, %.0f row steps; %.0f clocks per visit\n", hc[0] / wv, hc[1] / wv,
         hc[2] / wv, hc[3] / wv, hc[4] / wv, hc[5] / wv, hc[6] / tiles, hc[7] / tiles, (double)hc[2] / (double)(hc[6] ? hc[6] : 1));
-    memset(hc, 0, sizeof(hc));
-    HOT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(hr_clk), hc, sizeof(hc)));
+    std::fill(hall.begin(), hall.end(), 0ull);
+    HOT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(hr_clk), hall.data(), hall.size() * 8));
 #endif
 }
 

@@ -1,4 +1,5 @@
-// libhotmi355x — Hessian assembly, production kernel: "row-tile owns its rows", no global atomics.
+// libhotmi355x — Hessian assembly of rounds 1 - 4 ("row-tile owns its rows", particle chunks staged in LDS): A/B build only since round 5
+// (production: hessian_rows.hip); the cell table of the sorted particles and the matrix-free block diagonal, which are production code.
 //
 // Same mathematics as hessian.hip's k_hessian (reference Projects/multigrid/ImplicitSolver.h:498-552): every ordered
 // node pair (i, j) of every particle contributes  V_p dt^2 sum_{v,q} dP_{(a,v),(b,q)} g_i[v] g_j[q]  to row dof_i,
@@ -147,9 +148,9 @@ void Ctx<T>::build_cell_table()
     HOT_LAUNCH(this, "group_cell0", k_group_cell0, div_up(Ng + 1, 256), 256, 0, group_first.p, cell_first.p, group_cell0.p, Ng, Ncell);
 }
 
+#ifdef HOT_AB_KERNELS
 constexpr int HT_THREADS = 1024; // one workgroup per CU (the LDS tile), so the workgroup itself must supply the waves
 
-#ifdef HOT_AB_KERNELS
 template <class T>
 struct TileLds {
     static constexpr int CH = 64; // particles per chunk
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hessian_tiles(const T* __restric
 
 #endif
 
+#ifdef HOT_AB_KERNELS
 // ---- second version of pass 2.  The first one evaluates block(i,j) = sum_{v,q} dP[(a,v),(b,q)] g_i[v] g_j[q] from scratch
 // for every (particle, row, column): 81 multiply-adds and 51 LDS reads each, and its work-item phase is bound by the
 // fp64 FMA rate of the CU (measured with clock64: 68 % of a tile's 124 us).  Here the contraction is split:
@@ -769,6 +771,8 @@ void Ctx<T>::assemble_tiles(Level<T>& L)
 #endif
 }
 
+#endif // HOT_AB_KERNELS
+
 // ------------------------------------------------------------------------------------------------ matrix-free diagonal
 // buildDiagonal (reference Projects/multigrid/ImplicitSolver.h:605-665): the 3x3 diagonal blocks of the matrix-free
 // operator,  D_i = m_i I + dt^2 sum_p V_p sum_{v,q} ddF[(.,v),(.,q)] g_i[v] g_i[q],  g_i = Fn^T grad w_i.  Column `cc`
@@ -867,7 +871,13 @@ void Ctx<T>::matfree_diagonal(T* dinv)
     HOT_LAUNCH(this, "matfree_diag_finish", k_mf_diag_finish<T>, div_up(Nn, 256), 256, 0, tile.p, dofSlot.p, mass.p, dinv, Nn, slots, cfg.Ainv);
 }
 
-template struct Ctx<float>;
-template struct Ctx<double>;
+template void Ctx<float>::build_cell_table();
+template void Ctx<double>::build_cell_table();
+template void Ctx<float>::matfree_diagonal(float*);
+template void Ctx<double>::matfree_diagonal(double*);
+#ifdef HOT_AB_KERNELS
+template void Ctx<float>::assemble_tiles(Level<float>&);
+template void Ctx<double>::assemble_tiles(Level<double>&);
+#endif
 
 } // namespace hot

@@ -147,6 +147,7 @@ struct Ctx : CtxBase {
     void matfree_diagonal(T* dinv); // 9 Nn: inverse (Ainv) of the block diagonal of the matrix-free operator
     void assemble_tiles(Level<T>& L); // A/B build: the LDS-staged kernels of rounds 1 - 4
     void assemble_rows(Level<T>& L); // production (hessian_rows.hip)
+    DBuf<int32_t> tile_tab; // its per-tile tables: [tile][64] {first particle, count} of the base cells around the tile, [tile][8] row DOFs
     // ---- atomic-free scatter: every particle group writes its (BX+2)(BY+2)(BZ+2) partial tile, then each node sums
     //      the <= 8 partial tiles that cover it in a fixed order (deterministic; global fp64 atomics top out at ~2e10/s)
     DBuf<int32_t> block_group; // Nb: group whose page is this block, or -1

@@ -35,6 +35,7 @@ CASES = [
     ({"HOT_CG_UNFUSED": "1"}, SOLVER, "smoothers or vcycle or iterates"),
     ({"HOT_CG_LAUNCHES": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # three launches per PCG iteration instead of the persistent launch on small top levels
     ({"HOT_HESSIAN_V1": "1"}, SOLVER, "hessian_and_hierarchy"),
+    ({"HOT_HESSIAN_TILES": "1"}, SOLVER, "hessian_and_hierarchy"),  # rounds 2 - 4: k_hessian_tiles2, particle chunks staged in LDS, pair phase with LDS atomics
     ({"HOT_HESSIAN_TILES_V1": "1"}, SOLVER, "hessian_and_hierarchy"),
     ({"HOT_HESSIAN_MFMA": "1"}, SOLVER, "hessian_and_hierarchy"),  # pair phase on v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32
     ({"HOT_P2G_V1": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),

@@ -9,7 +9,7 @@ from collections import defaultdict
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-hs = [i for i, r in enumerate(rows) if "k_hessian_tiles2" in r["Kernel_Name"]]
+hs = [i for i, r in enumerate(rows) if "k_hessian_rows" in r["Kernel_Name"]]
 def bounds(lo):
     g2p = [i for i, r in enumerate(rows) if i > lo and "k_g2p" in r["Kernel_Name"]]
     return lo, (g2p[0] if g2p else len(rows) - 1)

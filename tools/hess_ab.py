@@ -1,5 +1,5 @@
-"""Hessian assembly at C2 / C3 size: scalar pair phase (product) vs the MFMA pair phase (A/B build, HOT_HESSIAN_MFMA); times from HIP events,
-matrices compared through SpMV with a random vector."""
+"""Hessian assembly at C2 / C3 size: k_hessian_rows (production) against the LDS-staged tile kernel of rounds 2 - 4 (A/B build, HOT_HESSIAN_TILES)
+and its MFMA pair phase (HOT_HESSIAN_MFMA); times from HIP events, matrices compared through SpMV with a random vector."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -16,8 +16,8 @@ ctx.sort(), ctx.p2g(), ctx.begin_step(cfg["dt"])
 ctx.update_state(ctx.get_dv())
 x = np.random.default_rng(1).standard_normal((ctx.Nn, 3))
 out = {}
-for label, env in (("mfma", "HOT_HESSIAN_MFMA"), ("scalar", None)):
-    os.environ.pop("HOT_HESSIAN_MFMA", None)
+for label, env in (("mfma", "HOT_HESSIAN_MFMA"), ("tiles", "HOT_HESSIAN_TILES"), ("rows", None)):
+    os.environ.pop("HOT_HESSIAN_MFMA", None), os.environ.pop("HOT_HESSIAN_TILES", None)
     if env:
         os.environ[env] = "1"
     ctx.build_hessian()
@@ -27,4 +27,5 @@ for label, env in (("mfma", "HOT_HESSIAN_MFMA"), ("scalar", None)):
     t = ctx.profile()
     out[label] = ctx.spmv(0, x).astype(np.float64)
     print(which, label, {k: round(v["total_ms"] / v["calls"], 3) for k, v in t.items() if k.startswith("hessian")})
-print("rel diff of A x:", np.abs(out["mfma"] - out["scalar"]).max() / np.abs(out["scalar"]).max())
+for k in ("mfma", "tiles"):
+    print("rel diff of A x, %s vs rows:" % k, np.abs(out[k] - out["rows"]).max() / np.abs(out["rows"]).max())
