@@ -52,6 +52,8 @@ struct Level {
     int gs_nslot = 0;
     int32_t gs_slot_rng[2][2][8] = {}; // [forward / backward][first / end][colour]: the off-block slots of the colour's blocks — on a row-partitioned level of the blocks THIS rank owns
     bool gs_img_ready = false;
+    DBuf<T> gs_w; // chained levels (k_gs_sweep<.., WINV>): nblocks * 2 * 9 * 2017: (I - N)^-1 - I of every colour block's in-block triangle, forward / backward (k_gs_winv, mg_build.hip)
+    bool gs_w_ready = false;
     DBuf<int32_t> rowcnt; // 4n: (precede-off, precede-in, follow-in, follow-off) slot counts of the regrouped rows
     bool split = false;
     // coarseSolver 7 (mg_ic.hip): block incomplete Cholesky of a top level.  ic_l: the strictly lower blocks by stencil slot; (ic_col, ic_val)
@@ -147,6 +149,7 @@ struct Ctx : CtxBase {
     void matfree_diagonal(T* dinv); // 9 Nn: inverse (Ainv) of the block diagonal of the matrix-free operator
     void assemble_tiles(Level<T>& L); // A/B build: the LDS-staged kernels of rounds 1 - 4
     void assemble_rows(Level<T>& L); // production (hessian_rows.hip)
+    void build_gs_winv(Level<T>& L); // inverse images of the in-block GS triangles of a chained level (mg_solve.hip)
     DBuf<int32_t> tile_tab; // its per-tile tables: [tile][64] {first particle, count} of the base cells around the tile, [tile][8] row DOFs
     // ---- atomic-free scatter: every particle group writes its (BX+2)(BY+2)(BZ+2) partial tile, then each node sums
     //      the <= 8 partial tiles that cover it in a fixed order (deterministic; global fp64 atomics top out at ~2e10/s)
@@ -308,7 +311,7 @@ struct Ctx : CtxBase {
     DBuf<double> cg_dep; // its dot-product deposits, two alternating sets of two per workgroup
     int cg_group = 2; // iterations the last fused top-level PCG took: size of the first group of launches of the next one
     int gs_epoch = 0; // sweep number, never reused inside a context
-    bool attr_tiles_set = false, attr_rows_set = false, attr_gs_set = false; // dynamic-LDS limits raised on this context's device (hipFuncSetAttribute is per device)
+    bool attr_tiles_set = false, attr_rows_set = false, attr_gs_set = false, attr_winv_set = false; // dynamic-LDS limits raised on this context's device (hipFuncSetAttribute is per device)
     DBuf<int> gs_done; // [0,40) pass counters of k_gs_sweep (the sticky wait-timeout flag lives in pinned host memory, hscal[250])
     double* hscal = nullptr; // pinned host mirror
     // ---- L-BFGS history

@@ -694,9 +694,18 @@ struct GsLds {
     static constexpr int TRI = SB * (SB - 1) / 2 + 1; // ordered pairs + one always-zero entry (last) for masked lanes
     static constexpr size_t bytes = (size_t)9 * TRI * sizeof(T) + SB * 3 * sizeof(T) + 5 * SB * sizeof(int32_t);
 };
+// inverse image of a colour block and direction: nine planes of TRI scalars, padded to a multiple of 16 bytes (the LDS-DMA pieces)
+template <class T>
+struct GsWinv {
+    static constexpr int img_elems = (9 * GsLds<T, 64>::TRI + 15) / 16 * 16;
+};
 template <int SB>
 __device__ __forceinline__ int gs_tri_fwd(int row, int colm) { return (SB - 1) * colm - (colm * (colm - 1)) / 2 + (row - colm - 1); } // row > colm
 __device__ __forceinline__ int gs_tri_bwd(int row, int colm) { return (colm * (colm - 1)) / 2 + row; } // row < colm
+// entry (row, column) of a block's inverse image (k_gs_winv -> k_gs_sweep<.., WINV>): packed row by row, so that the lanes of a row (lane = column)
+// read consecutive scalars of each of the nine planes; forward: columns before the row, backward (mirrored): columns after it
+template <bool FWD>
+__device__ __forceinline__ int gs_winv_idx(int row, int colm) { return FWD ? (row * (row - 1)) / 2 + colm : ((63 - row) * (62 - row)) / 2 + (63 - colm); }
 
 // The LDS triangle holds -(Dinv_i A_ij) and the right-hand sides Dinv_i s_i, so that the substitution phase is a pure
 // multiply-add chain: h_i = Dinv_i s_i + sum_j (-(Dinv_i A_ij)) h_j  (same value as Dinv_i (s_i - sum_j A_ij h_j) up to
@@ -714,6 +723,92 @@ __device__ __forceinline__ void gs_store_rhs(T* sv, int ii, const T* __restrict_
 {
 #pragma unroll
     for (int r = 0; r < 3; ++r) sv[ii * 3 + r] = di[r] * r0 + di[r + 3] * r1 + di[r + 6] * r2;
+}
+
+// ---- inverse images of the in-block triangles (chained levels).  With N the strictly lower (forward) / upper (backward) in-block couplings of a
+// colour block, premultiplied as -(D_r^-1 A_rc), the block's half-sweep solve is h = a + N h, i.e. h = (I - N)^-1 a =: a + W a.  W is dense
+// (every node of a 4^3 block reaches every later one through the chain), 64 x 63 / 2 blocks of 3 x 3 = 145 KB in fp64 — what the substitution
+// reads of N is 2/3 of that, so on a level bound by the 64-step dependency chain and not by bytes the product with W is the better trade.
+// One workgroup per (block, direction): N into the LDS triangle exactly as the sweep kernels file it, then column c0 of W is the substitution
+// applied to the three unit vectors of position c0 (lane = row, the three right-hand sides together: 9 LDS reads, 27 multiply-adds per step),
+// four columns per wavefront; the result goes out row-packed (gs_winv_idx).  Built once per hierarchy build.
+template <class T>
+__global__ __launch_bounds__(1024) void k_gs_winv(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
+    const int32_t* __restrict__ block_start, const int32_t* __restrict__ rowcnt, const T* __restrict__ diagBlockInv, T* __restrict__ gs_w)
+{
+    extern __shared__ __attribute__((aligned(16))) char gs_smem[];
+    constexpr int TRI = GsLds<T, 64>::TRI;
+    T* tri = (T*)gs_smem; // [9][TRI]
+    int32_t* nodes = (int32_t*)(tri + 9 * TRI); // [64]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x;
+    const bool fwd = blockIdx.y == 0;
+    const int start = block_start[b], cnt = min(64, block_start[b + 1] - start);
+    for (int e = tid; e < 9 * TRI; e += 1024) tri[e] = (T)0;
+    if (tid < 64) nodes[tid] = tid < cnt ? gs_order[start + tid] : -1;
+    __syncthreads();
+    for (int e = tid; e < 64 * cnt; e += 1024) { // (row position, in-block slot of the row's half)
+        const int ii = e >> 6, ks = e & 63;
+        const int64_t i = nodes[ii];
+        const int po = rowcnt[4 * i], pi = rowcnt[4 * i + 1], fi = rowcnt[4 * i + 2];
+        const int ibeg = fwd ? po : po + pi + 1, n_in = fwd ? pi : fi;
+        if (ks >= n_in) continue;
+        const int k = ibeg + ks, j = col[i * 125 + k];
+        const int l = (int)(ckey[j] & 127u) - 1;
+        T bb[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) bb[q] = val[(i * 125 + k) * 9 + q];
+        gs_store_tri<T>(tri, TRI, fwd ? gs_tri_fwd<64>(ii, l) : gs_tri_bwd(ii, l), diagBlockInv + 9 * i, bb);
+    }
+    __syncthreads();
+    T* out = gs_w + ((size_t)b * 2 + (fwd ? 0 : 1)) * GsWinv<T>::img_elems;
+    if (tid == 0)
+        for (int e = 0; e < 9; ++e) out[e * TRI + TRI - 1] = (T)0; // the entry masked lanes read
+    for (int k4 = 0; k4 < 4; ++k4) {
+        const int c0 = w + 16 * k4; // wave-uniform
+        if (c0 >= cnt) break;
+        T a[3][3]; // [right-hand side s][component]: column c0 of W, row = lane, as it builds up
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[s_][q] = (lane == c0 && s_ == q) ? (T)1 : (T)0;
+        const int nstep = fwd ? cnt - 1 - c0 : c0; // columns c0, c0 +- 1, ... : every one but the last has later rows to update
+        for (int st = 0; st < nstep; ++st) {
+            const int c = fwd ? c0 + st : c0 - st;
+            const bool act = fwd ? (lane > c && lane < cnt) : lane < c;
+            const int idx = act ? (fwd ? gs_tri_fwd<64>(lane, c) : gs_tri_bwd(lane, c)) : TRI - 1;
+            T Lc[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) Lc[e] = tri[e * TRI + idx];
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) {
+                const T b0 = lane_bcast(a[s_][0], c), b1 = lane_bcast(a[s_][1], c), b2 = lane_bcast(a[s_][2], c);
+                a[s_][0] = fma(Lc[0], b0, a[s_][0]), a[s_][1] = fma(Lc[1], b0, a[s_][1]), a[s_][2] = fma(Lc[2], b0, a[s_][2]);
+                a[s_][0] = fma(Lc[3], b1, a[s_][0]), a[s_][1] = fma(Lc[4], b1, a[s_][1]), a[s_][2] = fma(Lc[5], b1, a[s_][2]);
+                a[s_][0] = fma(Lc[6], b2, a[s_][0]), a[s_][1] = fma(Lc[7], b2, a[s_][1]), a[s_][2] = fma(Lc[8], b2, a[s_][2]);
+            }
+        }
+        const bool mine = fwd ? (lane > c0 && lane < cnt) : lane < c0; // W(lane, c0), strictly off the diagonal
+        if (mine) {
+            const int idx = fwd ? gs_winv_idx<true>(lane, c0) : gs_winv_idx<false>(lane, c0);
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) out[(q + 3 * s_) * TRI + idx] = a[s_][q];
+        }
+    }
+}
+template <class T>
+void Ctx<T>::build_gs_winv(Level<T>& L)
+{
+    constexpr size_t per = 2 * (size_t)GsWinv<T>::img_elems;
+    L.gs_w.reserve(per * (size_t)L.nblocks + 256);
+    const size_t lds = (size_t)9 * GsLds<T, 64>::TRI * sizeof(T) + 64 * sizeof(int32_t);
+    if (!attr_winv_set) {
+        HOT_HIP(hipFuncSetAttribute((const void*)k_gs_winv<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_winv_set = true;
+    }
+    HOT_LAUNCH(this, lname("gs_winv", L.id).c_str(), k_gs_winv<T>, dim3(L.nblocks, 2), 1024, lds, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.rowcnt.p, L.diagBlockInv.p, L.gs_w.p);
+    L.gs_w_ready = true;
 }
 
 template <class T, bool FWD, int SB, bool WT = false>
@@ -1109,14 +1204,35 @@ struct GsPasses {
     int color[33]; // colour of the pass
 };
 
-template <class T, bool FWD, int SB>
+// Development aid (-DHOT_GS_CLOCKS, tools/gs_phases.sh): shader clocks of wavefront 0 of every workgroup of k_gs_sweep between its phase boundaries,
+// summed per pass: [pass][0 header + image copy issued, 1 rows streamed (first barrier), 2 early gathers, 3 wait + late gathers, 4 in-block solve + stores]
+#ifdef HOT_GS_CLOCKS
+__device__ unsigned long long gs_clk[34 * 8];
+#define GS_CLK(i) \
+    do { \
+        const unsigned long long t_ = clock64(); \
+        gclk_[i] += t_ - gt0_, gt0_ = t_; \
+    } while (0)
+#else
+#define GS_CLK(i)
+#endif
+// WINV (SB = 64): the block's in-block triangular solve is ONE dense product with the precomputed inverse (gs_w: (I - N)^-1 - I of the block and
+// direction, row-packed planes, k_gs_winv in mg_build.hip): h = a + W a, a = D^-1 (rhs - off-block products).  The image is copied into the LDS
+// area the triangle of in-block couplings occupied (before the wait for the previous pass), every wavefront forms four rows of the product
+// (lane = column, fixed-order DPP sums) — 64 dependent broadcast-FMA steps of 150 - 190 ns become one round of ~1 us.
+template <class T, bool FWD, int SB, bool WINV = false>
 __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
     const int32_t* __restrict__ block_start, const T* __restrict__ diagVal, const T* __restrict__ diagBlockInv, const T* __restrict__ rhs, T* x, T* hD, GsPasses P,
     const int32_t* __restrict__ rowcnt, int* done, int* err, const int32_t* __restrict__ nbr, int* flag, int epoch, int dataflag,
-    T* unset_next /*not null: the target of the NEXT half sweep (nobody reads it during this one): every workgroup marks its rows' unknowns there "not written yet", instead of a fill launch between the sweeps*/)
+    T* unset_next /*not null: the target of the NEXT half sweep (nobody reads it during this one): every workgroup marks its rows' unknowns there "not written yet", instead of a fill launch between the sweeps*/,
+    const T* __restrict__ gs_w /*WINV: [block][direction][9][TRI]*/)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     constexpr int TRI = GsLds<T, SB>::TRI;
+    static_assert(!WINV || SB == 64, "the inverse images are whole-block images");
+#ifdef HOT_GS_CLOCKS
+    unsigned long long gclk_[5] = { 0, 0, 0, 0, 0 }, gt0_ = clock64();
+#endif
     constexpr int RQ = 4, NW = SB / RQ; // rows per wave, waves per workgroup (blockDim.x == 64 * NW)
     // dataflag: the unknowns are their own flags.  The host fills x with a bit pattern no computation produces (GsUnset) before the
     // sweep; a reader of another block's unknown re-loads it until it is something else.  No flag array, no "data, wait for the
@@ -1138,7 +1254,7 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
         }
     };
     T* tri = (T*)gs_smem; // [9][TRI]
-    T* sv = tri + 9 * TRI; // [SB][3]
+    T* sv = tri + (WINV ? GsWinv<T>::img_elems : 9 * TRI); // [SB][3] (WINV: behind the image's 16-byte padding, which the DMA writes too)
     int32_t* nodes = (int32_t*)(sv + 3 * SB);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int p = 0;
@@ -1149,9 +1265,22 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     T* sDinv = (T*)(nodes + 5 * SB); // [SB][9] D_i^-1 and (forward) [SB][9] D_i of the rows: fetched before the wait, so that
     T* sD = sDinv + 9 * SB; // nothing after it has to go to global memory for them
     T* srhs = sD + 9 * SB; // [SB][3] right-hand sides of the rows, likewise
-    for (int e = tid; e < 9 * TRI; e += 64 * NW) tri[e] = (T)0;
+    if (!WINV)
+        for (int e = tid; e < 9 * TRI; e += 64 * NW) tri[e] = (T)0;
     if (tid < SB) nodes[tid] = tid < cnt ? gs_order[start + tid] : -1;
     __syncthreads();
+    GS_CLK(0);
+    if (WINV) {
+        // the block's inverse image -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per wavefront instruction, lane i lands at base + 16 i, no
+        // registers; issued behind the first barrier, which would drain it, so that it travels beside the rows' loads): 142 pieces dealt to the 16 wavefronts
+        constexpr int IMG_BYTES = GsWinv<T>::img_elems * (int)sizeof(T);
+        const char* wg = (const char*)(gs_w + ((size_t)b * 2 + (FWD ? 0 : 1)) * GsWinv<T>::img_elems);
+        for (int c = w; c * 1024 < IMG_BYTES; c += NW) {
+            const int off = c * 1024 + lane * 16;
+            if (off < IMG_BYTES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + off), (__attribute__((address_space(3))) void*)((char*)tri + c * 1024), 16, 0, 0);
+        }
+    }
     for (int e = tid; e < 9 * cnt; e += 64 * NW) {
         const int64_t i = nodes[e / 9];
         sDinv[e] = diagBlockInv[9 * i + e % 9];
@@ -1170,6 +1299,44 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     const bool head = FWD ? first_sub : !first_sub;
     bool late[RQ]; // the column is published by pass p-1: its x is gathered after the wait, every other one before
     const uint32_t prevkey = p > 0 ? ((uint32_t)P.color[p - 1] << 8) | (uint32_t)P.sub[p - 1] : 0xffffffffu;
+    if constexpr (WINV) {
+        // only the OFF-block half of every row is read (the in-block couplings are inside the image), and the four rows of a wavefront go
+        // through the dependent loads together — class counts, then column ids + values, then the columns' colour keys: three round trips per
+        // wavefront instead of twelve (measured: the workgroups of the look-ahead passes needed 19 us to stream their 245 KB, longer than the
+        // passes in front of them took to finish)
+        int4 rc[RQ];
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) {
+            const int ii = w + NW * q;
+            jj[q] = -1, kb2[q] = 0, ke[q] = 0, late[q] = false;
+            node[q] = ii < cnt ? nodes[ii] : -1;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) bv[q][e] = (T)0;
+        }
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) rc[q] = node[q] >= 0 ? *(const int4*)(rowcnt + 4 * (int64_t)node[q]) : make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) {
+            if (node[q] < 0) continue; // wave-uniform
+            const int64_t i = node[q];
+            const int kbeg = FWD ? 0 : rc[q].x + rc[q].y + 1 + rc[q].z, kend = FWD ? rc[q].x : kbeg + rc[q].w;
+            kb2[q] = head ? kbeg + 64 : kbeg, ke[q] = head ? kend : kend - 64;
+            const int k = head ? kbeg + lane : kend - 64 + lane;
+            if (k >= kbeg && k < kend) {
+                jj[q] = col[i * 125 + k];
+                const T* bb = val + (i * 125 + k) * 9;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) bv[q][e] = bb[e];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RQ; ++q)
+            if (jj[q] >= 0) {
+                const uint32_t keyj = ckey[jj[q]];
+                late[q] = (((keyj >> 28) << 8) | (((keyj & 127u) - 1u) / (uint32_t)SB)) == prevkey;
+            }
+    }
+    else
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
         const int ii = w + NW * q;
@@ -1196,8 +1363,10 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
                 if (k >= ibeg && k < iend) {
                     const int l = (int)(keyj & 127u) - 1 - lo;
                     if (l >= 0 && l < SB) {
-                        const int idx = FWD ? gs_tri_fwd<SB>(ii, l) : gs_tri_bwd(ii, l);
-                        gs_store_tri<T>(tri, TRI, idx, diagBlockInv + 9 * (int64_t)i, bv[q]);
+                        if (!WINV) { // (WINV: the in-block couplings are inside the inverse image)
+                            const int idx = FWD ? gs_tri_fwd<SB>(ii, l) : gs_tri_bwd(ii, l);
+                            gs_store_tri<T>(tri, TRI, idx, diagBlockInv + 9 * (int64_t)i, bv[q]);
+                        }
                         jj[q] = -1;
                     }
                 }
@@ -1258,6 +1427,7 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
         }
     }
     __syncthreads(); // also orders the staging of D^-1 / D / rhs (and the zeroed triangle) before their users
+    GS_CLK(1);
     auto is_late = [&](uint32_t keyj) { return (((keyj >> 28) << 8) | (((keyj & 127u) - 1u) / (uint32_t)SB)) == prevkey; };
     bool tail_late[RQ]; // the tail of the half row (slots past the first 64) holds columns of pass p-1 (rows are sorted to avoid it)
 #pragma unroll
@@ -1284,11 +1454,13 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
             const uint32_t keyj = ckey[j], keyi = ckey[i];
             const int l = (int)(keyj & 127u) - 1 - lo;
             if ((keyj >> 7) == (keyi >> 7) && l >= 0 && l < SB) {
-                const int idx = FWD ? gs_tri_fwd<SB>(ii, l) : gs_tri_bwd(ii, l);
-                T bt[9];
+                if (!WINV) {
+                    const int idx = FWD ? gs_tri_fwd<SB>(ii, l) : gs_tri_bwd(ii, l);
+                    T bt[9];
 #pragma unroll
-                for (int e = 0; e < 9; ++e) bt[e] = bb[e];
-                gs_store_tri<T>(tri, TRI, idx, diagBlockInv + 9 * (int64_t)i, bt);
+                    for (int e = 0; e < 9; ++e) bt[e] = bb[e];
+                    gs_store_tri<T>(tri, TRI, idx, diagBlockInv + 9 * (int64_t)i, bt);
+                }
             }
             else if (is_late(keyj))
                 tl = true;
@@ -1304,6 +1476,7 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
         e0 = wave_sum(e0), e1 = wave_sum(e1), e2 = wave_sum(e2);
         if (lane == 0) srhs[3 * ii] -= e0, srhs[3 * ii + 1] -= e1, srhs[3 * ii + 2] -= e2;
     }
+    GS_CLK(2);
     // ---- 2b. wait for the previous pass
     if (!dataflag) {
         if (nbr)
@@ -1359,8 +1532,55 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
         if (lane == 0) gs_store_rhs<T>(sv, ii, sDinv + 9 * ii, srhs[3 * ii] - s0, srhs[3 * ii + 1] - s1, srhs[3 * ii + 2] - s2);
     }
     __syncthreads();
+    GS_CLK(3);
+#ifdef HOT_GS_CLOCKS
+#define GS_CLK_OUT() \
+    do { \
+        GS_CLK(4); \
+        if (tid == 0) \
+            for (int i = 0; i < 5; ++i) atomicAdd(&gs_clk[p * 8 + i], gclk_[i]); \
+        if (tid == 0) atomicAdd(&gs_clk[p * 8 + 7], 1ull); \
+    } while (0)
+#else
+#define GS_CLK_OUT()
+#endif
+    if (WINV) {
+        // h_r = a_r + sum_c W_rc a_c over the columns before (forward) / after (backward) row r; wavefront w forms rows 4 w .. 4 w + 3, lane = column
+        const bool cin = lane < cnt;
+        const T ac0 = cin ? sv[3 * lane] : (T)0, ac1 = cin ? sv[3 * lane + 1] : (T)0, ac2 = cin ? sv[3 * lane + 2] : (T)0;
+        T h0 = 0, h1 = 0, h2 = 0; // of row 4 w + lane, lanes 0..3
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rr = 4 * w + k;
+            if (rr >= cnt) break; // wave-uniform
+            const bool act = FWD ? lane < rr : (lane > rr && cin);
+            const int idx = act ? gs_winv_idx<FWD>(rr, lane) : TRI - 1; // masked lanes read the all-zero entry
+            T Lw[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) Lw[e] = tri[e * TRI + idx];
+            T t0 = Lw[0] * ac0 + Lw[3] * ac1 + Lw[6] * ac2, t1 = Lw[1] * ac0 + Lw[4] * ac1 + Lw[7] * ac2, t2 = Lw[2] * ac0 + Lw[5] * ac1 + Lw[8] * ac2;
+            t0 = wave_sum(t0), t1 = wave_sum(t1), t2 = wave_sum(t2);
+            if (lane == k) h0 = sv[3 * rr] + t0, h1 = sv[3 * rr + 1] + t1, h2 = sv[3 * rr + 2] + t2;
+        }
+        const int me = 4 * w + lane;
+        if (lane < 4 && me < cnt) {
+            const int64_t i = nodes[me];
+            __hip_atomic_store(x + 3 * i, h0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(x + 3 * i + 1, h1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(x + 3 * i + 2, h2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (FWD) {
+                const T* dd = sD + 9 * me;
+                hD[3 * i] = dd[0] * h0 + dd[3] * h1 + dd[6] * h2, hD[3 * i + 1] = dd[1] * h0 + dd[4] * h1 + dd[7] * h2, hD[3 * i + 2] = dd[2] * h0 + dd[5] * h1 + dd[8] * h2;
+            }
+            else if (hD)
+                hD[3 * i] += h0, hD[3 * i + 1] += h1, hD[3 * i + 2] += h2;
+        }
+        GS_CLK_OUT();
+        return; // (data-flag hand-off only: the write-through stores are the publication)
+    }
     if (w != 0) return;
     if (cnt > 0) gs_phase_b<T, FWD, SB, true>(tri, sv, nodes, cnt, lane, diagVal, diagBlockInv, x, hD, sD);
+    GS_CLK_OUT();
     // ---- publish: the write-through stores of every lane have left the CU before lane 0 bumps the pass counter
     if (dataflag) return; // the write-through stores of phase B are the publication
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1571,8 +1791,10 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         if (!attr_gs_set) {
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
-            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T))));
-            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T))));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T) + 128)));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T) + 128)));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T) + 128)));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T) + 128)));
             attr_gs_set = true;
         }
         T* y = L.tmp.p;
@@ -1601,8 +1823,10 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         if (!attr_gs_set) {
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
             HOT_HIP(hipFuncSetAttribute((const void*)k_gs_block<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GsLds<T, 64>::bytes));
-            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T))));
-            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T))));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T) + 128)));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T) + 128)));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, true, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T) + 128)));
+            HOT_HIP(hipFuncSetAttribute((const void*)k_gs_sweep<T, false, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GsLds<T, 64>::bytes + 21 * 64 * sizeof(T) + 128)));
             attr_gs_set = true;
 #ifdef HOT_AB_KERNELS
             if (const char* e = getenv("HOT_GS_DBG")) {
@@ -1623,7 +1847,8 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         const bool dataflow = !gs_no_chain && !multilaunch && !simple_gs && L.split && !L.part && (force_dataflow || max_nb <= 256); // a chained launch cannot stop for the exchange
         // (chained levels of more than 32 blocks a colour run half blocks too: twice the workgroups stream a colour's off-block rows — C2
         // level 1, 91 blocks a colour: 159 against 178 us per half sweep, 10.9 against 12.2 ms per step)
-        const int sb = env_sb ? env_sb : ((max_nb > 256 || (dataflow && max_nb > 32)) ? 32 : 64);
+        // (chained levels with inverse images, k_gs_winv: whole blocks — the 64-row pass costs one dense product, not 64 dependent steps)
+        const int sb = env_sb ? env_sb : ((max_nb > 256 || (dataflow && max_nb > 32 && !L.gs_w_ready)) ? 32 : 64);
         const int gs_threads = sb == 64 ? 1024 : 512;
         const int nsub = 64 / sb;
         HOT_CHECK(L.split || simple_gs, HOT_ERR_INVALID, "block GS kernels need the regrouped rows (k_gs_split_rows)");
@@ -1786,12 +2011,20 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             else
                 HOT_HIP(hipMemsetAsync(gs_done.p, 0, 40 * sizeof(int), stream));
             const int grid = P.wg_begin[P.npass];
-#define HOT_GS_CASE(F, S)                                                                                                                                              \
-    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_sweep<T, F, S>), grid, 16 * S, (GsLds<T, S>::bytes + 21 * S * sizeof(T)), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
+#define HOT_GS_CASE(F, S, ...)                                                                                                                                         \
+    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_sweep<T, F, S, ##__VA_ARGS__>), grid, 16 * S, (GsLds<T, S>::bytes + 21 * S * sizeof(T) + 128), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
         L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, P, rc, gs_done.p, (int*)(hscal + 250), p2p ? L.gs_nbr.p : (const int32_t*)nullptr, L.gs_flag.p, gs_epoch, dataflag, \
-        (fwd && dataflag) ? du : (T*)nullptr)
+        (fwd && dataflag) ? du : (T*)nullptr, L.gs_w.p)
             du_marked = fwd && dataflag;
-            if (fwd) {
+            // whole-block passes on the precomputed inverses of the in-block triangles (A/B build: HOT_GS_NO_WINV = the 64-step substitution)
+            const bool winv = sb == 64 && L.gs_w_ready && dataflag && !ab_flag("HOT_GS_NO_WINV");
+            if (winv) {
+                if (fwd)
+                    HOT_GS_CASE(true, 64, true);
+                else
+                    HOT_GS_CASE(false, 64, true);
+            }
+            else if (fwd) {
                 if (sb == 64) HOT_GS_CASE(true, 64);
                 else if (sb == 32) HOT_GS_CASE(true, 32);
                 else HOT_GS_CASE(true, 16);
@@ -1803,14 +2036,32 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             }
 #undef HOT_GS_CASE
         };
+#ifdef HOT_GS_CLOCKS
+        auto clk_report = [&](const char* what) {
+            unsigned long long h[34 * 8];
+            HOT_HIP(hipStreamSynchronize(stream));
+            HOT_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(gs_clk), sizeof(h)));
+            if (h[7]) {
+                fprintf(stderr, "k_gs_sweep %s level %d, clocks per workgroup [header, rows, early gathers, wait + late gathers, solve]:", what, L.id);
+                for (int q = 0; q < 33 && h[q * 8 + 7]; ++q) fprintf(stderr, " | p%d(%llu wg) %.0f %.0f %.0f %.0f %.0f", q, h[q * 8 + 7], (double)h[q * 8] / h[q * 8 + 7], (double)h[q * 8 + 1] / h[q * 8 + 7], (double)h[q * 8 + 2] / h[q * 8 + 7], (double)h[q * 8 + 3] / h[q * 8 + 7], (double)h[q * 8 + 4] / h[q * 8 + 7]);
+                fprintf(stderr, "\n");
+            }
+            memset(h, 0, sizeof(h));
+            HOT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gs_clk), h, sizeof(h)));
+        };
+#endif
         iterations = ((iterations + 1) >> 1);
         for (; iterations--;) {
             prof.count(lname("gs_symsweeps", L.id));
             // no memset of hdu / du: a sweep writes every node before any later node reads it (only preceding nodes are read) —
             // except with rank-local sweeps, where the other ranks' unknowns are read as the zeros the sweep starts from
             if (rank_local) zero(n3, hdu), zero(n3, du);
-            if (dataflow)
+            if (dataflow) {
                 sweep(true);
+#ifdef HOT_GS_CLOCKS
+                clk_report("forward");
+#endif
+            }
             else if (pair_path)
                 pair_sweep(true);
             else

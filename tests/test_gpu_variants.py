@@ -20,6 +20,8 @@ CASES = [
     ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=64"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_TEST_CFG": "gs_chain=2,gs_sub_block=32"}, SOLVER, "smoothers or vcycle or iterates"),
     ({"HOT_TEST_CFG": "gs_chain=2,gs_sub_block=16"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_GS_NO_WINV": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # chained whole-block passes with the 64-step substitution instead of the product with the blocks' inverse images (k_gs_winv)
+    ({"HOT_TEST_CFG": "gs_chain=2", "HOT_GS_NO_WINV": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_GS_PASS_COUNTERS": "1"}, SOLVER, "smoothers or vcycle or iterates"),
     ({"HOT_TEST_CFG": "gs_chain=2,gs_sub_block=32", "HOT_GS_PASS_COUNTERS": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_TEST_CFG": "gs_chain=2,gs_sub_block=32", "HOT_GS_BLOCK_FLAGS": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # hand-off through per-block sweep stamps
