@@ -156,6 +156,7 @@ def parse_args():
                     "cannot be attached) or hot_amd.dist.TorchComm (torch.distributed collectives, host-synchronous)")
     ap.add_argument("--shard-gs", type=int, default=1, choices=[0, 1], help="N > 1, coloured GS across ranks: 1 = processor-block (one exchange per symmetric sweep; default), "
                     "0 = colour-synchronous (the single-rank iterates, sixteen exchanges per symmetric sweep)")
+    ap.add_argument("--shard-owner", type=int, default=0, help="N > 1, hot_config.shard_owner: 0 = balanced row ownership along the cuts (default), 1 = the first-touching rank owns (rounds 2 - 4), k >= 2 = balanced with a period of 2^k nodes")
     ap.add_argument("--watchdog-s", type=float, default=1500.0, help="N > 1: abort the rank (exit code 3) if the run has not finished after this many seconds (a peer that died or a wedged collective would otherwise hang the job); 0 = off")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = the body grows so that every GPU keeps the configuration's particle count (default); "
                     "strong = the configuration's own body (e.g. --config C4 --gpus 4: BASELINE's 16 M particles over four GPUs), every rank generating only its cell planes")
@@ -232,7 +233,7 @@ def main():
     s = 8 if cfg["dtype"] == np.float64 else 4
     dt = cfg["dt"]
 
-    ctx = make_ctx(lib, cloud, cfg, device=local, comm=comm, **(dict(shard_gs=args.shard_gs) if world > 1 else {}))
+    ctx = make_ctx(lib, cloud, cfg, device=local, comm=comm, **(dict(shard_gs=args.shard_gs, shard_owner=args.shard_owner) if world > 1 else {}))
     for _ in range(args.warmup):
         ctx.advance(dt)
     barrier()

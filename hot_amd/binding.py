@@ -25,7 +25,7 @@ class hot_config(C.Structure):
         ("useCN", C.c_int32), ("project", C.c_int32), ("systemBCProject", C.c_int32), ("linesearch", C.c_int32),
         ("matrixFree", C.c_int32), ("boundaryType", C.c_int32), ("useAdaptiveHessian", C.c_int32),
         ("topDownMGS", C.c_int32), ("max_iterations", C.c_int32), ("plasticity", C.c_int32),
-        ("yield_stress", C.c_double), ("snow", C.c_double * 5), ("profile", C.c_int32), ("debug_store", C.c_int32), ("useBaselineMultigrid", C.c_int32), ("gs_chain", C.c_int32), ("gs_sub_block", C.c_int32), ("shard_gs", C.c_int32), ("shard_replicated", C.c_int32), ("ls_energy_only", C.c_int32), ("linear_iteration_cap", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("yield_stress", C.c_double), ("snow", C.c_double * 5), ("profile", C.c_int32), ("debug_store", C.c_int32), ("useBaselineMultigrid", C.c_int32), ("gs_chain", C.c_int32), ("gs_sub_block", C.c_int32), ("shard_gs", C.c_int32), ("shard_replicated", C.c_int32), ("ls_energy_only", C.c_int32), ("linear_iteration_cap", C.c_int32), ("shard_owner", C.c_int32), ("reserved", C.c_int32 * 5),
     ]
 
 

@@ -20,6 +20,18 @@ struct GsImg {
     static constexpr size_t idx_per_dir = 64 * 64; // 16-bit entry indices [row][step of the direction's walk] (0 = no entry in that column: the all-zero entry)
 };
 
+// Sharded runs, hot_config.shard_owner = 0: the rank whose particle range — the SPGrid pages [split[r - 1], split[r]) of the page order — contains the
+// page of the 4^3 colour block around node (x, y, z) of level `level` (a level-l node sits at (x, y, z) << l on the finest grid).
+template <class T>
+__host__ __device__ inline int home_rank(const uint64_t* split, int R, int x, int y, int z, int level)
+{
+    using G = Geo<T>;
+    const uint64_t page = G::linear_offset((x & ~3) << level, (y & ~3) << level, (z & ~3) << level) >> 12;
+    int r = 0;
+    while (r < R - 1 && page >= split[r]) ++r;
+    return r;
+}
+
 // one multigrid level: system matrix in 125-slot stencil ELL + transfer tables to the next coarser level
 template <class T>
 struct Level {
@@ -81,6 +93,8 @@ struct Level {
     std::vector<int> nstart; // [ranks + 1] id prefixes: rank r's particles first touch the nodes [nstart[r], nstart[r+1])
     DBuf<uint8_t> owner; // n: owning rank of every row = rank whose prefix holds the lowest node of the row's 4^3 colour block
     DBuf<uint8_t> own; // n: owner == this rank (row mask of the operator kernels)
+    DBuf<uint8_t> block_owner; // [nblocks] sharded: owner of every colour block (mark_colors orders a colour's blocks by owner, then first touch)
+    std::vector<uint8_t> block_owner_h;
     std::vector<int> csplit; // [8 * (ranks + 1)] colour c: blocks color_block_begin[c] + [csplit[c][r], csplit[c][r+1]) belong to rank r
     std::vector<int> xbeg, xcnt; // [ranks * 8] position range in gs_order of the nodes rank r owns of colour c
     DBuf<int32_t> dxtab; // the same two tables on the device (xbeg | xcnt)
@@ -185,6 +199,7 @@ struct Ctx : CtxBase {
     hot_comm comm{};
     bool sharded() const { return comm.size > 1; }
     std::vector<int> block_first; // [ranks + 1] first global block first touched by each rank's particle groups
+    std::vector<uint64_t> page_split; // [ranks - 1] sharded: rank r holds the SPGrid pages [page_split[r - 1], page_split[r]) of the page order (migrate_particles)
     std::vector<int> nstart0; // [ranks + 1] level-0 id prefixes (nodes of those blocks)
     DBuf<char> xsend, xrecv; // staging of the collectives
     DBuf<uint8_t> written; // level-0 rows this rank's tile kernel has written (its partial rows)

@@ -327,6 +327,73 @@ static void build_coord_map(Ctx<T>* ctx, Level<T>& L)
     HOT_LAUNCH(ctx, "mg_coord_map", k_coord_map_insert, div_up(L.n, 256), 256, 0, L.map, L.coord.p, L.n);
 }
 
+// ---- sharded runs: owner of every colour block and the order of a colour's blocks (owner, then first touch), so that every rank owns a
+// contiguous run of each colour's list whatever the ownership rule (hot_config.shard_owner):
+//   1  the rank whose id prefix holds the block's lowest node, i.e. whose particles first touch it (rounds 2 - 4: the lower rank of a cut owned
+//      every block the two share and received every partial matrix row);
+//   0  finest level: the rank whose particle range (pages of the SPGrid page order) contains the block's own page, home_rank (hot_impl.h), if its
+//      particles reach the block at all, else the reaching rank nearest to it in rank order — every rank owns the rows inside its own range, the boundary between the
+//      ranks' rows is the boundary between their particles, both sides of a cut send the same amount of partial rows; coarser levels: the owner
+//      of the first existing child of the block's lowest node.
+// (Measured, DESIGN.md section 7: a rule that lets a rank own blocks none of its particles reach scatters single blocks over far ranks — the page
+// order jumps — and a rank-local Gauss-Seidel sweep, hot_config.shard_gs = 1, then needs twice the iterations; alternating the owner along a cut
+// in patches balances as well but lengthens the boundary: +13 .. +38 % iterations.)
+struct RankPrefix {
+    int v[65];
+    uint64_t split[63];
+    int R;
+};
+template <class T>
+__global__ void k_color_owner_keys(HashMap h, const int32_t* __restrict__ coord, const int32_t* __restrict__ flags, const int32_t* __restrict__ scan, RankPrefix np, int mode /*0 first touch, 1 home page (finest level), 2 first child's owner*/,
+    HashMap block_map, const uint64_t* __restrict__ sharers, const int32_t* __restrict__ child, const uint8_t* __restrict__ fine_owner, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int n)
+{
+    using G = Geo<T>;
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 8 * n || !flags[e]) return;
+    const int c = e / n, i = e - c * n; // i: the block's lowest node
+    const int x = coord[3 * i], y = coord[3 * i + 1], z = coord[3 * i + 2];
+    const int32_t slot = hash_find_slot(h, coord_key(x >> 2, y >> 2, z >> 2));
+    int r = 0;
+    while (r + 1 < np.R && i >= np.v[r + 1]) ++r; // the first-touching rank
+    if (mode == 1) {
+        const int hr = home_rank<T>(np.split, np.R, x, y, z, 0);
+        // does rank hr reach the block?  (sharers of an SPGrid block: the ranks whose particle tiles cover it or, fp64, its x-companion inside the colour block)
+        int32_t b = hash_find_id(block_map, G::linear_offset(x & ~3, y & ~3, z & ~3) >> 12);
+        if (b < 0 && G::BX == 2) b = hash_find_id(block_map, G::linear_offset((x & ~3) + 2, y & ~3, z & ~3) >> 12);
+        if (b >= 0 && sharers[b]) { // the reaching rank nearest to hr in rank (= page) order, the lower one on a tie: hr itself wherever it reaches the block
+            const uint64_t sh = sharers[b];
+            for (int d = 0; d < np.R; ++d) {
+                if (hr - d >= 0 && ((sh >> (hr - d)) & 1ULL)) {
+                    r = hr - d;
+                    break;
+                }
+                if (hr + d < np.R && ((sh >> (hr + d)) & 1ULL)) {
+                    r = hr + d;
+                    break;
+                }
+            }
+        }
+    }
+    else if (mode == 2) {
+        for (int q = 0; q < 27; ++q) {
+            const int ci = child[(int64_t)i * 27 + q];
+            if (ci >= 0) {
+                r = fine_owner[ci];
+                break;
+            }
+        }
+    }
+    keys[scan[e]] = ((uint64_t)c << 56) | ((uint64_t)r << 48) | (uint32_t)i;
+    vals[scan[e]] = (uint32_t)slot;
+}
+__global__ void k_color_owner_assign(HashMap h, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ slots, const int32_t* __restrict__ scan, uint8_t* __restrict__ owner, int nb, int n)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nb) return;
+    const int c = (int)(keys[p] >> 56);
+    h.id[slots[p]] = p - scan[(size_t)c * n]; // block id inside its colour: position among the colour's blocks in (owner, first touch) order
+    owner[p] = (uint8_t)((keys[p] >> 48) & 0xff);
+}
 template <class T>
 static void mark_colors(Ctx<T>* ctx, Level<T>& L)
 {
@@ -344,9 +411,41 @@ static void mark_colors(Ctx<T>* ctx, Level<T>& L)
     HOT_LAUNCH(ctx, "color_block_insert", k_color_insert, div_up(n, 256), 256, 0, h, L.coord.p, n);
     ctx->flags.reserve(8 * (size_t)n), ctx->scan.reserve(8 * (size_t)n);
     HOT_LAUNCH(ctx, "color_block_flag", k_color_flag, div_up(8 * (size_t)n, 256), 256, 0, h, L.coord.p, ctx->flags.p, n);
-    ctx->exclusive_scan_i32(ctx->flags.p, ctx->scan.p, 8 * (size_t)n);
-    HOT_LAUNCH(ctx, "color_block_assign", k_color_assign, div_up(8 * (size_t)n, 256), 256, 0, h, L.coord.p, ctx->flags.p, ctx->scan.p, n);
+    const int nb_all = ctx->exclusive_scan_i32(ctx->flags.p, ctx->scan.p, 8 * (size_t)n);
     ctx->keys.reserve(n), ctx->keys2.reserve(n), ctx->vals.reserve(n), ctx->vals2.reserve(n);
+    L.block_owner_h.clear();
+    if (ctx->sharded() && (int)L.nstart.size() == ctx->comm.size + 1 && nb_all > 0) {
+        // block ids inside a colour in (owner, first touch) order; the owners go to level_ownership
+        RankPrefix np{};
+        np.R = ctx->comm.size;
+        for (int r = 0; r <= np.R; ++r) np.v[r] = L.nstart[r];
+        int mode = 0;
+        const uint8_t* fine_owner = nullptr;
+        if (ctx->cfg.shard_owner == 0) {
+            if (L.id == 0 && (int)ctx->page_split.size() == np.R - 1 && ctx->halo_mode() && ctx->sharers.p) {
+                mode = 1;
+                for (int r = 0; r < np.R - 1; ++r) np.split[r] = ctx->page_split[r];
+            }
+            else if (L.id > 0 && L.id - 1 < (int)ctx->levels.size() && ctx->levels[L.id - 1]->part && L.child.p) {
+                mode = 2;
+                fine_owner = ctx->levels[L.id - 1]->owner.p;
+            }
+        }
+        HOT_LAUNCH(ctx, "color_owner_keys", k_color_owner_keys<T>, div_up(8 * (size_t)n, 256), 256, 0, h, L.coord.p, ctx->flags.p, ctx->scan.p, np, mode, ctx->block_map, ctx->sharers.p, L.child.p, fine_owner, ctx->keys.p, ctx->vals.p, n);
+        size_t sb = 0;
+        HOT_HIP(rocprim::radix_sort_pairs(nullptr, sb, ctx->keys.p, ctx->keys2.p, ctx->vals.p, ctx->vals2.p, (size_t)nb_all, 0, 64, ctx->stream));
+        if (sb > ctx->sort_tmp_bytes) {
+            ctx->sort_tmp.reserve(sb);
+            ctx->sort_tmp_bytes = ctx->sort_tmp.cap;
+        }
+        HOT_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, sb, ctx->keys.p, ctx->keys2.p, ctx->vals.p, ctx->vals2.p, (size_t)nb_all, 0, 64, ctx->stream));
+        L.block_owner.reserve(nb_all);
+        HOT_LAUNCH(ctx, "color_owner_assign", k_color_owner_assign, div_up(nb_all, 256), 256, 0, h, ctx->keys2.p, ctx->vals2.p, ctx->scan.p, L.block_owner.p, nb_all, n);
+        L.block_owner_h.resize(nb_all);
+        HOT_HIP(hipMemcpyAsync(L.block_owner_h.data(), L.block_owner.p, nb_all, hipMemcpyDeviceToHost, ctx->stream)); // (the sync at the end of this function)
+    }
+    else
+        HOT_LAUNCH(ctx, "color_block_assign", k_color_assign, div_up(8 * (size_t)n, 256), 256, 0, h, L.coord.p, ctx->flags.p, ctx->scan.p, n);
     HOT_LAUNCH(ctx, "color_keys", k_color_keys, div_up(n, 256), 256, 0, h, L.coord.p, ctx->keys.p, ctx->vals.p, n);
     size_t bytes = 0;
     HOT_HIP(rocprim::radix_sort_pairs(nullptr, bytes, ctx->keys.p, ctx->keys2.p, ctx->vals.p, ctx->vals2.p, (size_t)n, 0, 64, ctx->stream));

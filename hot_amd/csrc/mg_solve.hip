@@ -731,38 +731,44 @@ __device__ __forceinline__ void gs_store_rhs(T* sv, int ii, const T* __restrict_
 // reads of N is 2/3 of that, so on a level bound by the 64-step dependency chain and not by bytes the product with W is the better trade.
 // One workgroup per (block, direction): N into the LDS triangle exactly as the sweep kernels file it, then column c0 of W is the substitution
 // applied to the three unit vectors of position c0 (lane = row, the three right-hand sides together: 9 LDS reads, 27 multiply-adds per step),
-// four columns per wavefront; the result goes out row-packed (gs_winv_idx).  Built once per hierarchy build.
+// four columns per wavefront; the result goes out row-packed (gs_winv_idx).  The backward image follows from the forward one (A symmetric).
+// Built once per hierarchy build.
 template <class T>
 __global__ __launch_bounds__(1024) void k_gs_winv(const int32_t* __restrict__ col, const T* __restrict__ val, const uint32_t* __restrict__ ckey, const int32_t* __restrict__ gs_order,
-    const int32_t* __restrict__ block_start, const int32_t* __restrict__ rowcnt, const T* __restrict__ diagBlockInv, T* __restrict__ gs_w)
+    const int32_t* __restrict__ block_start, const int32_t* __restrict__ rowcnt, const T* __restrict__ diagBlockInv, const T* __restrict__ diagVal, T* __restrict__ gs_w)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     constexpr int TRI = GsLds<T, 64>::TRI;
     T* tri = (T*)gs_smem; // [9][TRI]
-    int32_t* nodes = (int32_t*)(tri + 9 * TRI); // [64]
+    T* sDi = tri + 9 * TRI; // [64][9] D^-1 of the block's rows
+    T* sDv = sDi + 64 * 9; // [64][9] D
+    int32_t* nodes = (int32_t*)(sDv + 64 * 9); // [64]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x;
-    const bool fwd = blockIdx.y == 0;
     const int start = block_start[b], cnt = min(64, block_start[b + 1] - start);
     for (int e = tid; e < 9 * TRI; e += 1024) tri[e] = (T)0;
     if (tid < 64) nodes[tid] = tid < cnt ? gs_order[start + tid] : -1;
     __syncthreads();
-    for (int e = tid; e < 64 * cnt; e += 1024) { // (row position, in-block slot of the row's half)
+    for (int e = tid; e < 9 * cnt; e += 1024) {
+        const int64_t i = nodes[e / 9];
+        sDi[e] = diagBlockInv[9 * i + e % 9], sDv[e] = diagVal[9 * i + e % 9];
+    }
+    for (int e = tid; e < 64 * cnt; e += 1024) { // (row position, in-block slot of the row's preceding half)
         const int ii = e >> 6, ks = e & 63;
         const int64_t i = nodes[ii];
-        const int po = rowcnt[4 * i], pi = rowcnt[4 * i + 1], fi = rowcnt[4 * i + 2];
-        const int ibeg = fwd ? po : po + pi + 1, n_in = fwd ? pi : fi;
-        if (ks >= n_in) continue;
-        const int k = ibeg + ks, j = col[i * 125 + k];
+        const int po = rowcnt[4 * i], pi = rowcnt[4 * i + 1];
+        if (ks >= pi) continue;
+        const int k = po + ks, j = col[i * 125 + k];
         const int l = (int)(ckey[j] & 127u) - 1;
         T bb[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) bb[q] = val[(i * 125 + k) * 9 + q];
-        gs_store_tri<T>(tri, TRI, fwd ? gs_tri_fwd<64>(ii, l) : gs_tri_bwd(ii, l), diagBlockInv + 9 * i, bb);
+        gs_store_tri<T>(tri, TRI, gs_tri_fwd<64>(ii, l), diagBlockInv + 9 * i, bb);
     }
     __syncthreads();
-    T* out = gs_w + ((size_t)b * 2 + (fwd ? 0 : 1)) * GsWinv<T>::img_elems;
-    if (tid == 0)
-        for (int e = 0; e < 9; ++e) out[e * TRI + TRI - 1] = (T)0; // the entry masked lanes read
+    T* outf = gs_w + ((size_t)b * 2) * GsWinv<T>::img_elems;
+    T* outb = outf + GsWinv<T>::img_elems;
+    if (tid < 9) outf[tid * TRI + TRI - 1] = (T)0, outb[tid * TRI + TRI - 1] = (T)0; // the entry masked lanes read
+    // ---- forward image: column c0 of W = the substitution applied to the three unit vectors of position c0
     for (int k4 = 0; k4 < 4; ++k4) {
         const int c0 = w + 16 * k4; // wave-uniform
         if (c0 >= cnt) break;
@@ -771,11 +777,9 @@ __global__ __launch_bounds__(1024) void k_gs_winv(const int32_t* __restrict__ co
         for (int s_ = 0; s_ < 3; ++s_)
 #pragma unroll
             for (int q = 0; q < 3; ++q) a[s_][q] = (lane == c0 && s_ == q) ? (T)1 : (T)0;
-        const int nstep = fwd ? cnt - 1 - c0 : c0; // columns c0, c0 +- 1, ... : every one but the last has later rows to update
-        for (int st = 0; st < nstep; ++st) {
-            const int c = fwd ? c0 + st : c0 - st;
-            const bool act = fwd ? (lane > c && lane < cnt) : lane < c;
-            const int idx = act ? (fwd ? gs_tri_fwd<64>(lane, c) : gs_tri_bwd(lane, c)) : TRI - 1;
+        for (int c = c0; c < cnt - 1; ++c) { // every column but the last has later rows to update
+            const bool act = lane > c && lane < cnt;
+            const int idx = act ? gs_tri_fwd<64>(lane, c) : TRI - 1;
             T Lc[9];
 #pragma unroll
             for (int e = 0; e < 9; ++e) Lc[e] = tri[e * TRI + idx];
@@ -787,14 +791,35 @@ __global__ __launch_bounds__(1024) void k_gs_winv(const int32_t* __restrict__ co
                 a[s_][0] = fma(Lc[6], b2, a[s_][0]), a[s_][1] = fma(Lc[7], b2, a[s_][1]), a[s_][2] = fma(Lc[8], b2, a[s_][2]);
             }
         }
-        const bool mine = fwd ? (lane > c0 && lane < cnt) : lane < c0; // W(lane, c0), strictly off the diagonal
-        if (mine) {
-            const int idx = fwd ? gs_winv_idx<true>(lane, c0) : gs_winv_idx<false>(lane, c0);
+        if (lane > c0 && lane < cnt) { // W(lane, c0), strictly below the diagonal
+            const int idx = gs_winv_idx<true>(lane, c0);
 #pragma unroll
             for (int s_ = 0; s_ < 3; ++s_)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) out[(q + 3 * s_) * TRI + idx] = a[s_][q];
+                for (int q = 0; q < 3; ++q) outf[(q + 3 * s_) * TRI + idx] = a[s_][q];
         }
+    }
+    // ---- backward image from the forward one: with U = L^T (A symmetric), I + W_b = (D + U)^-1 D = ((D + L)^-1)^T D = D^-1 (I + W_f)^T D, i.e.
+    // W_b(r, c) = D_r^-1 W_f(c, r)^T D_c for c > r: two 3 x 3 products per entry instead of a second substitution
+    __threadfence();
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += 1024) {
+        const int r = e >> 6, c = e & 63;
+        if (c <= r || c >= cnt) continue;
+        const int fi = gs_winv_idx<true>(c, r), bi = gs_winv_idx<false>(r, c);
+        T M[9], T1[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) M[q] = __builtin_nontemporal_load(outf + q * TRI + fi);
+        const T* Dc = sDv + 9 * c;
+        const T* Ir = sDi + 9 * r;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) T1[i + 3 * j] = M[3 * i] * Dc[3 * j] + M[1 + 3 * i] * Dc[1 + 3 * j] + M[2 + 3 * i] * Dc[2 + 3 * j]; // (M^T D_c)(i, j) = sum_k M(k, i) D_c(k, j)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) outb[(i + 3 * j) * TRI + bi] = Ir[i] * T1[3 * j] + Ir[i + 3] * T1[1 + 3 * j] + Ir[i + 6] * T1[2 + 3 * j];
     }
 }
 template <class T>
@@ -802,12 +827,12 @@ void Ctx<T>::build_gs_winv(Level<T>& L)
 {
     constexpr size_t per = 2 * (size_t)GsWinv<T>::img_elems;
     L.gs_w.reserve(per * (size_t)L.nblocks + 256);
-    const size_t lds = (size_t)9 * GsLds<T, 64>::TRI * sizeof(T) + 64 * sizeof(int32_t);
+    const size_t lds = ((size_t)9 * GsLds<T, 64>::TRI + 2 * 64 * 9) * sizeof(T) + 64 * sizeof(int32_t);
     if (!attr_winv_set) {
         HOT_HIP(hipFuncSetAttribute((const void*)k_gs_winv<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_winv_set = true;
     }
-    HOT_LAUNCH(this, lname("gs_winv", L.id).c_str(), k_gs_winv<T>, dim3(L.nblocks, 2), 1024, lds, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.rowcnt.p, L.diagBlockInv.p, L.gs_w.p);
+    HOT_LAUNCH(this, lname("gs_winv", L.id).c_str(), k_gs_winv<T>, L.nblocks, 1024, lds, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.rowcnt.p, L.diagBlockInv.p, L.diagVal.p, L.gs_w.p);
     L.gs_w_ready = true;
 }
 

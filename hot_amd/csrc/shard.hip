@@ -141,11 +141,6 @@ void Ctx<T>::merge_block_lists()
 struct Int9 {
     int v[9];
 };
-__global__ void k_block_minid(const int32_t* __restrict__ gs_order, const int32_t* __restrict__ block_start, int32_t* out, int nb)
-{
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nb) out[b] = gs_order[block_start[b]]; // nodes of a block are ordered by id
-}
 __global__ void k_node_owner(const uint32_t* __restrict__ ckey, const uint8_t* __restrict__ owner_b, Int9 cb, uint8_t* owner, uint8_t* own, int me, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,19 +150,15 @@ __global__ void k_node_owner(const uint32_t* __restrict__ ckey, const uint8_t* _
     owner[i] = o, own[i] = o == (uint8_t)me;
 }
 
-// A 4^3 colour block is owned by the rank whose id prefix [nstart[r], nstart[r+1]) holds the block's lowest node, i.e. the rank
-// whose particles touch it first.  Blocks of a colour are ordered by that lowest node (first-touch order), so every rank owns
-// a contiguous run of each colour's block list, and its nodes of colour c are one contiguous position range of gs_order.
+// The owner of a 4^3 colour block comes from the colouring (mark_colors, mg_build.hip: hot_config.shard_owner — balanced between the two sides of
+// a cut by default), which also orders the blocks of a colour by (owner, first touch): every rank owns a contiguous run of each colour's block
+// list, and its nodes of colour c are one contiguous position range of gs_order.
 template <class T>
 void Ctx<T>::level_ownership(Level<T>& L)
 {
     const int R = comm.size, me = comm.rank, nb = L.nblocks;
     HOT_CHECK((int)L.nstart.size() == R + 1 && L.colored && nb > 0, HOT_ERR_INVALID, "level_ownership: prefixes / colouring missing");
-    DBuf<int32_t> minid;
-    minid.reserve(nb);
-    HOT_LAUNCH(this, "shard_block_minid", k_block_minid, div_up(nb, 256), 256, 0, L.gs_order.p, L.gs_block_start.p, minid.p, nb);
-    std::vector<int32_t> hmin(nb), hstart(nb + 1);
-    HOT_HIP(hipMemcpyAsync(hmin.data(), minid.p, (size_t)nb * 4, hipMemcpyDeviceToHost, stream));
+    std::vector<int32_t> hstart(nb + 1);
     HOT_HIP(hipMemcpyAsync(hstart.data(), L.gs_block_start.p, (size_t)(nb + 1) * 4, hipMemcpyDeviceToHost, stream));
     sync();
     std::vector<uint8_t> ob(nb);
@@ -175,11 +166,10 @@ void Ctx<T>::level_ownership(Level<T>& L)
     L.xbeg.assign(R * 8, 0), L.xcnt.assign(R * 8, 0);
     for (int c = 0; c < 8; ++c) {
         const int b0 = L.color_block_begin[c], b1 = L.color_block_begin[c + 1];
-        int r = 0;
+        HOT_CHECK((int)L.block_owner_h.size() == nb, HOT_ERR_INVALID, "level_ownership: the colouring carries no block owners");
         for (int b = b0; b < b1; ++b) {
-            while (r + 1 < R && hmin[b] >= L.nstart[r + 1]) ++r;
-            HOT_CHECK(hmin[b] >= L.nstart[r], HOT_ERR_INVALID, "level_ownership: colour blocks are not in first-touch order");
-            ob[b] = (uint8_t)r;
+            ob[b] = L.block_owner_h[b];
+            HOT_CHECK(ob[b] < R && (b == b0 || ob[b] >= ob[b - 1]), HOT_ERR_INVALID, "level_ownership: colour blocks are not ordered by owner");
         }
         // split[c][r] = first block (relative to b0) owned by a rank >= r
         int b = b0;
@@ -738,6 +728,7 @@ void Ctx<T>::migrate_particles()
             sp.v[r - 1] = prev = v;
         }
     }
+    page_split.assign(sp.v, sp.v + sp.n);
     // ---- who goes where: one compacted list per destination (ascending slot order), the kept particles included
     DBuf<int32_t> lists;
     lists.reserve(n);

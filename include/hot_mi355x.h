@@ -89,7 +89,12 @@ typedef struct hot_config {
                                1 = never (every trial is a full pass), 2 = always */
     int32_t linear_iteration_cap; /* lsolver 1 / 2: iterations of one MINRES / PCG solve at most; 0 = the reference's 10000 (ImplicitSolver.h: the solvers' max_iterations).  A fixed
                                      small count makes two implementations stop at the same Lanczos step, whatever round-off does to the stopping test (parity tests) */
-    int32_t reserved[6];
+    int32_t shard_owner; /* sharded runs: which rank owns the rows of a 4^3 colour block.  0 (default) = the rank whose particle range (a contiguous range of the SPGrid
+                            page order) contains the block's own page, on a coarse level the page at the block's position on the finest grid: every rank owns the
+                            rows inside its own particle range, both sides of a cut send the same amount of partial matrix rows, and the boundary between the ranks'
+                            rows is as compact as the boundary between their particles; 1 = the rank whose particles first touch the block (rounds 2 - 4): the lower
+                            rank of every cut owns all blocks the two share */
+    int32_t reserved[5];
 } hot_config;
 
 typedef struct hot_stats {

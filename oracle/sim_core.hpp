@@ -119,6 +119,71 @@ struct Sim {
         while (r + 1 < comm.size && node >= ns[r + 1]) ++r;
         return r;
     }
+    // Owner of a 4^3 colour block (nodes in ascending id order): the product's rule (hot_config.shard_owner; a design choice of the sharded
+    // decomposition, not of the reference, which is one process), restated from hot_amd/csrc/mg_build.hip k_color_owner_keys.
+    //   1  the rank that first touches the block's lowest node;
+    //   0  (default) finest level: the rank whose particle range — a contiguous range of the SPGrid page order; page_split[r] = the lowest page
+    //      rank r + 1 holds — contains the block's own page, if its particle tiles reach the block (or, fp64, its x-companion page), else the
+    //      reaching rank nearest to it in rank order (the lower one on a tie); coarser levels: the owner of the first existing child (2 C + d,
+    //      d in {-1, 0, 1}^3, x slowest) of the block's lowest node.
+    std::vector<uint64_t> page_split; // [size - 1]
+    std::vector<uint64_t> block_touch; // per SPGrid block of the merged list: bit r = rank r's particle tiles cover it or its x-companion
+    std::vector<std::vector<uint8_t>> node_owner; // per partitioned level and node: owner of the node's colour block (compute_owners)
+    int owner_of_block(int level, const std::vector<int>& blockNodes) const
+    {
+        if (level < (int)node_owner.size() && !node_owner[level].empty()) return node_owner[level][blockNodes.front()];
+        return owner_of(level, blockNodes.front());
+    }
+    void compute_owners()
+    {
+        node_owner.clear();
+        if (!sharded() || cfg.shard_owner == 1 || (int)page_split.size() != comm.size - 1) return;
+        const int R = comm.size;
+        for (int level = 0; level < (int)sysmats.size() && level < (int)level_nstart.size() && level < (int)level_coords.size(); ++level) {
+            const auto& coords = level_coords[level];
+            std::vector<uint8_t> own(coords.size(), 0);
+            std::unordered_map<unsigned long long, int> fine; // coordinate -> id of the next finer level
+            auto ckey = [](int x, int y, int z) { return ((unsigned long long)(unsigned)x << 42) | ((unsigned long long)(unsigned)y << 21) | (unsigned long long)(unsigned)z; };
+            if (level > 0)
+                for (int j = 0; j < (int)level_coords[level - 1].size(); ++j) fine[ckey(level_coords[level - 1][j][0], level_coords[level - 1][j][1], level_coords[level - 1][j][2])] = j;
+            for (int c = 0; c < 8; ++c)
+                for (const auto& blockNodes : sysmats[level].coloredBlockDofs[c]) {
+                    const int i = blockNodes.front();
+                    int r = owner_of(level, i); // the first-touching rank
+                    const int x = coords[i][0], y = coords[i][1], z = coords[i][2];
+                    if (level == 0) {
+                        const uint64_t page = Mask::linear_offset(x & ~3, y & ~3, z & ~3) >> 12;
+                        int hr = 0;
+                        while (hr < R - 1 && page >= page_split[hr]) ++hr;
+                        auto it = page2block.find(Mask::linear_offset(x & ~3, y & ~3, z & ~3));
+                        if (it == page2block.end() && Mask::block_xbits == 1) it = page2block.find(Mask::linear_offset((x & ~3) + 2, y & ~3, z & ~3));
+                        const uint64_t sh = it != page2block.end() && it->second < (int)block_touch.size() ? block_touch[it->second] : 0;
+                        if (sh)
+                            for (int d = 0; d < R; ++d) {
+                                if (hr - d >= 0 && ((sh >> (hr - d)) & 1ULL)) {
+                                    r = hr - d;
+                                    break;
+                                }
+                                if (hr + d < R && ((sh >> (hr + d)) & 1ULL)) {
+                                    r = hr + d;
+                                    break;
+                                }
+                            }
+                    }
+                    else if (level - 1 < (int)node_owner.size()) {
+                        bool found = false;
+                        for (int q = 0; q < 27 && !found; ++q) {
+                            const int cx = 2 * x + q / 9 - 1, cy = 2 * y + (q / 3) % 3 - 1, cz = 2 * z + q % 3 - 1;
+                            if ((cx | cy | cz) < 0) continue;
+                            auto f = fine.find(ckey(cx, cy, cz));
+                            if (f != fine.end()) r = node_owner[level - 1][f->second], found = true;
+                        }
+                    }
+                    for (int n : blockNodes) own[n] = (uint8_t)r;
+                }
+            node_owner.push_back(std::move(own));
+        }
+    }
 
     // ---- particles
     int64_t Np = 0;
@@ -384,6 +449,19 @@ struct Sim {
                 for (int64_t k = 0; k < counts[r]; ++k) set_page(recv[(size_t)r * maxn + k]);
             }
             block_first[comm.size] = (int)blocks.size();
+            // which ranks' particle tiles cover a block (the product's tile plan, shard.hip build_tile_plan): the pages of a rank's list and, fp64, the
+            // x-companion of each inside its 4^3 colour block
+            block_touch.assign(blocks.size(), 0);
+            for (int r = 0; r < comm.size; ++r)
+                for (int64_t k = 0; k < counts[r]; ++k) {
+                    const uint64_t page = (recv[(size_t)r * maxn + k] >> 12) << 12;
+                    block_touch[page2block[page]] |= 1ULL << r;
+                    if (Mask::block_xbits == 1) {
+                        const auto c = Mask::linear_to_coord(page);
+                        auto it = page2block.find(Mask::linear_offset(c[0] ^ 2, c[1], c[2]));
+                        if (it != page2block.end()) block_touch[it->second] |= 1ULL << r;
+                    }
+                }
         }
         // neighbour table (replaces the reference's virtual-memory addressing)
         group_nb.resize(particle_group.size());
@@ -472,6 +550,13 @@ struct Sim {
             for (size_t s = 0; s < nodes.size(); ++s) nodes[s].m = buf[4 * s], nodes[s].v = TV{ { buf[4 * s + 1], buf[4 * s + 2], buf[4 * s + 3] } };
         }
         num_nodes = get_num_nodes();
+        if (sharded()) { // the ranks' page ranges: every rank's lowest page
+            std::vector<uint64_t> lo(comm.size, 0);
+            uint64_t mine = ~0ull;
+            for (int64_t p = 0; p < Np; ++p) mine = std::min<uint64_t>(mine, particle_base_offset[p] >> 12);
+            if (comm.allgather(comm.user, &mine, lo.data(), sizeof(uint64_t), 0) != 0) throw std::runtime_error("hot_comm.allgather failed");
+            page_split.assign(lo.begin() + 1, lo.end());
+        }
         if (sharded()) { // id prefix of every rank: the nodes of the blocks first touched by lower ranks
             level_nstart.assign(1, std::vector<int>(comm.size + 1, num_nodes));
             for (int r = 0; r <= comm.size; ++r) {

@@ -456,6 +456,7 @@ void Sim<T>::build_mg()
         sysmats.push_back(std::move(RAP));
         level_coords.push_back(std::move(new_coords));
     }
+    compute_owners(); // sharded: who sweeps which colour block (hot_config.shard_owner)
     int L = (int)sysmats.size();
     mg_residuals.resize(L), mg_initialResiduals.resize(L), mg_sols.resize(L), mg_dus.resize(L), mg_dAus.resize(L), mg_tmps.resize(L);
     for (int l = 0; l < L; ++l) {
@@ -698,8 +699,7 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
     else if (kind == 5) {
         std::vector<TV>& hdu = mg_tmps[level];
         iterations = ((iterations + 1) >> 1);
-        // sharded, partitioned level: a colour block is processed by the rank whose id prefix holds its lowest node (the rank whose
-        // particles first touch it); after each colour the owners' values are handed to everybody (colour-synchronous: the
+        // sharded, partitioned level: a colour block is processed by its owner (owner_of_block: one of the ranks whose particles touch it); after each colour the owners' values are handed to everybody (colour-synchronous: the
         // sequence of updates every node sees is the single-rank one).  The exchange here is the simplest possible: an all-reduce
         // of a vector that is zero off the rank's own blocks.
         // hot_config.shard_gs = 1 (processor-block GS): no hand-off between the colours — a rank's rows see the other ranks' unknowns as
@@ -707,7 +707,7 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
         // du after the backward sweep.  The couplings across ranks enter through the residual update r -= A du below (full rows).
         const bool part = partitioned(level);
         const bool rank_local = part && cfg.shard_gs != 0;
-        auto mine = [&](const std::vector<int>& blockNodes) { return !part || owner_of(level, blockNodes[0]) == comm.rank; };
+        auto mine = [&](const std::vector<int>& blockNodes) { return !part || owner_of_block(level, blockNodes) == comm.rank; };
         auto exchange_colour = [&](std::vector<TV>& x, int c) {
             if (!part) return;
             std::vector<T> buf((size_t)n * 3, (T)0);

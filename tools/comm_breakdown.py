@@ -11,8 +11,8 @@ def main():
     gs = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     minrows = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     n = round(per * world ** (1.0 / 3.0))
-    for rep in (0, 1):
-        kw = dict(lsolver=3, levelCnt=3, cneps=1e-7, shard_gs=gs, shard_replicated=rep, profile=1)
+    for rep in ((0,) if os.environ.get("HOT_HALO_ONLY") else (0, 1)):
+        kw = dict(lsolver=3, levelCnt=3, cneps=1e-7, shard_gs=gs, shard_replicated=rep, profile=1, shard_owner=int(os.environ.get("HOT_SHARD_OWNER", "0")))
         r = mw.launch(world, "hip", n, 1, kw, steps=1, partition_min_rows=minrows, timeout=1800)
         for rk in range(world):
             st = r[rk]["stats"]
