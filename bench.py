@@ -97,6 +97,9 @@ def make_ctx(lib, cloud, cfg, device=0, profile=0, comm=None, **over):
             print("bench: native RCCL communicator not used (%r on this rank), using TorchComm" % (why,), file=sys.stderr)
             ctx._fallback_comm = hdist.TorchComm(device=torch.device("cuda", device))
             ctx.set_comm(ctx._fallback_comm)
+        elif tdist.get_rank() == 0:
+            print("bench: pre-flight: hot_rccl_selftest passed on all %d ranks (all-gather, all-reduce, personalised Send / Recv exchange with checked contents); communicator = native RCCL on the context's stream"
+                  % tdist.get_world_size(), file=sys.stderr)
     elif comm is not None:
         ctx.set_comm(comm)  # this rank's shard of ONE body (hot_amd/dist.py)
     ctx.set_particles(cloud["X"], cloud["V"], cloud["mass"], cloud["vol"], cloud["mu"], cloud["lam"])
@@ -367,12 +370,12 @@ def main():
     if world > 1:  # what every rank handed to the collectives and where its step went (a sharded run's balance, not only rank 0's view)
         import torch
         last = stats[-1]
-        mine = torch.tensor([float(Np), float(last["comm_calls"]), float(last["comm_bytes_index"]), float(last["comm_bytes_data"]), last["ms_sort"], last["ms_p2g"], last["ms_begin"],
+        mine = torch.tensor([float(Np), float(last["comm_calls"]), float(last["comm_calls_index"]), float(last["comm_bytes_index"]), float(last["comm_bytes_data"]), last["ms_sort"], last["ms_p2g"], last["ms_begin"],
                              last["ms_hessian"], last["ms_mg_build"], last["ms_solve"], last["ms_g2p"], last["ms_total"]], dtype=torch.float64, device=torch.device("cuda", local) if args.backend == "nccl" else "cpu")
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
-        keys = ("particles", "collective_calls", "index_bytes", "data_bytes", "ms_sort", "ms_p2g", "ms_begin", "ms_hessian", "ms_mg_build", "ms_solve", "ms_g2p", "ms_total")
-        by_rank = [{k: (int(v) if i < 4 else round(float(v), 2)) for i, (k, v) in enumerate(zip(keys, t.tolist()))} for t in allv]
+        keys = ("particles", "collective_calls", "index_collective_calls", "index_bytes", "data_bytes", "ms_sort", "ms_p2g", "ms_begin", "ms_hessian", "ms_mg_build", "ms_solve", "ms_g2p", "ms_total")
+        by_rank = [{k: (int(v) if i < 5 else round(float(v), 2)) for i, (k, v) in enumerate(zip(keys, t.tolist()))} for t in allv]
     if rank == 0:
         out = {
             "metric": "ms per nonlinear (L-BFGS) iteration; P2G+G2P Mparticles/s; achieved HBM GB/s vs roofline",

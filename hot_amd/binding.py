@@ -45,7 +45,7 @@ class hot_stats(C.Structure):
         ("num_nodes", C.c_int32), ("num_levels", C.c_int32), ("final_scaled_residual", C.c_double),
         ("energy", C.c_double), ("ms_sort", C.c_double), ("ms_p2g", C.c_double), ("ms_begin", C.c_double),
         ("ms_hessian", C.c_double), ("ms_mg_build", C.c_double), ("ms_solve", C.c_double), ("ms_g2p", C.c_double),
-        ("ms_total", C.c_double), ("comm_calls", C.c_int64), ("comm_bytes_index", C.c_int64), ("comm_bytes_data", C.c_int64),
+        ("ms_total", C.c_double), ("comm_calls", C.c_int64), ("comm_bytes_index", C.c_int64), ("comm_bytes_data", C.c_int64), ("comm_calls_index", C.c_int64),
     ]
 
     def as_dict(self):

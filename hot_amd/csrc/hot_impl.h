@@ -218,7 +218,7 @@ struct Ctx : CtxBase {
     void allreduce_tiles(T* tiles, int q); // q * Nb * EPB node-tile values, summed over the ranks
     // ---- halo mode
     bool halo_mode() const { return sharded() && !cfg.shard_replicated; }
-    int64_t comm_calls = 0, comm_bytes_index = 0, comm_bytes_data = 0; // since the last hot_sort
+    int64_t comm_calls = 0, comm_calls_index = 0, comm_bytes_index = 0, comm_bytes_data = 0; // since the last hot_sort
     bool comm_index_phase = false; // the collectives called now carry integers that describe the grid, not field data
     struct IndexPhase {
         Ctx<T>* c;
@@ -235,13 +235,13 @@ struct Ctx : CtxBase {
     };
     void account(int64_t bytes)
     {
-        ++comm_calls, (comm_index_phase ? comm_bytes_index : comm_bytes_data) += bytes;
+        ++comm_calls, comm_calls_index += comm_index_phase ? 1 : 0, (comm_index_phase ? comm_bytes_index : comm_bytes_data) += bytes;
         if (prof.on) {
             auto& r = prof.recs[std::string("commMB_") + (comm_index_phase ? "index" : comm_tag)];
             r.calls++, r.ms += (double)bytes * 1e-6;
         }
     }
-    void export_comm_stats() { stats.comm_calls = comm_calls, stats.comm_bytes_index = comm_bytes_index, stats.comm_bytes_data = comm_bytes_data; }
+    void export_comm_stats() { stats.comm_calls = comm_calls, stats.comm_calls_index = comm_calls_index, stats.comm_bytes_index = comm_bytes_index, stats.comm_bytes_data = comm_bytes_data; }
     // node tiles: the ranks whose particle groups cover a block ("sharers") exchange their partial tiles and add them in rank order
     DBuf<uint8_t> touch; // Nb: this rank's tiles cover the block
     DBuf<uint64_t> sharers; // Nb: bit r = rank r covers the block

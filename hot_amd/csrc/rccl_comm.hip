@@ -47,6 +47,7 @@ struct Rccl {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     int rank = 0, size = 1;
+    bool self_via_p2p = false; // self-test: a rank's message to itself goes through the grouped ncclSend / ncclRecv as well
     char* scratch = nullptr; // device staging of host payloads (scalars, counts)
     size_t scratch_bytes = 0;
     char* stage(size_t bytes)
@@ -93,11 +94,11 @@ int32_t cb_alltoallv(void* user, const void* send, const int64_t* soff, const in
     Rccl* r = (Rccl*)user;
     if (!on_device) return 1; // the library only exchanges device payloads this way
     bool ok = true;
-    if (sbytes[r->rank] > 0) // a rank's message to itself (the library sends none today; the contract allows it)
+    if (sbytes[r->rank] > 0 && !r->self_via_p2p) // a rank's message to itself (the library sends none today; the contract allows it)
         ok = hipMemcpyAsync((char*)recv + roff[r->rank], (const char*)send + soff[r->rank], (size_t)sbytes[r->rank], hipMemcpyDeviceToDevice, r->stream) == hipSuccess;
     if (!ok || api().GroupStart() != ncclSuccess) return 1; // no GroupEnd without a GroupStart
     for (int p = 0; p < r->size && ok; ++p) {
-        if (p == r->rank) continue;
+        if (p == r->rank && !r->self_via_p2p) continue; // (self_via_p2p, self-test only: the message to itself takes the grouped Send / Recv like a peer's)
         if (rbytes[p] > 0) ok = ok && api().Recv((char*)recv + roff[p], (size_t)rbytes[p], ncclChar, p, r->comm, r->stream) == ncclSuccess;
         if (sbytes[p] > 0) ok = ok && api().Send((const char*)send + soff[p], (size_t)sbytes[p], ncclChar, p, r->comm, r->stream) == ncclSuccess;
     }
@@ -187,8 +188,10 @@ int hot_rccl_attach(hot_ctx* ctx, const void* unique_id128, int32_t rank, int32_
     return HOT_OK;
 }
 
-// Drives every callback of the attached communicator once with known data (device and host payloads) and checks the results
-// that do not depend on the other ranks' data being different: used by the one-GPU test box, where a group has a single rank.
+// Drives every callback of the attached communicator with known data (device and host payloads) and checks the results: all-gather,
+// all-reduce (sum, max), and a personalised exchange in which every (source, destination) pair has its own length and contents.  On the
+// one-GPU test box a group has a single rank: the exchange then consists of the rank's message to itself, sent once by copy and once through
+// the grouped ncclSend / ncclRecv.  bench.py --gpus N runs it on every rank before the first step.
 int hot_rccl_selftest(hot_ctx* ctx)
 {
     if (!ctx || !ctx->impl || !ctx->impl->native_comm) return HOT_ERR_INVALID;
@@ -219,10 +222,30 @@ int hot_rccl_selftest(hot_ctx* ctx)
     std::vector<int64_t> all(r->size, -1);
     ok = ok && cb_allgather(r, &cnt, all.data(), sizeof(int64_t), 0) == 0;
     for (int q = 0; q < r->size && ok; ++q) ok = all[q] == 40 + q;
-    // ring exchange: every rank sends 8 doubles to its right neighbour (nothing when alone)
+    // personalised exchange, every (source, destination) pair — a rank's message to itself included — with its own length and contents:
+    // rank s sends len(s, p) = 8 (1 + (s + 2 p) % 5) doubles  1e6 s + 1e3 p + k  to rank p.  Run twice: the message to itself by the
+    // stream-ordered copy (what the library's calls take), then through the grouped ncclSend / ncclRecv like a peer's, so that the
+    // Send / Recv loop has carried real, checked traffic on a one-rank group too.
+    auto len = [](int s_, int p_) { return (int64_t)8 * (1 + (s_ + 2 * p_) % 5); };
     std::vector<int64_t> so(r->size, 0), sb(r->size, 0), ro(r->size, 0), rb(r->size, 0);
-    if (r->size > 1) sb[(r->rank + 1) % r->size] = 64, rb[(r->rank + r->size - 1) % r->size] = 64;
-    ok = ok && cb_alltoallv(r, g, so.data(), sb.data(), d, ro.data(), rb.data(), 1) == 0 && hipStreamSynchronize(r->stream) == hipSuccess;
+    int64_t stot = 0, rtot = 0;
+    for (int p = 0; p < r->size; ++p) so[p] = stot * 8, sb[p] = len(r->rank, p) * 8, stot += len(r->rank, p), ro[p] = rtot * 8, rb[p] = len(p, r->rank) * 8, rtot += len(p, r->rank);
+    std::vector<double> hsend(stot), hrecv(rtot);
+    for (int p = 0; p < r->size; ++p)
+        for (int64_t k = 0; k < len(r->rank, p); ++k) hsend[so[p] / 8 + k] = 1e6 * r->rank + 1e3 * p + (double)k;
+    double *xs = nullptr, *xr = nullptr;
+    ok = ok && hipMalloc((void**)&xs, stot * sizeof(double)) == hipSuccess && hipMalloc((void**)&xr, rtot * sizeof(double)) == hipSuccess;
+    for (int pass = 0; pass < 2 && ok; ++pass) {
+        r->self_via_p2p = pass == 1;
+        ok = hipMemcpyAsync(xs, hsend.data(), stot * sizeof(double), hipMemcpyHostToDevice, r->stream) == hipSuccess && hipMemsetAsync(xr, 0xff, rtot * sizeof(double), r->stream) == hipSuccess;
+        ok = ok && cb_alltoallv(r, xs, so.data(), sb.data(), xr, ro.data(), rb.data(), 1) == 0;
+        ok = ok && hipMemcpyAsync(hrecv.data(), xr, rtot * sizeof(double), hipMemcpyDeviceToHost, r->stream) == hipSuccess && hipStreamSynchronize(r->stream) == hipSuccess;
+        for (int p = 0; p < r->size && ok; ++p)
+            for (int64_t k = 0; k < len(p, r->rank) && ok; ++k) ok = hrecv[ro[p] / 8 + k] == 1e6 * p + 1e3 * r->rank + (double)k;
+    }
+    r->self_via_p2p = false;
+    if (xs) (void)hipFree(xs);
+    if (xr) (void)hipFree(xr);
     (void)hipFree(d), (void)hipFree(g);
     if (!ok) ctx->err = "hot_rccl_selftest: a collective returned an error or a wrong result";
     return ok ? HOT_OK : HOT_ERR_DEVICE;

@@ -690,19 +690,21 @@ void Ctx<T>::migrate_particles()
     keys.reserve(std::max<int64_t>(n, S)), flags.reserve(std::max<size_t>(n, 64)), scan.reserve(std::max<size_t>(n, 64));
     uint64_t* page = keys.p;
     HOT_LAUNCH(this, "migrate_page_ids", k_page_ids<T>, div_up(n, 256), 256, 0, pX.p, page, n, (T)1 / dx);
-    // ---- splitters from a strided sample of every rank's pages
-    xsend.reserve((size_t)S * 8), xrecv.reserve((size_t)S * 8 * R);
+    // ---- splitters from a strided sample of every rank's pages; a rank's particle count rides behind its samples (one all-gather, not two)
+    xsend.reserve((size_t)(S + 1) * 8), xrecv.reserve((size_t)(S + 1) * 8 * R);
     HOT_LAUNCH(this, "migrate_sample", k_page_sample, div_up(S, 256), 256, 0, page, n, (uint64_t*)xsend.p, S);
-    c_allgather(xsend.p, xrecv.p, (int64_t)S * 8, true);
-    std::vector<uint64_t> samp((size_t)S * R);
-    HOT_HIP(hipMemcpyAsync(samp.data(), xrecv.p, samp.size() * 8, hipMemcpyDeviceToHost, stream));
+    const uint64_t my_count = (uint64_t)n; // (lives until the collective has synchronised the stream)
+    HOT_HIP(hipMemcpyAsync((uint64_t*)xsend.p + S, &my_count, 8, hipMemcpyHostToDevice, stream));
+    c_allgather(xsend.p, xrecv.p, (int64_t)(S + 1) * 8, true);
+    std::vector<uint64_t> gathered((size_t)(S + 1) * R), samp((size_t)S * R);
+    HOT_HIP(hipMemcpyAsync(gathered.data(), xrecv.p, gathered.size() * 8, hipMemcpyDeviceToHost, stream));
     sync();
     // every rank contributes S samples whatever it holds: a sample of rank r stands for Np_r / S particles.  Splitters = weighted
     // quantiles, so that a skewed distribution (a body drifting out of some ranks' page ranges) is re-balanced instead of re-derived
     std::vector<int64_t> cnts(R, 0);
-    {
-        int64_t mine = n;
-        c_allgather(&mine, cnts.data(), sizeof(int64_t), false);
+    for (int r = 0; r < R; ++r) {
+        std::copy(gathered.begin() + (size_t)r * (S + 1), gathered.begin() + (size_t)r * (S + 1) + S, samp.begin() + (size_t)r * S);
+        cnts[r] = (int64_t)gathered[(size_t)r * (S + 1) + S];
     }
     std::vector<std::pair<uint64_t, int64_t>> ws; // (page, weight = particles of the sample's rank; every rank has S samples) — integers: exact quantiles
     ws.reserve(samp.size());

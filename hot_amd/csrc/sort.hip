@@ -366,7 +366,7 @@ void Ctx<T>::sort()
 {
     need(Np > 0, "hot_sort: no particles");
     double t0 = wall_ms();
-    comm_calls = comm_bytes_index = comm_bytes_data = 0; // hot_stats.comm_*: since this call
+    comm_calls = comm_calls_index = comm_bytes_index = comm_bytes_data = 0; // hot_stats.comm_*: since this call
     vmask = nullptr; // no row ownership until hot_p2g has numbered the nodes
     if (sharded()) migrate_particles(); // every particle to the rank that holds its SPGrid page range (changes Np)
     int64_t n = Np;

@@ -112,6 +112,7 @@ typedef struct hot_stats {
     /* sharded runs: what this rank handed to the collectives of hot_comm since the last hot_sort (hot_advance: during the step).  "index": integers that
      * describe the grid (block lists, node numbering, exchange lists: once per step); "data": floating-point payloads (tiles, halos, matrix rows, scalars) */
     int64_t comm_calls, comm_bytes_index, comm_bytes_data;
+    int64_t comm_calls_index; /* of comm_calls: the collectives of the index structure (block lists, numbering, exchange lists) — the host waits for each of them */
 } hot_stats;
 
 void hot_default_config(hot_config* cfg); /* HOT's tog.sh command set: -lsolver 3 -Ainv 1 --project --linesearch --bcproject -mg_level 3 -mg_times 1 -coarseSolver 2 -smoother 5 --usecn -cneps 1e-7 */
