@@ -192,11 +192,107 @@ void run(int np, uint64_t seed)
     printf("]\n}\n");
 }
 
+
+// ---- tie points: particles whose index-space coordinate X / dx - 0.5 lies within a few ulp of an integer, where the base node — and with it the
+// SPGrid sort key — depends on how the product X * (1 / dx) is rounded before 0.5 is subtracted.  The reference evaluates
+//     baseNode<2>(Xarray[i] * one_over_dx)        (Lib/MPM/MpmSimulationBase.cpp:1080-1084, Lib/Ziran/Math/Splines/BSplines.h:16-20)
+// i.e. the product goes into an Eigen temporary and int_floor(x(d) - 0.5) is taken component by component; whether the subtraction is fused
+// with the multiply is the compiler's choice.  Emitted per point and axis-0 coordinate: the base node with the product ROUNDED first (kept from
+// fusing by a volatile store), with ONE rounding (std::fma), and `as_compiled`: what the statement in the reference's shape — the three products
+// stored in an array, then int_floor(t[d] - 0.5) in another function — yields under the flags THIS binary was built with.  oracle/Makefile
+// builds the driver twice: -O2 (no FMA instructions: x86-64 baseline) and -O3 -march=native -fno-math-errno (the reference's Release flags,
+// CMakeLists.txt:28, on a machine with FMA); tests/golden/spgrid_tie_*.json hold both.
+template <class T>
+struct Vec3 {
+    T v[3];
+    T operator()(int d) const { return v[d]; }
+};
+template <class T>
+static inline int base_node_shape(const T& x) { return int_floor(x - (T)0.5 * (2 - 1)); } // BSplines.h:16-20 with interpolation_degree = 2
+template <class T>
+static inline Vec3<T> scaled(const std::array<T, 3>& X, T c) // stands for the Eigen temporary of Xarray[i] * one_over_dx
+{
+    Vec3<T> t;
+    for (int d = 0; d < 3; ++d) t.v[d] = X[d] * c;
+    return t;
+}
+template <class T>
+static inline std::array<int, 3> base_as_compiled(const std::array<T, 3>& X, T c)
+{
+    const Vec3<T>& x = scaled(X, c);
+    std::array<int, 3> b;
+    for (int d = 0; d < 3; ++d) b[d] = base_node_shape<T>(x(d));
+    return b;
+}
+template <class T, int BYTES>
+void run_tie()
+{
+    using Alloc = SPGrid_Allocator<Node<BYTES>, 3, 12>;
+    using Mask = typename Alloc::template Array_type<>::MASK;
+    // candidates: the floating-point numbers next to (N + 0.5) dx for cell faces N + 0.5 around 500 and 3800 and around the powers of two 256,
+    // 512, 1024, 2048, for several grid spacings; kept: every candidate at which the two roundings give different base nodes and, for contrast,
+    // every 16th other.  RN(X c) - 0.5 and RN(X c - 0.5) are the same number whenever N + 0.5 and N share a binade (rounding commutes with
+    // subtracting a multiple of the spacing), so the two roundings can only disagree where N is a power of two: just below N the spacing of
+    // the floating-point numbers is half that of N + 0.5.
+    std::vector<std::array<T, 3>> X;
+    std::vector<T> DX;
+    int others = 0;
+    for (double dxd : { 0.01, 0.013, 0.007, 0.0093, 0.0117, 0.0101, 0.0087, 0.0123 }) {
+        const T dx = (T)dxd, c = (T)1 / dx;
+        auto rounded_base = [&](T x) {
+            volatile T t = x * c;
+            return int_floor((T)t - (T)0.5);
+        };
+        for (int lo : { 498, 3798, 254, 510, 1022, 2046 })
+            for (int N = lo; N < lo + 4; ++N) {
+                T x0 = (T)(((double)N + 0.5) * (double)dx);
+                for (int j = -2; j <= 2; ++j) {
+                    T x = x0;
+                    for (int q = 0; q < (j < 0 ? -j : j); ++q) x = std::nextafter(x, j < 0 ? (T)0 : (T)1e30);
+                    const bool differ = rounded_base(x) != int_floor(std::fma(x, c, -(T)0.5));
+                    if (differ || (others++ % 16) == 0) X.push_back({ x, (T)(503.3 * dxd), (T)(499.7 * dxd) }), DX.push_back(dx);
+                }
+            }
+    }
+    printf("{\n\"struct_bytes\": %d,\n\"dx\": [", BYTES);
+    for (size_t p = 0; p < X.size(); ++p) printf("%s%.17g", p ? "," : "", (double)DX[p]);
+    printf("],\n\"X\": [");
+    for (size_t p = 0; p < X.size(); ++p) printf("%s[%.17g,%.17g,%.17g]", p ? "," : "", (double)X[p][0], (double)X[p][1], (double)X[p][2]);
+    const char* names[3] = { "base_rounded_product", "base_fma", "base_as_compiled" };
+    for (int mode = 0; mode < 3; ++mode) {
+        printf("],\n\"%s\": [", names[mode]);
+        for (size_t p = 0; p < X.size(); ++p) {
+            const T c = (T)1 / DX[p];
+            std::array<int, 3> b;
+            if (mode == 2)
+                b = base_as_compiled<T>(X[p], c);
+            else
+                for (int d = 0; d < 3; ++d) {
+                    if (mode == 0) {
+                        volatile T t = X[p][d] * c; // the rounded product, whatever the flags
+                        b[d] = int_floor((T)t - (T)0.5);
+                    }
+                    else
+                        b[d] = int_floor(std::fma(X[p][d], c, -(T)0.5));
+                }
+            printf("%s[%d,%d,%d,%llu]", p ? "," : "", b[0], b[1], b[2], (unsigned long long)Mask::Linear_Offset(b));
+        }
+    }
+    printf("]\n}\n");
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s <float|double> <n_particles> <seed>\n", argv[0]);
+        fprintf(stderr, "usage: %s <float|double> <n_particles> <seed>   |   %s <float|double> tie 0\n", argv[0], argv[0]);
         return 2;
+    }
+    if (!strcmp(argv[2], "tie")) {
+        if (!strcmp(argv[1], "float"))
+            run_tie<float, 64>();
+        else
+            run_tie<double, 128>();
+        return 0;
     }
     int np = atoi(argv[2]);
     uint64_t seed = strtoull(argv[3], 0, 10);

@@ -15,3 +15,11 @@ for kind in ("float", "double"):
     with open(path, "wb") as f:
         f.write(out)
     print("wrote", path, len(out), "bytes")
+    # tie points (base node within a few ulp of a cell face): both builds of the driver — x86-64 baseline (-O2: no FMA instruction exists) and the
+    # reference's Release flags (-O3 -march=native -fno-math-errno) on this FMA-capable host
+    for build, binary in (("O2", "spgrid_ref"), ("native", "spgrid_ref_native")):
+        out = subprocess.check_output([os.path.join(ROOT, "oracle", "_ref", binary), kind, "tie", "0"])
+        path = os.path.join(ROOT, "tests", "golden", f"spgrid_tie_{kind}_{build}.json")
+        with open(path, "wb") as f:
+            f.write(out)
+        print("wrote", path, len(out), "bytes")

@@ -273,3 +273,41 @@ def check_step_numpy_regression():
     assert relerr(ns.Hierarchy(H, st.coord).vcycle(g["lex_rhs"]), g["lex_vcycle"]) < 1e-10
     x2, trials, _ = ns.lbfgs(st, 2)
     assert relerr(x2, g["lex_lbfgs_dv"]) < 1e-9 and trials == int(g["lex_linesearch_trials"])
+
+
+def load_tie(kind):
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    return {b: json.load(open(os.path.join(here, "golden", f"spgrid_tie_{kind}_{b}.json"))) for b in ("O2", "native")}
+
+
+def check_tie_points(lib, kind, dtype):
+    """Base nodes at cell faces (tests/golden/spgrid_tie_*.json, oracle/spgrid_ref_driver.cpp run_tie): particles whose X / dx - 0.5 lies within
+    an ulp of an integer, where floor(RN(X / dx) - 0.5) — the product rounded first — and floor(RN(X / dx - 0.5)) — one rounding, an fma —
+    can differ (they do only where the integer is a power of two: 256, 512, 1024, 2048).  What the vectors establish:
+      * the driver built with the reference's own Release flags (-O3 -march=native -fno-math-errno, CMakeLists.txt:28) on an FMA machine evaluates
+        the reference's statement shape (product into a temporary, int_floor(x - 0.5) in another function) with ONE rounding: as_compiled == fma;
+      * built for the x86-64 baseline (-O2, no FMA instruction) the same source gives the rounded product;
+      * the library under test (`lib`: the CPU oracle or the HIP library) takes the fma: its sort keys at these points are the `base_fma` ones,
+        i.e. what the reference yields when built the way its CMakeLists builds it."""
+    t = load_tie(kind)
+    o2, nat = t["O2"], t["native"]
+    assert o2["X"] == nat["X"] and o2["base_fma"] == nat["base_fma"] and o2["base_rounded_product"] == nat["base_rounded_product"]
+    n = len(o2["X"])
+    differ = [i for i in range(n) if o2["base_fma"][i] != o2["base_rounded_product"][i]]
+    assert len(differ) >= 8  # real tie points, not only near misses
+    assert all(o2["base_fma"][i][0] + 1 == o2["base_rounded_product"][i][0] and o2["base_rounded_product"][i][0] in (256, 512, 1024, 2048) for i in differ)
+    assert nat["base_as_compiled"] == nat["base_fma"] and o2["base_as_compiled"] == o2["base_rounded_product"]
+    T = np.float32 if dtype == 0 else np.float64
+    X, dxs = np.array(o2["X"], T), np.array(o2["dx"], np.float64)
+    for dx in np.unique(dxs):
+        sel = np.nonzero(dxs == dx)[0]
+        m = len(sel)
+        one = np.ones(m, T)
+        ctx = lib.context(dtype=dtype, dx=float(dx))
+        ctx.set_particles(X[sel], np.zeros((m, 3), T), one, one, one, one)
+        ctx.sort()
+        got = ctx.indexing()["particle_base_offset"].tolist()
+        assert got == [o2["base_fma"][i][3] for i in sel], (float(dx), got, [o2["base_fma"][i][3] for i in sel])
+    return len(differ)

@@ -35,6 +35,15 @@ def test_indexing_against_reference_golden(hotlib, kind, dtype):
     assert ctx.grid()["id2coord"].tolist() == g["id2coord"]
 
 
+@pytest.mark.parametrize("kind,dtype", [("float", 0), ("double", 1)])
+def test_tie_points_take_the_fma_rounding(hotlib, kind, dtype):
+    """Particles within an ulp of a cell face, where the rounding of X / dx decides the base node (only at the powers of two 256 .. 2048): the HIP
+    library's sort keys are those of floor(fma(X, 1 / dx, -0.5)), which the golden driver — compiled with the reference's Release flags — shows to be
+    what the reference's statement computes on an FMA machine (tests/golden_checks.check_tie_points, tests/golden/spgrid_tie_*.json)."""
+    from tests import golden_checks
+    assert golden_checks.check_tie_points(hotlib, kind, dtype) >= 8
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("n,ppc", [(6, 8), (16, 8), (9, 20)])
 def test_sort_p2g_g2p_against_oracle(hotlib, oracle, dtype, n, ppc):

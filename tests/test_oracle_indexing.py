@@ -66,3 +66,11 @@ def test_sort_and_numbering_against_reference(oracle, kind, dtype):
     assert grid["id2coord"].tolist() == g["id2coord"]
     # mass conservation / partition of unity on the way
     assert abs(grid["mass"].sum() - n) < (1e-3 if dtype == 0 else 1e-9) * n
+
+
+@pytest.mark.parametrize("kind,dtype", [("float", 0), ("double", 1)])
+def test_tie_points_take_the_fma_rounding(oracle, kind, dtype):
+    """Cell-face tie points: the oracle's base nodes are the single-rounding (fma) ones, which is what the reference's statement yields under the
+    reference's own Release flags (shown by the second build of the golden driver); see tests/golden_checks.check_tie_points."""
+    from tests import golden_checks
+    assert golden_checks.check_tie_points(oracle, kind, dtype) >= 8
