@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
     }
     __syncthreads();
     const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
-    double e = 0;
+    double e = 0, es = 0;
     for (int p = first + threadIdx.x; p < last; p += 256) {
         Mat3<T> Fnew;
         {
@@ -397,10 +397,11 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
         }
 #pragma unroll
         for (int c = 0; c < 9; ++c) Ft[(int64_t)c * Np + p] = Fnew.a[c];
-        T psi;
+        T psi, psis;
         Mat3<T> P;
-        corotated_state(Fnew, mu, la, psi, P);
+        corotated_state(Fnew, mu, la, psi, P, &psis);
         e += (double)(vol * psi);
+        es += (double)(vol * psis); // the sum an energy-only trial of the next line search is compared with: the same formula, the same singular values
         // stress = V_p P Fn^T  (Fn re-read after the SVD instead of being kept live across it)
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -411,7 +412,12 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
         }
     }
     double tot = block_sum_256<double>(e, red);
-    grid_sum_store(tot, 0.0, 1, gr, energy, nullptr, red);
+    if constexpr (ENERGY_ONLY)
+        grid_sum_store(tot, 0.0, 1, gr, energy, nullptr, red);
+    else {
+        const double tots = block_sum_256<double>(es, red);
+        grid_sum_store(tot, tots, 2, gr, energy, energy + 3, red);
+    }
 }
 
 #ifdef HOT_AB_KERNELS
@@ -698,20 +704,29 @@ double Ctx<T>::state_pass(const T* dv_in, bool want_force, bool energy_only)
             group_nb.p, tileDof.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p, gred(Ng, hscal));
     else
         HOT_LAUNCH(this, "state_update", (k_state<T, false>), Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, pFt.p, pStress.p, keep_debug ? pGradV.p : (T*)nullptr, Np, group_first.p, group_origin.p,
-            group_nb.p, tileDof.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p, gred(Ng, hscal)); // the sums land in the pinned host slots too: one stream sync, no copy
+            group_nb.p, tileDof.p, vn.p, dv_in, dx, (T)1 / dx, dt, dscal.p, gred2(Ng, hscal, hscal + 3)); // the sums land in the pinned host slots too: one stream sync, no copy
     if (want_force) force_pass();
     {
         const int grid = std::min(div_up(Nn, 1024), 1024);
         HOT_LAUNCH(this, "inertia_energy", k_inertia_energy<T>, grid, 256, 0, dv_in, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + 1, gred(grid, hscal + 1, true), vmask);
     }
     wait_ticket();
+    if (energy_only) hscal[3] = hscal[0]; // (an energy-only pass has the one sum)
     if (halo_mode())
-        c_allreduce(hscal, 3, HOT_COMM_F64, HOT_COMM_SUM, false); // strain energy of the shards, inertia terms of the rows every rank owns
-    else if (sharded())
-        c_allreduce(hscal, 1, HOT_COMM_F64, HOT_COMM_SUM, false); // the shards' strain energies; the inertia terms are computed from replicated vectors
+        c_allreduce(hscal, 4, HOT_COMM_F64, HOT_COMM_SUM, false); // strain energy of the shards (both summation formulas), inertia terms of the rows every rank owns
+    else if (sharded()) {
+        double two[2] = { hscal[0], hscal[3] };
+        c_allreduce(two, 2, HOT_COMM_F64, HOT_COMM_SUM, false); // the shards' strain energies; the inertia terms are computed from replicated vectors
+        hscal[0] = two[0], hscal[3] = two[1];
+    }
     double result = (double)(T)hscal[0];
     result += hscal[1] / 2;
     result -= (double)dt * hscal[2];
+    if (!energy_only) { // the same total with psi summed from the singular values: what the energy-only trials of the next line search are compared with
+        Ek_sigma = (double)(T)hscal[3];
+        Ek_sigma += hscal[1] / 2;
+        Ek_sigma -= (double)dt * hscal[2];
+    }
     return result;
 }
 

@@ -251,6 +251,7 @@ struct GridRed {
     double* mirror; // optional: pinned host memory that also receives the result(s), so that the host needs no copy
     double* ticket; // optional (with mirror): pinned host word that receives ticket_val after the results — the host spins on it
     double ticket_val; //   instead of paying a hipStreamSynchronize wake-up (Ctx::wait_ticket)
+    double* mirror1 = nullptr; // optional: where the SECOND result of a two-sum launch goes instead of mirror[1]
 };
 // results first, then the ticket.  A system-scope release is needed here: s_waitcnt vmcnt(0) only waits for the L2's acknowledgement
 // of the result stores, and the ticket (another cache line, another channel) can overtake them on the way to host memory.
@@ -283,7 +284,7 @@ __device__ inline void grid_sum_store(double t0, double t1, int nv, GridRed gr, 
         if (nv > 1) *o1 = b;
         if (gr.mirror) {
             gr.mirror[0] = a;
-            if (nv > 1) gr.mirror[1] = b;
+            if (nv > 1) (gr.mirror1 ? *gr.mirror1 : gr.mirror[1]) = b;
             if (gr.ticket) host_ticket_store(gr.ticket, gr.ticket_val);
         }
         __hip_atomic_store(gr.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

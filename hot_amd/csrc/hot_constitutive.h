@@ -22,7 +22,7 @@ __device__ __forceinline__ T clamp_small_magnitude(T x, T eps)
 
 // psi and P = 2 mu (F - R) + lambda (J - 1) J F^-T from one SVD
 template <class T>
-__device__ inline void corotated_state(const Mat3<T>& F, T mu, T lambda, T& psi, Mat3<T>& P)
+__device__ inline void corotated_state(const Mat3<T>& F, T mu, T lambda, T& psi, Mat3<T>& P, T* psi_sigma = nullptr /*psi evaluated as corotated_psi_sigma does, from the same singular values*/)
 {
     Mat3<T> U, V;
     T sg[3];
@@ -39,6 +39,10 @@ __device__ inline void corotated_state(const Mat3<T>& F, T mu, T lambda, T& psi,
     }
     T Jm1 = J - (T)1;
     psi = mu * fr + (T)0.5 * lambda * Jm1 * Jm1;
+    if (psi_sigma) {
+        const T d0 = sg[0] - (T)1, d1 = sg[1] - (T)1, d2 = sg[2] - (T)1;
+        *psi_sigma = mu * (d0 * d0 + d1 * d1 + d2 * d2) + (T)0.5 * lambda * Jm1 * Jm1;
+    }
 }
 
 // psi alone, from the singular values: |F - R|_F^2 = sum (sigma_i - 1)^2.  U and V are never used, so their rotations are dead code after

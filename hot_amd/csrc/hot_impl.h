@@ -190,7 +190,7 @@ struct Ctx : CtxBase {
     DBuf<char> d_cobjs;
     DBuf<double> d_hs;
     // ---- objective
-    double Ek = 0;
+    double Ek = 0, Ek_sigma = 0; // incremental potential at the current iterate: the reference's formula, and with psi summed from the singular values (state_pass)
     bool updated = false;
     int ls_prev_trials = 1; // trials the previous line search of this step took (hot_config.ls_energy_only = 0 starts energy-only after a search that halved)
     T max_cn_tolerance = 0;
@@ -287,6 +287,12 @@ struct Ctx : CtxBase {
         }
         GridRed g{ red_part.p, red_count.p, mirror, nullptr, 0.0 };
         if (ticket) g.ticket = hscal + 251, g.ticket_val = new_ticket();
+        return g;
+    }
+    GridRed gred2(size_t grid, double* mirror, double* mirror1) // two sums, the second one mirrored to its own host slot
+    {
+        GridRed g = gred(grid, mirror);
+        g.mirror1 = mirror1;
         return g;
     }
     GridRed gred_n(size_t grid, int nv) // grid_sum_store_n: nv deposits per workgroup

@@ -235,7 +235,10 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
     size_t n3 = 3 * (size_t)Nn;
     T* dvnew = work3.p;
     transform_dev(ddv, true); // recoverSolution
-    double Ek0 = Ek;
+    // (an energy-only trial sums psi from the singular values, mu sum (sigma_i - 1)^2; the full pass — the reference's formula, mu |F - R|^2 — emits
+    // that sum as well, Ek_sigma, so that a trial is compared with a base of its own rounding: as the step shrinks the trial energy tends to
+    // Ek_sigma of the base point, not to Ek, and a positive round-off gap between the two would reject every halving)
+    const double Ek0 = Ek, Ek0_sigma = Ek_sigma;
     int guard = 0;
     // Energy-only trials (hot_config.ls_energy_only): a rejected trial pays for singular values and the sum, not for U, V, the stress and
     // 18 stores per particle; the accepted point then gets the full pass.  0 = adaptive: the first trial is a full pass unless the previous
@@ -257,7 +260,7 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
         // `Ek > Ek0` in the reference (ImplicitSolver.h:325), written so that a NaN energy — an exploded L-BFGS direction in float puts
         // the trial point outside anything representable — is a rejection like any other and the step is halved; the reference would
         // end the search there with NaN accepted.  Identical for every finite energy.
-    } while (!(Ek <= Ek0) && ++guard < 60);
+    } while (!(Ek <= (last_eo ? Ek0_sigma : Ek0)) && ++guard < 60);
     if (!(Ek == Ek)) {
         // sixty halvings and still no number: is the search direction itself non-finite?
         double dd = dot_host(n3, ddv, ddv), d0 = dot_host(n3, dv0.p, dv0.p);
