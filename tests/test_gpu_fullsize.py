@@ -46,7 +46,9 @@ def test_c1_full_step_against_oracle(hotlib, oracle):
     pg, pcpu = out["gpu"][0], out["cpu"][0]
     # both stop at the same CN tolerance: positions agree far below a cell, velocities at the solver tolerance
     assert np.abs(pg["X"] - pcpu["X"]).max() < 1e-3 * 0.01  # a thousandth of a cell (dt times the velocity tolerance)
-    assert np.abs(pg["V"] - pcpu["V"]).max() < 5e-3 * max(np.abs(pcpu["V"]).max(), 1e-3)
+    ev = np.abs(pg["V"] - pcpu["V"]).max() / max(np.abs(pcpu["V"]).max(), 1e-3)
+    print("C1 whole step: max |dV| / max |V| = %.3g, iterations %d / %d, line-search trials %d / %d" % (ev, sg["iterations"], sc["iterations"], sg["linesearch_trials"], sc["linesearch_trials"]))
+    assert ev < 1e-3, ev
     assert abs(sg["energy"] - sc["energy"]) < 1e-5 * max(abs(sc["energy"]), 1e-6)
 
 

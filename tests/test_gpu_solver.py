@@ -169,7 +169,12 @@ def test_solve_to_convergence_against_oracle(hotlib, oracle, kw):
     assert abs(sg["iterations"] - sc["iterations"]) <= max(2, sc["iterations"] // 10), (sg, sc)
     m = out["cpu"][2][:, None]
     a, b = out["gpu"][0], out["cpu"][0]
-    assert np.sqrt((m * (a - b) ** 2).sum()) < 1e-2 * np.sqrt((m * b ** 2).sum())
+    err = np.sqrt((m * (a - b) ** 2).sum()) / np.sqrt((m * b ** 2).sum())
+    same = all(sg[k] == sc[k] for k in ("iterations", "linesearch_trials", "linear_iterations", "vcycles", "dropped_pairs"))
+    print("converged solve %s: mass-weighted |ddv| / |dv| = %.3g, counters %s (%d / %d iterations)" % (kw, err, "equal" if same else "differ", sg["iterations"], sc["iterations"]))
+    # equal counters: the two runs took the same discrete decisions and differ by amplified round-off only; different counters: both stopped
+    # by the same test, at different points of the same convergence history
+    assert err < (1e-3 if same else 1e-2), (err, same)
     assert abs(sg["energy"] - sc["energy"]) < 1e-4 * max(abs(sc["energy"]), 1e-6)
 
 
