@@ -311,3 +311,39 @@ def check_tie_points(lib, kind, dtype):
         got = ctx.indexing()["particle_base_offset"].tolist()
         assert got == [o2["base_fma"][i][3] for i in sel], (float(dx), got, [o2["base_fma"][i][3] for i in sel])
     return len(differ)
+
+
+class Stats(C.Structure):  # include/hot_mi355x.h: hot_stats
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("linesearch_trials", C.c_int32), ("linear_iterations", C.c_int32), ("vcycles", C.c_int32), ("dropped_pairs", C.c_int32),
+                ("num_nodes", C.c_int32), ("num_levels", C.c_int32), ("final_scaled_residual", C.c_double), ("energy", C.c_double), ("ms", C.c_double * 8),
+                ("comm_calls", C.c_int64), ("comm_bytes_index", C.c_int64), ("comm_bytes_data", C.c_int64), ("comm_calls_index", C.c_int64)]
+
+
+def fixed_iterations_raw(path, prefix, n=8, iterations=5, **kw):
+    """Five L-BFGS iterations of one time step of an n^3-cell cube over a sticky floor, driven through the ctypes mirror of THIS file (no
+    hot_amd/binding.py): returns (dv, counters, energy).  The fixed-iteration parity test runs it on the HIP library and on the oracle, so that
+    an argument the shared binding passes wrongly to both cannot cancel."""
+    rng = np.random.default_rng(11)
+    dx, ppc = 0.01, 8
+    cells = np.stack(np.meshgrid(*(np.arange(n),) * 3, indexing="ij"), -1).reshape(-1, 3)
+    X = ((500 + np.repeat(cells, ppc, 0)) + rng.random((len(cells) * ppc, 3))) * dx
+    N = len(X)
+    rho, E, nu = 1000.0, 5e4, 0.3
+    V = np.tile(np.array([0.3, -1.0, 0.2]), (N, 1)) + 0.05 * rng.standard_normal((N, 3))
+    vol = np.full(N, dx ** 3 / ppc)
+    mass, mu, lam = rho * vol, np.full(N, E / (2 * (1 + nu))), np.full(N, E * nu / ((1 + nu) * (1 - 2 * nu)))
+    r = Raw(path, prefix)
+    h = r.create(1, dx=dx, max_iterations=iterations, cneps=1e-7, **kw)
+    X, V, mass, vol, mu, lam = (np.ascontiguousarray(a, np.float64) for a in (X, V, mass, vol, mu, lam))
+    r.call("set_particles", h, C.c_int64(N), vp(X), vp(V), vp(mass), None, None, vp(vol), vp(mu), vp(lam), None)
+    org, nrm = np.array([0.0, 5.0, 0.0]), np.array([0.0, 1.0, 0.0])
+    r.call("set_sticky_halfspaces", h, C.c_int32(1), vp(org), vp(nrm))
+    r.call("sort", h)
+    r.call("p2g", h)
+    r.call("begin_step", h, C.c_double(1.0 / 24))
+    st = Stats()
+    r.call("solve", h, C.byref(st))
+    dv = np.empty((st.num_nodes, 3), np.float64)
+    r.call("get_dv", h, vp(dv))
+    r.f("destroy", None)(h)
+    return dv, {k: getattr(st, k) for k in ("iterations", "linesearch_trials", "linear_iterations", "vcycles", "dropped_pairs", "num_levels", "num_nodes")}, st.energy

@@ -1,5 +1,7 @@
 """GPU parity: assembled Hessian, Galerkin hierarchy, smoothers, V-cycle, L-BFGS / PN solves and whole time steps
 through the C ABI against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -128,6 +130,21 @@ def test_solver_iterates_against_oracle(hotlib, oracle, kw):
     assert rel(out["gpu"][0], out["cpu"][0]) < 1e-9
     assert abs(sg["energy"] - sc["energy"]) < 1e-10 * max(abs(sc["energy"]), 1e-6)
     assert abs(sg["final_scaled_residual"] - sc["final_scaled_residual"]) < 1e-7 * sc["final_scaled_residual"]
+
+
+@pytest.mark.parametrize("kw", [dict(lsolver=3, levelCnt=3), dict(lsolver=2, levelCnt=2)], ids=["lbfgs_mg3", "pn_mgpcg2"])
+def test_solver_iterates_through_the_independent_mirror(kw):
+    """The fixed-iteration parity once more with BOTH libraries driven through tests/golden_checks.py's own ctypes mirror of the C ABI (its own
+    hot_config / hot_stats layouts, its own argument marshalling) instead of hot_amd/binding.py: a mistake of the shared binding — an argument
+    in the wrong order, a field at the wrong offset — would reach the HIP library and the oracle alike and cancel in every other test here."""
+    import hot_amd
+    from tests import golden_checks, oracle_lib
+    oracle_lib.load_oracle()  # (builds oracle/liboracle.so if needed)
+    dg, cg, eg = golden_checks.fixed_iterations_raw(hot_amd.LIB_PATH, "hot_", **kw)
+    dc, cc, ec = golden_checks.fixed_iterations_raw(os.path.join(oracle_lib.ORACLE_DIR, "liboracle.so"), "hoto_", **kw)
+    assert cg == cc and cg["iterations"] == 5, (cg, cc)
+    assert rel(dg, dc) < 1e-9, rel(dg, dc)
+    assert abs(eg - ec) < 1e-10 * max(abs(ec), 1e-6)
 
 
 @pytest.mark.parametrize("Ainv", [2, 1])
