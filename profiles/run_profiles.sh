@@ -7,10 +7,10 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu"
+BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu"
 
 # 1. the bench line itself (with CPU baseline)
-timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+timeout 1200 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"   # the driver's shape
 tail -c 3000 "$OUT/bench.json"
 
 # 2. kernel trace + stats of the same command
