@@ -789,7 +789,7 @@ __device__ __forceinline__ void bc_project(int c, const T* __restrict__ P, const
 
 template <class T>
 __global__ void k_residual(const T* __restrict__ gF, const int32_t* __restrict__ dofSlot, const T* __restrict__ mass, const T* __restrict__ dv, const int32_t* __restrict__ bcIdx,
-    const T* __restrict__ bcP, const T* __restrict__ bcR, const uint8_t* __restrict__ bcSlip, T* r, int nn, int64_t slots, T g0, T g1, T g2, T dt, int slipmode)
+    const T* __restrict__ bcP, const T* __restrict__ bcR, const uint8_t* __restrict__ bcSlip, T* r, T* r2 /*a second copy (the right-hand side kept for the exit test)*/, int nn, int64_t slots, T g0, T g1, T g2, T dt, int slipmode)
 {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= nn) return;
@@ -806,6 +806,7 @@ __global__ void k_residual(const T* __restrict__ gF, const int32_t* __restrict__
         bc_project(c, bcP, bcSlip, slipmode != 0, v);
     }
     r[3 * n] = v[0], r[3 * n + 1] = v[1], r[3 * n + 2] = v[2];
+    r2[3 * n] = v[0], r2[3 * n + 1] = v[1], r2[3 * n + 2] = v[2];
 }
 template <class T>
 __global__ void k_project(const int32_t* __restrict__ bcNode, const T* __restrict__ bcP, const uint8_t* __restrict__ bcSlip, T* v, int nc, int slipmode)
@@ -832,9 +833,8 @@ template <class T>
 void Ctx<T>::residual_dev(T* r)
 {
     int slipmode = (cfg.systemBCProject && cfg.boundaryType == 1) ? 1 : 0;
-    HOT_LAUNCH(this, "residual", k_residual<T>, div_up(Nn, 256), 256, 0, gF.p, dofSlot.p, mass.p, dv.p, bcIdx.p, bcP.p, bcR.p, bcSlip.p, r, Nn, (int64_t)Nb * EPB, (T)cfg.gravity[0],
+    HOT_LAUNCH(this, "residual", k_residual<T>, div_up(Nn, 256), 256, 0, gF.p, dofSlot.p, mass.p, dv.p, bcIdx.p, bcP.p, bcR.p, bcSlip.p, r, rhs.p, Nn, (int64_t)Nb * EPB, (T)cfg.gravity[0],
         (T)cfg.gravity[1], (T)cfg.gravity[2], dt, slipmode);
-    copy(3 * (size_t)Nn, r, rhs.p);
 }
 template <class T>
 void Ctx<T>::project_dev(T* v)

@@ -486,7 +486,7 @@ struct Ctx : CtxBase {
     int minres_dev(const std::function<void(const T*, T*)>& Amul, const std::function<void(const T*, T*)>& prec, T* x, const T* b, T relative_tolerance, T tolerance, int max_iterations);
     void scal(size_t n, T a, T* x); // x *= a
     bool gs_marks_wanted(int level) const; // the level's next smoother is the chained GS sweep that takes its forward target's "not written yet" marks from the kernel before it
-    void restrict_dev(int level, const T* fine, T* coarse);
+    void restrict_dev(int level, const T* fine, T* coarse, T* zero_coarse = nullptr);
     void prolong_dev(int level, const T* coarse, T* fine);
     void smooth_dev(int level, int kind, int iterations, T tol, T* u, T* r, T* du, T* dAu, bool final_residual = true);
     void vcycle_dev(const T* in, T* out);

@@ -711,7 +711,12 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
     // sub-blocks): the inverses of the blocks' in-block triangles, so that a pass is a dense product instead of a 64-step substitution
     L.gs_w_ready = false;
     // (fp64 only: in fp32 the explicit inverse is formed and applied at 6e-8 per operation, and the fp32 configurations' chained levels are the small ones)
-    if (sizeof(T) == 8 && !L.part && ctx->cfg.gs_chain != 1 && (ctx->cfg.gs_sub_block == 0 || ctx->cfg.gs_sub_block == 64) && (max_nb <= 256 || ctx->cfg.gs_chain == 2)) ctx->build_gs_winv(L);
+    {
+        const bool baseline = ctx->cfg.useBaselineMultigrid != 0;
+        const int splitLevel = ctx->cfg.topDownMGS ? 1 : ctx->cfg.levelCnt - 1;
+        const int kind = L.id < splitLevel ? (baseline ? 5 : ctx->cfg.smoother) : (baseline ? 2 : ctx->cfg.coarseSolver); // what smooth_dev runs on this level
+        if (sizeof(T) == 8 && kind == 5 && !L.part && ctx->cfg.gs_chain != 1 && (ctx->cfg.gs_sub_block == 0 || ctx->cfg.gs_sub_block == 64) && (max_nb <= 256 || ctx->cfg.gs_chain == 2)) ctx->build_gs_winv(L);
+    }
     L.gs_img_ready = false;
     if (max_nb > 256 || ctx->cfg.gs_sub_block == 32) { // (row-partitioned levels too: the rows of other ranks have zero counts, hence no slots and empty images)
         L.gs_img.reserve(GsImg<T>::per_block * (size_t)L.nblocks + 16), // + one entry: k_gs_subst's unconditional loads

@@ -80,6 +80,16 @@ __global__ __launch_bounds__(256) void k_copy(size_t n, const T* __restrict__ x,
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = x[i];
 }
+// y := x, y2 := x (if not null), z := 0: the head of a V-cycle
+template <class T>
+__global__ __launch_bounds__(256) void k_vcycle_start(size_t n, const T* __restrict__ x, T* __restrict__ y, T* __restrict__ y2, T* __restrict__ z)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const T v = x[i];
+        y[i] = v, z[i] = (T)0;
+        if (y2) y2[i] = v;
+    }
+}
 template <class T>
 void Ctx<T>::copy(size_t n, const T* x, T* y)
 {
@@ -457,11 +467,12 @@ void Ctx<T>::spmv_dev(Level<T>& L, const T* x, T* y)
 // ------------------------------------------------------------------------------------------------ transfers
 template <class T>
 __global__ void k_restrict(const int32_t* __restrict__ child, const T* __restrict__ fine, T* coarse, int nc, const uint8_t* __restrict__ coarse_own, const uint8_t* __restrict__ fine_own,
-    T* unset /*not null: the coarse level's GS forward target, marked "not written yet" here (see smooth_dev)*/)
+    T* unset /*not null: the coarse level's GS forward target, marked "not written yet" here (see smooth_dev)*/, T* zero_out = nullptr /*not null: a coarse-level vector cleared on the way (the V-cycle's coarse iterate, instead of a fill launch)*/)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 3 * nc) return;
     if (unset) gs_store_unset(unset + e);
+    if (zero_out) zero_out[e] = (T)0;
     int I = e / 3, d = e - 3 * I;
     if (coarse_own && !coarse_own[I]) return; // sharded, both levels partitioned: the coarse rows this rank owns (their children are in the fine halo)
     // all 27 child ids first, then all 27 values (clamped index, dropped by the select): two rounds of independent loads instead of
@@ -506,11 +517,12 @@ bool Ctx<T>::gs_marks_wanted(int level) const
     return cfg.gs_chain == 2 || max_nb <= 256;
 }
 template <class T>
-void Ctx<T>::restrict_dev(int level, const T* fine, T* coarse)
+void Ctx<T>::restrict_dev(int level, const T* fine, T* coarse, T* zero_coarse)
 {
     Level<T>& C = *levels[level + 1];
     Level<T>& F = *levels[level];
     if (F.part && halo_mode()) {
+        if (zero_coarse) zero(3 * (size_t)C.n, zero_coarse);
         if (C.part) { // owner of a coarse row sums its 27 children: those owned elsewhere come with the fine level's halo
             halo_gather(F, const_cast<T*>(fine));
             HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n, C.own.p, (const uint8_t*)nullptr, (T*)nullptr);
@@ -524,7 +536,7 @@ void Ctx<T>::restrict_dev(int level, const T* fine, T* coarse)
     }
     // (every smoother on the coarse level is preceded by a restriction into it: its GS forward target gets its marks here)
     T* mark = gs_marks_wanted(level + 1) ? C.tmp.p : (T*)nullptr;
-    HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n, (const uint8_t*)nullptr, (const uint8_t*)nullptr, mark);
+    HOT_LAUNCH(this, "restrict", k_restrict<T>, div_up(3 * (size_t)C.n, 256), 256, 0, C.child.p, fine, coarse, C.n, (const uint8_t*)nullptr, (const uint8_t*)nullptr, mark, zero_coarse);
     unset_level = mark ? level + 1 : -1;
 }
 template <class T>
@@ -2145,19 +2157,16 @@ void Ctx<T>::vcycle_dev(const T* in, T* out)
     stats.vcycles++;
     Level<T>& L0 = *levels[0];
     size_t n0 = 3 * (size_t)L0.n;
-    copy(n0, in, L0.residual.p); // dRhs == 0 (ImplicitSolver.h:483-484,579), correctResidualProjection is the identity
-    zero(n0, out);
-    if (levelCnt > 1)
-        restrict_dev(0, L0.residual.p, levels[1]->initialResidual.p);
-    else
-        copy(n0, L0.residual.p, L0.initialResidual.p);
+    // residual := in (dRhs == 0, ImplicitSolver.h:483-484,579: correctResidualProjection is the identity), out := 0 and, on a single level, the
+    // top solver's initial residual: one launch instead of two copies and a fill
+    HOT_LAUNCH(this, "vcycle_start", k_vcycle_start<T>, (int)std::min<size_t>(div_up(n0, 256), 2048), 256, 0, n0, in, L0.residual.p, levelCnt > 1 ? (T*)nullptr : L0.initialResidual.p, out);
+    if (levelCnt > 1) restrict_dev(0, L0.residual.p, levels[1]->initialResidual.p);
     for (int l = 1; l < levelCnt - 1; ++l) restrict_dev(l, levels[l]->initialResidual.p, levels[l + 1]->initialResidual.p);
     int level;
     for (level = 0; level < levelCnt - 1; ++level) {
         T* sol = level == 0 ? out : levels[level]->sol.p;
         run(level < splitLevel, level, sol, level < splitLevel ? upIter(level) : topIter(level));
-        restrict_dev(level, levels[level]->residual.p, levels[level + 1]->residual.p);
-        zero(3 * (size_t)levels[level + 1]->n, levels[level + 1]->sol.p);
+        restrict_dev(level, levels[level]->residual.p, levels[level + 1]->residual.p, levels[level + 1]->sol.p); // (clears the coarse iterate on the way)
     }
     run(false, level, level == 0 ? out : levels[level]->sol.p, topIter(level));
     for (--level; level >= 0; --level) {

@@ -58,10 +58,10 @@ __global__ __launch_bounds__(256) void k_scaled_norm(const T* __restrict__ r, co
 }
 // out = dv0 + alpha * ddv
 template <class T>
-__global__ void k_combine(size_t n, const T* __restrict__ a, T alpha, const T* __restrict__ b, T* out)
+__global__ void k_combine(size_t n, const T* __restrict__ a, T alpha, const T* __restrict__ b, T* out, T* out2)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a[i] + b[i] * alpha;
+    if (i < n) out[i] = out2[i] = a[i] + b[i] * alpha;
 }
 template <class T>
 __global__ void k_scal(size_t n, T alpha, T* x)
@@ -248,8 +248,7 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
     bool eo = eo_mode == 2 || (eo_mode == 0 && ls_prev_trials > 1), last_eo = false;
     int trials = 0;
     do {
-        HOT_LAUNCH(this, "linesearch_combine", k_combine<T>, div_up(n3, 256), 256, 0, n3, dv0.p, alpha, ddv, dvnew);
-        copy(n3, dvnew, dv.p); // moveNodes
+        HOT_LAUNCH(this, "linesearch_combine", k_combine<T>, div_up(n3, 256), 256, 0, n3, dv0.p, alpha, ddv, dvnew, dv.p); // the trial point, also as moveNodes' dv
         Ek = state_pass(dv.p, false, eo); // a trial needs the energy only; the force is rasterised once, at the accepted point
         last_eo = eo;
         if (eo_mode != 1) eo = true;
@@ -276,7 +275,7 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
     force_pass(); // the stresses of the last (accepted) trial are still in place
     residual_dev(residual_out);
     updated = true;
-    copy(n3, dvnew, dv0.p);
+    std::swap(dv0.p, work3.p), std::swap(dv0.cap, work3.cap); // dv0 := the accepted point (work3 holds it: dvnew), by exchanging the buffers
     return alpha;
 }
 
