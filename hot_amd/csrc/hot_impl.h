@@ -15,7 +15,9 @@ namespace hot {
 template <class T>
 struct GsImg {
     static constexpr size_t hdr_elems = 2 * 64 * 9;
-    static constexpr size_t cap_entries = 64 * 63 / 2 + 1; // + the all-zero entry 0
+    // strictly lower (upper) in-block couplings of a 4^3 block under the 5^3 stencil: per axis 14 of the 16 ordered position pairs are within
+    // reach 2, so (14^3 - 64) / 2 = 1340 of the 2016 node pairs can couple
+    static constexpr size_t cap_entries = 1340 + 1; // + the all-zero entry 0
     static constexpr size_t per_dir = cap_entries * 9, per_block = hdr_elems + 2 * per_dir;
     static constexpr size_t idx_per_dir = 64 * 64; // 16-bit entry indices [row][step of the direction's walk] (0 = no entry in that column: the all-zero entry)
 };
