@@ -247,7 +247,8 @@ int hot_advance(hot_ctx*, double dt, hot_stats* stats);
 
 /* ---- MpmSimulationBase::calculateDt (Lib/MPM/MpmSimulationBase.cpp:789-814) with evalMaxParticleSpeed (:1186-1218):
  *      dt = cfl * dx / max_p |v_p| (step.max_dt when nothing moves); the particle bounding box is returned as well.
- *      Collision objects are static here, so their evalMaxSpeed term is 0. */
+ *      The speed bound includes the collision objects' own evalMaxSpeed over the particle bounding box (hot_set_collision_objects: moving and
+ *      rotating primitives, members of unions / differences riding along with their composite; static objects contribute 0). */
 int hot_calculate_dt(hot_ctx*, double max_dt, double* dt, double* max_speed, double* min_corner /*3 or NULL*/, double* max_corner /*3 or NULL*/);
 /* ---- SimulationBase::advanceOneFrame (Lib/Ziran/Sim/SimulationBase.h:291-327) with TimeStepping::nextDt / advance
  *      (Lib/Ziran/Sim/TimeStepping.h:45-76): substeps of hot_advance with dt = nextDt(calculateDt()) until frame_dt is
