@@ -299,6 +299,9 @@ def main():
 
     # ---- profiled pass (HIP events on the launch stream) for the roofline and the transfer half of the metric
     roof, transfers, prof_top = None, None, None
+    used_fallback_comm = hasattr(ctx, "_fallback_comm")
+    if world == 1:
+        del ctx  # the timed context's device memory goes before the profiled one is created (C5's whole body: two of them do not fit 288 GB)
     if rank == 0 and world == 1:
         pctx = make_ctx(lib, cloud, cfg, device=local, profile=1)
         pctx.advance(dt)
@@ -444,7 +447,7 @@ def main():
             "hessian_mg_build_ms_per_step": build_ms / max(args.steps, 1),
             "ms_per_iter_build_amortised": solve_ms / max(iters, 1),
             "p2g_g2p_mparticles_per_s": transfers["mparticles_per_s"] if transfers else None,
-            "communicator": (None if comm is None else ("native RCCL on the context's stream" if isinstance(comm, str) and not hasattr(ctx, "_fallback_comm") else f"torch.distributed ({args.backend})")),
+            "communicator": (None if comm is None else ("native RCCL on the context's stream" if isinstance(comm, str) and not used_fallback_comm else f"torch.distributed ({args.backend})")),
             "comm_calls_per_step": ({k: v / max(args.steps + args.warmup, 1) for k, v in comm.calls.items()} if (comm is not None and not isinstance(comm, str)) else None),
             "comm_per_step_rank0": ({"collective_calls": stats[-1]["comm_calls"], "index_bytes": stats[-1]["comm_bytes_index"], "data_bytes": stats[-1]["comm_bytes_data"]} if world > 1 else None),
             "last_step_by_rank": by_rank,

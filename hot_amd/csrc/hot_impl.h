@@ -66,6 +66,7 @@ struct Level {
     int gs_nslot = 0;
     int32_t gs_slot_rng[2][2][8] = {}; // [forward / backward][first / end][colour]: the off-block slots of the colour's blocks — on a row-partitioned level of the blocks THIS rank owns
     bool gs_img_ready = false;
+    long long gs_img_shift[8] = {}; // per colour: image index of a block = its block id + this (row-partitioned level: only the blocks this rank owns — one contiguous run per colour — have images; else 0)
     DBuf<T> gs_w; // chained levels (k_gs_sweep<.., WINV>): nblocks * 2 * 9 * 2017: (I - N)^-1 - I of every colour block's in-block triangle, forward / backward (k_gs_winv, mg_build.hip)
     bool gs_w_ready = false;
     DBuf<int32_t> rowcnt; // 4n: (precede-off, precede-in, follow-in, follow-off) slot counts of the regrouped rows

@@ -609,14 +609,14 @@ __global__ void k_gs_slot_fill(int32_t* __restrict__ pad, const int32_t* __restr
 // (3) every entry -(D_r^-1 A_rc) goes to [offset of column c + rank of r among the column's rows]; the same index, per row and step of the walk, goes to the index table.
 template <class T>
 __global__ __launch_bounds__(512) void k_gs_images(const int32_t* __restrict__ gcol, const T* __restrict__ val, const T* __restrict__ diagBlockInv, const T* __restrict__ diagVal,
-    const int32_t* __restrict__ gs_pad, T* __restrict__ img, uint16_t* __restrict__ imgi, int nblocks)
+    const int32_t* __restrict__ gs_pad, T* __restrict__ img /*of block 0 (shifted for the colour on a row-partitioned level: Level::gs_img_shift)*/, uint16_t* __restrict__ imgi, int block0)
 {
     using I = GsImg<T>;
     __shared__ int32_t nodes[64], rcl[64 * 4];
     __shared__ unsigned int mlo[2][64], mhi[2][64];
     __shared__ int32_t coff[2][64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.x;
+    const int b = block0 + blockIdx.x;
     T* hdr = img + (size_t)b * I::per_block;
     for (int e = tid; e < 2 * 64 * 9; e += 512) { // header: D and D^-1 by position
         const int pos = (e % 576) / 9;
@@ -719,8 +719,18 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
     }
     L.gs_img_ready = false;
     if (max_nb > 256 || ctx->cfg.gs_sub_block == 32) { // (row-partitioned levels too: the rows of other ranks have zero counts, hence no slots and empty images)
-        L.gs_img.reserve(GsImg<T>::per_block * (size_t)L.nblocks + 16), // + one entry: k_gs_subst's unconditional loads
-        L.gs_imgi.reserve(2 * GsImg<T>::idx_per_dir * (size_t)L.nblocks);
+        // images only for the blocks this rank owns (a row-partitioned level: one contiguous run of every colour's list; 193 KB per block in fp64)
+        {
+            const int R1 = ctx->comm.size + 1, me = ctx->comm.rank;
+            long long have = 0;
+            for (int c = 0; c < 8; ++c) {
+                const int b0 = L.color_block_begin[c] + (L.part ? L.csplit[c * R1 + me] : 0), b1 = L.part ? L.color_block_begin[c] + L.csplit[c * R1 + me + 1] : L.color_block_begin[c + 1];
+                L.gs_img_shift[c] = have - b0;
+                have += b1 - b0;
+            }
+            L.gs_img.reserve(GsImg<T>::per_block * (size_t)std::max<long long>(have, 1) + 16), // + one entry: k_gs_subst's unconditional loads
+            L.gs_imgi.reserve(2 * GsImg<T>::idx_per_dir * (size_t)std::max<long long>(have, 1));
+        }
         const int npos = 64 * L.nblocks;
         ctx->flags.reserve(2 * (size_t)npos), ctx->scan.reserve(2 * (size_t)npos);
         HOT_LAUNCH(ctx, "gs_slot_count", k_gs_slot_count, div_up((size_t)npos, 256), 256, 0, L.gs_pad.p, ctx->flags.p, npos);
@@ -744,7 +754,13 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
                 for (int fe = 0; fe < 2; ++fe)
                     for (int c = 0; c < 8; ++c) L.gs_slot_rng[dir][fe][c] = h[16 * dir + 8 * fe + c];
         }
-        HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, L.nblocks, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p, L.gs_imgi.p, L.nblocks);
+        for (int c = 0; c < 8; ++c) {
+            const int R1 = ctx->comm.size + 1, me = ctx->comm.rank;
+            const int b0 = L.color_block_begin[c] + (L.part ? L.csplit[c * R1 + me] : 0), b1 = L.part ? L.color_block_begin[c] + L.csplit[c * R1 + me + 1] : L.color_block_begin[c + 1];
+            if (b1 > b0)
+                HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, b1 - b0, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p + L.gs_img_shift[c] * (long long)GsImg<T>::per_block,
+                    L.gs_imgi.p + L.gs_img_shift[c] * 2 * (long long)GsImg<T>::idx_per_dir, b0);
+        }
         L.gs_img_ready = true;
     }
 }

@@ -1731,8 +1731,10 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         if (fused && sizeof(T) == 8 && L.n <= 65536 && !gs_no_chain && !sharded() && !ab_flag("HOT_CG_LAUNCHES")) { // A/B build: HOT_CG_LAUNCHES = three launches per iteration on small levels too
             // the whole solve in one persistent launch (k_cg_persist), one host round trip for the iteration count
             const int G = std::min(256, div_up(L.n, 16));
-            cg_bar.reserve(32 * 9 + 8), cg_dep.reserve(4 * 256);
-            HOT_HIP(hipMemsetAsync(cg_bar.p, 0, (32 * 9 + 8) * sizeof(unsigned), stream));
+            if (!cg_bar.p) { // cleared once: the last workgroup to leave a launch re-arms the counters; a launch that gave up (a barrier timed out) switches this path off for good
+                cg_bar.reserve(32 * 9 + 8), cg_dep.reserve(4 * 256);
+                HOT_HIP(hipMemsetAsync(cg_bar.p, 0, (32 * 9 + 8) * sizeof(unsigned), stream));
+            }
             HOT_LAUNCH(this, lname("cg_persistent", L.id).c_str(), k_cg_persist<T>, G, 1024, 0, L.col.p, L.val.p, L.diagInv.p, L.initialResidual.p, u, r, z, du, dAu, L.n, iterations, cg_bar.p, cg_dep.p,
                 hscal + 40, hscal + 251, new_ticket(), (int*)(hscal + 250));
             wait_ticket(); // a timed-out barrier shows in hscal[250]: sync() inside throws ERR_RETRY and the caller redoes the operation with launches
@@ -1979,6 +1981,8 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 }
                 // (the first colour walked has no off-block columns before it — an empty slot range, like a rank without rows of the colour: no launch)
                 const int s0 = L.gs_slot_rng[fwd ? 0 : 1][0][c], s1 = L.gs_slot_rng[fwd ? 0 : 1][1][c];
+                const T* img_c = L.gs_img.p + L.gs_img_shift[c] * (long long)GsImg<T>::per_block; // (images exist for the owned blocks only: the colour's base, shifted)
+                const uint16_t* imgi_c = L.gs_imgi.p + L.gs_img_shift[c] * 2 * (long long)GsImg<T>::idx_per_dir;
                 const int grid = std::max(1, ab_int("HOT_GS_OFF_WAVES", 4096) / 4);
                 if (s1 > s0) HOT_LAUNCH(this, lname(nmO, L.id).c_str(), k_gs_offblock<T>, grid, 256, 0, L.gs_slot.p, L.gs_col.p, L.val.p, L.gs_pad.p, xx, L.gs_p1.p, s0, s1);
                 // (eight columns in flight per block: 4 .. 16 change nothing, §6 of DESIGN.md)
@@ -1987,9 +1991,9 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
 #define HOT_SUBST_D(DD)                                                                                                                                                       \
     if (depth == DD) {                                                                                                                                                        \
         if (fwd)                                                                                                                                                              \
-            HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, DD>), nb, 64, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);                 \
+            HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, DD>), nb, 64, 0, img_c, imgi_c, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);                 \
         else                                                                                                                                                                  \
-            HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, DD>), nb, 64, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);                \
+            HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, DD>), nb, 64, 0, img_c, imgi_c, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);                \
         continue;                                                                                                                                                             \
     }
                 HOT_SUBST_D(4)
@@ -2000,9 +2004,9 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
 #undef HOT_SUBST_D
 #endif
                 if (fwd)
-                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
+                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, img_c, imgi_c, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
                 else
-                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, 8>), nb, 64, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
+                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, 8>), nb, 64, 0, img_c, imgi_c, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
             }
         };
         HOT_CHECK(sb == 16 || sb == 32 || sb == 64, HOT_ERR_INVALID, "hot_config.gs_sub_block must be 0 (auto), 16, 32 or 64");
