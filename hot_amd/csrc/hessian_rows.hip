@@ -1,5 +1,5 @@
 // libhotmi355x — Hessian assembly, production kernel of round 5: output-stationary row tiles, barrier-free wavefront tasks,
-// the contraction on broadcast FMAs (v_fmac_*_dpp row_newbcast), no staging of particle data in LDS.
+// the contraction on broadcast FMAs (v_fmac_*_dpp row_newbcast), particle data staged per wavefront, never per workgroup.
 //
 // Mathematics (reference Projects/multigrid/ImplicitSolver.h:498-552): every ordered node pair (i, j) of every particle adds
 //   H(i, j)[a][b] = V_p dt^2 sum_{v,q} dP_{(a,v),(b,q)} g_i[v] g_j[q],   g_i = Fn^T grad w_i
@@ -11,22 +11,23 @@
 //
 // k_hessian_tiles2 (round 2 - 4, hessian_tiles.hip, now A/B build only) staged dP, g and K of 40-particle chunks in LDS behind four
 // barriers per chunk and paid 18 LDS reads per 27 multiply-adds in its pair phase: 13.7 ms at C2, 62 % of the wave cycles parked on
-// barriers, 10 % of the FP64 rate.  Here:
-//   * one workgroup (8 wavefronts) per aligned 2x2x2 tile of grid nodes, its 8 rows x 125 slots x 9 values in LDS (72 KB, two
+// barriers, 10 % of the FP64 rate.  Here (5.2 ms at C2):
+//   * pass 1, k_dpdf_rec: one 128-scalar record per particle: E (45) and grad w of the 27 kernel nodes (81);
+//   * pass 1b, k_tile_cells: per 2x2x2 row tile the particle ranges of the 4x4x4 base cells around it and its 8 row DOFs;
+//   * pass 2, k_hessian_rows: one workgroup (7 wavefronts in fp64, 8 in fp32) per tile, its 8 rows x 125 slots x 9 values in LDS (72 KB, two
 //     workgroups per CU); nothing else of the workgroup is shared, there is no barrier between the prologue and the write-out;
-//   * a TASK = (base cell among the 4x4x4 cells around the tile, x-plane of the tile): the <= 4 tile rows of that plane inside the
-//     cell's 3x3x3 support.  Wavefronts draw tasks, heaviest first, from an LDS counter.  A wavefront walks the cell's particles
-//     (contiguous records, the next one requested while the current one is worked on) with lane = (half h, column node j): the 27
+//   * a TASK = (base cell, x-plane of the tile): the <= 4 tile rows of that plane inside the cell's 3x3x3 support.  Wavefronts draw tasks
+//     from an LDS counter, planes of four rows first.  A wavefront walks the cell's particles with lane = (half h, column node j): the 27
 //     column nodes of the cell twice, half 0 owning the (a, b) entries 0..4 of every 3x3 block, half 1 the entries 4..8;
-//   * per particle a lane loads its three E values and six 1-D weights straight from the particle record (global memory, L2),
-//     forms gw_j, parks it in a 768-byte wavefront-private LDS strip (the only LDS traffic of the inner loop: 3 stores per
-//     particle, 3 wave-uniform loads per row);
+//   * per particle the record comes with two coalesced loads (requested one particle ahead) and is parked in the wavefront's LDS stage;
+//     a lane picks its three E values, grad w of its column node and — at wave-uniform addresses — grad w of the task's row nodes from
+//     there: one LDS round trip per particle;
 //   * per (particle, row): lanes 0..14 of every 16-lane DPP row form the 15 K values of their half (3 FMAs), then every lane runs
 //     15 broadcast FMAs  acc[ab] += K[lane 3 ab + s of my DPP row] * gw_j[s]  — the K operand never leaves the register file —
 //     into 5 accumulators per row (40 VGPRs for the task's 4 rows);
 //   * after the cell's last particle the accumulators go to the LDS tile with 5 (4) ds_add_f64 per lane and row.
 // 18 VALU instructions per (particle, row) for 27 x 27 multiply-adds on 64 lanes: 70 % of them useful, no LDS atomics or index
-// decoding inside the particle loop.
+// decoding inside the particle loop.  How it got from 8.1 to 5.2 ms: DESIGN.md section 6.
 #include "hot_impl.h"
 #include "hot_constitutive.h"
 
@@ -203,7 +204,7 @@ struct RowsTask { // wave-uniform
 };
 
 // One task: the particles [rp, rp + cnt records) of a cell against NR rows of a tile plane.  Records are requested one particle ahead into
-// two alternating register sets (no copies); the NR x 3 wave-uniform strip loads of a particle are issued together.
+// two alternating register sets (no copies); the NR x 3 wave-uniform stage loads of a particle are issued together.
 template <class T, int NR>
 __device__ __forceinline__ void hr_walk(const T* __restrict__ rp /*wave-uniform*/, int cnt, const RowsTask& tk, T* __restrict__ stage, AccT<T>* __restrict__ tile, int lane, const RowsLane& ld)
 {
