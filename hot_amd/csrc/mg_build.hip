@@ -754,9 +754,11 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
                 for (int fe = 0; fe < 2; ++fe)
                     for (int c = 0; c < 8; ++c) L.gs_slot_rng[dir][fe][c] = h[16 * dir + 8 * fe + c];
         }
-        for (int c = 0; c < 8; ++c) {
+        if (!L.part) // every block, one launch (all shifts are 0)
+            HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, L.nblocks, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p, L.gs_imgi.p, 0);
+        for (int c = 0; c < 8 && L.part; ++c) {
             const int R1 = ctx->comm.size + 1, me = ctx->comm.rank;
-            const int b0 = L.color_block_begin[c] + (L.part ? L.csplit[c * R1 + me] : 0), b1 = L.part ? L.color_block_begin[c] + L.csplit[c * R1 + me + 1] : L.color_block_begin[c + 1];
+            const int b0 = L.color_block_begin[c] + L.csplit[c * R1 + me], b1 = L.color_block_begin[c] + L.csplit[c * R1 + me + 1];
             if (b1 > b0)
                 HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, b1 - b0, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p + L.gs_img_shift[c] * (long long)GsImg<T>::per_block,
                     L.gs_imgi.p + L.gs_img_shift[c] * 2 * (long long)GsImg<T>::idx_per_dir, b0);
