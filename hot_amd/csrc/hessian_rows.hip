@@ -16,8 +16,8 @@
 //   * pass 1b, k_tile_cells: per 2x2x2 row tile the particle ranges of the 4x4x4 base cells around it and its 8 row DOFs;
 //   * pass 2, k_hessian_rows: one workgroup (7 wavefronts in fp64, 8 in fp32) per tile, its 8 rows x 125 slots x 9 values in LDS (72 KB, two
 //     workgroups per CU); nothing else of the workgroup is shared, there is no barrier between the prologue and the write-out;
-//   * a TASK = (base cell, x-plane of the tile): the <= 4 tile rows of that plane inside the cell's 3x3x3 support.  Wavefronts draw tasks
-//     from an LDS counter, planes of four rows first.  A wavefront walks the cell's particles with lane = (half h, column node j): the 27
+//   * a TASK = (base cell, x-plane of the tile): the <= 4 tile rows of that plane inside the cell's 3x3x3 support (fp32: the whole cell,
+//     <= 8 rows — kHrCellTasks below).  Wavefronts draw tasks from an LDS counter, those with most rows first.  A wavefront walks the cell's particles with lane = (half h, column node j): the 27
 //     column nodes of the cell twice, half 0 owning the (a, b) entries 0..4 of every 3x3 block, half 1 the entries 4..8;
 //   * per particle the record comes with two coalesced loads (requested one particle ahead) and is parked in the wavefront's LDS stage;
 //     a lane picks its three E values, grad w of its column node and — at wave-uniform addresses — grad w of the task's row nodes from
@@ -198,9 +198,8 @@ __device__ __forceinline__ RowsLane rows_lane(int lane)
     return L;
 }
 struct RowsTask { // wave-uniform
-    int px; // x-plane of the tile
-    int lx, ly0, lz0; // kernel index of the plane's row (0, 0) inside the cell: row (ry, rz) sits at (lx, ly0 + ry, lz0 + rz)
-    int m4; // rows (ry << 1 | rz) of the plane inside the cell's support (and active)
+    int lx0, ly0, lz0; // kernel index of the tile's row 0 inside the cell: row (rx, ry, rz) sits at (lx0 + rx, ly0 + ry, lz0 + rz)
+    int m8; // the task's rows (rx << 2 | ry << 1 | rz): inside the cell's support and active; one x-plane of the tile or (kHrCellTasks) both
 };
 
 // One task: the particles [rp, rp + cnt records) of a cell against NR rows of a tile plane.  Records are requested one particle ahead into
@@ -211,12 +210,12 @@ __device__ __forceinline__ void hr_walk(const T* __restrict__ rp /*wave-uniform*
     using AT = AccT<T>;
     int qs[NR], so[NR]; // rows of the task in ascending order (ordinals beyond the row count repeat row 0: computed, not stored), record offsets of their grad w
     {
-        int m = tk.m4;
+        int m = tk.m8;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            qs[r] = m ? __builtin_ctz(m) : __builtin_ctz(tk.m4);
+            qs[r] = m ? __builtin_ctz(m) : __builtin_ctz(tk.m8);
             m &= m - 1;
-            so[r] = 45 + 3 * (tk.lx * 9 + (tk.ly0 + (qs[r] >> 1)) * 3 + (tk.lz0 + (qs[r] & 1)));
+            so[r] = 45 + 3 * ((tk.lx0 + (qs[r] >> 2)) * 9 + (tk.ly0 + ((qs[r] >> 1) & 1)) * 3 + (tk.lz0 + (qs[r] & 1)));
         }
     }
     T acc[NR][5];
@@ -234,15 +233,19 @@ __device__ __forceinline__ void hr_walk(const T* __restrict__ rp /*wave-uniform*
         __builtin_amdgcn_wave_barrier();
         const T e0 = stage[ld.eo0], e1 = stage[ld.eo1], e2 = stage[ld.eo2];
         const T g0 = stage[ld.go], g1 = stage[ld.go + 1], g2 = stage[ld.go + 2];
-        T gw[NR][3];
+        constexpr int RG = NR < 4 ? NR : 4; // rows per group of stage loads (eight rows: two groups, 24 registers of operands instead of 48)
 #pragma unroll
-        for (int r = 0; r < NR; ++r)
+        for (int r0 = 0; r0 < NR; r0 += RG) {
+            T gw[RG][3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) gw[r][k] = stage[so[r] + k];
+            for (int r = 0; r < RG; ++r)
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const T K = e0 * gw[r][0] + e1 * gw[r][1] + e2 * gw[r][2];
-            dpp_row_fma(acc[r], K, g0, g1, g2);
+                for (int k = 0; k < 3; ++k) gw[r][k] = stage[so[r0 + r] + k];
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const T K = e0 * gw[r][0] + e1 * gw[r][1] + e2 * gw[r][2];
+                dpp_row_fma(acc[r0 + r], K, g0, g1, g2);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -258,12 +261,12 @@ __device__ __forceinline__ void hr_walk(const T* __restrict__ rp /*wave-uniform*
     }
     // ---- accumulators -> LDS tile: half 0 holds the block entries 0..4, half 1 the entries 4..8 (its entry 4 is the duplicate)
     if ((lane & 31) < 27) {
-        const int nrow = __popc(tk.m4);
+        const int nrow = __popc(tk.m8);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (r < nrow) { // wave-uniform
-                const int q = qs[r], row = 4 * tk.px + q;
-                AT* o = tile + row * 1125 + ((tk.lx - ld.j0 + 2) * 25 + (tk.ly0 + (q >> 1) - ld.j1 + 2) * 5 + (tk.lz0 + (q & 1) - ld.j2 + 2)) * 9 + 4 * ld.h;
+                const int row = qs[r];
+                AT* o = tile + row * 1125 + ((tk.lx0 + (row >> 2) - ld.j0 + 2) * 25 + (tk.ly0 + ((row >> 1) & 1) - ld.j1 + 2) * 5 + (tk.lz0 + (row & 1) - ld.j2 + 2)) * 9 + 4 * ld.h;
                 if (ld.h == 0) lds_atomic_add(o, (AT)acc[r][0]);
 #pragma unroll
                 for (int e = 1; e < 5; ++e) lds_atomic_add(o + e, (AT)acc[r][e]);
@@ -291,8 +294,28 @@ constexpr HrOrder hr_order()
     }
     return o;
 }
-__constant__ HrOrder kHrOrderTab = hr_order();
-#define kHrOrder kHrOrderTab.v
+// A task of the fp32 build = a whole cell (up to 8 rows, 40 accumulator registers): 8 instead of 12 visits per particle, 12.4 instead of 14.0 ms at C3.
+// In fp64 the 80 accumulator registers cost a wavefront per SIMD (162 VGPRs) and the kernel is slower (C2: 6.3 against 5.35 ms), so fp64 keeps the
+// (cell, x-plane) tasks.  HOT_HR_CELL_TASKS = 0 / 1 forces either for both types (A/B builds).
+#ifndef HOT_HR_CELL_TASKS
+#define HOT_HR_CELL_TASKS 2
+#endif
+template <class T>
+constexpr bool kHrCellTasks = HOT_HR_CELL_TASKS == 2 ? sizeof(T) == 4 : HOT_HR_CELL_TASKS != 0;
+// Candidates = cells (entries 64 .. 127 of the table are unused), ordered by rows 8, 4, 2, 1.
+constexpr HrOrder hr_order_cells()
+{
+    HrOrder o{};
+    int n = 0;
+    for (int want = 8; want >= 1; want >>= 1)
+        for (int cell = 0; cell < 64; ++cell) {
+            const int ox = (cell >> 4) - 2, oy = ((cell >> 2) & 3) - 2, oz = (cell & 3) - 2;
+            const int rows = ((ox == -1 || ox == 0) ? 2 : 1) * ((oy == -1 || oy == 0) ? 2 : 1) * ((oz == -1 || oz == 0) ? 2 : 1);
+            if (rows == want) o.v[n++] = (uint8_t)cell;
+        }
+    return o;
+}
+__constant__ HrOrder kHrOrderTab = hr_order(), kHrOrderCellsTab = hr_order_cells();
 
 // LDS of a workgroup: the tile (72 000 bytes in either build), per wavefront a record stage (128 scalars), the integer tables.  Two
 // workgroups per CU: 7 wavefronts each in fp64 (81 024 bytes), 8 in fp32.
@@ -355,21 +378,32 @@ __global__ __launch_bounds__(RowsLds<T>::THREADS) void k_hessian_rows(const T* _
     bool any = false;
     for (int r = 0; r < 8; ++r) any = any || rdof[r] >= 0;
     if (!any) return;
-    // ---- task list: candidates (cell, x-plane) in the static order kHrOrder — four-row planes first, then two, then one — with the rows that
+    // ---- task list: candidates (cell, x-plane) in the static order kHrOrderTab (cells: kHrOrderCellsTab) — four-row planes first, then two, then one — with the rows that
     // are inside the cell's 3x3x3 support AND active; those with rows and particles are compacted by the first wavefront (two candidates per
     // lane).  (A rank sort by rows x particles took a seventh of the kernel: 770 VALU instructions on two wavefronts beside a busy neighbour.)
     if (tid < 64) {
         int tk[2], nz[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int t = kHrOrder[64 * k + tid], cell = t >> 1, px = t & 1, ox = (cell >> 4) - 2, oy = ((cell >> 2) & 3) - 2, oz = (cell & 3) - 2;
-            int m4 = 0;
-            if ((unsigned)(px - ox) < 3u) {
+            int cell, m8 = 0;
+            if (kHrCellTasks<T>) {
+                cell = kHrOrderCellsTab.v[tid];
+                const int ox = (cell >> 4) - 2, oy = ((cell >> 2) & 3) - 2, oz = (cell & 3) - 2;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if ((unsigned)((q >> 1) - oy) < 3u && (unsigned)((q & 1) - oz) < 3u && rdof[4 * px + q] >= 0) m4 |= 1 << q;
+                for (int r = 0; r < 8; ++r)
+                    if (k == 0 && (unsigned)((r >> 2) - ox) < 3u && (unsigned)(((r >> 1) & 1) - oy) < 3u && (unsigned)((r & 1) - oz) < 3u && rdof[r] >= 0) m8 |= 1 << r;
             }
-            tk[k] = cell | (px << 6) | (m4 << 8), nz[k] = m4 != 0 && ccnt[cell] > 0;
+            else {
+                const int t = kHrOrderTab.v[64 * k + tid], px = t & 1;
+                cell = t >> 1;
+                const int ox = (cell >> 4) - 2, oy = ((cell >> 2) & 3) - 2, oz = (cell & 3) - 2;
+                if ((unsigned)(px - ox) < 3u) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((unsigned)((q >> 1) - oy) < 3u && (unsigned)((q & 1) - oz) < 3u && rdof[4 * px + q] >= 0) m8 |= 1 << (4 * px + q);
+                }
+            }
+            tk[k] = cell | (m8 << 8), nz[k] = m8 != 0 && ccnt[cell] > 0;
         }
         const unsigned long long b0 = __ballot(nz[0]), b1 = __ballot(nz[1]), below = (1ull << tid) - 1ull;
         const int n0 = __popcll(b0);
@@ -394,20 +428,23 @@ __global__ __launch_bounds__(RowsLds<T>::THREADS) void k_hessian_rows(const T* _
         if (lane == 0) k = atomicAdd(ctl, 1);
         k = __builtin_amdgcn_readfirstlane(k);
         if (k >= ntask) break;
-        const int task = __builtin_amdgcn_readfirstlane(tasks[k]), cell = task & 63, px = (task >> 6) & 1, m4 = task >> 8;
+        const int task = __builtin_amdgcn_readfirstlane(tasks[k]), cell = task & 63, m8 = task >> 8;
         const int first = __builtin_amdgcn_readfirstlane(cstart[cell]), cnt = __builtin_amdgcn_readfirstlane(ccnt[cell]);
         HR_CNT(6, cnt);
-        HR_CNT(7, cnt * __popc(m4));
-        const int nr = __popc(m4);
-        const RowsTask tk = { px, px - ((cell >> 4) - 2), -(((cell >> 2) & 3) - 2), -((cell & 3) - 2), m4 };
+        HR_CNT(7, cnt * __popc(m8));
+        const int nr = __popc(m8);
+        const RowsTask tk = { -((cell >> 4) - 2), -(((cell >> 2) & 3) - 2), -((cell & 3) - 2), m8 };
         const T* rp = rec + (int64_t)first * REC;
-        // the particle walk is compiled for 1, 2 and 4 rows (3 rows — an inactive node in the plane — run as 4 with a row computed and dropped)
+        // the particle walk is compiled for 1, 2, 4 (and 8) rows; a count between — an inactive node — runs as the next size with rows computed
+        // and dropped
         if (nr == 1)
             hr_walk<T, 1>(rp, cnt, tk, stage, tile, lane, ld);
         else if (nr == 2)
             hr_walk<T, 2>(rp, cnt, tk, stage, tile, lane, ld);
-        else
+        else if (!kHrCellTasks<T> || nr <= 4)
             hr_walk<T, 4>(rp, cnt, tk, stage, tile, lane, ld);
+        else
+            hr_walk<T, kHrCellTasks<T> ? 8 : 4>(rp, cnt, tk, stage, tile, lane, ld);
     }
     HR_CLK(2);
     __syncthreads();
