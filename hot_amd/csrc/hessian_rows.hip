@@ -202,10 +202,18 @@ struct RowsTask { // wave-uniform
     int m8; // the task's rows (rx << 2 | ry << 1 | rz): inside the cell's support and active; one x-plane of the tile or (kHrCellTasks) both
 };
 
-// One task: the particles [rp, rp + cnt records) of a cell against NR rows of a tile plane.  Records are requested one particle ahead into
-// two alternating register sets (no copies); the NR x 3 wave-uniform stage loads of a particle are issued together.
+// One task: the particles [rp, rp + cnt records) of a cell against NR rows of a tile plane.  Records are requested TWO particles ahead into three
+// rotating register sets, and the request stream runs on into the wavefront's NEXT task (its first two records: [nrp, nrp + ncnt)), so that a
+// task starts with its records 0 and 1 in flight since the previous task's last two particles — with 8 particles per cell a cold start per
+// task left a memory round trip exposed per ~8 visits (one record ahead, no look-ahead: 5.3 ms at C2).  The NR x 3 wave-uniform stage
+// loads of a particle are issued together.
+template <class T>
+struct RowsPre { // the wavefront's records in flight: on entry of a walk [0] = its record 0, [1] = its record 1 (valid if cnt > 1)
+    T r[3][2];
+};
 template <class T, int NR>
-__device__ __forceinline__ void hr_walk(const T* __restrict__ rp /*wave-uniform*/, int cnt, const RowsTask& tk, T* __restrict__ stage, AccT<T>* __restrict__ tile, int lane, const RowsLane& ld)
+__device__ __forceinline__ void hr_walk(const T* __restrict__ rp /*wave-uniform*/, int cnt, const T* __restrict__ nrp, int ncnt, RowsPre<T>& P, const RowsTask& tk, T* __restrict__ stage,
+    AccT<T>* __restrict__ tile, int lane, const RowsLane& ld)
 {
     using AT = AccT<T>;
     int qs[NR], so[NR]; // rows of the task in ascending order (ordinals beyond the row count repeat row 0: computed, not stored), record offsets of their grad w
@@ -249,15 +257,36 @@ __device__ __forceinline__ void hr_walk(const T* __restrict__ rp /*wave-uniform*
         }
         __builtin_amdgcn_wave_barrier();
     };
-    T A0 = rp[lane], A1 = rp[64 + lane], B0, B1;
-    for (int l = 0; l < cnt; l += 2) {
-        const T* rb = rp + (l + 1 < cnt ? l + 1 : l) * REC;
-        B0 = rb[lane], B1 = rb[64 + lane];
-        work(A0, A1);
+    // request i of the stream: own record i, past the end the next task's records 0 and 1 (a next task of one particle: its record 0 twice)
+    auto request = [&](int i, T(&R)[2]) {
+        const T* q = i < cnt ? rp + i * REC : nrp + (i - cnt < ncnt ? i - cnt : ncnt - 1) * REC;
+        R[0] = q[lane], R[1] = q[64 + lane];
+        asm volatile("" ::: "memory"); // issued HERE, two visits ahead of its use
+    };
+    if (cnt == 1) request(1, P.r[1]); // (what arrived as "record 1" was this task's record 0 again)
+    for (int l = 0; l < cnt; l += 3) {
+        request(l + 2, P.r[2]);
+        work(P.r[0][0], P.r[0][1]);
         if (l + 1 >= cnt) break;
-        const T* ra = rp + (l + 2 < cnt ? l + 2 : l + 1) * REC;
-        A0 = ra[lane], A1 = ra[64 + lane];
-        work(B0, B1);
+        request(l + 3, P.r[0]);
+        work(P.r[1][0], P.r[1][1]);
+        if (l + 2 >= cnt) break;
+        request(l + 4, P.r[1]);
+        work(P.r[2][0], P.r[2][1]);
+    }
+    { // the next task's records 0 and 1 sit in the sets cnt % 3 and (cnt + 1) % 3: make them sets 0 and 1
+        const int ph = cnt % 3; // wave-uniform
+        if (ph == 1) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) P.r[0][e] = P.r[1][e], P.r[1][e] = P.r[2][e];
+        }
+        else if (ph == 2) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const T t = P.r[0][e];
+                P.r[0][e] = P.r[2][e], P.r[1][e] = t;
+            }
+        }
     }
     // ---- accumulators -> LDS tile: half 0 holds the block entries 0..4, half 1 the entries 4..8 (its entry 4 is the duplicate)
     if ((lane & 31) < 27) {
@@ -423,28 +452,50 @@ __global__ __launch_bounds__(RowsLds<T>::THREADS) void k_hessian_rows(const T* _
     const int lane = tid & 63, wv = tid >> 6;
     const RowsLane ld = rows_lane(lane);
     T* stage = stages + wv * REC;
-    while (true) {
+    // a wavefront knows its next task while it walks the current one (the request stream above runs on into it)
+    auto draw = [&]() {
         int k = 0;
         if (lane == 0) k = atomicAdd(ctl, 1);
-        k = __builtin_amdgcn_readfirstlane(k);
-        if (k >= ntask) break;
-        const int task = __builtin_amdgcn_readfirstlane(tasks[k]), cell = task & 63, m8 = task >> 8;
-        const int first = __builtin_amdgcn_readfirstlane(cstart[cell]), cnt = __builtin_amdgcn_readfirstlane(ccnt[cell]);
-        HR_CNT(6, cnt);
-        HR_CNT(7, cnt * __popc(m8));
-        const int nr = __popc(m8);
-        const RowsTask tk = { -((cell >> 4) - 2), -(((cell >> 2) & 3) - 2), -((cell & 3) - 2), m8 };
-        const T* rp = rec + (int64_t)first * REC;
-        // the particle walk is compiled for 1, 2, 4 (and 8) rows; a count between — an inactive node — runs as the next size with rows computed
-        // and dropped
-        if (nr == 1)
-            hr_walk<T, 1>(rp, cnt, tk, stage, tile, lane, ld);
-        else if (nr == 2)
-            hr_walk<T, 2>(rp, cnt, tk, stage, tile, lane, ld);
-        else if (!kHrCellTasks<T> || nr <= 4)
-            hr_walk<T, 4>(rp, cnt, tk, stage, tile, lane, ld);
-        else
-            hr_walk<T, kHrCellTasks<T> ? 8 : 4>(rp, cnt, tk, stage, tile, lane, ld);
+        return __builtin_amdgcn_readfirstlane(k);
+    };
+    auto task_range = [&](int k, int& task, const T*& rp, int& cnt) {
+        task = __builtin_amdgcn_readfirstlane(tasks[k < ntask ? k : 0]);
+        const int cell = task & 63;
+        rp = rec + (int64_t) __builtin_amdgcn_readfirstlane(cstart[cell]) * REC, cnt = __builtin_amdgcn_readfirstlane(ccnt[cell]);
+    };
+    int k = draw();
+    if (k < ntask) {
+        int task, cnt;
+        const T* rp;
+        task_range(k, task, rp, cnt);
+        RowsPre<T> P;
+        P.r[0][0] = rp[lane], P.r[0][1] = rp[64 + lane];
+        {
+            const T* q = rp + (cnt > 1 ? REC : 0);
+            P.r[1][0] = q[lane], P.r[1][1] = q[64 + lane];
+        }
+        while (true) {
+            const int kn = draw();
+            int ntk = task, ncnt = 1;
+            const T* nrp = rp; // no next task: the stream ends on a record that is there
+            if (kn < ntask) task_range(kn, ntk, nrp, ncnt);
+            const int m8 = task >> 8, nr = __popc(m8), cell = task & 63;
+            HR_CNT(6, cnt);
+            HR_CNT(7, cnt * nr);
+            const RowsTask tk = { -((cell >> 4) - 2), -(((cell >> 2) & 3) - 2), -((cell & 3) - 2), m8 };
+            // the particle walk is compiled for 1, 2, 4 (and 8) rows; a count between — an inactive node — runs as the next size with rows
+            // computed and dropped
+            if (nr == 1)
+                hr_walk<T, 1>(rp, cnt, nrp, ncnt, P, tk, stage, tile, lane, ld);
+            else if (nr == 2)
+                hr_walk<T, 2>(rp, cnt, nrp, ncnt, P, tk, stage, tile, lane, ld);
+            else if (!kHrCellTasks<T> || nr <= 4)
+                hr_walk<T, 4>(rp, cnt, nrp, ncnt, P, tk, stage, tile, lane, ld);
+            else
+                hr_walk<T, kHrCellTasks<T> ? 8 : 4>(rp, cnt, nrp, ncnt, P, tk, stage, tile, lane, ld);
+            if (kn >= ntask) break;
+            k = kn, task = ntk, rp = nrp, cnt = ncnt;
+        }
     }
     HR_CLK(2);
     __syncthreads();
