@@ -207,6 +207,9 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
 // VALU 44 % + LDS 56 % of the kernel's cycles (profiles/r03_sq_counters_C2.json).)
 // Development aid (-DHOT_HT_CLOCKS, tools/hess_phases.sh): shader clocks of thread 0 between the barriers of k_p2g_cells2, summed
 // over the workgroups: 0 header + zeroing, 1 staging, 2 items, 3 write-out.
+#ifndef HOT_P2G_NO_ITEMS
+#define HOT_P2G_NO_ITEMS 0
+#endif
 #ifdef HOT_HT_CLOCKS
 __device__ unsigned long long p2g_clk[8];
 #define P2G_CLK(i) \
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                         if (MASK & (1 << q)) lds_atomic_add(&acc[q][t], (AT)a[i][k][q]);
                 }
         };
-        const int n6 = nseg * 6;
+        const int n6 = HOT_P2G_NO_ITEMS ? 0 : nseg * 6; // (HOT_P2G_NO_ITEMS: experiment, staging alone)
         if constexpr (sizeof(T) == 4) {
             for (int it = tid; it < n6; it += THREADS) run9(std::integral_constant<int, (1 << NQ) - 1>{}, it);
         }

@@ -1,6 +1,6 @@
 """P2G / G2P / force-pass time (HIP events from the context profile) at C2 / C3 size; HOT_LIB selects another build of the library
 (e.g. the per-phase clock build of tools/hess_phases.sh).  HOT_COLD=1 overwrites 2 GB of device memory before every call (the 256 MB
-last-level cache then holds none of the particle arrays, as in a real step where the solve ran in between); HOT_PRESTEPS=n advances n
+last-level cache then holds none of the particle arrays, as in a real step where the solve ran in between); HOT_P2G_ONLY=1 times hot_p2g alone; HOT_PRESTEPS=n advances n
 time steps first (the bench measures the transfers inside steps 2..: 0.153 + 0.029 / 0.165 ms at C2 where the untouched lattice gives 0.118 +
 0.029 / 0.150)."""
 import os, sys
@@ -29,6 +29,14 @@ for which in (sys.argv[1:] or ["C2", "C3"]):
     ctx.set_particles(cloud["X"], cloud["V"], cloud["mass"], cloud["vol"], cloud["mu"], cloud["lam"])
     for _ in range(int(os.environ.get("HOT_PRESTEPS", "0"))):  # a moved body: cell populations no longer the lattice's 8 per cell
         ctx.advance(cfg["dt"])
+    if os.environ.get("HOT_P2G_ONLY"):  # experiment builds whose P2G leaves no grid behind (tools/variant.sh ... -DHOT_P2G_NO_ITEMS=1)
+        ctx.sort(), ctx.p2g()
+        ctx.profile_reset()
+        for _ in range(6):
+            flush()
+            ctx.p2g()
+        print(which, {k: round(v["total_ms"] / v["calls"], 4) for k, v in ctx.profile().items() if "p2g" in k})
+        continue
     ctx.sort(), ctx.p2g(), ctx.begin_step(cfg["dt"])
     ctx.profile_reset()
     for _ in range(6):
