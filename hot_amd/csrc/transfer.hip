@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         if (tid == 0) nseg = 0;
         __syncthreads();
         P2G_CLK(0);
-        for (int l = tid; l < CH && ch + l < last; l += THREADS) {
+        for (int l = tid; l < (HOT_P2G_NO_ITEMS == 3 ? 0 : CH) && ch + l < last; l += THREADS) { // (3: experiment, no particle loads)
             const int p = ch + l;
             const T m = M[p];
 #pragma unroll
@@ -348,7 +348,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     __syncthreads();
     P2G_CLK(2);
     T* out = part + (int64_t)g * NQ * TILE;
+#if HOT_P2G_NO_ITEMS != 2 // (2: experiment, no write-out either)
     for (int t = tid; t < NQ * TILE; t += THREADS) out[t] = (T)(&acc[0][0])[t];
+#endif
 #ifdef HOT_HT_CLOCKS
     P2G_CLK(3);
     if (tid == 0)
