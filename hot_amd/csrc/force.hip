@@ -272,6 +272,7 @@ void Ctx<T>::begin_step(double dt_)
 {
     need(Nn > 0, "hot_begin_step before hot_p2g");
     double t0 = wall_ms();
+    rearm_chain();
     dt = (T)dt_;
     eval_halfspaces();
     eval_collision_objects();

@@ -388,21 +388,52 @@ struct Ctx : CtxBase {
     // flag in pinned host memory and leaves a half-updated iterate behind.  The next sync() then switches this context to the
     // launch-per-pass path for good and throws ERR_RETRY, which the operations that can contain such a sweep (solve, vcycle,
     // smooth) catch to redo themselves from their saved inputs — the context is never left poisoned.
+    // A time-out is not for life: one transient event (another process holding compute units while a spinning kernel waited) must not cost a
+    // long-running context its chained sweeps and persistent PCG for good.  After REARM_STEPS clean time steps the chained path is tried again;
+    // the third time-out on a context is final.
     static constexpr int ERR_RETRY = -100; // internal, never crosses the C ABI
+    static constexpr int REARM_STEPS = 32, MAX_TIMEOUTS = 3;
     bool gs_no_chain = false, gs_chain_timed_out = false;
+    int gs_timeouts = 0, steps_since_timeout = 0;
+    void rearm_chain() // hot_begin_step
+    {
+        if (!gs_chain_timed_out || gs_timeouts >= MAX_TIMEOUTS || ++steps_since_timeout < REARM_STEPS) return;
+        gs_chain_timed_out = false, steps_since_timeout = 0;
+        if (!sharded()) gs_no_chain = false; // (several ranks: launch-per-pass sweeps whatever happened, set_comm)
+    }
+    int n_cu = 0; // compute units of the device (persistent kernels size their grids by it)
+    int device_cus()
+    {
+        if (n_cu == 0) {
+            int dev = 0;
+            HOT_HIP(hipGetDevice(&dev));
+            HOT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        return n_cu;
+    }
     int unset_level = -1; // the level whose GS forward target (Level::tmp) carries "not written yet" marks from the kernel launched last on it (restrict_dev / vcycle_dev -> smooth_dev)
+    int retry_scope = 0, fake_syncs = 0; // inside with_gs_retry; A/B build: synchronisations counted for HOT_GS_FAKE_TIMEOUT
     void sync()
     {
         HOT_HIP(hipStreamSynchronize(stream));
+        // A/B build: HOT_GS_FAKE_TIMEOUT=n raises the time-out flag at the n-th synchronisation inside an operation that can retry — the
+        // redo-from-saved-inputs path then runs in a test (tests/test_gpu_variants.py) without a kernel that really hangs
+        if (retry_scope > 0 && !gs_no_chain && ab_int("HOT_GS_FAKE_TIMEOUT", 0) > 0 && ++fake_syncs == ab_int("HOT_GS_FAKE_TIMEOUT", 0)) *(volatile int*)(hscal + 250) = 1;
         if (*(volatile int*)(hscal + 250) != 0) {
             *(volatile int*)(hscal + 250) = 0;
             gs_no_chain = gs_chain_timed_out = true;
+            ++gs_timeouts, steps_since_timeout = 0;
             throw Error{ ERR_RETRY, "k_gs_sweep: wait on a neighbouring block timed out; redoing the operation with one launch per pass" };
         }
     }
     template <class Fn>
     void with_gs_retry(Fn&& fn)
     {
+        struct Scope {
+            int& n;
+            Scope(int& n_) : n(n_) { ++n; }
+            ~Scope() { --n; }
+        } scope(retry_scope);
         try {
             fn();
         }

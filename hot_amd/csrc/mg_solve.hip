@@ -1730,7 +1730,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         // parity test was validated against the launch-per-operation sums)
         if (fused && sizeof(T) == 8 && L.n <= 65536 && !gs_no_chain && !sharded() && !ab_flag("HOT_CG_LAUNCHES")) { // A/B build: HOT_CG_LAUNCHES = three launches per iteration on small levels too
             // the whole solve in one persistent launch (k_cg_persist), one host round trip for the iteration count
-            const int G = std::min(256, div_up(L.n, 16));
+            const int G = std::min(std::min(256, device_cus()), div_up(L.n, 16)); // 1024-thread workgroups that must all be resident: one per compute unit at most
             if (!cg_bar.p) { // cleared once: the last workgroup to leave a launch re-arms the counters; a launch that gave up (a barrier timed out) switches this path off for good
                 cg_bar.reserve(32 * 9 + 8), cg_dep.reserve(4 * 256);
                 HOT_HIP(hipMemsetAsync(cg_bar.p, 0, (32 * 9 + 8) * sizeof(unsigned), stream));

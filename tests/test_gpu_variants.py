@@ -36,6 +36,7 @@ CASES = [
     ({"HOT_LBFGS_UNFUSED": "1"}, SOLVER, "iterates"),
     ({"HOT_CG_UNFUSED": "1"}, SOLVER, "smoothers or vcycle or iterates"),
     ({"HOT_CG_LAUNCHES": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # three launches per PCG iteration instead of the persistent launch on small top levels
+    ({"HOT_GS_FAKE_TIMEOUT": "2"}, SOLVER, "smoothers or vcycle or iterates"),  # a chained sweep "times out" at the second synchronisation of every context: the operation is redone with one launch per pass
     ({"HOT_HESSIAN_V1": "1"}, SOLVER, "hessian_and_hierarchy"),
     ({"HOT_HESSIAN_TILES": "1"}, SOLVER, "hessian_and_hierarchy"),  # rounds 2 - 4: k_hessian_tiles2, particle chunks staged in LDS, pair phase with LDS atomics
     ({"HOT_HESSIAN_TILES_V1": "1"}, SOLVER, "hessian_and_hierarchy"),
