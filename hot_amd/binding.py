@@ -531,6 +531,16 @@ class Context:
         self._call("constitutive_eval", C.c_int32(n), _ptr(F), _ptr(mu), _ptr(lam), C.c_int32(int(project)), _ptr(psi), _ptr(P), _ptr(D))
         return psi, P, D
 
+    def trial_energy(self, F, mu, lam):
+        """psi (n) as the line search's energy-only trials evaluate it (hot_constitutive_eval with project = 2)."""
+        F = np.ascontiguousarray(F, self.T).reshape(-1, 9)
+        n = F.shape[0]
+        mu = np.ascontiguousarray(np.broadcast_to(mu, (n,)), self.T)
+        lam = np.ascontiguousarray(np.broadcast_to(lam, (n,)), self.T)
+        psi = np.empty(n, self.T)
+        self._call("constitutive_eval", C.c_int32(n), _ptr(F), _ptr(mu), _ptr(lam), C.c_int32(2), _ptr(psi), None, None)
+        return psi
+
     def plasticity_eval(self, kind, F, mu, lam, Jp=None):
         """In-place return mapping (1 von Mises with cfg.yield_stress, 2 snow with cfg.snow) on copies: (F, mu, lam, Jp)."""
         F = np.array(F, self.T, order="C").reshape(-1, 9)

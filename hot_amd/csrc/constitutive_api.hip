@@ -24,6 +24,10 @@ __global__ __launch_bounds__(256) void k_constitutive_eval(const T* __restrict__
 #pragma unroll
     for (int c = 0; c < 9; ++c) Fc.a[c] = F[9 * (int64_t)p + c];
     const T mu = Mu[p], la = Lam[p];
+    if (project == 2) { // the line search's energy-only evaluation (k_state<T, true>): psi alone, no SVD where the invariants serve
+        if (psi) psi[p] = corotated_psi_sigma(Fc, mu, la);
+        return;
+    }
     if (psi || P) {
         T e;
         Mat3<T> Pm;
@@ -72,6 +76,8 @@ template <class T>
 void Ctx<T>::constitutive_eval(int32_t n, const void* F, const void* mu, const void* lambda, int32_t project, void* psi, void* P, void* dPdF)
 {
     need(n > 0 && F && mu && lambda, "hot_constitutive_eval: n > 0, F, mu and lambda are required");
+    need(project >= 0 && project <= 2, "hot_constitutive_eval: project must be 0, 1 or 2 (psi as a line-search trial evaluates it)");
+    if (project == 2) P = nullptr, dPdF = nullptr;
     DBuf<T> dF, dMu, dLam, dPsi, dP, dD;
     dF.reserve(9 * (size_t)n), dMu.reserve(n), dLam.reserve(n), dPsi.reserve(n), dP.reserve(9 * (size_t)n), dD.reserve(dPdF ? 81 * (size_t)n : 1);
     HOT_HIP(hipMemcpyAsync(dF.p, F, 9 * (size_t)n * sizeof(T), hipMemcpyDefault, stream));

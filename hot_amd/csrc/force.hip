@@ -312,13 +312,74 @@ __device__ __forceinline__ void rot3(const T (&in)[3], int r, T (&out)[3])
     out[2] = r == 0 ? in[2] : (r == 1 ? in[0] : in[1]);
 }
 
+// grad(v) at a particle from the LDS node tile (evalInterpolantAndGradient's sum over the 27 nodes): one body for the state pass and
+// the batched line-search trials, so that both round alike.  fp64: sum-factorised like k_g2p's (round 5): the tensor-product weights are
+// contracted one axis at a time — along z per (i, j): value and derivative sums (18 multiply-adds), along y per i (27), along x (27) —
+// 280 operations instead of the 378 of the node-by-node sum (135 weight products + 243 multiply-adds); the state passes are bound by FP64 issue.
+template <class T>
+__device__ __forceinline__ void gather_grad(const T* __restrict__ n0, const T* __restrict__ n1, const T* __restrict__ n2, int t0, int sx, int sy, const T (&w)[3][3], const T (&dw)[3][3],
+    T one_over_dx, T (&gv)[9])
+{
+#ifdef HOT_GATHER_NODEWISE // (experiment builds, tools/variant.sh: the node-by-node sum in fp64 too)
+    constexpr bool nodewise = true;
+#else
+    constexpr bool nodewise = sizeof(T) == 4;
+#endif
+    if constexpr (nodewise) { // fp32: node by node, the oracle's float arithmetic (the fp32 whole-step parity test compares energies to 1e-5); not bound by issue there
+#pragma unroll
+        for (int c = 0; c < 9; ++c) gv[c] = (T)0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            T wi = w[0][i], dwi = one_over_dx * dw[0][i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                T wij = wi * w[1][j];
+                T dwij_i = dwi * w[1][j], dwij_j = wi * one_over_dx * dw[1][j];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    T g0 = dwij_i * w[2][k], g1 = dwij_j * w[2][k], g2 = wij * one_over_dx * dw[2][k];
+                    int t = t0 + i * sx + j * sy + k;
+                    T v0 = n0[t], v1 = n1[t], v2 = n2[t];
+                    gv[0] += v0 * g0, gv[1] += v1 * g0, gv[2] += v2 * g0;
+                    gv[3] += v0 * g1, gv[4] += v1 * g1, gv[5] += v2 * g1;
+                    gv[6] += v0 * g2, gv[7] += v1 * g2, gv[8] += v2 * g2;
+                }
+            }
+        }
+        return;
+    }
+    T gx[3] = { 0, 0, 0 }, gy[3] = { 0, 0, 0 }, gz[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        T a[3] = { 0, 0, 0 }, b[3] = { 0, 0, 0 }, c[3] = { 0, 0, 0 }; // sums over (j, k) with weights w1 w2, dw1 w2, w1 dw2
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int t = t0 + i * sx + j * sy;
+            const T v0[3] = { n0[t], n0[t + 1], n0[t + 2] }, v1[3] = { n1[t], n1[t + 1], n1[t + 2] }, v2[3] = { n2[t], n2[t + 1], n2[t + 2] };
+            const T s0 = w[2][0] * v0[0] + w[2][1] * v0[1] + w[2][2] * v0[2], d0 = dw[2][0] * v0[0] + dw[2][1] * v0[1] + dw[2][2] * v0[2];
+            const T s1 = w[2][0] * v1[0] + w[2][1] * v1[1] + w[2][2] * v1[2], d1 = dw[2][0] * v1[0] + dw[2][1] * v1[1] + dw[2][2] * v1[2];
+            const T s2 = w[2][0] * v2[0] + w[2][1] * v2[1] + w[2][2] * v2[2], d2 = dw[2][0] * v2[0] + dw[2][1] * v2[1] + dw[2][2] * v2[2];
+            a[0] += w[1][j] * s0, a[1] += w[1][j] * s1, a[2] += w[1][j] * s2;
+            b[0] += dw[1][j] * s0, b[1] += dw[1][j] * s1, b[2] += dw[1][j] * s2;
+            c[0] += w[1][j] * d0, c[1] += w[1][j] * d1, c[2] += w[1][j] * d2;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gx[q] += dw[0][i] * a[q], gy[q] += w[0][i] * b[q], gz[q] += w[0][i] * c[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) gv[q] = one_over_dx * gx[q], gv[3 + q] = one_over_dx * gy[q], gv[6 + q] = one_over_dx * gz[q];
+}
+
 // pass A: gather grad(vn+dv) from the LDS node tile -> trial F -> one SVD -> psi, P -> stress = V_p P Fn^T, energy
 // ENERGY_ONLY (a line-search trial that may be rejected, ImplicitSolver.h:312-333 reads nothing but the energy): no trial-F / stress
-// stores, singular values only — the rotations that would accumulate U and V are dead code, the bidiagonal sees the same ones, so sigma is
-// bit-identical — and psi from sigma: mu sum (sigma_i - 1)^2 = mu |F - R|_F^2 up to round-off (CorotatedIsotropic.h:151-155).  The accepted
+// stores, and no SVD: psi from the invariants of F^T F (corotated_psi_invariants, hot_constitutive.h; where those decline — det F <= 0.1 — from the
+// singular values alone: the rotations that would accumulate U and V are dead code).  mu |F - R|_F^2 up to round-off (CorotatedIsotropic.h:151-155);
+// the full pass emits the same evaluation of its F beside its own energy (es), which is what a trial is compared with.  The accepted
 // point is always re-evaluated by the full pass, whose energy is the one the solver keeps.
+// Occupancy is stated (waves per SIMD: 4 / 3 in fp64, 6 / 4 in fp32 — 128 / 168 registers without spills): a workgroup's life is a chain of
+// dependent round trips and the trial pass is bound by how many of them a compute unit holds, not by arithmetic or bytes.
 template <class T, bool ENERGY_ONLY = false>
-__global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ Vol, const T* __restrict__ Mu, const T* __restrict__ Lam,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ENERGY_ONLY ? (sizeof(T) == 8 ? 4 : 6) : (sizeof(T) == 8 ? 3 : 4)))) void k_state(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ Vol, const T* __restrict__ Mu, const T* __restrict__ Lam,
     T* __restrict__ Ft, T* __restrict__ stress_out, T* __restrict__ gradV_out, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
     const int32_t* __restrict__ group_nb, const int32_t* __restrict__ gIdx, const T* __restrict__ vn, const T* __restrict__ dv, T dx, T one_over_dx, T dt, double* energy, GridRed gr)
 {
@@ -361,26 +422,7 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
             for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx, xp[d], base[d], w[d], dw[d]);
             const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
             T gv[9];
-#pragma unroll
-            for (int c = 0; c < 9; ++c) gv[c] = (T)0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                T wi = w[0][i], dwi = one_over_dx * dw[0][i];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    T wij = wi * w[1][j];
-                    T dwij_i = dwi * w[1][j], dwij_j = wi * one_over_dx * dw[1][j];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        T g0 = dwij_i * w[2][k], g1 = dwij_j * w[2][k], g2 = wij * one_over_dx * dw[2][k];
-                        int t = ((cx + i) * TY + (cy + j)) * TZ + (cz + k);
-                        T v0 = nv[0][t], v1 = nv[1][t], v2 = nv[2][t];
-                        gv[0] += v0 * g0, gv[1] += v1 * g0, gv[2] += v2 * g0;
-                        gv[3] += v0 * g1, gv[4] += v1 * g1, gv[5] += v2 * g1;
-                        gv[6] += v0 * g2, gv[7] += v1 * g2, gv[8] += v2 * g2;
-                    }
-                }
-            }
+            gather_grad(nv[0], nv[1], nv[2], ((cx * TY) + cy) * TZ + cz, TY * TZ, TZ, w, dw, one_over_dx, gv);
             if (gradV_out) {
 #pragma unroll
                 for (int c = 0; c < 9; ++c) gradV_out[(int64_t)c * Np + p] = gv[c];
@@ -418,6 +460,153 @@ __global__ __launch_bounds__(256) void k_state(const T* __restrict__ X, const T*
     else {
         const double tots = block_sum_256<double>(es, red);
         grid_sum_store(tot, tots, 2, gr, energy, energy + 3, red);
+    }
+}
+
+// K line-search trials in ONE pass (round 5): the trial points dv0 + alpha_k ddv, alpha_k = alpha / 2^k, are never written out — every trial gets
+// its own node tile in LDS, formed as k_combine + the tile gather of k_state form it, and every particle (position, Fn, weights read and
+// computed once) gathers K gradients and sums K energies with k_state<T, true>'s arithmetic in k_state<T, true>'s order: the K totals are
+// bit-identical to K energy-only passes.  lineSearch (ImplicitSolver.h:312-333) halves until the energy has not risen; at the stiffness of
+// C3 - C5 that is 4 - 5 trials an iteration, each of which used to be a launch bound by its workgroups' chains of dependent round trips
+// (header -> tile ids -> nodal values -> barrier -> particles -> block sum -> deposit), not by arithmetic or bytes: K trials per chain.
+template <class T, int K>
+struct TrialAlphas {
+    T a[K];
+};
+template <class T, int K>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? 3 : 4))) void k_state_trials(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ Vol,
+    const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin, const int32_t* __restrict__ gIdx,
+    const T* __restrict__ vn, const T* __restrict__ dv0, const T* __restrict__ ddv, TrialAlphas<T, K> al, T one_over_dx, T dt, double* energy, GridRed gr)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
+    __shared__ T nv[K][3][TILE];
+    __shared__ double red[4 * K];
+    const int g = blockIdx.x;
+    const int first = group_first[g], last = group_first[g + 1];
+    for (int t = threadIdx.x; t < TILE; t += 256) {
+        const int idx = gIdx[(int64_t)g * TILE + t];
+        T v[3] = { 0, 0, 0 }, b[3] = { 0, 0, 0 }, d[3] = { 0, 0, 0 };
+        if (idx >= 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = vn[3 * idx + c], b[c] = dv0[3 * idx + c], d[c] = ddv[3 * idx + c];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const T trial = b[c] + d[c] * al.a[k]; // k_combine's expression
+                nv[k][c][t] = idx >= 0 ? v[c] + trial : (T)0;
+            }
+    }
+    __syncthreads();
+    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
+    double e[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) e[k] = 0;
+    for (int p = first + threadIdx.x; p < last; p += 256) {
+        T xp[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xp[d] = X[(int64_t)d * Np + p];
+        int base[3];
+        T w[3][3], dw[3][3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx, xp[d], base[d], w[d], dw[d]);
+        const int t0 = (((base[0] - ox) * TY) + (base[1] - oy)) * TZ + (base[2] - oz);
+#pragma unroll 1 // one trial after the other, each with the register footprint of a pass of its own
+        for (int k = 0; k < K; ++k) {
+            // Nothing that a trial shares with the next is kept in registers across the loop but the weights: the 81 weight products (162 registers in
+            // fp64 if hoisted) are recomputed — the weights pass through an empty asm —, Fn and the material constants are re-read (cache hits; the
+            // particle index passes through an empty asm likewise).
+            T wl[3][3], dwl[3][3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    wl[d][i] = w[d][i], dwl[d][i] = dw[d][i];
+                    asm volatile("" : "+v"(wl[d][i]), "+v"(dwl[d][i]));
+                }
+            T gv[9];
+            gather_grad(nv[k][0], nv[k][1], nv[k][2], t0, TY * TZ, TZ, wl, dwl, one_over_dx, gv);
+            int pk = p;
+            asm volatile("" : "+v"(pk));
+            Mat3<T> A, Fo;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) A.a[c] = dt * gv[c] + ((c % 4 == 0) ? (T)1 : (T)0), Fo.a[c] = Fn[(int64_t)c * Np + pk];
+            const Mat3<T> Fnew = m3_mul(A, Fo);
+            const T mu = Mu[pk], la = Lam[pk], vol = Vol[pk];
+            const double val = (double)(vol * corotated_psi_sigma(Fnew, mu, la));
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) e[kk] += kk == k ? val : 0.0; // (the sums stay in registers; + 0.0 changes nothing)
+        }
+    }
+    block_sum_256_n<K>(e, [](int) { return true; }, red);
+    grid_sum_store_n<K>(e, [](int k) { return k; }, K, gr, energy, red);
+}
+
+// the inertia / gravity sums of k_inertia_energy for the K trial points (same sums, same order: bit-identical)
+template <class T, int K>
+__global__ __launch_bounds__(256) void k_inertia_energy_trials(const T* __restrict__ dv0, const T* __restrict__ ddv, TrialAlphas<T, K> al, const T* __restrict__ mass, int nn, T g0, T g1, T g2,
+    double* out /*[2 K]: K kinetic sums, K gravity sums*/, GridRed gr)
+{
+    __shared__ double red[8 * K];
+    double s[2 * K];
+#pragma unroll
+    for (int k = 0; k < 2 * K; ++k) s[k] = 0;
+    const int stride = gridDim.x * 256;
+    for (int n0 = blockIdx.x * 256 + threadIdx.x; n0 < nn; n0 += 4 * stride) {
+        T b[4][3], d[4][3], m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = n0 + u * stride < nn ? n0 + u * stride : n0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) b[u][c] = dv0[3 * n + c], d[u][c] = ddv[3 * n + c];
+            m[u] = mass[n];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (n0 + u * stride < nn) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const T a0 = b[u][0] + d[u][0] * al.a[k], a1 = b[u][1] + d[u][1] * al.a[k], a2 = b[u][2] + d[u][2] * al.a[k]; // k_combine's expression
+                    s[k] += (double)((a0 * a0 + a1 * a1 + a2 * a2) * m[u]);
+                    s[K + k] += (double)((g0 * a0 + g1 * a1 + g2 * a2) * m[u]);
+                }
+            }
+    }
+    block_sum_256_n<2 * K>(s, [](int) { return true; }, red);
+    grid_sum_store_n<2 * K>(s, [](int k) { return k; }, 2 * K, gr, out, red);
+}
+
+// energies of the K trial points dv0 + (alpha / 2^k) ddv, k = 0 .. K - 1, as K calls of state_pass(.., energy_only = true) would return them
+template <class T>
+void Ctx<T>::trial_batch(const T* ddv, T alpha, int K, double* Ek_out)
+{
+    HOT_CHECK(!sharded() && !halo_mode() && (K == 2 || K == 4 || K == 8), HOT_ERR_INVALID, "trial_batch: one rank, 2 / 4 / 8 trials");
+    constexpr int S0 = 140, S1 = 148; // dscal / hscal slots: K strain energies, then K kinetic + K gravity sums
+    const int grid = std::min(div_up(Nn, 1024), 1024);
+    auto run = [&](auto kc) {
+        constexpr int KK = decltype(kc)::value;
+        TrialAlphas<T, KK> al;
+        T a = alpha;
+        for (int k = 0; k < KK; ++k) al.a[k] = a, a *= (T)0.5;
+        GridRed g1 = gred_n(Ng, KK);
+        g1.mirror = hscal + S0;
+        HOT_LAUNCH(this, KK == 2 ? "state_trials2" : (KK == 4 ? "state_trials4" : "state_trials8"), (k_state_trials<T, KK>), Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, tileDof.p, vn.p, dv0.p, ddv, al, (T)1 / dx, dt,
+            dscal.p + S0, g1);
+        GridRed g2 = gred_n(grid, 2 * KK);
+        g2.mirror = hscal + S1, g2.ticket = hscal + 251, g2.ticket_val = new_ticket();
+        HOT_LAUNCH(this, "inertia_trials", (k_inertia_energy_trials<T, KK>), grid, 256, 0, dv0.p, ddv, al, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + S1, g2);
+    };
+    if (K == 2) run(std::integral_constant<int, 2>());
+    else if (K == 4) run(std::integral_constant<int, 4>());
+    else run(std::integral_constant<int, 8>());
+    wait_ticket();
+    for (int k = 0; k < K; ++k) {
+        double r = (double)(T)hscal[S0 + k]; // state_pass's assembly
+        r += hscal[S1 + k] / 2;
+        r -= (double)dt * hscal[S1 + K + k];
+        Ek_out[k] = r;
     }
 }
 

@@ -266,9 +266,13 @@ __device__ inline void grid_sum_store(double t0, double t1, int nv, GridRed gr, 
     if (threadIdx.x == 0) {
         __hip_atomic_store(gr.part + blockIdx.x, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (nv > 1) __hip_atomic_store(gr.part + nb + blockIdx.x, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef HOT_GRIDSUM_DEPOSIT_ONLY // (timing experiment, tools/variant.sh: what the acknowledged deposit + the counter's round trip cost a workgroup; no result)
+        s_last = blockIdx.x == nb - 1u;
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned prev = __hip_atomic_fetch_add(gr.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = prev == nb - 1u;
+#endif
     }
     __syncthreads();
     if (!s_last) return; // workgroup-uniform

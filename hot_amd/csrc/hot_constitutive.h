@@ -20,10 +20,60 @@ __device__ __forceinline__ T clamp_small_magnitude(T x, T eps)
     return x;
 }
 
+// psi WITHOUT an SVD, for the line search's energy-only trials (round 5; at C4 the trials' SVDs were 30 % of a step).
+//   psi = mu |F - R|_F^2 + lambda/2 (J - 1)^2 (CorotatedIsotropic.h:151-155) needs of the polar decomposition only s = tr S = sigma_0 + sigma_1 + sigma_2:
+//   |F - R|^2 = |F|^2 - 2 s + 3.  With I1, I2, J the invariants of C = F^T F: a = sigma_0 sigma_1 + ... = (s^2 - I1) / 2 and a^2 = I2 + 2 J s, so s is the
+//   largest root of  s^4 - 2 I1 s^2 - 8 J s + I1^2 - 4 I2 = 0  (the other three are s with two signs flipped).
+// Near a rotation all of this cancels, so the unknown is u = |F - R|^2 / 2 = e1 - (s - 3) itself and everything is written in the invariants
+// e1, e2, e3 of the Green strain E = (C - I) / 2 (I1 = 3 + 2 e1, I2 = 3 + 4 e1 + 4 e2, J^2 = 1 + q, q = 2 e1 + 4 e2 + 8 e3, j = J - 1 = q / (sqrt(1 + q) + 1),
+// e1 - j = j^2 / 2 - 2 e2 - 4 e3):  g(u) = u^4 + g3 u^3 + g2 u^2 + g1 u + g0 = 0 with g0 = O(strain^2) free of first-order terms.  u = 0 is the upper bound
+// sigma - 1 <= (sigma^2 - 1) / 2 of every term, i.e. a point beyond the quartic's largest root in s where it is convex: Newton from there is monotone, 2 - 4
+// steps at the strains of a time step, ~10 at 100 %.  Measured against 60-digit arithmetic (tests/test_gpu_force.py): relative error of u 8e-9 at strain
+// 1e-8, 1e-12 at 1e-4, 2e-15 at 0.1 in fp64 — a factor 3 - 6 BELOW the sigma form's (whose sigma_i - 1 cancels the same way), 4e-6 at 100 % in fp32.
+// Not for det F <= 0.1 (the sign convention puts an inverted element's negative singular value last, where the largest root may be a double one) nor
+// where Newton has not settled in 12 steps: false, and the caller takes the singular values.
+template <class T>
+__device__ __forceinline__ bool corotated_psi_invariants(const Mat3<T>& F, T mu, T lambda, T& psi)
+{
+    // E = (F^T F - I) / 2, the -1 inside the fma chain
+    T E00 = (T)0.5 * fma(F(0, 0), F(0, 0), fma(F(1, 0), F(1, 0), fma(F(2, 0), F(2, 0), (T)-1)));
+    T E11 = (T)0.5 * fma(F(0, 1), F(0, 1), fma(F(1, 1), F(1, 1), fma(F(2, 1), F(2, 1), (T)-1)));
+    T E22 = (T)0.5 * fma(F(0, 2), F(0, 2), fma(F(1, 2), F(1, 2), fma(F(2, 2), F(2, 2), (T)-1)));
+    T E01 = (T)0.5 * (F(0, 0) * F(0, 1) + F(1, 0) * F(1, 1) + F(2, 0) * F(2, 1));
+    T E02 = (T)0.5 * (F(0, 0) * F(0, 2) + F(1, 0) * F(1, 2) + F(2, 0) * F(2, 2));
+    T E12 = (T)0.5 * (F(0, 1) * F(0, 2) + F(1, 1) * F(1, 2) + F(2, 1) * F(2, 2));
+    const T e1 = E00 + E11 + E22;
+    const T e2 = E00 * E11 + E11 * E22 + E00 * E22 - E01 * E01 - E12 * E12 - E02 * E02;
+    const T e3 = E00 * (E11 * E22 - E12 * E12) - E01 * (E01 * E22 - E12 * E02) + E02 * (E01 * E12 - E11 * E02);
+    const T q = (T)2 * e1 + (T)4 * e2 + (T)8 * e3; // J^2 - 1
+    if (!(q > (T)-0.99) || !(m3_det(F) > (T)0)) return false;
+    const T j = q / (hsqrt((T)1 + q) + (T)1);
+    const T g0 = ((e1 + (T)8) * e1 + (T)28) * e1 * e1 - (T)8 * j * e1 + (T)12 * j * j - (T)64 * e2 - (T)96 * e3;
+    const T g1 = -((((T)4 * e1 + (T)28) * e1 + (T)72) * e1 + (T)64 - (T)8 * j);
+    const T g2 = ((T)6 * e1 + (T)32) * e1 + (T)48;
+    const T g3 = -((T)4 * e1 + (T)12);
+    const T tol = sizeof(T) == 8 ? (T)8.9e-16 : (T)4.8e-7; // 4 eps
+    T u = (T)0;
+    bool settled = false;
+    for (int it = 0; it < 12 && !settled; ++it) {
+        const T g = (((u + g3) * u + g2) * u + g1) * u + g0;
+        const T gp = (((T)4 * u + (T)3 * g3) * u + (T)2 * g2) * u + g1;
+        const T du = -g / gp;
+        u += du;
+        settled = !(du > tol * u);
+    }
+    u = u > (T)0 ? u : (T)0; // (round-off of g0 at F = a rotation)
+    psi = (T)2 * mu * u + (T)0.5 * lambda * j * j;
+    return settled;
+}
+
 // psi and P = 2 mu (F - R) + lambda (J - 1) J F^-T from one SVD
 template <class T>
-__device__ inline void corotated_state(const Mat3<T>& F, T mu, T lambda, T& psi, Mat3<T>& P, T* psi_sigma = nullptr /*psi evaluated as corotated_psi_sigma does, from the same singular values*/)
+__device__ inline void corotated_state(const Mat3<T>& F, T mu, T lambda, T& psi, Mat3<T>& P, T* psi_sigma = nullptr /*psi evaluated as corotated_psi_sigma does: what an energy-only trial of the same F would return*/)
 {
+    // (the trial form first: nothing of it but two registers lives across the SVD)
+    T pt = (T)0;
+    const bool have_pt = psi_sigma && corotated_psi_invariants(F, mu, lambda, pt);
     Mat3<T> U, V;
     T sg[3];
     svd3(F, U, sg, V);
@@ -40,16 +90,25 @@ __device__ inline void corotated_state(const Mat3<T>& F, T mu, T lambda, T& psi,
     T Jm1 = J - (T)1;
     psi = mu * fr + (T)0.5 * lambda * Jm1 * Jm1;
     if (psi_sigma) {
-        const T d0 = sg[0] - (T)1, d1 = sg[1] - (T)1, d2 = sg[2] - (T)1;
-        *psi_sigma = mu * (d0 * d0 + d1 * d1 + d2 * d2) + (T)0.5 * lambda * Jm1 * Jm1;
+        if (!have_pt) {
+            const T d0 = sg[0] - (T)1, d1 = sg[1] - (T)1, d2 = sg[2] - (T)1;
+            pt = mu * (d0 * d0 + d1 * d1 + d2 * d2) + (T)0.5 * lambda * Jm1 * Jm1;
+        }
+        *psi_sigma = pt;
     }
 }
 
-// psi alone, from the singular values: |F - R|_F^2 = sum (sigma_i - 1)^2.  U and V are never used, so their rotations are dead code after
-// inlining; the bidiagonal and with it sigma are bit-identical to corotated_state's.
+// psi alone: from the invariants (above); where those decline, from the singular values: |F - R|_F^2 = sum (sigma_i - 1)^2.  U and V are never used,
+// so their rotations are dead code after inlining; the bidiagonal and with it sigma are bit-identical to corotated_state's — either way the value is
+// the one corotated_state returns in *psi_sigma for the same F.
 template <class T>
 __device__ inline T corotated_psi_sigma(const Mat3<T>& F, T mu, T lambda)
 {
+    T pt;
+    if (corotated_psi_invariants(F, mu, lambda, pt)) return pt;
+#ifdef HOT_NO_SVD_FALLBACK // (experiment: what the trial pass costs without the singular-value path in the kernel)
+    return pt;
+#endif
     Mat3<T> U, V;
     T sg[3];
     svd3(F, U, sg, V);

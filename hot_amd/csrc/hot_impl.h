@@ -503,6 +503,7 @@ struct Ctx : CtxBase {
     // ---- device-side building blocks (device pointers)
     void eval_halfspaces();
     void eval_collision_objects();
+    void trial_batch(const T* ddv, T alpha, int K, double* Ek_out); // the energies of K line-search trials (alpha, alpha / 2, ...) from one pass: what K energy-only state_pass calls return
     double state_pass(const T* dv_in, bool want_force, bool energy_only = false); // G2P(vn+dv) -> F, energy, force scatter; returns total energy (syncs)
     void force_pass(); // force scatter from the stresses of the last state_pass
     void residual_dev(T* r); // from the force tiles of the last state_pass / force_pass

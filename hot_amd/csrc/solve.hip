@@ -247,7 +247,34 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
     const int eo_mode = cfg.ls_energy_only;
     bool eo = eo_mode == 2 || (eo_mode == 0 && ls_prev_trials > 1), last_eo = false;
     int trials = 0;
+    // Energy-only trials in batches (one rank; trial_batch, force.hip): the energies of alpha, alpha / 2, ... from ONE pass, bit-identical to the
+    // passes they replace, looked at in order — the search accepts what it would have accepted and counts the trials it would have run.  (A/B build: HOT_LS_NO_BATCH = 1 runs them one by one.)
+    const bool batched = !sharded() && !halo_mode() && !ab_flag("HOT_LS_NO_BATCH");
+    bool last_from_batch = false;
+    int batches = 0, first_K = 0;
     do {
+        if (eo && batched && guard + 2 <= 59) {
+            // a batch costs a fixed part (~1.7 trials' worth at C4) + its trials: as many as the previous search needed, 5 or 6 as 4 + 2
+            const int pv = ls_prev_trials;
+            int K = batches == 0 ? (pv <= 2 ? 2 : (pv <= 6 ? 4 : 8)) : ((batches == 1 && first_K == 4 && (pv == 5 || pv == 6)) ? 2 : 4);
+            if (batches == 0) first_K = K;
+            ++batches;
+            while (guard + K > 59) K >>= 1; // (the search gives up after 60 trials)
+            double Eb[8];
+            trial_batch(ddv, alpha, K, Eb);
+            int k = 0;
+            for (;; ++k) {
+                Ek = Eb[k];
+                ++trials, stats.linesearch_trials++;
+                if (ab_flag("HOT_DEBUG")) fprintf(stderr, "[hot]   linesearch alpha=%g Ek=%.12e Ek0=%.12e (batch of %d)\n", (double)alpha, Ek, Ek0, K);
+                alpha *= (T)0.5;
+                if (Ek <= Ek0_sigma || k == K - 1) break;
+                ++guard;
+            }
+            last_eo = true, last_from_batch = true;
+            continue; // (the loop test below: rejected -> ++guard and the next batch)
+        }
+        last_from_batch = false;
         HOT_LAUNCH(this, "linesearch_combine", k_combine<T>, div_up(n3, 256), 256, 0, n3, dv0.p, alpha, ddv, dvnew, dv.p); // the trial point, also as moveNodes' dv
         Ek = state_pass(dv.p, false, eo); // a trial needs the energy only; the force is rasterised once, at the accepted point
         last_eo = eo;
@@ -260,6 +287,8 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
         // the trial point outside anything representable — is a rejection like any other and the step is halved; the reference would
         // end the search there with NaN accepted.  Identical for every finite energy.
     } while (!(Ek <= (last_eo ? Ek0_sigma : Ek0)) && ++guard < 60);
+    if (last_from_batch) // a batch never wrote its trial points: the accepted one (after 60 rejections: the last), as the one-by-one search leaves it in dv and work3
+        HOT_LAUNCH(this, "linesearch_combine", k_combine<T>, div_up(n3, 256), 256, 0, n3, dv0.p, alpha * 2, ddv, dvnew, dv.p);
     if (!(Ek == Ek)) {
         // sixty halvings and still no number: is the search direction itself non-finite?
         double dd = dot_host(n3, ddv, ddv), d0 = dot_host(n3, dv0.p, dv0.p);

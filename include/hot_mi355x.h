@@ -320,7 +320,8 @@ int hot_rccl_selftest(hot_ctx*); /* runs every collective of the attached commun
 /* ---- the constitutive model and the plastic return mappings for caller-supplied deformation gradients (arrays of `real`,
  *      3x3 column-major, per-sample mu / lambda): CorotatedIsotropic<T,3>::updateScratch + psi + firstPiola +
  *      firstPiolaDerivative (Lib/Ziran/Physics/ConstitutiveModel/CorotatedIsotropic.h:110-230; dPdF is the 9x9 derivative, column-major
- *      over the column-major vectorisations of P and F, PSD-projected when project != 0), and
+ *      over the column-major vectorisations of P and F, PSD-projected when project == 1; project == 2: psi alone, evaluated as the line
+ *      search's energy-only trials evaluate it — from the invariants of F^T F without an SVD where det F > 0.1 —, P and dPdF untouched), and
  *      VonMisesFixedCorotated / SnowPlasticity::projectStrain (Lib/Ziran/Physics/PlasticityApplier.cpp:96-131, :18-50) with
  *      cfg.yield_stress / cfg.snow, in place.  NULL outputs are skipped. */
 int hot_constitutive_eval(hot_ctx*, int32_t n, const void* F /*9n*/, const void* mu /*n*/, const void* lambda /*n*/, int32_t project,

@@ -69,3 +69,64 @@ def test_explicit_bc_list_matches_halfspace(hotlib, oracle):
         out[name] = (dv, ctx.residual())
     assert rel(out["gpu"][0], out["cpu"][0]) < 1e-10
     assert rel(out["gpu"][1], out["cpu"][1]) < 1e-9
+
+
+def _exact_half_fr2_and_j(F):
+    """|F - R|_F^2 / 2 and J - 1 in 50-digit arithmetic (singular values with the reference's convention: an inverted element's negative one last)."""
+    import mpmath as mp
+    mp.mp.dps = 50
+    Fm = mp.matrix(F.tolist())
+    _, S, _ = mp.svd_r(Fm)
+    s = [S[i] for i in range(3)]
+    d = mp.det(Fm)
+    if d < 0:
+        s[2] = -s[2]
+    return float(sum((x - 1) ** 2 for x in s) / 2), float(d - 1)
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_trial_energy_without_svd(hotlib, oracle, dtype):
+    """The line search's energy-only evaluation (hot_constitutive.h corotated_psi_invariants: the polar decomposition's trace from the
+    invariants of F^T F, no SVD) against 50-digit arithmetic, against the full evaluation (one SVD, mu |F - R|^2: CorotatedIsotropic.h:151-155)
+    of the same library and against the oracle's; F = rotation x (I + strain x random) at strains 1e-8 .. 1, plus compressed / inverted
+    samples where the evaluation falls back on the singular values."""
+    pytest.importorskip("mpmath")
+    T = np.float64 if dtype == 1 else np.float32
+    eps = np.finfo(T).eps
+    mu, lam = 3.0e4, 7.0e4
+    rng = np.random.default_rng(11)
+    Fs, strain = [], []
+    for scale in (1e-8, 1e-6, 1e-4, 1e-2, 0.1, 0.3, 1.0):
+        k = 0
+        while k < 40:
+            Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+            if np.linalg.det(Q) < 0:
+                Q[:, 0] *= -1
+            F = (Q if k % 2 else np.eye(3)) @ (np.eye(3) + scale * rng.standard_normal((3, 3)))
+            if np.linalg.det(F) < 0.15:
+                continue
+            Fs.append(F), strain.append(scale)
+            k += 1
+    n_regular = len(Fs)
+    for s3 in (0.05, 1e-3, 0.0, -1e-3, -0.3, -0.9, -1.0):  # det F <= 0.1: the singular-value path
+        Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        Q2, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        Fs.append(Q @ np.diag([1.2, 1.0, s3]) @ Q2.T * np.sign(np.linalg.det(Q) * np.linalg.det(Q2))), strain.append(1.0)
+    F = np.stack(Fs).astype(T)
+    Fcm = np.ascontiguousarray(F.transpose(0, 2, 1).reshape(-1, 9))  # column-major 3x3
+    ctx = hotlib.context(dtype=dtype)
+    trial = ctx.trial_energy(Fcm, mu, lam).astype(np.float64)
+    full, _, _ = ctx.constitutive_eval(Fcm, mu, lam, project=0, derivative=False)
+    octx = oracle.context(dtype=dtype)
+    ofull, _, _ = octx.constitutive_eval(Fcm, mu, lam, project=0, derivative=False)
+    exact = np.array([_exact_half_fr2_and_j(f.astype(np.float64)) for f in F])
+    psi_exact = 2 * mu * exact[:, 0] + 0.5 * lam * exact[:, 1] ** 2
+    strain = np.array(strain)
+    # what any evaluation from F in T can deliver: F^T F - I (or sigma - 1) carries eps absolute, the energy is quadratic in a strain of size `strain`
+    bound = (40 if dtype == 1 else 200) * eps * ((mu + lam) * strain * (1 + strain) + psi_exact) + 1e-300
+    err_trial, err_full = np.abs(trial - psi_exact), np.abs(full.astype(np.float64) - psi_exact)
+    assert (err_trial / bound).max() < 1, (err_trial / bound).max()
+    assert (err_full / bound).max() < 1, (err_full / bound).max()
+    assert (np.abs(trial - ofull.astype(np.float64)) / bound).max() < 2
+    # and it is not the less accurate of the two where it replaces the SVD
+    assert np.median(err_trial[:n_regular] / np.maximum(err_full[:n_regular], 1e-300)) < 1.5

@@ -34,6 +34,7 @@ CASES = [
     ({"HOT_GS_FULL_RESIDUAL": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_MG_FULL_SPMV": "1"}, SOLVER, "vcycle or iterates"),
     ({"HOT_LBFGS_UNFUSED": "1"}, SOLVER, "iterates"),
+    ({"HOT_LS_NO_BATCH": "1"}, SOLVER, "iterates or objective_concept or knobs"),  # line-search trials one pass each instead of batches of 2 / 4 / 8 (trial_batch, force.hip)
     ({"HOT_CG_UNFUSED": "1"}, SOLVER, "smoothers or vcycle or iterates"),
     ({"HOT_CG_LAUNCHES": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # three launches per PCG iteration instead of the persistent launch on small top levels
     ({"HOT_GS_FAKE_TIMEOUT": "2"}, SOLVER, "smoothers or vcycle or iterates"),  # a chained sweep "times out" at the second synchronisation of every context: the operation is redone with one launch per pass
@@ -60,3 +61,42 @@ def test_kernel_variant_parity(env, path, expr):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_batched_line_search_trials_are_the_single_ones(dtype):
+    """A search that has to halve 3 .. 12 times, from the same state, with the trial energies taken from batches (one pass for 2 / 4 / 8 of them,
+    Ctx::trial_batch) and one pass each (A/B switch HOT_LS_NO_BATCH): the same step lengths (hence trial counts), the same accepted point
+    and residual (the batch's energies are bit-identical to the single passes' by construction)."""
+    import numpy as np
+    import hot_amd
+    from tests import pipeline_checks as pc
+    lib = hot_amd.HotLib(hot_amd.AB_LIB_PATH)
+    try:
+        d0 = None
+        for scale in (8.0, 100.0, 4000.0):
+            out = []
+            for no_batch in (False, True):
+                os.environ.pop("HOT_LS_NO_BATCH", None)
+                if no_batch:
+                    os.environ["HOT_LS_NO_BATCH"] = "1"
+                ctx, c = pc.make_ctx(lib, n=8, dtype=dtype, levelCnt=2, ls_energy_only=2)
+                pc.prepare(ctx)
+                ctx.update_state(ctx.get_dv())
+                r = ctx.residual()
+                if d0 is None:  # one direction for every context (two assemblies of the Hessian differ in the last bits: the order of the LDS atomics)
+                    ctx.build_hessian(), ctx.build_mg()
+                    d0 = ctx.project(ctx.vcycle(r))
+                d = d0 * scale  # an overlong step: the energy rises until it has been halved often enough
+                dd, r2, alpha = ctx.line_search(d, 1.0)
+                out.append((alpha, None, dd, r2, ctx.get_dv()))
+                ctx.line_search(d, 1.0)  # (a second search, whose first batch is sized by the first search's count; from the accepted point there is nothing to gain along d, where it stops is round-off)
+            a, b = out
+            assert a[0] == b[0], (scale, a[0], b[0])
+            assert a[0] <= 0.25, (scale, a[0])  # (three trials or more)
+            for k in (2, 3, 4):  # (the scatters' LDS-atomic order differs from context to context: equal to round-off, bitwise where no scatter is involved)
+                err = np.abs(a[k].astype(np.float64) - b[k]).max() / max(np.abs(b[k]).max(), 1e-300)
+                assert err < (1e-11 if dtype == 1 else 1e-4), (scale, k, err)
+    finally:
+        os.environ.pop("HOT_LS_NO_BATCH", None)
