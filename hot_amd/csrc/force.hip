@@ -325,7 +325,7 @@ __device__ __forceinline__ void gather_grad(const T* __restrict__ n0, const T* _
 #else
     constexpr bool nodewise = sizeof(T) == 4;
 #endif
-    if constexpr (nodewise) { // fp32: node by node, the oracle's float arithmetic (the fp32 whole-step parity test compares energies to 1e-5); not bound by issue there
+    if constexpr (nodewise) { // fp32: node by node, the reference's summation order in float (the fp32 whole-step parity test compares energies to 1e-5); not bound by issue there
 #pragma unroll
         for (int c = 0; c < 9; ++c) gv[c] = (T)0;
 #pragma unroll
