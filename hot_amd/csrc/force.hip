@@ -463,41 +463,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ENERGY_ONLY
     }
 }
 
-// K line-search trials in ONE pass (round 5): the trial points dv0 + alpha_k ddv, alpha_k = alpha / 2^k, are never written out — every trial gets
-// its own node tile in LDS, formed as k_combine + the tile gather of k_state form it, and every particle (position, Fn, weights read and
-// computed once) gathers K gradients and sums K energies with k_state<T, true>'s arithmetic in k_state<T, true>'s order: the K totals are
-// bit-identical to K energy-only passes.  lineSearch (ImplicitSolver.h:312-333) halves until the energy has not risen; at the stiffness of
-// C3 - C5 that is 4 - 5 trials an iteration, each of which used to be a launch bound by its workgroups' chains of dependent round trips
-// (header -> tile ids -> nodal values -> barrier -> particles -> block sum -> deposit), not by arithmetic or bytes: K trials per chain.
+// K line-search trials in ONE pass (round 5): the energies at dv0 + alpha_k ddv, alpha_k = alpha / 2^k.  grad v is linear in the nodal values and the
+// trial deformation gradient affine in alpha:  F(alpha) = (I + dt grad(vn + dv0 + alpha ddv)) Fn = A0 + alpha A1,  A0 = (I + dt G0) Fn, A1 = dt G1 Fn with
+// G0 = grad(vn + dv0), G1 = grad(ddv) — TWO gathers per particle (two node tiles in LDS) and two 3 x 3 products whatever K is, then 9 multiply-adds and the
+// SVD-free psi (corotated_psi_sigma) per trial: ~250 instructions a trial instead of the ~900 of a pass that gathers its own gradient.  G0 and A0 are the
+// full pass's own numbers (same tile values, same gather, same product), so F(alpha) -> the base point's F bit for bit as alpha -> 0 and a trial's energy
+// tends to Ek_sigma of the base point exactly (what line_search compares with).  Against a single energy-only pass of the same trial point (sharded runs,
+// A/B switch HOT_LS_NO_BATCH) F differs by rounding — eps |F|, the level at which the accepted point's own full pass differs as well.
+// lineSearch (ImplicitSolver.h:312-333) halves until the energy has not risen; at the stiffness of C3 - C5 that is 4 - 8 trials an iteration, each of
+// which used to be a launch bound by its workgroups' chains of dependent round trips (header -> tile ids -> nodal values -> barrier -> particles ->
+// block sum -> deposit), not by arithmetic or bytes: K trials per chain.
 template <class T, int K>
 struct TrialAlphas {
     T a[K];
 };
 template <class T, int K>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? 3 : 4))) void k_state_trials(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ Vol,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_state_trials(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ Vol,
     const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin, const int32_t* __restrict__ gIdx,
     const T* __restrict__ vn, const T* __restrict__ dv0, const T* __restrict__ ddv, TrialAlphas<T, K> al, T one_over_dx, T dt, double* energy, GridRed gr)
 {
     using G = Geo<T>;
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
-    __shared__ T nv[K][3][TILE];
+    __shared__ T nv[2][3][TILE]; // [0]: vn + dv0 (the base point, as the full pass stages it), [1]: ddv
     __shared__ double red[4 * K];
     const int g = blockIdx.x;
     const int first = group_first[g], last = group_first[g + 1];
     for (int t = threadIdx.x; t < TILE; t += 256) {
         const int idx = gIdx[(int64_t)g * TILE + t];
-        T v[3] = { 0, 0, 0 }, b[3] = { 0, 0, 0 }, d[3] = { 0, 0, 0 };
+        T a = 0, b = 0, c = 0, d0 = 0, d1 = 0, d2 = 0;
         if (idx >= 0) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) v[c] = vn[3 * idx + c], b[c] = dv0[3 * idx + c], d[c] = ddv[3 * idx + c];
+            a = vn[3 * idx] + dv0[3 * idx], b = vn[3 * idx + 1] + dv0[3 * idx + 1], c = vn[3 * idx + 2] + dv0[3 * idx + 2]; // k_state's expression
+            d0 = ddv[3 * idx], d1 = ddv[3 * idx + 1], d2 = ddv[3 * idx + 2];
         }
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const T trial = b[c] + d[c] * al.a[k]; // k_combine's expression
-                nv[k][c][t] = idx >= 0 ? v[c] + trial : (T)0;
-            }
+        nv[0][0][t] = a, nv[0][1][t] = b, nv[0][2][t] = c;
+        nv[1][0][t] = d0, nv[1][1][t] = d1, nv[1][2][t] = d2;
     }
     __syncthreads();
     const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
@@ -505,37 +504,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 #pragma unroll
     for (int k = 0; k < K; ++k) e[k] = 0;
     for (int p = first + threadIdx.x; p < last; p += 256) {
-        T xp[3];
+        Mat3<T> A0, A1;
+        {
+            T xp[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) xp[d] = X[(int64_t)d * Np + p];
-        int base[3];
-        T w[3][3], dw[3][3];
+            for (int d = 0; d < 3; ++d) xp[d] = X[(int64_t)d * Np + p];
+            int base[3];
+            T w[3][3], dw[3][3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx, xp[d], base[d], w[d], dw[d]);
-        const int t0 = (((base[0] - ox) * TY) + (base[1] - oy)) * TZ + (base[2] - oz);
-#pragma unroll 1 // one trial after the other, each with the register footprint of a pass of its own
-        for (int k = 0; k < K; ++k) {
-            // Nothing that a trial shares with the next is kept in registers across the loop but the weights: the 81 weight products (162 registers in
-            // fp64 if hoisted) are recomputed — the weights pass through an empty asm —, Fn and the material constants are re-read (cache hits; the
-            // particle index passes through an empty asm likewise).
-            T wl[3][3], dwl[3][3];
+            for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx, xp[d], base[d], w[d], dw[d]);
+            const int t0 = (((base[0] - ox) * TY) + (base[1] - oy)) * TZ + (base[2] - oz);
+            Mat3<T> Fo;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) Fo.a[c] = Fn[(int64_t)c * Np + p];
+            T gv[9];
+            gather_grad(nv[0][0], nv[0][1], nv[0][2], t0, TY * TZ, TZ, w, dw, one_over_dx, gv);
+            Mat3<T> A;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) A.a[c] = dt * gv[c] + ((c % 4 == 0) ? (T)1 : (T)0); // k_state's expressions: A0 is the base point's F
+            A0 = m3_mul(A, Fo);
+            // (the second gather after the first: its weight products recomputed — shared, they would be 81 live values — behind an empty asm)
 #pragma unroll
             for (int d = 0; d < 3; ++d)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    wl[d][i] = w[d][i], dwl[d][i] = dw[d][i];
-                    asm volatile("" : "+v"(wl[d][i]), "+v"(dwl[d][i]));
-                }
-            T gv[9];
-            gather_grad(nv[k][0], nv[k][1], nv[k][2], t0, TY * TZ, TZ, wl, dwl, one_over_dx, gv);
-            int pk = p;
-            asm volatile("" : "+v"(pk));
-            Mat3<T> A, Fo;
+                for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(w[d][i]), "+v"(dw[d][i]));
+            gather_grad(nv[1][0], nv[1][1], nv[1][2], t0, TY * TZ, TZ, w, dw, one_over_dx, gv);
 #pragma unroll
-            for (int c = 0; c < 9; ++c) A.a[c] = dt * gv[c] + ((c % 4 == 0) ? (T)1 : (T)0), Fo.a[c] = Fn[(int64_t)c * Np + pk];
-            const Mat3<T> Fnew = m3_mul(A, Fo);
-            const T mu = Mu[pk], la = Lam[pk], vol = Vol[pk];
-            const double val = (double)(vol * corotated_psi_sigma(Fnew, mu, la));
+            for (int c = 0; c < 9; ++c) A.a[c] = dt * gv[c];
+            A1 = m3_mul(A, Fo);
+        }
+        const T mu = Mu[p], la = Lam[p], vol = Vol[p];
+#pragma unroll 1 // one trial after the other: the Newton iterations of K trials interleaved would only cost registers
+        for (int k = 0; k < K; ++k) {
+            T ak = al.a[0];
+#pragma unroll
+            for (int kk = 1; kk < K; ++kk) ak = kk == k ? al.a[kk] : ak;
+            Mat3<T> Fk;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) Fk.a[c] = A0.a[c] + ak * A1.a[c];
+            const double val = (double)(vol * corotated_psi_sigma(Fk, mu, la));
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) e[kk] += kk == k ? val : 0.0; // (the sums stay in registers; + 0.0 changes nothing)
         }
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     grid_sum_store_n<K>(e, [](int k) { return k; }, K, gr, energy, red);
 }
 
-// the inertia / gravity sums of k_inertia_energy for the K trial points (same sums, same order: bit-identical)
+// the inertia / gravity sums of k_inertia_energy for the K trial points (k_combine's trial point, the same sums in the same order: bit-identical)
 template <class T, int K>
 __global__ __launch_bounds__(256) void k_inertia_energy_trials(const T* __restrict__ dv0, const T* __restrict__ ddv, TrialAlphas<T, K> al, const T* __restrict__ mass, int nn, T g0, T g1, T g2,
     double* out /*[2 K]: K kinetic sums, K gravity sums*/, GridRed gr)
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(256) void k_inertia_energy_trials(const T* __restri
     grid_sum_store_n<2 * K>(s, [](int k) { return k; }, 2 * K, gr, out, red);
 }
 
-// energies of the K trial points dv0 + (alpha / 2^k) ddv, k = 0 .. K - 1, as K calls of state_pass(.., energy_only = true) would return them
+// energies of the K trial points dv0 + (alpha / 2^k) ddv, k = 0 .. K - 1: what K calls of state_pass(.., energy_only = true) return, up to the rounding of F (above)
 template <class T>
 void Ctx<T>::trial_batch(const T* ddv, T alpha, int K, double* Ek_out)
 {

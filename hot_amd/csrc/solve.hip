@@ -247,17 +247,17 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
     const int eo_mode = cfg.ls_energy_only;
     bool eo = eo_mode == 2 || (eo_mode == 0 && ls_prev_trials > 1), last_eo = false;
     int trials = 0;
-    // Energy-only trials in batches (one rank; trial_batch, force.hip): the energies of alpha, alpha / 2, ... from ONE pass, bit-identical to the
-    // passes they replace, looked at in order — the search accepts what it would have accepted and counts the trials it would have run.  (A/B build: HOT_LS_NO_BATCH = 1 runs them one by one.)
+    // Energy-only trials in batches (one rank; trial_batch, force.hip): the energies of alpha, alpha / 2, ... from ONE pass (equal to the passes they
+    // replace up to the rounding of the trial F), looked at in order — the search accepts what it would have accepted and counts the trials it would have run.  (A/B build: HOT_LS_NO_BATCH = 1 runs them one by one.)
     const bool batched = !sharded() && !halo_mode() && !ab_flag("HOT_LS_NO_BATCH");
     bool last_from_batch = false;
-    int batches = 0, first_K = 0;
+    int batches = 0;
     do {
         if (eo && batched && guard + 2 <= 59) {
-            // a batch costs a fixed part (~1.7 trials' worth at C4) + its trials: as many as the previous search needed, 5 or 6 as 4 + 2
+            // a batch costs a fixed part (C4: 0.63 ms, the chain of a pass with two gathers) + 0.15 ms per trial: as many as the previous search needed,
+            // eights once a batch has failed
             const int pv = ls_prev_trials;
-            int K = batches == 0 ? (pv <= 2 ? 2 : (pv <= 6 ? 4 : 8)) : ((batches == 1 && first_K == 4 && (pv == 5 || pv == 6)) ? 2 : 4);
-            if (batches == 0) first_K = K;
+            int K = batches == 0 ? (pv <= 2 ? 2 : (pv <= 4 ? 4 : 8)) : 8;
             ++batches;
             while (guard + K > 59) K >>= 1; // (the search gives up after 60 trials)
             double Eb[8];

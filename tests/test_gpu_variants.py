@@ -34,7 +34,7 @@ CASES = [
     ({"HOT_GS_FULL_RESIDUAL": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_MG_FULL_SPMV": "1"}, SOLVER, "vcycle or iterates"),
     ({"HOT_LBFGS_UNFUSED": "1"}, SOLVER, "iterates"),
-    ({"HOT_LS_NO_BATCH": "1"}, SOLVER, "iterates or objective_concept or knobs"),  # line-search trials one pass each instead of batches of 2 / 4 / 8 (trial_batch, force.hip)
+    ({"HOT_LS_NO_BATCH": "1"}, SOLVER, "iterates or objective_concept or knobs"),  # line-search trials one pass each (their own gradient gather) instead of batches of 2 / 4 / 8 on F(alpha) = A0 + alpha A1 (trial_batch, force.hip)
     ({"HOT_CG_UNFUSED": "1"}, SOLVER, "smoothers or vcycle or iterates"),
     ({"HOT_CG_LAUNCHES": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # three launches per PCG iteration instead of the persistent launch on small top levels
     ({"HOT_GS_FAKE_TIMEOUT": "2"}, SOLVER, "smoothers or vcycle or iterates"),  # a chained sweep "times out" at the second synchronisation of every context: the operation is redone with one launch per pass
@@ -68,7 +68,7 @@ def test_kernel_variant_parity(env, path, expr):
 def test_batched_line_search_trials_are_the_single_ones(dtype):
     """A search that has to halve 3 .. 12 times, from the same state, with the trial energies taken from batches (one pass for 2 / 4 / 8 of them,
     Ctx::trial_batch) and one pass each (A/B switch HOT_LS_NO_BATCH): the same step lengths (hence trial counts), the same accepted point
-    and residual (the batch's energies are bit-identical to the single passes' by construction)."""
+    and residual (the batch evaluates F(alpha) = A0 + alpha A1, the single pass gathers the trial point's own gradient: equal to rounding)."""
     import numpy as np
     import hot_amd
     from tests import pipeline_checks as pc
