@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 // the inertia / gravity sums of k_inertia_energy for the K trial points (k_combine's trial point, the same sums in the same order: bit-identical)
 template <class T, int K>
 __global__ __launch_bounds__(256) void k_inertia_energy_trials(const T* __restrict__ dv0, const T* __restrict__ ddv, TrialAlphas<T, K> al, const T* __restrict__ mass, int nn, T g0, T g1, T g2,
-    double* out /*[2 K]: K kinetic sums, K gravity sums*/, GridRed gr)
+    double* out /*[2 K]: K kinetic sums, K gravity sums*/, GridRed gr, const uint8_t* __restrict__ mask /*the rows this rank owns (sharded, halo mode), else null*/)
 {
     __shared__ double red[8 * K];
     double s[2 * K];
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void k_inertia_energy_trials(const T* __restri
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (n0 + u * stride < nn) {
+            if (n0 + u * stride < nn && (!mask || mask[n0 + u * stride])) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const T a0 = b[u][0] + d[u][0] * al.a[k], a1 = b[u][1] + d[u][1] * al.a[k], a2 = b[u][2] + d[u][2] * al.a[k]; // k_combine's expression
@@ -589,7 +589,11 @@ __global__ __launch_bounds__(256) void k_inertia_energy_trials(const T* __restri
 template <class T>
 void Ctx<T>::trial_batch(const T* ddv, T alpha, int K, double* Ek_out)
 {
-    HOT_CHECK(!sharded() && !halo_mode() && (K == 2 || K == 4 || K == 8), HOT_ERR_INVALID, "trial_batch: one rank, 2 / 4 / 8 trials");
+    HOT_CHECK(K == 2 || K == 4 || K == 8, HOT_ERR_INVALID, "trial_batch: 2 / 4 / 8 trials");
+    if (halo_mode()) { // the base point and the direction at the nodes of this rank's particle tiles that other ranks own: two exchanges for K trials (a single pass: one per trial)
+        halo_gather(*levels[0], dv0.p);
+        halo_gather(*levels[0], const_cast<T*>(ddv));
+    }
     constexpr int S0 = 140, S1 = 148; // dscal / hscal slots: K strain energies, then K kinetic + K gravity sums
     const int grid = std::min(div_up(Nn, 1024), 1024);
     auto run = [&](auto kc) {
@@ -603,12 +607,22 @@ void Ctx<T>::trial_batch(const T* ddv, T alpha, int K, double* Ek_out)
             dscal.p + S0, g1);
         GridRed g2 = gred_n(grid, 2 * KK);
         g2.mirror = hscal + S1, g2.ticket = hscal + 251, g2.ticket_val = new_ticket();
-        HOT_LAUNCH(this, "inertia_trials", (k_inertia_energy_trials<T, KK>), grid, 256, 0, dv0.p, ddv, al, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + S1, g2);
+        HOT_LAUNCH(this, "inertia_trials", (k_inertia_energy_trials<T, KK>), grid, 256, 0, dv0.p, ddv, al, mass.p, Nn, (T)cfg.gravity[0], (T)cfg.gravity[1], (T)cfg.gravity[2], dscal.p + S1, g2, vmask);
     };
     if (K == 2) run(std::integral_constant<int, 2>());
     else if (K == 4) run(std::integral_constant<int, 4>());
     else run(std::integral_constant<int, 8>());
     wait_ticket();
+    if (sharded()) { // state_pass's sums over the ranks, for the K trials at once: the shards' strain energies; in halo mode the inertia terms of the rows every rank owns too
+        double buf[24];
+        const int nb = halo_mode() ? 3 * K : K;
+        for (int k = 0; k < K; ++k) buf[k] = hscal[S0 + k];
+        for (int k = 0; k < 2 * K; ++k) buf[K + k] = hscal[S1 + k];
+        c_allreduce(buf, nb, HOT_COMM_F64, HOT_COMM_SUM, false);
+        for (int k = 0; k < K; ++k) hscal[S0 + k] = buf[k];
+        if (halo_mode())
+            for (int k = 0; k < 2 * K; ++k) hscal[S1 + k] = buf[K + k];
+    }
     for (int k = 0; k < K; ++k) {
         double r = (double)(T)hscal[S0 + k]; // state_pass's assembly
         r += hscal[S1 + k] / 2;

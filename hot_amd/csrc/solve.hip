@@ -247,9 +247,9 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
     const int eo_mode = cfg.ls_energy_only;
     bool eo = eo_mode == 2 || (eo_mode == 0 && ls_prev_trials > 1), last_eo = false;
     int trials = 0;
-    // Energy-only trials in batches (one rank; trial_batch, force.hip): the energies of alpha, alpha / 2, ... from ONE pass (equal to the passes they
+    // Energy-only trials in batches (trial_batch, force.hip; sharded runs too: two halo exchanges and one all-reduce per batch instead of one each per trial): the energies of alpha, alpha / 2, ... from ONE pass (equal to the passes they
     // replace up to the rounding of the trial F), looked at in order — the search accepts what it would have accepted and counts the trials it would have run.  (A/B build: HOT_LS_NO_BATCH = 1 runs them one by one.)
-    const bool batched = !sharded() && !halo_mode() && !ab_flag("HOT_LS_NO_BATCH");
+    const bool batched = !ab_flag("HOT_LS_NO_BATCH");
     bool last_from_batch = false;
     int batches = 0;
     do {

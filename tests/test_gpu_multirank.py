@@ -101,11 +101,13 @@ def test_halo_bytes_scale_with_the_cut_surface():
     assert out[(48, 0)][0] < 0.3 * out[(48, 1)][0], out
 
 
-def test_whole_steps_over_ranks_with_migration_hip(hotlib):
+@pytest.mark.parametrize("eo", [0, 2], ids=["adaptive_trials", "energy_only_trials"])
+def test_whole_steps_over_ranks_with_migration_hip(hotlib, eo):
     """Four whole time steps on three ranks: the body falls and spins, particles change SPGrid pages every step and are handed to
     the rank of their page range at each hot_sort (hot_amd/csrc/shard.hip migrate_particles); the union of the ranks' particles,
-    matched by global id, follows the single-rank trajectory."""
-    kw = dict(lsolver=3, levelCnt=2, cneps=1e-6)
+    matched by global id, follows the single-rank trajectory.  ls_energy_only = 2: every line-search trial comes from a batch
+    (Ctx::trial_batch: the halos of the base point and the direction, one all-reduce for the batch's energies)."""
+    kw = dict(lsolver=3, levelCnt=2, cneps=1e-6, ls_energy_only=eo)
     ranks = mw.launch(3, "hip", 10, 1, kw, steps=4, partition_min_rows=1)
     ref = mw.single(hotlib, 10, 1, kw, steps=4)
     sizes = [len(o["ids"]) for o in ranks]
