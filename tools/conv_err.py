@@ -1,3 +1,5 @@
+"""Converged solves (tests/test_gpu_solver.py::test_solve_to_convergence_against_oracle) of three configurations against the oracle: mass-weighted
+|ddv| / |dv| and the counters, to see how far amplified round-off carries a long solve apart.  HOT_LIB selects another build of the library."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
