@@ -106,9 +106,6 @@ __device__ inline T corotated_psi_sigma(const Mat3<T>& F, T mu, T lambda)
 {
     T pt;
     if (corotated_psi_invariants(F, mu, lambda, pt)) return pt;
-#ifdef HOT_NO_SVD_FALLBACK // (experiment: what the trial pass costs without the singular-value path in the kernel)
-    return pt;
-#endif
     Mat3<T> U, V;
     T sg[3];
     svd3(F, U, sg, V);
