@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
     __shared__ T nv[2][3][TILE]; // [0]: vn + dv0 (the base point, as the full pass stages it), [1]: ddv
     __shared__ double red[4 * K];
+    __shared__ double esum[K][256]; // the thread's K running sums (in registers they are 2 K VGPRs live across everything: K = 16 would spill)
     const int g = blockIdx.x;
     const int first = group_first[g], last = group_first[g + 1];
     for (int t = threadIdx.x; t < TILE; t += 256) {
@@ -500,9 +501,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     }
     __syncthreads();
     const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
-    double e[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) e[k] = 0;
+    for (int k = 0; k < K; ++k) esum[k][threadIdx.x] = 0;
     for (int p = first + threadIdx.x; p < last; p += 256) {
         Mat3<T> A0, A1;
         {
@@ -542,11 +542,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
             Mat3<T> Fk;
 #pragma unroll
             for (int c = 0; c < 9; ++c) Fk.a[c] = A0.a[c] + ak * A1.a[c];
-            const double val = (double)(vol * corotated_psi_sigma(Fk, mu, la));
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk) e[kk] += kk == k ? val : 0.0; // (the sums stay in registers; + 0.0 changes nothing)
+            esum[k][threadIdx.x] += (double)(vol * corotated_psi_sigma(Fk, mu, la));
         }
     }
+    double e[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) e[k] = esum[k][threadIdx.x];
     block_sum_256_n<K>(e, [](int) { return true; }, red);
     grid_sum_store_n<K>(e, [](int k) { return k; }, K, gr, energy, red);
 }
@@ -589,12 +590,12 @@ __global__ __launch_bounds__(256) void k_inertia_energy_trials(const T* __restri
 template <class T>
 void Ctx<T>::trial_batch(const T* ddv, T alpha, int K, double* Ek_out)
 {
-    HOT_CHECK(K == 2 || K == 4 || K == 8, HOT_ERR_INVALID, "trial_batch: 2 / 4 / 8 trials");
+    HOT_CHECK(K == 2 || K == 4 || K == 8 || K == 16, HOT_ERR_INVALID, "trial_batch: 2 / 4 / 8 / 16 trials");
     if (halo_mode()) { // the base point and the direction at the nodes of this rank's particle tiles that other ranks own: two exchanges for K trials (a single pass: one per trial)
         halo_gather(*levels[0], dv0.p);
         halo_gather(*levels[0], const_cast<T*>(ddv));
     }
-    constexpr int S0 = 140, S1 = 148; // dscal / hscal slots: K strain energies, then K kinetic + K gravity sums
+    constexpr int S0 = 140, S1 = 160; // dscal / hscal slots: K <= 16 strain energies, then K kinetic + K gravity sums
     const int grid = std::min(div_up(Nn, 1024), 1024);
     auto run = [&](auto kc) {
         constexpr int KK = decltype(kc)::value;
@@ -603,7 +604,7 @@ void Ctx<T>::trial_batch(const T* ddv, T alpha, int K, double* Ek_out)
         for (int k = 0; k < KK; ++k) al.a[k] = a, a *= (T)0.5;
         GridRed g1 = gred_n(Ng, KK);
         g1.mirror = hscal + S0;
-        HOT_LAUNCH(this, KK == 2 ? "state_trials2" : (KK == 4 ? "state_trials4" : "state_trials8"), (k_state_trials<T, KK>), Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, tileDof.p, vn.p, dv0.p, ddv, al, (T)1 / dx, dt,
+        HOT_LAUNCH(this, KK == 2 ? "state_trials2" : (KK == 4 ? "state_trials4" : (KK == 8 ? "state_trials8" : "state_trials16")), (k_state_trials<T, KK>), Ng, 256, 0, pX.p, pFn.p, pVol.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, tileDof.p, vn.p, dv0.p, ddv, al, (T)1 / dx, dt,
             dscal.p + S0, g1);
         GridRed g2 = gred_n(grid, 2 * KK);
         g2.mirror = hscal + S1, g2.ticket = hscal + 251, g2.ticket_val = new_ticket();
@@ -611,10 +612,11 @@ void Ctx<T>::trial_batch(const T* ddv, T alpha, int K, double* Ek_out)
     };
     if (K == 2) run(std::integral_constant<int, 2>());
     else if (K == 4) run(std::integral_constant<int, 4>());
-    else run(std::integral_constant<int, 8>());
+    else if (K == 8) run(std::integral_constant<int, 8>());
+    else run(std::integral_constant<int, 16>());
     wait_ticket();
     if (sharded()) { // state_pass's sums over the ranks, for the K trials at once: the shards' strain energies; in halo mode the inertia terms of the rows every rank owns too
-        double buf[24];
+        double buf[48];
         const int nb = halo_mode() ? 3 * K : K;
         for (int k = 0; k < K; ++k) buf[k] = hscal[S0 + k];
         for (int k = 0; k < 2 * K; ++k) buf[K + k] = hscal[S1 + k];

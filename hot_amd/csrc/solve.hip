@@ -255,12 +255,12 @@ T Ctx<T>::line_search(T* ddv, T* residual_out, T alpha)
     do {
         if (eo && batched && guard + 2 <= 59) {
             // a batch costs a fixed part (C4: 0.63 ms, the chain of a pass with two gathers) + 0.15 ms per trial: as many as the previous search needed,
-            // eights once a batch has failed
+            // (2 / 4 / 8 / 16), eights once a batch has failed
             const int pv = ls_prev_trials;
-            int K = batches == 0 ? (pv <= 2 ? 2 : (pv <= 4 ? 4 : 8)) : 8;
+            int K = batches == 0 ? (pv <= 2 ? 2 : (pv <= 4 ? 4 : (pv <= 8 ? 8 : 16))) : 8;
             ++batches;
             while (guard + K > 59) K >>= 1; // (the search gives up after 60 trials)
-            double Eb[8];
+            double Eb[16];
             trial_batch(ddv, alpha, K, Eb);
             int k = 0;
             for (;; ++k) {
