@@ -84,8 +84,8 @@ typedef struct hot_config {
     int32_t shard_replicated; /* sharded runs: 0 (default) = halo mode: DOF vectors live on the rows a rank owns plus the halo it reads, node tiles are summed
                                  between the ranks that share a block, inner products are summed with one small all-reduce per batch; 1 = the first-generation
                                  decomposition: every DOF vector replicated, whole-array all-reduce per scatter and all-gather per operator (kept for A/B) */
-    int32_t ls_energy_only; /* line-search trials that evaluate nothing but the energy (psi from the invariants of F^T F — no SVD, no stress / trial-F stores —, on one rank
-                               up to 16 trials per pass), full state pass once at the accepted step: 0 = adaptive (default: from the second trial of a search on, and from the first when the previous search had to halve),
+    int32_t ls_energy_only; /* line-search trials that evaluate nothing but the energy (psi from the invariants of F^T F — no SVD, no stress / trial-F stores —, up to 16
+                               trials per pass: the trial F is affine in the step length), full state pass once at the accepted step: 0 = adaptive (default: from the second trial of a search on, and from the first when the previous search had to halve),
                                1 = never (every trial is a full pass), 2 = always */
     int32_t linear_iteration_cap; /* lsolver 1 / 2: iterations of one MINRES / PCG solve at most; 0 = the reference's 10000 (ImplicitSolver.h: the solvers' max_iterations).  A fixed
                                      small count makes two implementations stop at the same Lanczos step, whatever round-off does to the stopping test (parity tests) */
