@@ -130,3 +130,30 @@ def test_trial_energy_without_svd(hotlib, oracle, dtype):
     assert (np.abs(trial - ofull.astype(np.float64)) / bound).max() < 2
     # and it is not the less accurate of the two where it replaces the SVD
     assert np.median(err_trial[:n_regular] / np.maximum(err_full[:n_regular], 1e-300)) < 1.5
+
+
+@pytest.mark.parametrize("dtype,tol", [(1, 1e-10), (0, 2e-5)])
+def test_state_pass_with_inverted_elements_against_oracle(hotlib, oracle, dtype, tol):
+    """A state update far outside the elastic range (nodal velocity increments that turn some elements inside out: det F < 0.1, where the sign
+    convention of the singular values matters and the energy-only form falls back on them), then a moderate one in the same time step: energy, trial F
+    and stresses as the oracle's."""
+    out = {}
+    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
+        ctx, c = pc.make_ctx(lib, n=8, dtype=dtype, bc=True)
+        pc.prepare(ctx)
+        dv0 = ctx.get_dv()
+        rng = np.random.default_rng(5)
+        big = dv0 + (0.6 * c["dx"] * 24.0) * rng.standard_normal(dv0.shape).astype(dv0.dtype)  # displacements of ~0.6 dx over the step
+        e1 = ctx.update_state(big)
+        st1 = ctx.particle_state()
+        small = dv0 + 0.02 * rng.standard_normal(dv0.shape).astype(dv0.dtype)
+        e2 = ctx.update_state(small)
+        st2 = ctx.particle_state()
+        out[name] = (e1, st1, e2, st2)
+    g, c_ = out["gpu"], out["cpu"]
+    F = c_[1]["F"].astype(np.float64).reshape(-1, 3, 3)
+    assert (np.linalg.det(F) < 0.1).any()  # the case is what it says
+    for e_g, st_g, e_c, st_c in ((g[0], g[1], c_[0], c_[1]), (g[2], g[3], c_[2], c_[3])):
+        assert abs(e_g - e_c) < tol * 10 * max(abs(e_c), 1e-6)
+        for k in ("F", "stress"):
+            assert rel(st_g[k], st_c[k]) < tol * 20, (k, rel(st_g[k], st_c[k]))
