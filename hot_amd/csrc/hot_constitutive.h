@@ -28,7 +28,7 @@ __device__ __forceinline__ T clamp_small_magnitude(T x, T eps)
 // e1, e2, e3 of the Green strain E = (C - I) / 2 (I1 = 3 + 2 e1, I2 = 3 + 4 e1 + 4 e2, J^2 = 1 + q, q = 2 e1 + 4 e2 + 8 e3, j = J - 1 = q / (sqrt(1 + q) + 1),
 // e1 - j = j^2 / 2 - 2 e2 - 4 e3):  g(u) = u^4 + g3 u^3 + g2 u^2 + g1 u + g0 = 0 with g0 = O(strain^2) free of first-order terms.  u = 0 is the upper bound
 // sigma - 1 <= (sigma^2 - 1) / 2 of every term, i.e. a point beyond the quartic's largest root in s where it is convex: Newton from there is monotone, 2 - 4
-// steps at the strains of a time step, ~10 at 100 %.  Measured against 60-digit arithmetic (tests/test_gpu_force.py): relative error of u 8e-9 at strain
+// steps at the strains of a time step, ~10 at 100 %.  Measured against 50-digit arithmetic (tests/test_gpu_force.py::test_trial_energy_without_svd): relative error of u 8e-9 at strain
 // 1e-8, 1e-12 at 1e-4, 2e-15 at 0.1 in fp64 — a factor 3 - 6 BELOW the sigma form's (whose sigma_i - 1 cancels the same way), 4e-6 at 100 % in fp32.
 // Not for det F <= 0.1 (the sign convention puts an inverted element's negative singular value last, where the largest root may be a double one) nor
 // where Newton has not settled in 12 steps: false, and the caller takes the singular values.
