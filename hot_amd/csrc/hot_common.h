@@ -276,10 +276,19 @@ __device__ inline void grid_sum_store(double t0, double t1, int nv, GridRed gr, 
     }
     __syncthreads();
     if (!s_last) return; // workgroup-uniform
+    // The deposits come from past the L2 (a few microseconds per dependent round): eight rounds of loads are in flight per thread before the
+    // first addition; the additions keep the order i = thread, thread + 256, ...
     double a = 0, b = 0;
-    for (unsigned i = threadIdx.x; i < nb; i += 256) {
-        a += __hip_atomic_load(gr.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (nv > 1) b += __hip_atomic_load(gr.part + nb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned base = threadIdx.x; base < nb; base += 8 * 256) {
+        double va[8], vb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned i = base + 256u * j;
+            va[j] = i < nb ? __hip_atomic_load(gr.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            vb[j] = (nv > 1 && i < nb) ? __hip_atomic_load(gr.part + nb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += va[j], b += vb[j];
     }
     a = block_sum_256<double>(a, sm4);
     if (nv > 1) b = block_sum_256<double>(b, sm4);
@@ -319,10 +328,20 @@ __device__ inline void grid_sum_store_n(const double (&tot)[NVMAX], Slot slot, i
     double a[NVMAX];
 #pragma unroll
     for (int k = 0; k < NVMAX; ++k) a[k] = 0;
-    for (unsigned i = threadIdx.x; i < nb; i += 256) {
+    constexpr int J = NVMAX > 8 ? 2 : 4; // rounds of loads in flight per thread (see grid_sum_store); same order of additions as one round at a time
+    for (unsigned base = threadIdx.x; base < nb; base += J * 256) {
+        double v[NVMAX][J];
 #pragma unroll
-        for (int k = 0; k < NVMAX; ++k)
-            if (k < nv) a[k] += __hip_atomic_load(gr.part + (size_t)k * nb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < J; ++j) {
+            const unsigned i = base + 256u * j;
+#pragma unroll
+            for (int k = 0; k < NVMAX; ++k)
+                v[k][j] = (k < nv && i < nb) ? __hip_atomic_load(gr.part + (size_t)k * nb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int k = 0; k < NVMAX; ++k) a[k] += v[k][j];
     }
     block_sum_256_n<NVMAX>(a, [nv](int k) { return k < nv; }, smn);
     if (threadIdx.x == 0) {

@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(256) void k_gs_offblock(const int2* __restrict__ sl
 // bound by HBM, not by its chain any more.)
 template <class T, bool FWD, int D>
 __global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, const uint16_t* __restrict__ imgi, const int32_t* __restrict__ gs_pad, const T* __restrict__ part, T* x,
-    T* hD, int block0, const T* __restrict__ rhs)
+    T* hD, int block0, const T* __restrict__ rhs, T* hsub /*backward, or null: the forward sweep's h, which becomes h - du row by row for k_gs_residual<T, true>*/)
 {
     using I = GsImg<T>;
     const int lane = threadIdx.x;
@@ -1207,8 +1207,9 @@ __global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, cons
         hD[3 * (int64_t)node + 1] = dd[1] * a0 + dd[4] * a1 + dd[7] * a2;
         hD[3 * (int64_t)node + 2] = dd[2] * a0 + dd[5] * a1 + dd[8] * a2;
     }
-    else if (hD) { // backward: hD is the iterate u, which takes the correction here (u += du of gs_smooth)
-        hD[3 * (int64_t)node] += a0, hD[3 * (int64_t)node + 1] += a1, hD[3 * (int64_t)node + 2] += a2;
+    else {
+        if (hD) hD[3 * (int64_t)node] += a0, hD[3 * (int64_t)node + 1] += a1, hD[3 * (int64_t)node + 2] += a2; // backward: hD is the iterate u, which takes the correction here (u += du of gs_smooth)
+        if (hsub) hsub[3 * (int64_t)node] -= a0, hsub[3 * (int64_t)node + 1] -= a1, hsub[3 * (int64_t)node + 2] -= a2; // (nothing in the backward sweep reads h)
     }
 }
 
@@ -1629,8 +1630,17 @@ __global__ __launch_bounds__(SB * 16) void k_gs_sweep(const int32_t* __restrict_
     }
 }
 
-// r_i = sum over the nl slots preceding row i of A_ik (h - du)_k   (rows regrouped by k_gs_split_rows)
+// h -= du in place (every entry, owned or not: what k_gs_residual<T, true> gathers)
 template <class T>
+__global__ void k_gs_hdiff(size_t n3, T* __restrict__ h, const T* __restrict__ du)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) h[i] -= du[i];
+}
+// r_i = sum over the nl slots preceding row i of A_ik (h - du)_k   (rows regrouped by k_gs_split_rows)
+// DIFF: h holds h - du already (k_gs_hdiff): three gathered loads per entry instead of six — the gathers, not the matrix stream, are what
+// the six-load version waits for (one cache line per lane and instruction)
+template <class T, bool DIFF = false>
 __global__ __launch_bounds__(256) void k_gs_residual(const int32_t* __restrict__ col, const T* __restrict__ val, const int32_t* __restrict__ rowcnt, const T* __restrict__ h,
     const T* __restrict__ du, T* __restrict__ r, int n, const uint8_t* __restrict__ own, const uint8_t* __restrict__ owner /*rank-local GS (hot_config.shard_gs): owning rank of every row, else null*/,
     int me)
@@ -1644,7 +1654,8 @@ __global__ __launch_bounds__(256) void k_gs_residual(const int32_t* __restrict__
     T s0 = 0, s1 = 0, s2 = 0;
     auto add = [&](int k, int j) {
         const T* b = v + k * 9;
-        T x0 = h[3 * (int64_t)j] - du[3 * (int64_t)j], x1 = h[3 * (int64_t)j + 1] - du[3 * (int64_t)j + 1], x2 = h[3 * (int64_t)j + 2] - du[3 * (int64_t)j + 2];
+        T x0 = h[3 * (int64_t)j], x1 = h[3 * (int64_t)j + 1], x2 = h[3 * (int64_t)j + 2];
+        if (!DIFF) x0 -= du[3 * (int64_t)j], x1 -= du[3 * (int64_t)j + 1], x2 -= du[3 * (int64_t)j + 2];
         s0 += b[0] * x0 + b[3] * x1 + b[6] * x2;
         s1 += b[1] * x0 + b[4] * x1 + b[7] * x2;
         s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
@@ -1956,6 +1967,7 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             T* hD = fwd ? dAu : u;
             const char* nmT = fwd ? "gs_forward" : "gs_backward";
             const char* nmO = fwd ? "gs_forward_off" : "gs_backward_off";
+            T* hsub = (!fwd && !L.part) ? hdu : (T*)nullptr; // h - du for the residual, row by row (partitioned level: a rank substitutes its own blocks only — k_gs_hdiff afterwards)
             if (L.part) hD = fwd ? dAu : (T*)nullptr; // partitioned level: u takes the correction in one axpy after the colour exchanges (only the owner's rows would get it here)
             for (int q = 0; q < 8; ++q) {
                 const int c = fwd ? q : 7 - q;
@@ -1991,9 +2003,9 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
 #define HOT_SUBST_D(DD)                                                                                                                                                       \
     if (depth == DD) {                                                                                                                                                        \
         if (fwd)                                                                                                                                                              \
-            HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, DD>), nb, 64, 0, img_c, imgi_c, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);                 \
+            HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, DD>), nb, 64, 0, img_c, imgi_c, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs, hsub);                 \
         else                                                                                                                                                                  \
-            HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, DD>), nb, 64, 0, img_c, imgi_c, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);                \
+            HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, DD>), nb, 64, 0, img_c, imgi_c, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs, hsub);                \
         continue;                                                                                                                                                             \
     }
                 HOT_SUBST_D(4)
@@ -2004,9 +2016,9 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
 #undef HOT_SUBST_D
 #endif
                 if (fwd)
-                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, img_c, imgi_c, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
+                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, true, 8>), nb, 64, 0, img_c, imgi_c, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs, hsub);
                 else
-                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, 8>), nb, 64, 0, img_c, imgi_c, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs);
+                    HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, 8>), nb, 64, 0, img_c, imgi_c, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs, hsub);
             }
         };
         HOT_CHECK(sb == 16 || sb == 32 || sb == 64, HOT_ERR_INVALID, "hot_config.gs_sub_block must be 0 (auto), 16, 32 or 64");
@@ -2122,8 +2134,14 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             if (L.split && !simple_gs && !(level == 0 && !cfg.systemBCProject) && !no_lres) {
                 // r - A du = L (h - du): with (D+L) h = r and (D+U) du = D h the full product A du collapses to the
                 // strictly-preceding half of the matrix applied to (h - du) (same value, half the bytes of an SpMV)
-                HOT_LAUNCH(this, lname("gs_residual", L.id).c_str(), k_gs_residual<T>, xcd_grid(div_up(L.n, 4)), 256, 0, L.col.p, L.val.p, L.rowcnt.p, hdu, du, r, L.n, L.mask(),
-                    rank_local ? L.owner.p : (const uint8_t*)nullptr, comm.rank);
+                if (!dataflow) { // (the chained sweeps keep marks in hdu)
+                    if (!(pair_path && !L.part)) HOT_LAUNCH(this, "gs_hdiff", k_gs_hdiff<T>, div_up(n3, 256), 256, 0, n3, hdu, du); // (the pair path's backward substitutions have subtracted already)
+                    HOT_LAUNCH(this, lname("gs_residual", L.id).c_str(), (k_gs_residual<T, true>), xcd_grid(div_up(L.n, 4)), 256, 0, L.col.p, L.val.p, L.rowcnt.p, hdu, du, r, L.n, L.mask(),
+                        rank_local ? L.owner.p : (const uint8_t*)nullptr, comm.rank);
+                }
+                else
+                    HOT_LAUNCH(this, lname("gs_residual", L.id).c_str(), k_gs_residual<T>, xcd_grid(div_up(L.n, 4)), 256, 0, L.col.p, L.val.p, L.rowcnt.p, hdu, du, r, L.n, L.mask(),
+                        rank_local ? L.owner.p : (const uint8_t*)nullptr, comm.rank);
                 if (!hm) exchange(L, r, -1); // first-generation sharding: the restriction / the next smoother read all of r (halo mode: r is needed on owned rows only; restrict_dev fetches what it reads)
             }
             else {

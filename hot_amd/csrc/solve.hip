@@ -371,7 +371,11 @@ bool Ctx<T>::lbfgs_solve()
         int wk = order.back();
         const int m = (int)order.size() - 1; // stored curvature pairs
         const bool unfused = ab_flag("HOT_LBFGS_UNFUSED"); // A/B build only: dot / scalar / axpy as separate launches
-        const int vgrid = (int)std::min<size_t>(div_up(n3, 1024), 1024);
+#ifndef HOT_LB_PER_WG // elements of a DOF vector per workgroup of the two-loop's launches, and the most workgroups (tools/variant.sh experiments)
+#define HOT_LB_PER_WG 1024
+#define HOT_LB_MAX_WG 1024
+#endif
+        const int vgrid = (int)std::min<size_t>(div_up(n3, HOT_LB_PER_WG), HOT_LB_MAX_WG);
         LbVecs<T> hv{};
         if (unfused) {
             copy(n3, residual, hist_dg[wk].p);
