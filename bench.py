@@ -52,12 +52,22 @@ def pmc_traffic(symbol, dtype_name):
     files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_summary.json")))
     if not files:
         return None, None
-    newest_src = max((os.path.getmtime(f) for f in glob.glob(os.path.join(here, "hot_amd", "csrc", "*.hip"))), default=0.0)
-    if newest_src > os.path.getmtime(files[-1]):
-        print("bench: %s is older than hot_amd/csrc/*.hip: roofline.traffic is a RECORDED value of an earlier build (re-run profiles/run_profiles.sh)" % os.path.basename(files[-1]), file=sys.stderr)
-    want = symbol.replace("<T", "<" + dtype_name).replace(" ", "")
     with open(files[-1]) as fh:
         table = json.load(fh)
+    stamp = table.get("_build", {}).get("source_sha16")
+    if stamp is not None:  # the summary names the sources it was measured on (profiles/summarize_pmc.py)
+        import hashlib
+        h = hashlib.sha256()
+        for f in sorted(glob.glob(os.path.join(here, "hot_amd", "csrc", "*.hip")) + glob.glob(os.path.join(here, "hot_amd", "csrc", "*.h"))):
+            h.update(os.path.basename(f).encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+        stale = h.hexdigest()[:16] != stamp
+    else:  # older summaries: file times
+        stale = max((os.path.getmtime(f) for f in glob.glob(os.path.join(here, "hot_amd", "csrc", "*.hip"))), default=0.0) > os.path.getmtime(files[-1])
+    if stale:
+        print("bench: %s was measured on other kernel sources than hot_amd/csrc now holds: roofline.traffic is a RECORDED value of an earlier build (re-run profiles/run_profiles.sh)" % os.path.basename(files[-1]), file=sys.stderr)
+    want = symbol.replace("<T", "<" + dtype_name).replace(" ", "")
     for name, rec in table.items():
         if want in name.replace(" ", "") and "hbm_bytes_per_launch" in rec:
             return rec["hbm_bytes_per_launch"], os.path.relpath(files[-1], here)
