@@ -11,13 +11,13 @@ for the same symbol (profiles/).  `cpu_baseline` = the CPU oracle (a port of the
 OpenMP), REBUILT ON THE BENCH HOST (-O3 -march=native there, like the reference's CMakeLists.txt:28) and timed on its cores on the
 headline configuration itself: the first --cpu-iters L-BFGS iterations (default 12) of the first time step, Hessian + hierarchy build
 timed separately, in each of two variants ("faithful": serial where the reference is serial; "fair": those sections parallelised as
-well); the GPU takes the same bounded step beside it.  ~30 s of CPU work.
+well); the GPU takes the same bounded step beside it.  ~15 s of CPU work per variant on a 16-core host.
 
 N > 1: one process per GPU (launched by torch.distributed.run, or spawned here when WORLD_SIZE is unset), RCCL through
 torch.distributed.  ONE connected body is sharded over the ranks (hot_set_comm, hot_amd/dist.py): particle
 ranges of the global sort order per rank, node tiles summed between the ranks that share a block, matrix rows owned by one rank
-each, DOF vectors on owned rows + halos, inner products all-reduced in batches, coloured Gauss-Seidel rank-local (processor-block:
-one halo exchange per symmetric sweep; --shard-gs 0 = colour-synchronous, the single-rank iterates at sixteen exchanges per sweep).  Weak scaling: the body grows so that every GPU keeps C2's particle count
+each, DOF vectors on owned rows + halos, inner products all-reduced in batches, coloured Gauss-Seidel colour-synchronous across the ranks (the
+reference's update order and the single-rank iterates, sixteen halo exchanges per symmetric sweep; --shard-gs 1 = rank-local / processor-block sweeps with one exchange, opt-in).  Weak scaling: the body grows so that every GPU keeps C2's particle count
 (N = 8: a 126^3-cell body of 16 M particles, BASELINE config 4's size).
 """
 import argparse
@@ -36,6 +36,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measu
 SYMBOL = {  # profile-record prefix -> device symbol as rocprofv3 names it
     "gs_forward": "hot::k_gs_subst<T,true,8>", "gs_backward": "hot::k_gs_subst<T,false,8>", "spmv": "hot::k_spmv<T>",
     "gs_forward_off": "hot::k_gs_offblock<T>", "gs_backward_off": "hot::k_gs_offblock<T>",
+    "gs_forward_fused": "hot::k_gs_colour<T,", "gs_backward_fused": "hot::k_gs_colour<T,",  # <T, true, 8> and <T, false, 8>: one kernel, two sweep directions
     "gs_forward_chained": "hot::k_gs_sweep<T,true,SB>", "gs_backward_chained": "hot::k_gs_sweep<T,false,SB>",
     "gs_residual": "hot::k_gs_residual<T>", "hessian_assemble": "hot::k_hessian_rows<T>", "state_update": "hot::k_state<T>",
     "force_scatter": "hot::k_force_cells2<T>", "p2g": "hot::k_p2g_cells2<T,true>", "g2p": "hot::k_g2p<T,0,true>",
@@ -68,10 +69,13 @@ def pmc_traffic(symbol, dtype_name):
     if stale:
         print("bench: %s was measured on other kernel sources than hot_amd/csrc now holds: roofline.traffic is a RECORDED value of an earlier build (re-run profiles/run_profiles.sh)" % os.path.basename(files[-1]), file=sys.stderr)
     want = symbol.replace("<T", "<" + dtype_name).replace(" ", "")
-    for name, rec in table.items():
+    tot, n = 0.0, 0.0
+    for name, rec in table.items():  # (a symbol prefix names all its instantiations: average over their launches)
         if want in name.replace(" ", "") and "hbm_bytes_per_launch" in rec:
-            return rec["hbm_bytes_per_launch"], os.path.relpath(files[-1], here)
-    return None, None
+            k = float(rec.get("FETCH_SIZE", {}).get("n", 1) or 1)
+            tot += rec["hbm_bytes_per_launch"] * k
+            n += k
+    return (tot / n, os.path.relpath(files[-1], here)) if n else (None, None)
 
 
 def host_cores():
@@ -123,11 +127,14 @@ def make_ctx(lib, cloud, cfg, device=0, profile=0, comm=None, **over):
 def algorithmic_bytes(name, s, Np, levels, launches_per_half_sweep=8.0):
     """SURVEY.md §8(d) per-launch algorithmic (compulsory) bytes of one profile record; None if not modelled."""
     base, _, lv = name.rpartition("_L")
-    if base in ("gs_forward_off", "gs_backward_off", "gs_forward", "gs_backward") and lv.isdigit() and len(levels[int(lv)]) > 2 and levels[int(lv)][2] is not None:
+    if base in ("gs_forward_off", "gs_backward_off", "gs_forward", "gs_backward", "gs_forward_fused", "gs_backward_fused") and lv.isdigit() and len(levels[int(lv)]) > 2 and levels[int(lv)][2] is not None:
         # the finest level's colour pass is two kernels (one launch each per colour): k_gs_offblock streams the off-block half rows
         # (values + tagged column ids, the gathered x is cache traffic), reads rhs and the 32-byte row record, writes rhs - sum;
         # k_gs_subst reads the premultiplied in-block couplings (no column ids), D^-1 (forward also D) and p1, writes x and hD
         N, nnzb, inb = levels[int(lv)]
+        if base.endswith("_fused"):  # both of the above in ONE launch per colour (k_gs_colour); the previous-colour sums stay in LDS
+            fw = base == "gs_forward_fused"
+            return ((nnzb - N - inb) / 2.0 * (9 * s + 4) + N * (6 * s + 32) + inb / 2.0 * 9 * s + N * ((18 if fw else 9) * s + 3 * s + 6 * s + 4)) / launches_per_half_sweep
         if base.endswith("_off"):
             return ((nnzb - N - inb) / 2.0 * (9 * s + 4) + N * (6 * s + 32)) / launches_per_half_sweep
         return (inb / 2.0 * 9 * s + N * ((18 if base == "gs_forward" else 9) * s + 3 * s + 6 * s + 4)) / launches_per_half_sweep
@@ -210,9 +217,11 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo with --share-gpu on a one-GPU box)")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N > 1: native stream-ordered RCCL communicator of the library (falls back to torch if RCCL "
                     "cannot be attached) or hot_amd.dist.TorchComm (torch.distributed collectives, host-synchronous)")
-    ap.add_argument("--shard-gs", type=int, default=1, choices=[0, 1], help="N > 1, coloured GS across ranks: 1 = processor-block (one exchange per symmetric sweep; default), "
-                    "0 = colour-synchronous (the single-rank iterates, sixteen exchanges per symmetric sweep)")
-    ap.add_argument("--shard-owner", type=int, default=0, help="N > 1, hot_config.shard_owner: 0 = balanced row ownership along the cuts (default), 1 = the first-touching rank owns (rounds 2 - 4), k >= 2 = balanced with a period of 2^k nodes")
+    ap.add_argument("--shard-gs", type=int, default=0, choices=[0, 1], help="N > 1, coloured GS across ranks: 0 = colour-synchronous (default since round 6: the reference's update order, the single-rank "
+                    "iterates and iteration counts, sixteen halo exchanges per symmetric sweep), 1 = processor-block / rank-local (one exchange per symmetric sweep; another smoother: "
+                    "iteration counts drift by +-15 - 25 % and small sub-domains — 24^3 cells per rank — do not converge, profiles/r05_shard_ownership.txt)")
+    ap.add_argument("--shard-owner", type=int, default=0, choices=[0, 1, 2], help="N > 1, hot_config.shard_owner: 0 = by the smoother (default: page-range ownership under --shard-gs 0, first touch under --shard-gs 1), "
+                    "1 = the first-touching rank owns a block (rounds 2 - 4), 2 = the rank whose page range holds the block (balanced along the cuts)")
     ap.add_argument("--watchdog-s", type=float, default=1500.0, help="N > 1: abort the rank (exit code 3) if the run has not finished after this many seconds (a peer that died or a wedged collective would otherwise hang the job); 0 = off")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = the body grows so that every GPU keeps the configuration's particle count (default); "
                     "strong = the configuration's own body (e.g. --config C4 --gpus 4: BASELINE's 16 M particles over four GPUs), every rank generating only its cell planes")
@@ -328,13 +337,13 @@ def main():
                 r["calls"] += v["calls"]
                 r["total_ms"] += v["total_ms"]
             xfer_steps.append({k: t1[k]["total_ms"] / t1[k]["calls"] for k in ("p2g", "p2g_reduce", "g2p") if k in t1})
-        levels = [(pctx.level(l, coords=False)["nrows"], pctx.level_nnzb(l), pctx.level_inblock_nnzb(l) if ("gs_forward_off_L%d" % l) in table else None) for l in range(pst[-1]["num_levels"])]
+        levels = [(pctx.level(l, coords=False)["nrows"], pctx.level_nnzb(l), pctx.level_inblock_nnzb(l) if ("gs_forward_off_L%d" % l) in table or ("gs_forward_fused_L%d" % l) in table else None) for l in range(pst[-1]["num_levels"])]
         total_ms = sum(v["total_ms"] for v in table.values())
         groups = {}
         for name, rec in table.items():
             base = name.rpartition("_L")[0] if name.rpartition("_L")[2].isdigit() else name
             sweeps = table.get("gs_symsweeps_L" + name.rpartition("_L")[2])
-            lph = rec["calls"] / sweeps["calls"] if sweeps and base in ("gs_forward", "gs_backward", "gs_forward_off", "gs_backward_off") else 8.0  # launches per half sweep
+            lph = rec["calls"] / sweeps["calls"] if sweeps and base in ("gs_forward", "gs_backward", "gs_forward_off", "gs_backward_off", "gs_forward_fused", "gs_backward_fused") else 8.0  # launches per half sweep
             if base in ("gs_forward", "gs_backward") and lph < 1.5:
                 base += "_chained"  # coarse levels: the whole half sweep is one k_gs_sweep launch (a different device symbol)
             g = groups.setdefault(SYMBOL.get(base, base), dict(ms=0.0, calls=0, bytes=0.0, modelled=True, records={}))  # by device symbol: the forward and backward off-block sums are one kernel

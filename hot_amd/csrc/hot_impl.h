@@ -65,6 +65,10 @@ struct Level {
     DBuf<int2> gs_slot; // {first stored entry (row * 125 + k), entries} per slot (k_gs_slot_fill); gs_pad[8 pos + 5 / 6]: the position's first forward / backward slot
     int gs_nslot = 0;
     int32_t gs_slot_rng[2][2][8] = {}; // [forward / backward][first / end][colour]: the off-block slots of the colour's blocks — on a row-partitioned level of the blocks THIS rank owns
+    DBuf<int32_t> gs_rowpn; // n: of a row's two off-block runs, the entries in the colour swept just before the row's own: forward | backward << 16 (k_gs_split_rows)
+    DBuf<int4> gs_srec; // one rank (k_gs_colour): nblocks*64 + 1: per (colour block, position) the first slot in each of the four lists {forward older, forward previous-colour, backward older, backward previous-colour} (k_gs_slot_fill2)
+    int32_t gs_slot_rng2[4][2][8] = {}; // [list][first / end][colour]
+    bool gs_fused_ready = false; // the slots are the four lists of k_gs_colour (else the two of k_gs_offblock)
     bool gs_img_ready = false;
     long long gs_img_shift[8] = {}; // per colour: image index of a block = its block id + this (row-partitioned level: only the blocks this rank owns — one contiguous run per colour — have images; else 0)
     DBuf<T> gs_w; // chained levels (k_gs_sweep<.., WINV>): nblocks * 2 * 9 * 2017: (I - N)^-1 - I of every colour block's in-block triangle, forward / backward (k_gs_winv, mg_build.hip)
@@ -332,6 +336,7 @@ struct Ctx : CtxBase {
     DBuf<unsigned long long> col_hr;
     DBuf<int32_t> col_hi, col_cb;
     DBuf<unsigned> cg_bar; // k_cg_persist: barrier arrival counter + exit counter (zero between launches)
+    bool cg_bar_dirty = false; // a spinning kernel timed out since the counters were last cleared (Ctx::sync): they may hold a partial count
     DBuf<double> cg_dep; // its dot-product deposits, two alternating sets of two per workgroup
     int cg_group = 2; // iterations the last fused top-level PCG took: size of the first group of launches of the next one
     int gs_epoch = 0; // sweep number, never reused inside a context
@@ -422,6 +427,7 @@ struct Ctx : CtxBase {
         if (*(volatile int*)(hscal + 250) != 0) {
             *(volatile int*)(hscal + 250) = 0;
             gs_no_chain = gs_chain_timed_out = true;
+            cg_bar_dirty = true; // a k_cg_persist workgroup that gave up did not re-arm the barrier counters: cleared before the next persistent launch (after rearm_chain)
             ++gs_timeouts, steps_since_timeout = 0;
             throw Error{ ERR_RETRY, "k_gs_sweep: wait on a neighbouring block timed out; redoing the operation with one launch per pass" };
         }

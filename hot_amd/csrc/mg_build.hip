@@ -421,7 +421,9 @@ static void mark_colors(Ctx<T>* ctx, Level<T>& L)
         for (int r = 0; r <= np.R; ++r) np.v[r] = L.nstart[r];
         int mode = 0;
         const uint8_t* fine_owner = nullptr;
-        if (ctx->cfg.shard_owner == 0) {
+        // 0 = by the sweep: page-range ownership under colour-synchronous sweeps; first touch under rank-local sweeps, which hold their iteration bound only under it
+        const bool page_owner = ctx->cfg.shard_owner == 2 || (ctx->cfg.shard_owner == 0 && ctx->cfg.shard_gs == 0);
+        if (page_owner) {
             if (L.id == 0 && (int)ctx->page_split.size() == np.R - 1 && ctx->halo_mode() && ctx->sharers.p) {
                 mode = 1;
                 for (int r = 0; r < np.R - 1; ++r) np.split[r] = ctx->page_split[r];
@@ -473,7 +475,8 @@ static void mark_colors(Ctx<T>* ctx, Level<T>& L)
 // per row, the row is staged in LDS and rewritten in place.  rowcnt[4 i ..] = the four off-diagonal class sizes.
 template <class T>
 __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col, T* __restrict__ val, const uint32_t* __restrict__ ckey, int32_t* __restrict__ rowcnt, int n,
-    const uint8_t* __restrict__ own, int32_t* __restrict__ gcol /*may be null: the tagged copy of col (in-block column -> -1 - its position in the colour block) the finest-level GS kernels read*/)
+    const uint8_t* __restrict__ own, int32_t* __restrict__ gcol /*may be null: the tagged copy of col (in-block column -> -1 - its position in the colour block) the finest-level GS kernels read*/,
+    int32_t* __restrict__ rowpn /*may be null: per row, class 0 (preceding off-block columns of the colour just before the row's) | class 6 (following ones of the colour just after) << 16*/)
 {
     __shared__ T sval[4][1125];
     __shared__ int32_t scol[4][125];
@@ -542,11 +545,13 @@ __global__ __launch_bounds__(256) void k_gs_split_rows(int32_t* __restrict__ col
     if (gcol)
         for (int k = lane; k < 125; k += 64) gcol[(int64_t)i * 125 + k] = sgcol[w][k];
     if (lane == 0) rowcnt[4 * i] = cnt[0] + cnt[1], rowcnt[4 * i + 1] = cnt[2], rowcnt[4 * i + 2] = cnt[4], rowcnt[4 * i + 3] = cnt[5] + cnt[6];
+    if (lane == 0 && rowpn) rowpn[i] = cnt[0] | (cnt[6] << 16);
 }
 
 // per (colour block, position in block) record {node or -1, the node's four row-class counts}: one 32-byte load gives a GS
 // workgroup everything it needs before it can start streaming rows (instead of block_start -> gs_order -> rowcnt)
-__global__ void k_gs_pad(const int32_t* __restrict__ block_start, const int32_t* __restrict__ gs_order, const int32_t* __restrict__ rowcnt, int32_t* __restrict__ pad, int nblocks)
+__global__ void k_gs_pad(const int32_t* __restrict__ block_start, const int32_t* __restrict__ gs_order, const int32_t* __restrict__ rowcnt, int32_t* __restrict__ pad, int nblocks,
+    const int32_t* __restrict__ rowpn /*may be null*/)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nblocks * 64) return;
@@ -556,7 +561,8 @@ __global__ void k_gs_pad(const int32_t* __restrict__ block_start, const int32_t*
     int32_t* o = pad + 8 * (int64_t)e;
     o[0] = node;
     for (int k = 0; k < 4; ++k) o[1 + k] = node >= 0 ? rowcnt[4 * node + k] : 0;
-    o[5] = o[6] = o[7] = 0;
+    o[5] = o[6] = 0;
+    o[7] = (node >= 0 && rowpn) ? rowpn[node] : 0; // the share of the two off-block runs that belongs to the neighbouring colour (k_gs_slot_fill2)
 }
 
 // Off-block slots for k_gs_offblock (mg_solve.hip): a row's preceding (forward sweep) / following (backward sweep) off-block columns are cut
@@ -602,6 +608,62 @@ __global__ void k_gs_slot_fill(int32_t* __restrict__ pad, const int32_t* __restr
     for (int q = 0; 16 * q < po; ++q) slot[sf + q] = make_int2(base + 16 * q, min(16, po - 16 * q));
     const int kb = po + pi + 1 + fi;
     for (int q = 0; 16 * q < fo; ++q) slot[sb + q] = make_int2(base + kb + 16 * q, min(16, fo - 16 * q));
+}
+
+// The same slots split by the AGE of what they read (k_gs_colour, mg_solve.hip): a row's off-block run of a direction is [columns of the colour
+// swept just before the row's own | older colours] (forward; backward: [older | the colour just before in the backward order], k_gs_split_rows'
+// classes 0 / 1 and 5 / 6).  The older part is final one colour pass earlier and streams beside the previous colour's substitutions; the part
+// that reads the previous colour is summed by the row's own colour block.  Four lists, each numbered in (colour block, position) order:
+// 0 forward older, 1 forward previous-colour, 2 backward older, 3 backward previous-colour; srec[pos] = the position's first slot in each
+// (record npos: the ends).
+__device__ __forceinline__ void gs_slot_runs(const int32_t* o, int (&first)[4], int (&cnt)[4]) // entry offsets inside the row and lengths of the four runs
+{
+    const int po = o[1], pi = o[2], fi = o[3], fo = o[4], c0 = o[7] & 0xffff, c6 = (o[7] >> 16) & 0xffff;
+    const int kb = po + pi + 1 + fi;
+    first[0] = c0, cnt[0] = po - c0; // forward older
+    first[1] = 0, cnt[1] = c0; // forward, of the previous colour
+    first[2] = kb, cnt[2] = fo - c6; // backward older
+    first[3] = kb + fo - c6, cnt[3] = c6; // backward, of the colour walked just before
+}
+__global__ void k_gs_slot_count2(const int32_t* __restrict__ pad, int32_t* __restrict__ flags, int npos)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npos) return;
+    const int32_t* o = pad + 8 * (int64_t)e;
+    int first[4], cnt[4];
+    gs_slot_runs(o, first, cnt);
+    for (int k = 0; k < 4; ++k) flags[(size_t)k * npos + e] = o[0] >= 0 ? (cnt[k] + 15) >> 4 : 0;
+}
+struct GsColourStarts2 {
+    int pos[2][8];
+};
+__global__ void k_gs_slot_starts2(const int32_t* __restrict__ scan, GsColourStarts2 cs, int npos, int total, int32_t* __restrict__ out)
+{
+    const int e = threadIdx.x; // [list][first / end][colour]
+    if (e >= 64) return;
+    const int k = e >> 4, p = cs.pos[(e >> 3) & 1][e & 7];
+    const size_t at = (size_t)k * npos + p;
+    out[e] = at < 4 * (size_t)npos ? scan[at] : total;
+}
+__global__ void k_gs_slot_fill2(const int32_t* __restrict__ pad, const int32_t* __restrict__ scan, int2* __restrict__ slot, int4* __restrict__ srec, int npos, int total)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > npos) return;
+    if (e == npos) { // where the lists end
+        srec[e] = make_int4(scan[(size_t)npos], scan[2 * (size_t)npos], scan[3 * (size_t)npos], total);
+        return;
+    }
+    const int32_t* o = pad + 8 * (int64_t)e;
+    int s[4];
+    for (int k = 0; k < 4; ++k) s[k] = scan[(size_t)k * npos + e];
+    srec[e] = make_int4(s[0], s[1], s[2], s[3]);
+    const int node = o[0];
+    if (node < 0) return;
+    int first[4], cnt[4];
+    gs_slot_runs(o, first, cnt);
+    const int base = node * 125;
+    for (int k = 0; k < 4; ++k)
+        for (int q = 0; 16 * q < cnt[k]; ++q) slot[s[k] + q] = make_int2(base + first[k] + 16 * q, min(16, cnt[k] - 16 * q));
 }
 
 // In-block images for the finest-level GS kernels (layout: GsImg, hot_impl.h; consumer: k_gs_subst, mg_solve.hip).  One workgroup per
@@ -699,9 +761,10 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
     L.rowcnt.reserve(4 * (size_t)L.n);
     if (L.part) HOT_HIP(hipMemsetAsync(L.rowcnt.p, 0, 4 * (size_t)L.n * sizeof(int32_t), ctx->stream)); // rows of other ranks: no matrix, zero counts
     L.gs_col.reserve(125 * (size_t)L.n);
-    HOT_LAUNCH(ctx, "gs_split_rows", k_gs_split_rows<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.ckey.p, L.rowcnt.p, L.n, L.mask(), L.gs_col.p);
+    L.gs_rowpn.reserve((size_t)L.n);
+    HOT_LAUNCH(ctx, "gs_split_rows", k_gs_split_rows<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.ckey.p, L.rowcnt.p, L.n, L.mask(), L.gs_col.p, L.gs_rowpn.p);
     L.gs_pad.reserve(512 * (size_t)L.nblocks + 8); // + the sentinel record of k_gs_slot_fill
-    HOT_LAUNCH(ctx, "gs_pad", k_gs_pad, div_up((size_t)L.nblocks * 64, 256), 256, 0, L.gs_block_start.p, L.gs_order.p, L.rowcnt.p, L.gs_pad.p, L.nblocks);
+    HOT_LAUNCH(ctx, "gs_pad", k_gs_pad, div_up((size_t)L.nblocks * 64, 256), 256, 0, L.gs_block_start.p, L.gs_order.p, L.rowcnt.p, L.gs_pad.p, L.nblocks, L.gs_rowpn.p);
     L.split = true;
     // levels whose colours hold more blocks than the chip has compute units (smooth_dev: below that the chained single-launch sweep is as fast) run the off-block / substitution kernel
     // pair, which reads the in-block couplings from premultiplied images
@@ -732,6 +795,29 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
             L.gs_imgi.reserve(2 * GsImg<T>::idx_per_dir * (size_t)std::max<long long>(have, 1));
         }
         const int npos = 64 * L.nblocks;
+        // one rank: the colour pass is ONE launch (k_gs_colour) that needs the slots split by the age of what they read (A/B build: HOT_GS_PAIR = the
+        // kernel pair k_gs_offblock + k_gs_subst, which a row-partitioned level runs — a colour exchange sits between its passes)
+        L.gs_fused_ready = false;
+        if (!L.part && !ab_flag("HOT_GS_PAIR")) {
+            ctx->flags.reserve(4 * (size_t)npos + 64), ctx->scan.reserve(4 * (size_t)npos);
+            HOT_LAUNCH(ctx, "gs_slot_count", k_gs_slot_count2, div_up((size_t)npos, 256), 256, 0, L.gs_pad.p, ctx->flags.p, npos);
+            L.gs_nslot = ctx->exclusive_scan_i32(ctx->flags.p, ctx->scan.p, 4 * (size_t)npos);
+            L.gs_slot.reserve((size_t)L.gs_nslot + 8), L.gs_p1.reserve(3 * ((size_t)L.gs_nslot + 8)), L.gs_srec.reserve((size_t)npos + 1);
+            HOT_LAUNCH(ctx, "gs_slot_fill", k_gs_slot_fill2, div_up((size_t)npos + 1, 256), 256, 0, L.gs_pad.p, ctx->scan.p, L.gs_slot.p, L.gs_srec.p, npos, L.gs_nslot);
+            GsColourStarts2 cs;
+            for (int c = 0; c < 8; ++c) cs.pos[0][c] = 64 * L.color_block_begin[c], cs.pos[1][c] = 64 * L.color_block_begin[c + 1];
+            int32_t* d = (int32_t*)(ctx->flags.p); // (flags: consumed by the scan above)
+            HOT_LAUNCH(ctx, "gs_slot_starts", k_gs_slot_starts2, 1, 64, 0, ctx->scan.p, cs, npos, L.gs_nslot, d);
+            int32_t h[64];
+            HOT_HIP(hipMemcpyAsync(h, d, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            ctx->sync();
+            for (int k = 0; k < 4; ++k)
+                for (int fe = 0; fe < 2; ++fe)
+                    for (int c = 0; c < 8; ++c) L.gs_slot_rng2[k][fe][c] = h[16 * k + 8 * fe + c];
+            HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, L.nblocks, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p, L.gs_imgi.p, 0);
+            L.gs_img_ready = L.gs_fused_ready = true;
+            return;
+        }
         ctx->flags.reserve(2 * (size_t)npos), ctx->scan.reserve(2 * (size_t)npos);
         HOT_LAUNCH(ctx, "gs_slot_count", k_gs_slot_count, div_up((size_t)npos, 256), 256, 0, L.gs_pad.p, ctx->flags.p, npos);
         L.gs_nslot = ctx->exclusive_scan_i32(ctx->flags.p, ctx->scan.p, 2 * (size_t)npos);
@@ -1044,8 +1130,8 @@ void Ctx<T>::build_mg()
         Level<T>& Top = *levels.back();
         build_ic(Top);
         Top.ic_rowcnt.reserve(4 * (size_t)Top.n), Top.ic_pad.reserve(512 * (size_t)Top.nblocks);
-        HOT_LAUNCH(this, "gs_split_rows", k_gs_split_rows<T>, div_up(Top.n, 4), 256, 0, Top.ic_col.p, Top.ic_val.p, Top.ckey.p, Top.ic_rowcnt.p, Top.n, (const uint8_t*)nullptr, (int32_t*)nullptr);
-        HOT_LAUNCH(this, "gs_pad", k_gs_pad, div_up((size_t)Top.nblocks * 64, 256), 256, 0, Top.gs_block_start.p, Top.gs_order.p, Top.ic_rowcnt.p, Top.ic_pad.p, Top.nblocks);
+        HOT_LAUNCH(this, "gs_split_rows", k_gs_split_rows<T>, div_up(Top.n, 4), 256, 0, Top.ic_col.p, Top.ic_val.p, Top.ckey.p, Top.ic_rowcnt.p, Top.n, (const uint8_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+        HOT_LAUNCH(this, "gs_pad", k_gs_pad, div_up((size_t)Top.nblocks * 64, 256), 256, 0, Top.gs_block_start.p, Top.gs_order.p, Top.ic_rowcnt.p, Top.ic_pad.p, Top.nblocks, (const int32_t*)nullptr);
     }
     if (colors) split_rows(this, *levels.back());
     sync();

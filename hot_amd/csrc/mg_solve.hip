@@ -1062,22 +1062,11 @@ struct GsOffItem { // what a 16-lane group has in flight for its slot between th
 // select — a load under a branch, even a wave-uniform one, is a join at which the compiler waits for ALL loads in flight.
 // Sums: fixed-order DPP tree over the group's 16 lanes (wave_sum's first four additions); the group's lane 15 stores the slot's three sums,
 // k_gs_subst subtracts a row's slots from its right-hand side in slot order.
-template <class T>
-__global__ __launch_bounds__(256) void k_gs_offblock(const int2* __restrict__ slot, const int32_t* __restrict__ gcol, const T* __restrict__ val, const int32_t* __restrict__ gs_pad,
-    const T* __restrict__ x, T* __restrict__ part, int s_begin, int s_end /*the colour's slots of this sweep direction (Level::gs_slot_start: known to the host since the build)*/)
+// The pipeline itself: steps w, w + W, ... below nstep of the slot range [s_begin, s_end); store(slot, s0, s1, s2) takes a slot's three sums.
+template <class T, class Store>
+__device__ __forceinline__ void gs_off_steps(const int2* __restrict__ slot, const int32_t* __restrict__ gcol, const T* __restrict__ val, const T* x, int s_begin, int s_end, int w, int W, int nstep, Store store)
 {
     const int lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
-    // Steps are dealt to the XCDs in eight contiguous runs (workgroup b runs on XCD b % 8 — observed placement, used for speed only; any
-    // placement gives the same sums): slots follow the colour's blocks in first-touch (page) order, so an XCD's run gathers x from one
-    // region of the grid and that part of x stays in ITS L2.  Dealt round robin, every XCD pulled all of x through its own L2 in every
-    // launch: measured 155 MB of fabric reads per launch against 109 MB algorithmic (profiles/r04_pmc_summary.json), the difference being
-    // eight copies of x (C2: 6.5 MB each).
-    const int nstep_all = (s_end - s_begin + 3) >> 2;
-    const bool by_xcd = (gridDim.x & 7) == 0;
-    const int chunk = by_xcd ? (nstep_all + 7) >> 3 : nstep_all, xcd = by_xcd ? (int)(blockIdx.x & 7) : 0;
-    const int W = by_xcd ? (int)(gridDim.x >> 3) * 4 : (int)gridDim.x * 4;
-    const int nstep = min(nstep_all, (xcd + 1) * chunk); // end of this XCD's run of steps
-    const int w = __builtin_amdgcn_readfirstlane(xcd * chunk + (int)((by_xcd ? blockIdx.x >> 3 : blockIdx.x) * 4 + (threadIdx.x >> 6))); // wave-uniform, and known to be: descriptors come through the scalar cache
     if (w >= nstep) return;
     auto descriptor = [&](int n) __attribute__((always_inline)) { // of this lane's group (past the colour's last slot: the last slot's again)
         return slot[min(s_begin + 4 * min(n, nstep - 1) + g, s_end - 1)];
@@ -1102,10 +1091,7 @@ __global__ __launch_bounds__(256) void k_gs_offblock(const int2* __restrict__ sl
 #pragma unroll
         for (int d = 0; d < 3; ++d) s[d] = row16_sum(R.valid ? s[d] : (T)0);
         const int sl = s_begin + 4 * n + g;
-        if (l16 == 15 && n < nstep && sl < s_end) {
-            T* o = part + 3 * (int64_t)sl;
-            o[0] = s[0], o[1] = s[1], o[2] = s[2];
-        }
+        if (l16 == 15 && n < nstep && sl < s_end) store(sl, s[0], s[1], s[2]);
     };
     GsOffItem<T> A, B;
     int2 d1 = descriptor(w + W), d2;
@@ -1118,6 +1104,32 @@ __global__ __launch_bounds__(256) void k_gs_offblock(const int2* __restrict__ sl
         finish(n + W, B, n + 2 * W, d2, A, n + 4 * W, d4); // (an odd number of steps: one step past the end, computed from the last step's descriptor and not stored)
         d1 = d3, d2 = d4;
     }
+}
+// The streaming role: workgroup `bid` of `nwg` (256 threads each) over the slots [s_begin, s_end), sums to part[3 slot ..].
+template <class T>
+__device__ __forceinline__ void gs_off_stream(const int2* __restrict__ slot, const int32_t* __restrict__ gcol, const T* __restrict__ val, const T* x, T* part, int s_begin, int s_end, int bid, int nwg)
+{
+    // Steps are dealt to the XCDs in eight contiguous runs (workgroup b runs on XCD b % 8 — observed placement, used for speed only; any
+    // placement gives the same sums): slots follow the colour's blocks in first-touch (page) order, so an XCD's run gathers x from one
+    // region of the grid and that part of x stays in ITS L2.  Dealt round robin, every XCD pulled all of x through its own L2 in every
+    // launch: measured 155 MB of fabric reads per launch against 109 MB algorithmic (profiles/r04_pmc_summary.json), the difference being
+    // eight copies of x (C2: 6.5 MB each).
+    const int nstep_all = (s_end - s_begin + 3) >> 2;
+    const bool by_xcd = (nwg & 7) == 0;
+    const int chunk = by_xcd ? (nstep_all + 7) >> 3 : nstep_all, xcd = by_xcd ? (bid & 7) : 0;
+    const int W = by_xcd ? (nwg >> 3) * 4 : nwg * 4;
+    const int nstep = min(nstep_all, (xcd + 1) * chunk); // end of this XCD's run of steps
+    const int w = __builtin_amdgcn_readfirstlane(xcd * chunk + (int)((by_xcd ? bid >> 3 : bid) * 4 + (threadIdx.x >> 6))); // wave-uniform, and known to be: descriptors come through the scalar cache
+    gs_off_steps<T>(slot, gcol, val, x, s_begin, s_end, w, W, nstep, [&](int sl, T s0, T s1, T s2) __attribute__((always_inline)) {
+        T* o = part + 3 * (int64_t)sl;
+        o[0] = s0, o[1] = s1, o[2] = s2;
+    });
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_gs_offblock(const int2* __restrict__ slot, const int32_t* __restrict__ gcol, const T* __restrict__ val, const int32_t* __restrict__ gs_pad,
+    const T* __restrict__ x, T* __restrict__ part, int s_begin, int s_end /*the colour's slots of this sweep direction (Level::gs_slot_start: known to the host since the build)*/)
+{
+    gs_off_stream<T>(slot, gcol, val, x, part, s_begin, s_end, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // The block's 64-row triangular solve, one wavefront per colour block, lane = row, NO LDS: column c of the premultiplied in-block image
@@ -1198,6 +1210,131 @@ __global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, cons
         a0 = fma(L[3], b1, a0), a1 = fma(L[4], b1, a1), a2 = fma(L[5], b1, a2);
         a0 = fma(L[6], b2, a0), a1 = fma(L[7], b2, a1), a2 = fma(L[8], b2, a2);
         if (s + D < 64) HOT_GS_ISSUE(s + D, L);
+    }
+#undef HOT_GS_ISSUE
+    if (node < 0) return;
+    x[3 * (int64_t)node] = a0, x[3 * (int64_t)node + 1] = a1, x[3 * (int64_t)node + 2] = a2;
+    if (FWD) {
+        hD[3 * (int64_t)node] = dd[0] * a0 + dd[3] * a1 + dd[6] * a2;
+        hD[3 * (int64_t)node + 1] = dd[1] * a0 + dd[4] * a1 + dd[7] * a2;
+        hD[3 * (int64_t)node + 2] = dd[2] * a0 + dd[5] * a1 + dd[8] * a2;
+    }
+    else {
+        if (hD) hD[3 * (int64_t)node] += a0, hD[3 * (int64_t)node + 1] += a1, hD[3 * (int64_t)node + 2] += a2; // backward: hD is the iterate u, which takes the correction here (u += du of gs_smooth)
+        if (hsub) hsub[3 * (int64_t)node] -= a0, hsub[3 * (int64_t)node + 1] -= a1, hsub[3 * (int64_t)node + 2] -= a2; // (nothing in the backward sweep reads h)
+    }
+}
+
+// ---------------- one rank, finest levels: the colour pass as ONE launch with two roles (levels prepared with the four slot lists of k_gs_slot_fill2)
+// A row's off-block columns of a half sweep are of two ages: those of the colour swept just before the row's own, which are final when that
+// colour's launch ends, and older ones, final one launch earlier.  So the launch of colour c runs, side by side and independent of one another,
+//   (a) workgroups [0, nb): one per block of colour c.  Wavefronts 1 .. 3 sum the slots of the block's rows that read the PREVIOUS colour
+//       (gs_off_steps, sums to LDS) while wavefront 0 walks the dependent loads at the head of the substitution (index table, first image
+//       columns, record, right-hand side, the older slots' sums from the launch before); one barrier; wavefront 0 then substitutes as
+//       k_gs_subst does.  The previous-colour sums never see memory and cost the substitution nothing: they land before its own prologue does;
+//   (b) workgroups [nb_pad, grid): the OLDER slots of the NEXT colour, streamed as k_gs_offblock does (they read nothing this launch writes).
+// The 729 substitution wavefronts of a C2 colour (< 1 per SIMD, a 64-step dependent chain each) no longer own the chip alone, and a half
+// sweep is 8 launches instead of 15.  Row sums: previous-colour slots first, then the older ones, each in slot order (the pair path cuts the
+// concatenated run into slots instead: equal to rounding).
+template <class T, bool FWD, int D>
+__global__ __launch_bounds__(256) void k_gs_colour(const T* __restrict__ img, const uint16_t* __restrict__ imgi, const int32_t* __restrict__ gs_pad, const int4* __restrict__ srec, T* x, T* hD, int block0,
+    int nb, int nb_pad /*nb rounded up to a multiple of 8: the streaming workgroups keep their XCD (workgroup id % 8)*/, const T* __restrict__ rhs, T* hsub, const int2* __restrict__ slot,
+    const int32_t* __restrict__ gcol, const T* __restrict__ val, T* part, int s_begin, int s_end /*streaming role: the next colour's older slots*/)
+{
+    if ((int)blockIdx.x >= nb_pad) {
+        gs_off_stream<T>(slot, gcol, val, x, part, s_begin, s_end, (int)blockIdx.x - nb_pad, (int)gridDim.x - nb_pad);
+        return;
+    }
+    if ((int)blockIdx.x >= nb) return;
+    using I = GsImg<T>;
+    __shared__ T lprev[3 * 512]; // sums of the block's previous-colour slots (a row has at most 124 off-block columns: eight slots)
+    __shared__ T la[3 * 64]; // a = D^-1 (rhs - the row's off-block products), by position
+    __shared__ uint32_t lidx[64 * 33]; // wavefront 0: its lanes' rows of the index table (33 words a row: lane l reads bank (33 l + s / 2) % 64)
+    const int b = block0 + blockIdx.x;
+    const int p0 = FWD ? srec[(int64_t)b * 64].y : srec[(int64_t)b * 64].w, p1 = FWD ? srec[(int64_t)b * 64 + 64].y : srec[(int64_t)b * 64 + 64].w; // the block's previous-colour slots
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const T* hdr = img + (size_t)b * I::per_block;
+    if (wave != 0) {
+        const int64_t pos = (int64_t)b * 64 + lane;
+        int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, sr = r0;
+        if (wave == 1) r0 = *(const int4*)(gs_pad + 8 * pos), r1 = *(const int4*)(gs_pad + 8 * pos + 4), sr = srec[pos]; // (in flight under the steps below)
+        gs_off_steps<T>(slot, gcol, val, x, p0, p1, wave - 1, 3, (p1 - p0 + 3) >> 2, [&](int sl, T s0, T s1, T s2) __attribute__((always_inline)) {
+            T* o = lprev + 3 * (sl - p0);
+            o[0] = s0, o[1] = s1, o[2] = s2;
+        });
+        if (wave == 1) { // lane = row: a = D^-1 (rhs - previous-colour slots - older slots (the launch before)), each run in slot order
+            const int node = r0.x, nall = FWD ? r0.y : r1.x, nprev_e = FWD ? (r1.w & 0xffff) : ((r1.w >> 16) & 0xffff);
+            const int nold = (nall - nprev_e + 15) >> 4, nprev = (nprev_e + 15) >> 4, so = FWD ? sr.x : sr.z, sp = (FWD ? sr.y : sr.w) - p0;
+            const T* src = rhs + 3 * (int64_t)max(node, 0);
+            T q0 = src[0], q1 = src[1], q2 = src[2];
+            T ps[8][3]; // branch-free: past the row's last slot its first one — or the padding — is read and dropped
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const T* pp = part + 3 * (int64_t)(so + (q < nold ? q : 0));
+                ps[q][0] = pp[0], ps[q][1] = pp[1], ps[q][2] = pp[2];
+            }
+            const T* di = hdr + 576 + 9 * lane;
+            T dv[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) dv[e] = di[e];
+            __syncthreads(); // (1) the previous colour's share is in LDS
+            T s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const T* pp = lprev + 3 * (q < nprev ? sp + q : 0);
+                const T v0 = pp[0], v1 = pp[1], v2 = pp[2];
+                s0 += q < nprev ? v0 : (T)0, s1 += q < nprev ? v1 : (T)0, s2 += q < nprev ? v2 : (T)0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s0 += q < nold ? ps[q][0] : (T)0, s1 += q < nold ? ps[q][1] : (T)0, s2 += q < nold ? ps[q][2] : (T)0;
+            q0 -= s0, q1 -= s1, q2 -= s2;
+            la[3 * lane] = dv[0] * q0 + dv[3] * q1 + dv[6] * q2, la[3 * lane + 1] = dv[1] * q0 + dv[4] * q1 + dv[7] * q2, la[3 * lane + 2] = dv[2] * q0 + dv[5] * q1 + dv[8] * q2; // gs_store_rhs's product
+        }
+        else
+            __syncthreads(); // (1)
+        __syncthreads(); // (2) a is in LDS
+        return;
+    }
+    // wavefront 0: the substitution.  A lane's row of the index table goes through LDS (its own 132 bytes: no barrier), not through 32 registers
+    const T* ent = hdr + I::hdr_elems + (FWD ? 0 : I::per_dir);
+    const int node = gs_pad[8 * ((int64_t)b * 64 + lane)];
+    {
+        const uint4* ip = (const uint4*)(imgi + ((size_t)b * 2 + (FWD ? 0 : 1)) * I::idx_per_dir + lane * 64);
+        uint4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = ip[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lidx[33 * lane + 4 * q] = v[q].x, lidx[33 * lane + 4 * q + 1] = v[q].y, lidx[33 * lane + 4 * q + 2] = v[q].z, lidx[33 * lane + 4 * q + 3] = v[q].w;
+    }
+    const uint16_t* lrow = (const uint16_t*)(lidx + 33 * lane);
+    T ring[D][9];
+#define HOT_GS_ISSUE(s, L)                                                                   \
+    do {                                                                                      \
+        const uint32_t idx_ = lrow[s];                                                        \
+        const T* p_ = ent + (size_t)idx_ * 9;                                                 \
+        _Pragma("unroll") for (int e_ = 0; e_ < 9; ++e_) L[e_] = p_[e_];                      \
+        asm volatile("" ::: "memory"); /* the loads stay HERE, D steps ahead of their use */ \
+    } while (0)
+#pragma unroll
+    for (int k = 0; k < D; ++k) HOT_GS_ISSUE(k, ring[k]);
+    __syncthreads(); // (1)
+    __syncthreads(); // (2)
+    T a0 = la[3 * lane], a1 = la[3 * lane + 1], a2 = la[3 * lane + 2];
+    T dd[9];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+        const int c = FWD ? s : 63 - s;
+        const T b0 = lane_bcast(a0, c), b1 = lane_bcast(a1, c), b2 = lane_bcast(a2, c);
+        T(&L)[9] = ring[s % D];
+        a0 = fma(L[0], b0, a0), a1 = fma(L[1], b0, a1), a2 = fma(L[2], b0, a2);
+        a0 = fma(L[3], b1, a0), a1 = fma(L[4], b1, a1), a2 = fma(L[5], b1, a2);
+        a0 = fma(L[6], b2, a0), a1 = fma(L[7], b2, a1), a2 = fma(L[8], b2, a2);
+        if (s + D < 64) HOT_GS_ISSUE(s + D, L);
+        if (FWD && s + D == 64) { // D by position (for hD = D h), into the registers the ring no longer needs
+#pragma unroll
+            for (int e = 0; e < 9; ++e) dd[e] = hdr[9 * lane + e];
+            asm volatile("" ::: "memory");
+        }
     }
 #undef HOT_GS_ISSUE
     if (node < 0) return;
@@ -1761,9 +1898,11 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         if (fused && sizeof(T) == 8 && L.n <= 65536 && !gs_no_chain && !sharded() && !ab_flag("HOT_CG_LAUNCHES")) { // A/B build: HOT_CG_LAUNCHES = three launches per iteration on small levels too
             // the whole solve in one persistent launch (k_cg_persist), one host round trip for the iteration count
             const int G = std::min(std::min(256, device_cus()), div_up(L.n, 16)); // 1024-thread workgroups that must all be resident: one per compute unit at most
-            if (!cg_bar.p) { // cleared once: the last workgroup to leave a launch re-arms the counters; a launch that gave up (a barrier timed out) switches this path off for good
+            if (!cg_bar.p || cg_bar_dirty) { // cleared once: the last workgroup to leave a launch re-arms the counters.  A launch that gave up (a barrier timed out) leaves them
+                // dirty and switches this path off until rearm_chain() switches it on again 32 clean steps later: cleared again then
                 cg_bar.reserve(32 * 9 + 8), cg_dep.reserve(4 * 256);
                 HOT_HIP(hipMemsetAsync(cg_bar.p, 0, (32 * 9 + 8) * sizeof(unsigned), stream));
+                cg_bar_dirty = false;
             }
             HOT_LAUNCH(this, lname("cg_persistent", L.id).c_str(), k_cg_persist<T>, G, 1024, 0, L.col.p, L.val.p, L.diagInv.p, L.initialResidual.p, u, r, z, du, dAu, L.n, iterations, cg_bar.p, cg_dep.p,
                 hscal + 40, hscal + 251, new_ticket(), (int*)(hscal + 250));
@@ -2040,6 +2179,45 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                     HOT_LAUNCH(this, lname(nmT, L.id).c_str(), (k_gs_subst<T, false, 8>), nb, 64, 0, img_c, imgi_c, L.gs_pad.p, L.gs_p1.p, xx, hD, b0, rhs, hsub);
             }
         };
+        // ---- one rank: the colour pass as ONE launch, the next colour's older off-block sums beside this colour's substitutions (k_gs_colour)
+        const bool fused_path = pair_path && L.gs_fused_ready && !L.part;
+        auto colour_sweep = [&](bool fwd) {
+            const T* rhs = fwd ? r : dAu;
+            T* xx = fwd ? hdu : du;
+            T* hD = fwd ? dAu : u;
+            const char* nm = fwd ? "gs_forward_fused" : "gs_backward_fused";
+            T* hsub = !fwd ? hdu : (T*)nullptr; // h - du for the residual, row by row
+            const int nstream = std::max(8, ab_int("HOT_GS_OFF_WAVES", 4096) / 4 / 8 * 8);
+            for (int q = 0; q < 8; ++q) {
+                const int c = fwd ? q : 7 - q, cn = fwd ? c + 1 : c - 1;
+                const int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0, nb_pad = (nb + 7) & ~7;
+                const int s0 = (cn >= 0 && cn < 8) ? L.gs_slot_rng2[fwd ? 0 : 2][0][cn] : 0, s1 = (cn >= 0 && cn < 8) ? L.gs_slot_rng2[fwd ? 0 : 2][1][cn] : 0;
+                const int grid = nb_pad + (s1 > s0 ? nstream : 0);
+                if (grid == 0) continue;
+#define HOT_COLOUR_D(DD)                                                                                                                                                       \
+    do {                                                                                                                                                                       \
+        if (fwd)                                                                                                                                                               \
+            HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_colour<T, true, DD>), grid, 256, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_srec.p, xx, hD, b0, nb, nb_pad, rhs, hsub, \
+                L.gs_slot.p, L.gs_col.p, L.val.p, L.gs_p1.p, s0, s1);                                                                                                          \
+        else                                                                                                                                                                   \
+            HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_colour<T, false, DD>), grid, 256, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_srec.p, xx, hD, b0, nb, nb_pad, rhs, hsub, \
+                L.gs_slot.p, L.gs_col.p, L.val.p, L.gs_p1.p, s0, s1);                                                                                                          \
+    } while (0)
+#ifdef HOT_AB_KERNELS
+                const int depth = ab_int("HOT_GS_SUBST_D", 8); // A/B build: image columns in flight per block
+                if (depth == 4) {
+                    HOT_COLOUR_D(4);
+                    continue;
+                }
+                if (depth == 6) {
+                    HOT_COLOUR_D(6);
+                    continue;
+                }
+#endif
+                HOT_COLOUR_D(8);
+#undef HOT_COLOUR_D
+            }
+        };
         HOT_CHECK(sb == 16 || sb == 32 || sb == 64, HOT_ERR_INVALID, "hot_config.gs_sub_block must be 0 (auto), 16, 32 or 64");
         HOT_CHECK(cfg.gs_chain >= 0 && cfg.gs_chain <= 2, HOT_ERR_INVALID, "hot_config.gs_chain must be 0 (auto), 1 (one launch per colour) or 2 (one chained launch per half sweep)");
         if (tmp_marked && !(dataflow && !ab_flag("HOT_GS_PASS_COUNTERS") && !ab_flag("HOT_GS_BLOCK_FLAGS"))) zero(n3, hdu), tmp_marked = false; // (cannot happen: gs_marks_wanted takes the same decision)
@@ -2134,6 +2312,8 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 clk_report("forward");
 #endif
             }
+            else if (fused_path)
+                colour_sweep(true);
             else if (pair_path)
                 pair_sweep(true);
             else
@@ -2142,6 +2322,8 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             // dAu now holds D h ; du = backward solve
             if (dataflow)
                 sweep(false);
+            else if (fused_path)
+                colour_sweep(false);
             else if (pair_path)
                 pair_sweep(false);
             else

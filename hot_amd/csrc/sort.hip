@@ -325,10 +325,11 @@ template <class T>
 void Ctx<T>::reserve_particles(int64_t n)
 {
     const double slack = sharded() ? 1.25 : 1.0; // shards grow and shrink as particles migrate
-    pX.reserve(3 * n, slack), pV.reserve(3 * n, slack), pM.reserve(n, slack), pC.reserve(9 * n, slack), pF.reserve(9 * n, slack), pVol.reserve(n, slack), pMu.reserve(n, slack), pLam.reserve(n, slack),
+    // (+ 4: k_p2g_stream's 16-byte DMA lanes may straddle the end of an array's last component)
+    pX.reserve(3 * n + 4, slack), pV.reserve(3 * n + 4, slack), pM.reserve(n + 4, slack), pC.reserve(9 * n + 4, slack), pF.reserve(9 * n, slack), pVol.reserve(n, slack), pMu.reserve(n, slack), pLam.reserve(n, slack),
         pJp.reserve(n, slack);
     pFn.reserve(9 * n, slack), pFt.reserve(9 * n, slack), pStress.reserve(9 * n, slack), pGradV.reserve(9 * n, slack);
-    spare1.reserve(n, slack), spare3.reserve(3 * n, slack), spare9.reserve(9 * n, slack), sparei.reserve(n, slack), slot2orig.reserve(n, slack), pGid.reserve(n, slack);
+    spare1.reserve(n + 4, slack), spare3.reserve(3 * n + 4, slack), spare9.reserve(9 * n + 4, slack), sparei.reserve(n, slack), slot2orig.reserve(n, slack), pGid.reserve(n, slack);
 }
 template <class T>
 void Ctx<T>::set_particle_ids(const int32_t* ids)

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
 }
 #endif
 
-// Production P2G: the (cell segment, node row, half) work items of k_p2g_cells (above, A/B build), but only the 16 (17 with the
+#ifdef HOT_AB_KERNELS
+// Rounds 2 - 5 (A/B build since round 6, HOT_P2G_CELLS2): the (cell segment, node row, half) work items of k_p2g_cells (above, A/B build), but only the 16 (17 with the
 // CN quantity) per-particle scalars x, m, m v, m C are staged — the nine 1-D weights are recomputed per item from x (a few
 // multiply-adds against nine LDS reads) and the base cell comes from the segment's first particle.  35 KB instead of 56 KB per
 // 256-particle chunk: four 256-thread workgroups per CU instead of two 512-thread ones, i.e. twice as many independent
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__
 #define HOT_P2G_NO_ITEMS 0
 #endif
 #ifdef HOT_HT_CLOCKS
-__device__ unsigned long long p2g_clk[8];
+extern __device__ unsigned long long p2g_clk[12];
 #define P2G_CLK(i) \
     do { \
         if (tid == 0) { \
@@ -357,6 +358,254 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         for (int i = 0; i < 4; ++i) atomicAdd(&p2g_clk[i], clk_[i]);
 #endif
 }
+#endif
+
+// Round 6: P2G as a stream.  k_p2g_cells2 (above) is one workgroup per particle group with ONE chain header -> staging loads -> barrier -> items ->
+// barrier -> write-out in its life; four of them share a compute unit and more than half of their wave cycles are spent parked in that chain
+// (profiles/r05_sq_counters_C2.json).  Here a workgroup is persistent (two per compute unit, groups dealt round robin) and runs the chain as a
+// pipeline over its units (a unit = up to CH particles of one group):
+//   * the 16 per-particle scalars x, m, v, C of unit n+1 travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wavefront instruction,
+//     no registers, no ds_write pass) into the second of two staging buffers while the items of unit n run; the unit's slice of cell_first likewise;
+//   * mass * C and mass * v are no longer formed while staging (the DMA moves raw arrays): an item multiplies its weight by the mass once per node,
+//     which is the product the mass sum needs anyway; the CN quantity's per-particle factor is formed by one thread per particle from mu / lambda
+//     requested a unit ahead;
+//   * with two workgroups per compute unit (LDS-bound) an item may use 256 registers: in fp64 too all five quantities of the item's nine nodes are
+//     summed in one item (45 sums), so a particle's 1-D weights are recomputed 3 times, not 6;
+//   * the partial tile of group n-1 is written out at the head of unit n and drains under its items.
+// The waits: ONE `s_waitcnt vmcnt(0)` per unit, at the head, where everything in flight (the unit's DMA, issued a unit ago; the tile stores) is old;
+// the barriers inside a unit are raw s_barrier + lgkmcnt(0) (a __syncthreads() would drain the DMA of the next unit).  The staging buffers are
+// two distinct __shared__ objects and the unit loop is unrolled by two, so that the compiler's wait-count insertion can tell the buffer the items
+// read from the buffer the DMA fills.
+#ifdef HOT_HT_CLOCKS
+__device__ unsigned long long p2g_clk[12]; // k_p2g_stream, thread 0 (an item wavefront) | thread 192 (the serving wavefront), summed over the workgroups: 0 wait at barrier (1), 1 items | serving, 2 wait at barrier (2), 3 tile write-out, 5 units
+#define P2GS_CLK(i) \
+    do { \
+        if (tid == 0 || tid == 192) { \
+            const unsigned long long t_ = clock64(); \
+            sclk_[i] += t_ - st0_, st0_ = t_; \
+        } \
+    } while (0)
+#else
+#define P2GS_CLK(i)
+#endif
+template <class T>
+__device__ __forceinline__ void lds_only_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// ds_add_f64 the compiler does not see as an LDS access: its wait-count insertion orders every LDS atomic behind a pending LDS-DMA
+// (s_waitcnt vmcnt(0) in front of the first ds_add of an item, measured in the ISA: the next unit's DMA would be drained under the current items),
+// whichever objects the two touch.  Nothing is returned; the barriers of k_p2g_stream wait for lgkmcnt(0) themselves.
+#ifndef HOT_P2GS_EXP
+#define HOT_P2GS_EXP 0
+#endif
+template <int OFFSET>
+__device__ __forceinline__ void lds_add_f64_asm(uint32_t lds_byte_address, double v)
+{
+    static_assert(OFFSET >= 0 && OFFSET < 65536, "ds offset field is 16 bits");
+    asm volatile("ds_add_f64 %0, %1 offset:%2" ::"v"(lds_byte_address), "v"(v), "n"(OFFSET) : "memory");
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F f)
+{
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+template <class T, bool WITH_CN>
+__global__ __launch_bounds__(256) void k_p2g_stream(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C, const T* __restrict__ Mu,
+    const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin, const int32_t* __restrict__ group_cell0,
+    const int32_t* __restrict__ cell_first, T* __restrict__ part, T dx, T one_over_dx, int Ng)
+{
+    using G = Geo<T>;
+    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
+    constexpr int NQ = WITH_CN ? 5 : 4, NS = 16 + (WITH_CN ? 1 : 0), CH = sizeof(T) == 4 ? 512 : 256;
+    constexpr int IT = 192; // threads that run items (wavefronts 0 - 2); wavefront 3 serves them
+    using AT = AccT<T>;
+    __shared__ __attribute__((aligned(16))) T sp[2][NS][CH];
+    __shared__ AT acc[NQ][TILE];
+    __shared__ int32_t segs[2][G::EPB + 2];
+    __shared__ int32_t nsegs[2];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t acc_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&acc[0][0];
+#ifdef HOT_HT_CLOCKS
+    unsigned long long sclk_[6] = { 0, 0, 0, 0, 0, 0 }, st0_ = clock64();
+#endif
+    struct Unit {
+        int g, ch, first, last, c0, c1, ox, oy, oz;
+    };
+    auto header = [&](int g, Unit& u) __attribute__((always_inline)) { // wave-uniform: scalar loads
+        u.g = g, u.first = group_first[g], u.last = group_first[g + 1], u.c0 = group_cell0[g], u.c1 = group_cell0[g + 1];
+        u.ox = group_origin[3 * g], u.oy = group_origin[3 * g + 1], u.oz = group_origin[3 * g + 2];
+        u.ch = u.first;
+    };
+    auto advance = [&](const Unit& u, Unit& n) __attribute__((always_inline)) -> bool { // the unit after u of this workgroup
+        if (u.ch + CH < u.last) {
+            n = u, n.ch = u.ch + CH;
+            return true;
+        }
+        const int g = u.g + (int)gridDim.x;
+        if (g >= Ng) return false;
+        header(g, n);
+        return true;
+    };
+    // ---- the serving wavefront: everything of unit u that does not need the tile.  32 DMA pieces of 1 KiB (16 scalars x 2 halves; lane i moves
+    // 16 bytes; a lane past the unit's last particle re-reads the unit's first bytes, its LDS slots are never looked at; the arrays carry 16 bytes
+    // of slack behind their last element, reserve_particles), the CN factor m sqrt(..) from mu / lambda (plain loads, one wait with the DMA), the
+    // cell segments of the unit from cell_first (lane = cell).
+    auto serve = [&](const Unit& u, int b) __attribute__((always_inline)) {
+        const int valid = (min(u.last, u.ch + CH) - u.ch) * (int)sizeof(T); // bytes per scalar
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int q = e >> 1, half = e & 1;
+            const T* src = q < 3 ? X + (int64_t)q * Np : (q == 3 ? M : (q < 7 ? V + (int64_t)(q - 4) * Np : C + (int64_t)(q - 7) * Np));
+            const int off = half * 1024 + lane * 16;
+            const char* ga = (const char*)(src + u.ch) + (off < valid ? off : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga, (__attribute__((address_space(3))) void*)((char*)&sp[b][q][0] + half * 1024), 16, 0, 0);
+        }
+        constexpr int PPL = CH / 64; // particles per lane
+        T rmu[PPL], rla[PPL];
+        if constexpr (WITH_CN) {
+#pragma unroll
+            for (int r = 0; r < PPL; ++r) {
+                const int64_t p = min((int64_t)u.ch + lane + 64 * r, Np - 1);
+                rmu[r] = Mu[p], rla[r] = Lam[p];
+            }
+        }
+        int cfa[(G::EPB + 63) / 64], cfb[(G::EPB + 63) / 64];
+#pragma unroll
+        for (int r = 0; r < (G::EPB + 63) / 64; ++r) {
+            const int c = min(lane + 64 * r, u.c1 - u.c0 - 1);
+            cfa[r] = cell_first[u.c0 + c], cfb[r] = cell_first[u.c0 + c + 1];
+        }
+        if (lane == 0) nsegs[b] = 0;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // the unit's scalars are in LDS
+        if constexpr (WITH_CN) {
+#pragma unroll
+            for (int r = 0; r < PPL; ++r) {
+                const int l = lane + 64 * r;
+                const T mu = rmu[r], la = rla[r];
+                sp[b][NS - 1][l] = sp[b][3][l] * hsqrt((T)3 * ((T)2 * mu + la) * ((T)2 * mu + la) + (T)6 * la * la + (T)12 * mu * mu);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < (G::EPB + 63) / 64; ++r) {
+            const int s0 = max(cfa[r], u.ch), s1 = min(cfb[r], min(u.ch + CH, u.last));
+            if (lane + 64 * r < u.c1 - u.c0 && s1 > s0) segs[b][atomicAdd(&nsegs[b], 1)] = (s0 - u.ch) | ((s1 - u.ch) << 16);
+        }
+    };
+    // ---- the item wavefronts: (cell segment, node row j, half of the segment) -> the nine nodes (i, k) of the row, all NQ quantities summed in
+    // registers; the two halves of a (segment, row) sit in neighbouring lanes and are added by a DPP move before ONE lane of the pair adds the 9 NQ
+    // sums to the tile (half the LDS atomics, and no two lanes of a wavefront instruction add to the same address)
+    auto items = [&](const Unit& u, int b) __attribute__((always_inline)) {
+        const int n6 = nsegs[b] * 6;
+        // (items numbered segment-major: the six lanes of a cell read the same particles — LDS broadcasts.  Numbered row-major — (j, segment, half), so that the lanes of
+        // one ds_add_f64 never meet on a node — the item phase took 9.6 k instead of 8.65 k clocks per unit: the reads of 32 different cells per wavefront cost more
+        // than the same-address atomics they avoid; profiles/r06_p2g_experiments.txt)
+        for (int it = tid; it < n6; it += IT) {
+            const int sd = segs[b][it / 6], j = (it % 6) >> 1, hf = it & 1, s0 = sd & 0xffff, s1 = sd >> 16;
+            const int mid = (s0 + s1 + 1) >> 1, l0 = hf ? mid : s0, l1 = hf ? s1 : mid;
+            T a[3][3][NQ]; // [i][k][quantity]
+#pragma unroll
+            for (int e = 0; e < 9 * NQ; ++e) (&a[0][0][0])[e] = (T)0;
+            // the base cell is the same for every particle of the segment
+            const int b0 = base_node_of<T>(one_over_dx, sp[b][0][s0]), b1 = base_node_of<T>(one_over_dx, sp[b][1][s0]), b2 = base_node_of<T>(one_over_dx, sp[b][2][s0]);
+            const T fb0 = (T)b0, fb1 = (T)b1, fb2 = (T)b2;
+            for (int l = l0; l < (HOT_P2GS_EXP == 2 ? l0 : l1); ++l) { // (HOT_P2GS_EXP, clock builds only: 1 = one atomic per item, 2 = no particle loop)
+                const T x0 = sp[b][0][l], x1 = sp[b][1][l], x2 = sp[b][2][l];
+                // 1-D quadratic B-spline weights, the arithmetic of bspline() (BSplines.h:55-81)
+                auto w3 = [&](T x, T fb, T(&w)[3]) {
+                    const T d0 = fma(one_over_dx, x, -fb); // exact product, like the fused multiply-add a -O3 -march=native host build makes of it (hot_common.h bspline)
+                    const T z = (T)1.5 - d0, d1 = d0 - (T)1, zz = (T)1.5 - ((T)1 - d1);
+                    w[0] = (T)0.5 * z * z, w[1] = (T)0.75 - d1 * d1, w[2] = (T)0.5 * zz * zz;
+                };
+                T wi[3], wj3[3], wk[3];
+                w3(x0, fb0, wi), w3(x1, fb1, wj3), w3(x2, fb2, wk);
+                const T wj = j == 0 ? wj3[0] : (j == 1 ? wj3[1] : wj3[2]);
+                const T d1 = (T)(b1 + j) * dx - x1;
+                const T m = sp[b][3][l];
+                T cn = (T)0, u3[3], cc[3], ee[3];
+                if constexpr (WITH_CN) cn = sp[b][NS - 1][l];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) u3[q] = sp[b][10 + q][l] * d1 + sp[b][4 + q][l], cc[q] = sp[b][7 + q][l], ee[q] = sp[b][13 + q][l];
+                T d0[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) d0[i] = (T)(b0 + i) * dx - x0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T d2 = (T)(b2 + k) * dx - x2, wjk = wj * wk[k], mwjk = m * wjk;
+                    T t[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) t[q] = ee[q] * d2 + u3[q];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const T mw = wi[i] * mwjk; // mass x weight
+                        a[i][k][0] += mw;
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) a[i][k][1 + q] += (cc[q] * d0[i] + t[q]) * mw;
+                        if constexpr (WITH_CN) a[i][k][NQ - 1] += cn * (wi[i] * wjk);
+                    }
+                }
+            }
+#if HOT_P2GS_EXP == 1
+            {
+                T sum = 0;
+#pragma unroll
+                for (int e = 0; e < 9 * NQ; ++e) sum += (&a[0][0][0])[e];
+                lds_add_f64_asm<0>(acc_base + 8 * (((b0 - u.ox) * TY + (b1 - u.oy + j)) * TZ + (b2 - u.oz)), (double)sum);
+                continue;
+            }
+#endif
+            // first half + second half (lanes 2 n, 2 n + 1: quad_perm [1, 0, 3, 2]); then the even lane adds sums 0 .. H - 1 to the tile, the odd lane sums
+            // H .. 9 NQ - 1: a ds_add_f64 costs the same ~100 clocks whether 32 or 64 of its lanes carry a sum (measured: 45 per item with every second
+            // lane switched off took as long as 45 on all lanes), so the pair's 9 NQ sums go out in H = ceil(9 NQ / 2) wavefront instructions, not 9 NQ
+#pragma unroll
+            for (int e = 0; e < 9 * NQ; ++e) (&a[0][0][0])[e] += dpp_move<0xb1, 0xf>((&a[0][0][0])[e]);
+            constexpr int H = (9 * NQ + 1) / 2;
+            const uint32_t abase = acc_base + 8 * (((b0 - u.ox) * TY + (b1 - u.oy + j)) * TZ + (b2 - u.oz));
+            static_for<H>([&](auto sc) __attribute__((always_inline)) {
+                constexpr int s0_ = decltype(sc)::value, s1_ = s0_ + H < 9 * NQ ? s0_ + H : 0; // (9 NQ odd: the odd lane's last slot adds 0 to sum 0's node)
+                constexpr int o0 = (((s0_ / NQ) / 3) * TY * TZ + (s0_ / NQ) % 3) * 8 + (s0_ % NQ) * TILE * 8, o1 = (((s1_ / NQ) / 3) * TY * TZ + (s1_ / NQ) % 3) * 8 + (s1_ % NQ) * TILE * 8;
+                const T v = hf ? (s0_ + H < 9 * NQ ? (&a[0][0][0])[s1_] : (T)0) : (&a[0][0][0])[s0_];
+                lds_add_f64_asm<0>(abase + (hf ? o1 : o0), (double)v);
+            });
+        }
+    };
+    if ((int)blockIdx.x >= Ng) return;
+    for (int t = tid; t < NQ * TILE; t += 256) (&acc[0][0])[t] = (AT)0;
+    Unit cur, nxt;
+    header((int)blockIdx.x, cur);
+    if (wave == 3) serve(cur, 0);
+    int b = 0;
+    for (;;) {
+        const bool have_next = advance(cur, nxt);
+        lds_only_barrier<T>(); // (1) unit cur is staged in buffer b; the tile is zero or holds the group's earlier units
+        P2GS_CLK(0);
+        if (wave == 3) {
+            if (have_next) serve(nxt, b ^ 1);
+        }
+        else
+            items(cur, b);
+        P2GS_CLK(1);
+        lds_only_barrier<T>(); // (2) the unit's sums are in the tile; the next unit is staged
+        P2GS_CLK(2);
+        if (cur.ch + CH >= cur.last) { // the group's partial tile, coalesced; summed per node by k_tile_reduce
+            T* out = part + (int64_t)cur.g * NQ * TILE;
+            for (int t = tid; t < NQ * TILE; t += 256) out[t] = (T)(&acc[0][0])[t], (&acc[0][0])[t] = (AT)0;
+        }
+        P2GS_CLK(3);
+#ifdef HOT_HT_CLOCKS
+        sclk_[5] += 1;
+#endif
+        if (!have_next) break;
+        cur = nxt, b ^= 1;
+    }
+#ifdef HOT_HT_CLOCKS
+    if (tid == 0 || tid == 192)
+        for (int i = 0; i < 6; ++i) atomicAdd(&p2g_clk[i + (tid ? 6 : 0)], sclk_[i]);
+#endif
+}
 
 template <class T>
 __global__ __launch_bounds__(256) void k_block_count(const T* __restrict__ gM, int32_t* block_count, int nb)
@@ -435,18 +684,32 @@ void Ctx<T>::p2g()
         else
             HOT_LAUNCH(this, "p2g", (k_p2g_cells<T, false>), Ng, P2G_THREADS, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
     }
+    else if (ab_flag("HOT_P2G_CELLS2")) { // rounds 2 - 5: one workgroup per particle group, register staging
+        if (cfg.useCN)
+            HOT_LAUNCH(this, "p2g", (k_p2g_cells2<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
+        else
+            HOT_LAUNCH(this, "p2g", (k_p2g_cells2<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
+    }
     else
 #endif
-    if (cfg.useCN)
-        HOT_LAUNCH(this, "p2g", (k_p2g_cells2<T, true>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
-    else
-        HOT_LAUNCH(this, "p2g", (k_p2g_cells2<T, false>), Ng, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx);
+    {
+        // persistent workgroups, two per compute unit (what their LDS allows), groups dealt round robin
+        const int grid = std::min(Ng, std::max(1, ab_int("HOT_P2G_WGS_PER_CU", 2)) * device_cus());
+        if (cfg.useCN)
+            HOT_LAUNCH(this, "p2g", (k_p2g_stream<T, true>), grid, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx, Ng);
+        else
+            HOT_LAUNCH(this, "p2g", (k_p2g_stream<T, false>), grid, 256, 0, pX.p, pV.p, pM.p, pC.p, pMu.p, pLam.p, Np, group_first.p, group_origin.p, group_cell0.p, cell_first.p, gPart.p, dx, one_over_dx, Ng);
+    }
 #ifdef HOT_HT_CLOCKS
     {
-        unsigned long long h[8] = {};
+        unsigned long long h[12] = {};
         HOT_HIP(hipStreamSynchronize(stream));
         HOT_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(p2g_clk), sizeof(h)));
-        fprintf(stderr, "p2g clocks per workgroup (%d groups): header %.0f staging %.0f items %.0f write-out %.0f\n", Ng, h[0] / (double)Ng, h[1] / (double)Ng, h[2] / (double)Ng, h[3] / (double)Ng);
+        if (h[5])
+            fprintf(stderr, "p2g_stream clocks per unit (%llu units, %d groups), item wavefront | serving wavefront: wait (1) %.0f | %.0f, items | serving %.0f | %.0f, wait (2) %.0f | %.0f, tile write-out %.0f | %.0f\n", h[5], Ng,
+                h[0] / (double)h[5], h[6] / (double)h[5], h[1] / (double)h[5], h[7] / (double)h[5], h[2] / (double)h[5], h[8] / (double)h[5], h[3] / (double)h[5], h[9] / (double)h[5]);
+        else
+            fprintf(stderr, "p2g clocks per workgroup (%d groups): header %.0f staging %.0f items %.0f write-out %.0f\n", Ng, h[0] / (double)Ng, h[1] / (double)Ng, h[2] / (double)Ng, h[3] / (double)Ng);
         memset(h, 0, sizeof(h));
         HOT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(p2g_clk), h, sizeof(h)));
     }

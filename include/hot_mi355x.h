@@ -89,11 +89,13 @@ typedef struct hot_config {
                                1 = never (every trial is a full pass), 2 = always */
     int32_t linear_iteration_cap; /* lsolver 1 / 2: iterations of one MINRES / PCG solve at most; 0 = the reference's 10000 (ImplicitSolver.h: the solvers' max_iterations).  A fixed
                                      small count makes two implementations stop at the same Lanczos step, whatever round-off does to the stopping test (parity tests) */
-    int32_t shard_owner; /* sharded runs: which rank owns the rows of a 4^3 colour block.  0 (default) = the rank whose particle range (a contiguous range of the SPGrid
+    int32_t shard_owner; /* sharded runs: which rank owns the rows of a 4^3 colour block.  2 = the rank whose particle range (a contiguous range of the SPGrid
                             page order) contains the block's own page, on a coarse level the page at the block's position on the finest grid: every rank owns the
                             rows inside its own particle range, both sides of a cut send the same amount of partial matrix rows, and the boundary between the ranks'
                             rows is as compact as the boundary between their particles; 1 = the rank whose particles first touch the block (rounds 2 - 4): the lower
-                            rank of every cut owns all blocks the two share */
+                            rank of every cut owns all blocks the two share; 0 (default) = by the smoother: 2 under colour-synchronous sweeps (shard_gs = 0), 1 under
+                            rank-local sweeps (shard_gs = 1), whose iteration counts stay within 15 % of the single-rank ones only under it (measured,
+                            profiles/r05_shard_ownership.txt).  Other values are rejected */
     int32_t reserved[5];
 } hot_config;
 

@@ -122,7 +122,8 @@ struct Sim {
     // Owner of a 4^3 colour block (nodes in ascending id order): the product's rule (hot_config.shard_owner; a design choice of the sharded
     // decomposition, not of the reference, which is one process), restated from hot_amd/csrc/mg_build.hip k_color_owner_keys.
     //   1  the rank that first touches the block's lowest node;
-    //   0  (default) finest level: the rank whose particle range — a contiguous range of the SPGrid page order; page_split[r] = the lowest page
+    //   0  (default) by the smoother: 2 under colour-synchronous sweeps, 1 under rank-local ones (shard_gs = 1);
+    //   2  finest level: the rank whose particle range — a contiguous range of the SPGrid page order; page_split[r] = the lowest page
     //      rank r + 1 holds — contains the block's own page, if its particle tiles reach the block (or, fp64, its x-companion page), else the
     //      reaching rank nearest to it in rank order (the lower one on a tie); coarser levels: the owner of the first existing child (2 C + d,
     //      d in {-1, 0, 1}^3, x slowest) of the block's lowest node.
@@ -137,7 +138,8 @@ struct Sim {
     void compute_owners()
     {
         node_owner.clear();
-        if (!sharded() || cfg.shard_owner == 1 || (int)page_split.size() != comm.size - 1) return;
+        const bool page_owner = cfg.shard_owner == 2 || (cfg.shard_owner == 0 && cfg.shard_gs == 0); // 0: by the smoother (hot_mi355x.h hot_config.shard_owner)
+        if (!sharded() || !page_owner || (int)page_split.size() != comm.size - 1) return;
         const int R = comm.size;
         for (int level = 0; level < (int)sysmats.size() && level < (int)level_nstart.size() && level < (int)level_coords.size(); ++level) {
             const auto& coords = level_coords[level];

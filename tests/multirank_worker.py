@@ -110,11 +110,22 @@ def worker(rank, world, port, q, libkind, n, dtype, cfgkw, steps, backend, parti
         raise
 
 
-def launch(world, libkind, n, dtype, cfgkw, steps=0, backend="gloo", partition_min_rows=1, timeout=900, shard_ids=None):
+def launch(world, libkind, n, dtype, cfgkw, steps=0, backend="gloo", partition_min_rows=1, timeout=900, shard_ids=None, attempt=0):
+    """One job of `world` processes.  A rendezvous that fails (the TCP store's port taken, a rank that starts too late on a loaded box: c10d's
+    DistNetworkError) is retried twice on another port; any other failure of a rank is raised."""
     import torch.multiprocessing as mp
+    try:
+        return _launch(mp, world, libkind, n, dtype, cfgkw, steps, backend, partition_min_rows, timeout, shard_ids, attempt)
+    except RuntimeError as e:
+        if attempt < 2 and ("DistNetworkError" in str(e) or "DistStoreError" in str(e) or "Address already in use" in str(e)):
+            return launch(world, libkind, n, dtype, cfgkw, steps, backend, partition_min_rows, timeout, shard_ids, attempt + 1)
+        raise
+
+
+def _launch(mp, world, libkind, n, dtype, cfgkw, steps, backend, partition_min_rows, timeout, shard_ids, attempt):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() * 7 + n) % 2000
+    port = 29500 + (os.getpid() * 7 + n + 977 * attempt) % 2000
     procs = [ctx.Process(target=worker, args=(r, world, port, q, libkind, n, dtype, cfgkw, steps, backend, partition_min_rows, shard_ids)) for r in range(world)]
     for p in procs:
         p.start()
@@ -131,7 +142,8 @@ def launch(world, libkind, n, dtype, cfgkw, steps=0, backend="gloo", partition_m
             if p.is_alive():
                 p.terminate()
     for p in procs:
-        assert p.exitcode == 0, p.exitcode
+        if p.exitcode != 0:
+            raise RuntimeError(f"a rank exited with code {p.exitcode}")
     return [res[r] for r in range(world)]
 
 

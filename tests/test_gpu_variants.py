@@ -26,6 +26,10 @@ CASES = [
     ({"HOT_TEST_CFG": "gs_chain=2,gs_sub_block=32", "HOT_GS_PASS_COUNTERS": "1"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_TEST_CFG": "gs_chain=2,gs_sub_block=32", "HOT_GS_BLOCK_FLAGS": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # hand-off through per-block sweep stamps
     ({"HOT_GS_BLOCK_FLAGS": "1"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_PAIR": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # round 4 / 5: the colour pass as the kernel pair k_gs_offblock + k_gs_subst (what a row-partitioned level runs) instead of the one launch k_gs_colour
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_PAIR": "1", "HOT_GS_OFF_WAVES": "64"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_SUBST_D": "4"}, SOLVER, "smoothers or vcycle"),  # image columns in flight per substitution wavefront
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_SUBST_D": "6"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_OFF_WAVES": "4100"}, SOLVER, "smoothers or vcycle"),  # a grid that is no multiple of 8: off-block steps dealt round robin instead of in per-XCD runs
     ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_OFF_WAVES": "64"}, SOLVER, "smoothers or vcycle"),  # few wavefronts: many steps per wavefront, odd and even step counts
     ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_V1": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # first-generation k_gs_block instead of the off-block / substitution pair
@@ -42,6 +46,8 @@ CASES = [
     ({"HOT_HESSIAN_TILES": "1"}, SOLVER, "hessian_and_hierarchy"),  # rounds 2 - 4: k_hessian_tiles2, particle chunks staged in LDS, pair phase with LDS atomics
     ({"HOT_HESSIAN_TILES_V1": "1"}, SOLVER, "hessian_and_hierarchy"),
     ({"HOT_HESSIAN_MFMA": "1"}, SOLVER, "hessian_and_hierarchy"),  # pair phase on v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32
+    ({"HOT_P2G_CELLS2": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),  # rounds 2 - 5: one workgroup per particle group with register staging (production since round 6: k_p2g_stream, persistent workgroups fed by LDS-DMA)
+    ({"HOT_P2G_WGS_PER_CU": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),  # k_p2g_stream with half the workgroups: twice the units per workgroup
     ({"HOT_P2G_V1": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),
     ({"HOT_P2G_CELLS1": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),
     ({"HOT_G2P_V1": "1"}, "tests/test_gpu_transfer.py", "sort_p2g_g2p or transfer_properties"),  # node-by-node sums instead of the sum-factorised ones

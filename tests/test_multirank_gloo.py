@@ -75,6 +75,22 @@ def test_rank_local_gs_two_and_three_ranks_gloo_oracle():
             assert ranks[0]["comm_calls"]["allreduce"] < 0.5 * exact[0]["comm_calls"]["allreduce"]
 
 
+def test_eight_ranks_small_subdomains_default_smoother_converges_gloo_oracle():
+    """What `bench.py --gpus 8` runs by default since round 6, at the sub-domain size where the rank-local sweep fails (round 5: 24^3 cells per rank
+    did not converge in 400 iterations): a 24^3-cell cube over EIGHT ranks — 12^3 cells each, every rank cut on three sides — with the default
+    sharding knobs (colour-synchronous GS, ownership by the sweep).  One whole time step to convergence: the single-rank iteration count and
+    particles, identical decisions on every rank.  (The rank-local sweep stays opt-in: hot_config.shard_gs = 1.)"""
+    from tests import multirank_worker as mw
+    from tests.oracle_lib import load_oracle
+    kw = dict(lsolver=3, levelCnt=3, cneps=1e-6)
+    ranks = mw.launch(8, "oracle", 24, 1, kw, steps=1, partition_min_rows=256, timeout=1500)
+    ref = mw.single(load_oracle(), 24, 1, kw, steps=1)
+    assert ref["stats"]["converged"] == 1 and all(o["stats"]["converged"] == 1 for o in ranks)
+    assert all(o["iterations"] == ranks[0]["iterations"] for o in ranks)
+    assert ranks[0]["iterations"] == ref["iterations"], (ranks[0]["iterations"], ref["iterations"])
+    mw.compare(ranks, ref, 1e-8, tolp=1e-8, exact_counts=False)
+
+
 def test_shard_by_page_order_partitions_in_sort_order():
     from hot_amd import dist as hdist, synth
     from tests.oracle_lib import load_oracle

@@ -1,4 +1,4 @@
-for gs in 1 0; do for so in 0 1; do
+for gs in 1 0; do for so in 1 2; do
 python bench.py --gpus 8 --share-gpu --cells 32 --steps 2 --warmup 1 --no-cpu --shard-gs $gs --shard-owner $so 2>/dev/null | grep '^{' | tail -1 > gpurun_out/own_${gs}_${so}.json
 python - <<PY
 import json

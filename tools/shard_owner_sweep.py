@@ -1,7 +1,7 @@
 """Row-ownership rule of a sharded run (hot_config.shard_owner) against (i) the balance of what the ranks hand to the collectives and (ii) the
 L-BFGS iteration drift of the rank-local Gauss-Seidel sweep (hot_config.shard_gs = 1) against the colour-synchronous one (= the single-rank
 iterates).  One whole converged time step of a cube of <cells>^3 cells (8 particles per cell, fp64, 3 levels, the bench's solver line) over <ranks>
-ranks sharing the test box's one GPU through gloo.  python tools/shard_owner_sweep.py <cells> <ranks> [owner rules, default 1 3 4 5]"""
+ranks sharing the test box's one GPU through gloo.  python tools/shard_owner_sweep.py <cells> <ranks> [owner rules, default 1 2: first touch, page range]"""
 import sys
 sys.path.insert(0, "/root/repo")
 import numpy as np
@@ -10,7 +10,7 @@ from tests import multirank_worker as mw
 
 def main():
     n, world = int(sys.argv[1]), int(sys.argv[2])
-    rules = [int(a) for a in sys.argv[3:]] or [1, 3, 4, 5]
+    rules = [int(a) for a in sys.argv[3:]] or [1, 2]
     kw = dict(lsolver=3, levelCnt=3, smoother=5, coarseSolver=2, project=1, linesearch=1, systemBCProject=1, useCN=1, cneps=1e-7, max_iterations=400)
     base = None
     for rule in rules:
