@@ -58,12 +58,13 @@ ABI_SYMBOLS = [
     "get_counts", "get_indexing", "p2g", "get_grid", "set_bc", "set_sticky_halfspaces", "set_collision_objects", "begin_step", "get_dv",
     "set_dv", "update_state", "get_particle_state", "residual", "project", "cn_tolerance", "build_hessian",
     "matfree_multiply", "build_mg", "get_level", "get_matrix", "get_level_nnzb", "get_prolongation", "spmv", "restrict", "prolong",
-    "smooth", "vcycle", "solve", "g2p", "line_search", "should_exit", "recover_solution", "transform_residual", "compute_step", "write_partio", "write_restart", "read_restart", "set_particle_ids", "get_particle_ids", "get_stream", "set_comm", "constitutive_eval", "plasticity_eval", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version",
+    "smooth", "vcycle", "solve", "g2p", "line_search", "should_exit", "recover_solution", "transform_residual", "compute_step", "write_partio", "write_restart", "read_restart", "set_particle_ids", "get_particle_ids", "get_stream", "set_comm", "constitutive_eval", "plasticity_eval", "advance", "calculate_dt", "advance_frame", "profile_reset", "profile_count", "profile_get", "version", "abi_version",
 ]
+ABI_VERSION = 6  # include/hot_mi355x.h HOT_ABI_VERSION: the layout of hot_config / hot_stats this module mirrors
 
 
 # declared by the header for the HIP product only (device-runtime services a host-memory implementation of the ABI has no use for)
-PRODUCT_ONLY_SYMBOLS = ["rccl_unique_id", "rccl_attach", "rccl_selftest", "get_level_inblock_nnzb"]
+PRODUCT_ONLY_SYMBOLS = ["rccl_unique_id", "rccl_attach", "rccl_selftest", "get_level_inblock_nnzb", "copy_bandwidth"]
 
 
 class HotError(RuntimeError):
@@ -144,6 +145,7 @@ class HotLib:
             "profile_count": (C.c_int, [vp, P(i32)]),
             "profile_get": (C.c_int, [vp, i32, C.c_char_p, P(i64), P(dbl)]),
             "version": (C.c_char_p, []),
+            "abi_version": (C.c_int, []),
         }
         self.fn = {}
         missing = []
@@ -157,6 +159,8 @@ class HotLib:
             self.fn[name] = f
         if missing:
             raise HotError(f"{self.path} does not export: {missing}")
+        if self.fn["abi_version"]() != ABI_VERSION:  # structures are passed by pointer and written whole: a mismatch is memory corruption, not a warning
+            raise HotError(f"{self.path}: ABI version {self.fn['abi_version']()} where this module mirrors {ABI_VERSION} (include/hot_mi355x.h HOT_ABI_VERSION)")
 
     def default_config(self, **kw):
         cfg = hot_config()
@@ -395,6 +399,16 @@ class Context:
         rc = f(self.h, C.c_int32(level), C.byref(v))
         if rc != 0:
             raise HotError(f"get_level_inblock_nnzb -> {rc}")
+        return v.value
+
+    def copy_bandwidth(self, nbytes=1 << 30, reps=20):
+        """GB/s (read + written) of the library's own 16-byte-per-lane copy kernel on the context's stream (HIP product only)"""
+        f = getattr(self.lib.lib, self.lib.prefix + "copy_bandwidth")
+        f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
+        v = C.c_double()
+        rc = f(self.h, C.c_int64(nbytes), C.c_int32(reps), C.byref(v))
+        if rc != 0:
+            raise HotError(f"copy_bandwidth -> {rc}")
         return v.value
 
     def prolongation(self, level):

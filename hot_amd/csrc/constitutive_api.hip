@@ -76,7 +76,7 @@ template <class T>
 void Ctx<T>::constitutive_eval(int32_t n, const void* F, const void* mu, const void* lambda, int32_t project, void* psi, void* P, void* dPdF)
 {
     need(n > 0 && F && mu && lambda, "hot_constitutive_eval: n > 0, F, mu and lambda are required");
-    need(project >= 0 && project <= 2, "hot_constitutive_eval: project must be 0, 1 or 2 (psi as a line-search trial evaluates it)");
+    if (project != 0 && project != 2) project = 1; // any other non-zero value: the PSD projection, as before the psi-only mode (2) existed
     if (project == 2) P = nullptr, dPdF = nullptr;
     DBuf<T> dF, dMu, dLam, dPsi, dP, dD;
     dF.reserve(9 * (size_t)n), dMu.reserve(n), dLam.reserve(n), dPsi.reserve(n), dP.reserve(9 * (size_t)n), dD.reserve(dPdF ? 81 * (size_t)n : 1);

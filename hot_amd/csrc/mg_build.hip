@@ -778,7 +778,15 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
         const bool baseline = ctx->cfg.useBaselineMultigrid != 0;
         const int splitLevel = ctx->cfg.topDownMGS ? 1 : ctx->cfg.levelCnt - 1;
         const int kind = L.id < splitLevel ? (baseline ? 5 : ctx->cfg.smoother) : (baseline ? 2 : ctx->cfg.coarseSolver); // what smooth_dev runs on this level
-        if (sizeof(T) == 8 && kind == 5 && !L.part && ctx->cfg.gs_chain != 1 && (ctx->cfg.gs_sub_block == 0 || ctx->cfg.gs_sub_block == 64) && (max_nb <= 256 || ctx->cfg.gs_chain == 2)) ctx->build_gs_winv(L);
+        // (not when the chained sweeps are switched off — a time-out, several ranks —, and never more than 2048 blocks: 290 KB of image per block in fp64,
+        // gs_chain = 2 forces the chained launch on levels of any size, which then substitute)
+        if (sizeof(T) == 8 && kind == 5 && !L.part && !ctx->gs_no_chain && ctx->cfg.gs_chain != 1 && (ctx->cfg.gs_sub_block == 0 || ctx->cfg.gs_sub_block == 64) && (max_nb <= 256 || ctx->cfg.gs_chain == 2) && L.nblocks <= 2048)
+            ctx->build_gs_winv(L);
+        if (!L.gs_w_ready && L.gs_w.p) { // the level stopped qualifying (it grew, the chain timed out): the images go
+            HOT_HIP(hipStreamSynchronize(ctx->stream));
+            HOT_HIP(hipFree(L.gs_w.p));
+            L.gs_w.p = nullptr, L.gs_w.cap = 0;
+        }
     }
     L.gs_img_ready = false;
     if (max_nb > 256 || ctx->cfg.gs_sub_block == 32) { // (row-partitioned levels too: the rows of other ranks have zero counts, hence no slots and empty images)

@@ -32,332 +32,15 @@ __device__ __forceinline__ int tile_slot(int t, const int32_t* __restrict__ nb8)
 }
 
 #ifdef HOT_AB_KERNELS
-template <class T, bool WITH_CN>
-__global__ __launch_bounds__(256) void k_p2g(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C,
-    const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
-    const int32_t* __restrict__ group_nb, T* __restrict__ part, T dx, T one_over_dx)
-{
-    using G = Geo<T>;
-    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
-    constexpr int NQ = WITH_CN ? 5 : 4;
-    __shared__ T acc[NQ][TILE];
-    __shared__ int32_t nb8[8];
-    const int g = blockIdx.x;
-    for (int t = threadIdx.x; t < NQ * TILE; t += 256) (&acc[0][0])[t] = (T)0;
-    if (threadIdx.x < 8) nb8[threadIdx.x] = group_nb[g * 8 + threadIdx.x];
-    __syncthreads();
-    const int first = group_first[g], last = group_first[g + 1];
-    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
-    for (int p = first + threadIdx.x; p < last; p += 256) {
-        T xp[3] = { X[p], X[Np + p], X[2 * Np + p] };
-        T m = M[p];
-        T mom[3] = { m * V[p], m * V[Np + p], m * V[2 * Np + p] };
-        T Cm[9];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) Cm[c] = m * C[(int64_t)c * Np + p];
-        int base[3];
-        T w[3][3], dw[3][3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) bspline<T>(one_over_dx, xp[d], base[d], w[d], dw[d]);
-        T cn = (T)0;
-        if (WITH_CN) {
-            // |dP/dF(F = I)|_F of the fixed-corotated model: A = 2 mu I + lambda 11^T, B blocks = mu [[1,1],[1,1]]
-            // (already PSD, so --project does not change it): sqrt(3(2mu+l)^2 + 6 l^2 + 12 mu^2)
-            T mu = Mu[p], la = Lam[p];
-            cn = m * hsqrt((T)3 * ((T)2 * mu + la) * ((T)2 * mu + la) + (T)6 * la * la + (T)12 * mu * mu);
-        }
-        const int cx = base[0] - ox, cy = base[1] - oy, cz = base[2] - oz;
-        // rotate the visiting order per lane so that the particles of one cell (adjacent lanes) hit different
-        // LDS addresses in the same instruction
-        int rot = threadIdx.x % 27;
-        for (int n = 0; n < 27; ++n) {
-            int q = n + rot;
-            q = q >= 27 ? q - 27 : q;
-            int i = q / 9, j = (q / 3) % 3, k = q % 3;
-            T wijk = w[0][i] * w[1][j] * w[2][k];
-            T d0 = (T)(base[0] + i) * dx - xp[0], d1 = (T)(base[1] + j) * dx - xp[1], d2 = (T)(base[2] + k) * dx - xp[2];
-            int t = ((cx + i) * TY + (cy + j)) * TZ + (cz + k);
-            lds_atomic_add(&acc[0][t], m * wijk);
-            lds_atomic_add(&acc[1][t], (Cm[0] * d0 + Cm[3] * d1 + Cm[6] * d2 + mom[0]) * wijk);
-            lds_atomic_add(&acc[2][t], (Cm[1] * d0 + Cm[4] * d1 + Cm[7] * d2 + mom[1]) * wijk);
-            lds_atomic_add(&acc[3][t], (Cm[2] * d0 + Cm[5] * d1 + Cm[8] * d2 + mom[2]) * wijk);
-            if (WITH_CN) lds_atomic_add(&acc[NQ - 1][t], cn * wijk);
-        }
-    }
-    __syncthreads();
-    // partial tile of this group, coalesced; summed per node by k_tile_reduce (no global atomics)
-    T* out = part + (int64_t)g * NQ * TILE;
-    for (int t = threadIdx.x; t < NQ * TILE; t += 256) out[t] = (&acc[0][0])[t];
-}
-
+#include "ab_src/transfer_ab1.hip"
 #endif
 
 #ifdef HOT_AB_KERNELS
-// Round-1 production P2G (A/B build only now).  The particles of one base cell share their 27 support nodes, so a (cell, node column) work item sums
-// the contributions of the whole cell to its 3 nodes in registers and touches the LDS accumulator once per node and
-// quantity: ~8x fewer ds_add_f64 than one-add-per-particle (k_p2g above, kept for A/B).  Particle data and the per-
-// particle 1-D weights are staged in LDS (coalesced loads, weights computed once per particle instead of once per
-// node) and read back with wave-broadcast reads (all lanes of a cell read the same particle).
-// 256 threads measured best (320 = one item round per fp64 page, but lower occupancy: P2G 0.27 vs 0.24 ms at 2 M particles)
-constexpr int P2G_THREADS = 512, P2G_CHUNK = 256; // particles are staged 256 at a time by the first 256 threads; all 512 work on the items
-
-template <class T, bool WITH_CN>
-__global__ __launch_bounds__(P2G_THREADS) void k_p2g_cells(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C,
-    const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
-    const int32_t* __restrict__ group_cell0, const int32_t* __restrict__ cell_first, T* __restrict__ part, T dx, T one_over_dx)
-{
-    using G = Geo<T>;
-    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
-    constexpr int NQ = WITH_CN ? 5 : 4, NS = 25 + (WITH_CN ? 1 : 0), CH = sizeof(T) == 4 ? 2 * P2G_CHUNK : P2G_CHUNK; // fp32 groups hold twice the particles: same LDS bytes, one staging round
-    using AT = AccT<T>; // double also in the fp32 build: LDS float atomics are ~40x slower (see k_force_cells)
-    __shared__ AT acc[NQ][TILE];
-    __shared__ T sp[NS][CH]; // x(3) m(1) m*v(3) m*C(9) w(3x3) [cn]
-    __shared__ int32_t sbase[3][CH];
-    __shared__ int32_t segs[G::EPB + 2];
-    __shared__ int32_t nseg;
-    const int g = blockIdx.x, tid = threadIdx.x;
-    for (int t = tid; t < NQ * TILE; t += P2G_THREADS) (&acc[0][0])[t] = (AT)0;
-    const int first = group_first[g], last = group_first[g + 1];
-    const int c0 = group_cell0[g], c1 = group_cell0[g + 1];
-    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
-    for (int ch = first; ch < last; ch += CH) {
-        if (tid == 0) nseg = 0;
-        __syncthreads(); // also orders the previous chunk's reads of sp / segs before they are overwritten
-        const int p = ch + tid;
-        if (tid < CH && p < last) {
-            const T m = M[p];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const T x = X[(int64_t)d * Np + p];
-                int base;
-                T w[3], dw[3];
-                bspline<T>(one_over_dx, x, base, w, dw);
-                sp[d][tid] = x, sp[4 + d][tid] = m * V[(int64_t)d * Np + p], sbase[d][tid] = base;
-                sp[16 + 3 * d][tid] = w[0], sp[17 + 3 * d][tid] = w[1], sp[18 + 3 * d][tid] = w[2];
-            }
-            sp[3][tid] = m;
-#pragma unroll
-            for (int c = 0; c < 9; ++c) sp[7 + c][tid] = m * C[(int64_t)c * Np + p];
-            if (WITH_CN) {
-                // |dP/dF(F = I)|_F of the fixed-corotated model: A = 2 mu I + lambda 11^T, B blocks = mu [[1,1],[1,1]]
-                // (already PSD, so --project does not change it): sqrt(3(2mu+l)^2 + 6 l^2 + 12 mu^2)
-                const T mu = Mu[p], la = Lam[p];
-                sp[NS - 1][tid] = m * hsqrt((T)3 * ((T)2 * mu + la) * ((T)2 * mu + la) + (T)6 * la * la + (T)12 * mu * mu);
-            }
-        }
-        for (int c = c0 + tid; c < c1; c += P2G_THREADS) {
-            const int s0 = max(cell_first[c], ch), s1 = min(cell_first[c + 1], min(ch + CH, last));
-            if (s1 > s0) segs[atomicAdd(&nseg, 1)] = (s0 - ch) | ((s1 - ch) << 16);
-        }
-        __syncthreads();
-        // items: (cell segment, node column, half of the segment).  A full fp64 page has 32 cells x 9 columns = 288
-        // columns, which would be one full round of the 256 threads plus a nearly empty one; splitting every segment in
-        // two gives 576 half-length items = 2.25 short rounds.
-        const int ni = nseg * 18;
-        for (int it = tid; it < ni; it += P2G_THREADS) {
-            const int sd = segs[it / 18], jk = (it % 18) >> 1, hf = it & 1, s0 = sd & 0xffff, s1 = sd >> 16;
-            const int mid = (s0 + s1 + 1) >> 1, l0 = hf ? mid : s0, l1 = hf ? s1 : mid;
-            if (l0 >= l1) continue;
-            const int j = jk / 3, k = jk - 3 * j;
-            T a[3][NQ];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) a[i][q] = (T)0;
-            const int b0 = sbase[0][l0], b1 = sbase[1][l0], b2 = sbase[2][l0]; // the same for every particle of the cell
-            for (int l = l0; l < l1; ++l) {
-                const T d1 = (T)(b1 + j) * dx - sp[1][l], d2 = (T)(b2 + k) * dx - sp[2][l];
-                const T m = sp[3][l];
-                const T c0_ = sp[7][l], c1_ = sp[8][l], c2_ = sp[9][l], m0 = sp[4][l], m1 = sp[5][l], m2 = sp[6][l], xp0 = sp[0][l];
-                T cn = (T)0;
-                if (WITH_CN) cn = sp[NS - 1][l];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const T wijk = sp[16 + i][l] * sp[19 + j][l] * sp[22 + k][l];
-                    const T d0 = (T)(b0 + i) * dx - xp0;
-                    a[i][0] += m * wijk;
-                    a[i][1] += (c0_ * d0 + sp[10][l] * d1 + sp[13][l] * d2 + m0) * wijk;
-                    a[i][2] += (c1_ * d0 + sp[11][l] * d1 + sp[14][l] * d2 + m1) * wijk;
-                    a[i][3] += (c2_ * d0 + sp[12][l] * d1 + sp[15][l] * d2 + m2) * wijk;
-                    if (WITH_CN) a[i][NQ - 1] += cn * wijk;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int t = ((b0 - ox + i) * TY + (b1 - oy + j)) * TZ + (b2 - oz + k);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) lds_atomic_add(&acc[q][t], (AT)a[i][q]);
-            }
-        }
-    }
-    __syncthreads();
-    // partial tile of this group, coalesced; summed per node by k_tile_reduce (no global atomics)
-    T* out = part + (int64_t)g * NQ * TILE;
-    for (int t = tid; t < NQ * TILE; t += P2G_THREADS) out[t] = (T)(&acc[0][0])[t];
-}
+#include "ab_src/transfer_ab2.hip"
 #endif
 
 #ifdef HOT_AB_KERNELS
-// Rounds 2 - 5 (A/B build since round 6, HOT_P2G_CELLS2): the (cell segment, node row, half) work items of k_p2g_cells (above, A/B build), but only the 16 (17 with the
-// CN quantity) per-particle scalars x, m, m v, m C are staged — the nine 1-D weights are recomputed per item from x (a few
-// multiply-adds against nine LDS reads) and the base cell comes from the segment's first particle.  35 KB instead of 56 KB per
-// 256-particle chunk: four 256-thread workgroups per CU instead of two 512-thread ones, i.e. twice as many independent
-// header -> staging -> items chains in flight per CU.  (Tried in round 3: persistent workgroups walking the groups with the next
-// unit's 16 scalars requested into registers before the item phase of the current one — C2 0.156 vs 0.132 ms, C3 0.405 vs 0.375:
-// with four workgroups per CU the staging latency is already covered by the other three, what is left is the item phase itself,
-// VALU 44 % + LDS 56 % of the kernel's cycles (profiles/r03_sq_counters_C2.json).)
-// Development aid (-DHOT_HT_CLOCKS, tools/hess_phases.sh): shader clocks of thread 0 between the barriers of k_p2g_cells2, summed
-// over the workgroups: 0 header + zeroing, 1 staging, 2 items, 3 write-out.
-#ifndef HOT_P2G_NO_ITEMS
-#define HOT_P2G_NO_ITEMS 0
-#endif
-#ifdef HOT_HT_CLOCKS
-extern __device__ unsigned long long p2g_clk[12];
-#define P2G_CLK(i) \
-    do { \
-        if (tid == 0) { \
-            const unsigned long long t_ = clock64(); \
-            clk_[i] += t_ - t0_, t0_ = t_; \
-        } \
-    } while (0)
-#else
-#define P2G_CLK(i)
-#endif
-
-template <class T, bool WITH_CN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_p2g_cells2(const T* __restrict__ X, const T* __restrict__ V, const T* __restrict__ M, const T* __restrict__ C,
-    const T* __restrict__ Mu, const T* __restrict__ Lam, int64_t Np, const int32_t* __restrict__ group_first, const int32_t* __restrict__ group_origin,
-    const int32_t* __restrict__ group_cell0, const int32_t* __restrict__ cell_first, T* __restrict__ part, T dx, T one_over_dx)
-{
-    using G = Geo<T>;
-    constexpr int TY = G::BY + 2, TZ = G::BZ + 2, TILE = (G::BX + 2) * TY * TZ;
-    constexpr int NQ = WITH_CN ? 5 : 4, NS = 16 + (WITH_CN ? 1 : 0), THREADS = 256, CH = sizeof(T) == 4 ? 512 : 256;
-    using AT = AccT<T>;
-    __shared__ AT acc[NQ][TILE];
-    __shared__ T sp[NS][CH]; // x(3) m(1) m*v(3) m*C(9) [cn]
-    __shared__ int32_t segs[G::EPB + 2];
-    __shared__ int32_t nseg;
-    const int g = blockIdx.x, tid = threadIdx.x;
-#ifdef HOT_HT_CLOCKS
-    unsigned long long clk_[4] = { 0, 0, 0, 0 }, t0_ = clock64();
-#endif
-    for (int t = tid; t < NQ * TILE; t += THREADS) (&acc[0][0])[t] = (AT)0;
-    const int first = group_first[g], last = group_first[g + 1];
-    const int c0 = group_cell0[g], c1 = group_cell0[g + 1];
-    const int ox = group_origin[3 * g], oy = group_origin[3 * g + 1], oz = group_origin[3 * g + 2];
-    for (int ch = first; ch < last; ch += CH) {
-        if (tid == 0) nseg = 0;
-        __syncthreads();
-        P2G_CLK(0);
-        for (int l = tid; l < (HOT_P2G_NO_ITEMS == 3 ? 0 : CH) && ch + l < last; l += THREADS) { // (3: experiment, no particle loads)
-            const int p = ch + l;
-            const T m = M[p];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) sp[d][l] = X[(int64_t)d * Np + p], sp[4 + d][l] = m * V[(int64_t)d * Np + p];
-            sp[3][l] = m;
-#pragma unroll
-            for (int c = 0; c < 9; ++c) sp[7 + c][l] = m * C[(int64_t)c * Np + p];
-            if (WITH_CN) {
-                const T mu = Mu[p], la = Lam[p];
-                sp[NS - 1][l] = m * hsqrt((T)3 * ((T)2 * mu + la) * ((T)2 * mu + la) + (T)6 * la * la + (T)12 * mu * mu);
-            }
-        }
-        for (int c = c0 + tid; c < c1; c += THREADS) {
-            const int s0 = max(cell_first[c], ch), s1 = min(cell_first[c + 1], min(ch + CH, last));
-            if (s1 > s0) segs[atomicAdd(&nseg, 1)] = (s0 - ch) | ((s1 - ch) << 16);
-        }
-        __syncthreads();
-        P2G_CLK(1);
-        // items: (cell segment, node row j, half of the segment) -> the 9 nodes (i, k) of that row with their sums in registers: the
-        // scalars of a particle are read from LDS once per 9 nodes instead of once per 3 (the item phase is LDS 56 % + VALU 44 % of the
-        // round-2 kernel's cycles).  fp32: all NQ quantities in one item (C3 0.302 from 0.375 ms).  fp64: 45 sums need 216 registers
-        // (two workgroups per CU instead of four: 0.141 ms against the 3-node items' 0.132), so the quantities are dealt to two items,
-        // {m, m v0, cn} and {m v1, m v2}.
-        auto run9 = [&](auto mask_c, int it) {
-            constexpr int MASK = decltype(mask_c)::value;
-            const int sd = segs[it / 6], j = (it % 6) >> 1, hf = it & 1, s0 = sd & 0xffff, s1 = sd >> 16;
-            const int mid = (s0 + s1 + 1) >> 1, l0 = hf ? mid : s0, l1 = hf ? s1 : mid;
-            if (l0 >= l1) return;
-            T a[3][3][NQ]; // [i][k][quantity]
-#pragma unroll
-            for (int e = 0; e < 9 * NQ; ++e) (&a[0][0][0])[e] = (T)0;
-            // the base cell is the same for every particle of the segment
-            const int b0 = base_node_of<T>(one_over_dx, sp[0][l0]), b1 = base_node_of<T>(one_over_dx, sp[1][l0]), b2 = base_node_of<T>(one_over_dx, sp[2][l0]);
-            const T fb0 = (T)b0, fb1 = (T)b1, fb2 = (T)b2;
-            for (int l = l0; l < l1; ++l) {
-                const T x0 = sp[0][l], x1 = sp[1][l], x2 = sp[2][l];
-                // 1-D quadratic B-spline weights, the arithmetic of bspline() (BSplines.h:55-81)
-                auto w3 = [&](T x, T fb, T(&w)[3]) {
-                    const T d0 = fma(one_over_dx, x, -fb); // exact product, like the fused multiply-add a -O3 -march=native host build makes of it (hot_common.h bspline)
-                    const T z = (T)1.5 - d0, d1 = d0 - (T)1, zz = (T)1.5 - ((T)1 - d1);
-                    w[0] = (T)0.5 * z * z, w[1] = (T)0.75 - d1 * d1, w[2] = (T)0.5 * zz * zz;
-                };
-                T wi[3], wj3[3], wk[3];
-                w3(x0, fb0, wi), w3(x1, fb1, wj3), w3(x2, fb2, wk);
-                const T wj = j == 0 ? wj3[0] : (j == 1 ? wj3[1] : wj3[2]);
-                const T d1 = (T)(b1 + j) * dx - x1;
-                T m = (T)0, cn = (T)0, u[3], cc[3], ee[3];
-                if constexpr ((MASK & 1) != 0) m = sp[3][l];
-                if constexpr (WITH_CN && (MASK & (1 << (NQ - 1))) != 0) cn = sp[NS - 1][l];
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    if (MASK & (2 << q)) u[q] = sp[10 + q][l] * d1 + sp[4 + q][l], cc[q] = sp[7 + q][l], ee[q] = sp[13 + q][l];
-                T d0[3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) d0[i] = (T)(b0 + i) * dx - x0;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const T d2 = (T)(b2 + k) * dx - x2, wjk = wj * wk[k];
-                    T t[3];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        if (MASK & (2 << q)) t[q] = ee[q] * d2 + u[q];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const T wijk = wi[i] * wjk;
-                        if constexpr ((MASK & 1) != 0) a[i][k][0] += m * wijk;
-#pragma unroll
-                        for (int q = 0; q < 3; ++q)
-                            if (MASK & (2 << q)) a[i][k][1 + q] += (cc[q] * d0[i] + t[q]) * wijk;
-                        if constexpr (WITH_CN && (MASK & (1 << (NQ - 1))) != 0) a[i][k][NQ - 1] += cn * wijk;
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int t = ((b0 - ox + i) * TY + (b1 - oy + j)) * TZ + (b2 - oz + k);
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        if (MASK & (1 << q)) lds_atomic_add(&acc[q][t], (AT)a[i][k][q]);
-                }
-        };
-        const int n6 = HOT_P2G_NO_ITEMS ? 0 : nseg * 6; // (HOT_P2G_NO_ITEMS: experiment, staging alone)
-        if constexpr (sizeof(T) == 4) {
-            for (int it = tid; it < n6; it += THREADS) run9(std::integral_constant<int, (1 << NQ) - 1>{}, it);
-        }
-        else {
-            for (int it = tid; it < 2 * n6; it += THREADS) {
-                if (it < n6)
-                    run9(std::integral_constant<int, 1 | 2 | (WITH_CN ? 16 : 0)>{}, it);
-                else
-                    run9(std::integral_constant<int, 4 | 8>{}, it - n6);
-            }
-        }
-    }
-    __syncthreads();
-    P2G_CLK(2);
-    T* out = part + (int64_t)g * NQ * TILE;
-#if HOT_P2G_NO_ITEMS != 2 // (2: experiment, no write-out either)
-    for (int t = tid; t < NQ * TILE; t += THREADS) out[t] = (T)(&acc[0][0])[t];
-#endif
-#ifdef HOT_HT_CLOCKS
-    P2G_CLK(3);
-    if (tid == 0)
-        for (int i = 0; i < 4; ++i) atomicAdd(&p2g_clk[i], clk_[i]);
-#endif
-}
+#include "ab_src/transfer_ab3.hip"
 #endif
 
 // Round 6: P2G as a stream.  k_p2g_cells2 (above) is one workgroup per particle group with ONE chain header -> staging loads -> barrier -> items ->

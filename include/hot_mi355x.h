@@ -99,6 +99,13 @@ typedef struct hot_config {
     int32_t reserved[5];
 } hot_config;
 
+/* Version of the structures below and of hot_config: it changes whenever a field is added (fields are only ever appended).  hot_solve / hot_advance /
+ * hot_advance_frame write a WHOLE hot_stats through the caller's pointer, so a caller compiled against an older header would be written past the end
+ * of its structure: check hot_abi_version() == HOT_ABI_VERSION once after loading the library (hot_amd/binding.py does).
+ *   5: hot_stats.comm_calls_index appended (round 5); 6: hot_config.shard_owner takes 0 / 1 / 2, hot_copy_bandwidth (round 6) */
+#define HOT_ABI_VERSION 6
+int hot_abi_version(void);
+
 typedef struct hot_stats {
     int32_t iterations; /* nonlinear (L-BFGS / Newton) iterations of the last solve */
     int32_t converged;
@@ -225,6 +232,10 @@ int hot_get_level_nnzb(hot_ctx*, int32_t level, int64_t* nnzb);
  * of the two kernels.  Valid after hot_build_mg on levels that were coloured; HIP product only. */
 int hot_get_level_inblock_nnzb(hot_ctx*, int32_t level, int64_t* nnzb);
 int hot_get_prolongation(hot_ctx*, int32_t level, int32_t* entryCol /*8*nrows(level)*/, void* weight /*8*nrows(level)*/);
+/* measurement aid, HIP product only: the rate (GB/s, bytes read + bytes written) of a device-to-device copy KERNEL (16 bytes per lane, four loads in
+ * flight per thread) over `bytes` bytes, `reps` launches between two events on the context's stream — the attainable streaming rate of the box the
+ * roofline fractions are quoted beside ("a device-to-device copy kernel"); allocates and frees two buffers of `bytes` bytes */
+int hot_copy_bandwidth(hot_ctx*, int64_t bytes, int32_t reps, double* gbytes_per_s);
 
 /* ---- operators */
 int hot_spmv(hot_ctx*, int32_t level, const void* x, void* y); /* SquareMatrix::multiply :477-487 */
@@ -322,7 +333,7 @@ int hot_rccl_selftest(hot_ctx*); /* runs every collective of the attached commun
 /* ---- the constitutive model and the plastic return mappings for caller-supplied deformation gradients (arrays of `real`,
  *      3x3 column-major, per-sample mu / lambda): CorotatedIsotropic<T,3>::updateScratch + psi + firstPiola +
  *      firstPiolaDerivative (Lib/Ziran/Physics/ConstitutiveModel/CorotatedIsotropic.h:110-230; dPdF is the 9x9 derivative, column-major
- *      over the column-major vectorisations of P and F, PSD-projected when project == 1; project == 2: psi alone, evaluated as the line
+ *      over the column-major vectorisations of P and F, PSD-projected when project is non-zero; project == 2 exactly: psi alone, evaluated as the line
  *      search's energy-only trials evaluate it — from the invariants of F^T F without an SVD where det F > 0.1 —, P and dPdF untouched), and
  *      VonMisesFixedCorotated / SnowPlasticity::projectStrain (Lib/Ziran/Physics/PlasticityApplier.cpp:96-131, :18-50) with
  *      cfg.yield_stress / cfg.snow, in place.  NULL outputs are skipped. */

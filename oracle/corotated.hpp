@@ -94,6 +94,55 @@ inline T corotated_psi(const CorotatedScratch<T>& s, T mu, T lambda)
     return mu * (s.F - s.R).squaredNorm() + (T).5 * lambda * Jm1 * Jm1;
 }
 
+// NOT a restatement of the reference: the PRODUCT's form of the same psi for the line search's trial energies (hot_amd/csrc/hot_constitutive.h
+// corotated_psi_invariants / corotated_psi_sigma — of the polar decomposition psi needs tr S alone, the largest root of a quartic in the invariants of
+// F^T F, and where that declines |F - R|^2 = sum (sigma_i - 1)^2), restated here so that the two forms can be compared where it matters: on the
+// accept / reject decisions `Ek <= Ek0` of lineSearch (ImplicitSolver.h:312-333).  Selected for every energy evaluation of a context by
+// HOT_ORACLE_PSI_INVARIANTS=1 at hoto_create (tests/oracle_lib.py psi_invariants()); the default is corotated_psi above.
+inline bool& psi_invariants_flag()
+{
+    static bool f = false;
+    return f;
+}
+template <class T>
+inline T corotated_psi_product_form(const CorotatedScratch<T>& s, T mu, T lambda)
+{
+    const M3<T>& F = s.F;
+    const T E00 = (T)0.5 * std::fma(F(0, 0), F(0, 0), std::fma(F(1, 0), F(1, 0), std::fma(F(2, 0), F(2, 0), (T)-1)));
+    const T E11 = (T)0.5 * std::fma(F(0, 1), F(0, 1), std::fma(F(1, 1), F(1, 1), std::fma(F(2, 1), F(2, 1), (T)-1)));
+    const T E22 = (T)0.5 * std::fma(F(0, 2), F(0, 2), std::fma(F(1, 2), F(1, 2), std::fma(F(2, 2), F(2, 2), (T)-1)));
+    const T E01 = (T)0.5 * (F(0, 0) * F(0, 1) + F(1, 0) * F(1, 1) + F(2, 0) * F(2, 1));
+    const T E02 = (T)0.5 * (F(0, 0) * F(0, 2) + F(1, 0) * F(1, 2) + F(2, 0) * F(2, 2));
+    const T E12 = (T)0.5 * (F(0, 1) * F(0, 2) + F(1, 1) * F(1, 2) + F(2, 1) * F(2, 2));
+    const T e1 = E00 + E11 + E22;
+    const T e2 = E00 * E11 + E11 * E22 + E00 * E22 - E01 * E01 - E12 * E12 - E02 * E02;
+    const T e3 = E00 * (E11 * E22 - E12 * E12) - E01 * (E01 * E22 - E12 * E02) + E02 * (E01 * E12 - E11 * E02);
+    const T q = (T)2 * e1 + (T)4 * e2 + (T)8 * e3; // J^2 - 1
+    bool settled = false;
+    T psi = 0;
+    if (q > (T)-0.99 && F.determinant() > (T)0) {
+        const T j = q / (std::sqrt((T)1 + q) + (T)1);
+        const T g0 = ((e1 + (T)8) * e1 + (T)28) * e1 * e1 - (T)8 * j * e1 + (T)12 * j * j - (T)64 * e2 - (T)96 * e3;
+        const T g1 = -((((T)4 * e1 + (T)28) * e1 + (T)72) * e1 + (T)64 - (T)8 * j);
+        const T g2 = ((T)6 * e1 + (T)32) * e1 + (T)48;
+        const T g3 = -((T)4 * e1 + (T)12);
+        const T tol = sizeof(T) == 8 ? (T)8.9e-16 : (T)4.8e-7;
+        T u = 0;
+        for (int it = 0; it < 12 && !settled; ++it) {
+            const T g = (((u + g3) * u + g2) * u + g1) * u + g0;
+            const T gp = (((T)4 * u + (T)3 * g3) * u + (T)2 * g2) * u + g1;
+            const T du = -g / gp;
+            u += du;
+            settled = !(du > tol * u);
+        }
+        u = u > (T)0 ? u : (T)0;
+        psi = (T)2 * mu * u + (T)0.5 * lambda * j * j;
+    }
+    if (settled) return psi;
+    const T d0 = s.sigma(0) - 1, d1 = s.sigma(1) - 1, d2 = s.sigma(2) - 1, Jm1 = s.J - 1;
+    return mu * (d0 * d0 + d1 * d1 + d2 * d2) + (T)0.5 * lambda * Jm1 * Jm1;
+}
+
 template <class T>
 inline M3<T> corotated_first_piola(const CorotatedScratch<T>& s, T mu, T lambda)
 {

@@ -90,6 +90,7 @@ void hoto_default_config(hot_config* c)
 }
 
 void hoto_set_wide(int on) { hot_oracle::wide_flag() = on != 0; } // tests/oracle_lib.py wide_sums(): restore the process-wide flag
+void hoto_set_psi_invariants(int on) { hot_oracle::psi_invariants_flag() = on != 0; } // tests/oracle_lib.py psi_invariants()
 
 int hoto_create(const hot_config* cfg, hoto_ctx** out)
 {
@@ -97,6 +98,7 @@ int hoto_create(const hot_config* cfg, hoto_ctx** out)
     c->dtype = cfg->dtype;
     hot_oracle::fair_flag() = getenv("HOT_ORACLE_FAIR") != nullptr; // CPU-baseline variant (sim_core.hpp), timing only
     hot_oracle::wide_flag() = getenv("HOT_ORACLE_WIDE") != nullptr; // fp32: node sums and dot products accumulated in double (sim_core.hpp)
+    hot_oracle::psi_invariants_flag() = getenv("HOT_ORACLE_PSI_INVARIANTS") != nullptr; // every energy in the product's trial form (corotated.hpp corotated_psi_product_form)
     DISPATCH(c, {
         auto* s = new Sim<T>();
         s->cfg = *cfg;
@@ -649,6 +651,7 @@ int hoto_profile_count(hoto_ctx*, int32_t* n)
 }
 int hoto_profile_get(hoto_ctx*, int32_t, char*, int64_t*, double*) { return HOT_ERR_INVALID; }
 const char* hoto_version(void) { return "hot-oracle-cpu 0.1"; }
+int hoto_abi_version(void) { return HOT_ABI_VERSION; } // the header this checker was compiled against
 
 // ---- small stand-alone probes used by the oracle's own pin tests
 void hoto_linear_offset(int dtype, int n, const int32_t* ijk, uint64_t* out)

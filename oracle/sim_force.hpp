@@ -59,7 +59,7 @@ double Sim<T>::force_total_energy()
     for (int64_t p = 0; p < Np; ++p) {
         CorotatedScratch<T> s;
         corotated_update_scratch(F[p], mu[p], lambda[p], proj, s);
-        e += vol[p] * corotated_psi(s, mu[p], lambda[p]);
+        e += vol[p] * (psi_invariants_flag() ? corotated_psi_product_form(s, mu[p], lambda[p]) : corotated_psi(s, mu[p], lambda[p]));
     }
     allreduce(&e, 1, HOT_COMM_F64); // sharded: sum of the shards' strain energies
     return e;

@@ -58,6 +58,23 @@ def wide_sums(on=True):
         load_oracle().lib.hoto_set_wide(1 if old is not None else 0)
 
 
+@contextlib.contextmanager
+def psi_invariants(on=True):
+    """Oracle contexts created and used inside this block evaluate EVERY strain energy in the product's line-search form (psi from the invariants of
+    F^T F, oracle/corotated.hpp corotated_psi_product_form) instead of the reference's mu |F - R|^2 + lambda / 2 (J - 1)^2: the two forms side by side
+    on the accept / reject decisions of the line search.  Process-wide like wide_sums()."""
+    old = os.environ.pop("HOT_ORACLE_PSI_INVARIANTS", None)
+    if on:
+        os.environ["HOT_ORACLE_PSI_INVARIANTS"] = "1"
+    try:
+        yield
+    finally:
+        os.environ.pop("HOT_ORACLE_PSI_INVARIANTS", None)
+        if old is not None:
+            os.environ["HOT_ORACLE_PSI_INVARIANTS"] = old
+        load_oracle().lib.hoto_set_psi_invariants(1 if old is not None else 0)
+
+
 def linear_offset(dtype, ijk):
     ijk = np.ascontiguousarray(ijk, np.int32).reshape(-1, 3)
     out = np.empty(len(ijk), np.uint64)

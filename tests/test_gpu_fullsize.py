@@ -35,14 +35,24 @@ def make(lib, cfg, n, floor=True, **kw):
 def test_c1_full_step_against_oracle(hotlib, oracle):
     cfg = synth.CONFIGS["C1"]
     out = {}
-    for name, lib in (("gpu", hotlib), ("cpu", oracle)):
-        ctx, cloud = make(lib, cfg, cfg["n"], cneps=1e-7)
+    for name, lib, over in (("gpu", hotlib, {}), ("cpu", oracle, {}), ("gpu_full_trials", hotlib, dict(ls_energy_only=1)), ("gpu_energy_only_trials", hotlib, dict(ls_energy_only=2))):
+        ctx, cloud = make(lib, cfg, cfg["n"], cneps=1e-7, **over)
         st = ctx.advance(cfg["dt"])
         out[name] = (ctx.get_particles(), st)
+        del ctx
     sg, sc = out["gpu"][1], out["cpu"][1]
     assert sg["converged"] == 1 and sc["converged"] == 1
     assert sg["num_nodes"] == sc["num_nodes"]
     assert abs(sg["iterations"] - sc["iterations"]) <= max(2, sc["iterations"] // 10), (sg, sc)
+    # the line search's decisions: a run that made the oracle's number of iterations evaluated the oracle's number of trials, whichever way the
+    # device evaluates a trial's energy (full state pass / invariants of F^T F / adaptive)
+    for name in ("gpu", "gpu_full_trials", "gpu_energy_only_trials"):
+        st = out[name][1]
+        assert st["converged"] == 1 and abs(st["iterations"] - sc["iterations"]) <= max(2, sc["iterations"] // 10), (name, st, sc)
+        if st["iterations"] == sc["iterations"]:
+            assert st["linesearch_trials"] == sc["linesearch_trials"], (name, st, sc)
+        else:  # a different history from some iteration on: the number of halvings per iteration stays the oracle's to within 10 %
+            assert abs((st["linesearch_trials"] - st["iterations"]) - (sc["linesearch_trials"] - sc["iterations"])) <= max(2, (sc["linesearch_trials"] - sc["iterations"]) // 10), (name, st, sc)
     pg, pcpu = out["gpu"][0], out["cpu"][0]
     # both stop at the same CN tolerance: positions agree far below a cell, velocities at the solver tolerance
     assert np.abs(pg["X"] - pcpu["X"]).max() < 1e-3 * 0.01  # a thousandth of a cell (dt times the velocity tolerance)

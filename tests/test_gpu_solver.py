@@ -197,6 +197,51 @@ def test_solve_to_convergence_against_oracle(hotlib, oracle, kw):
     assert abs(sg["energy"] - sc["energy"]) < 1e-4 * max(abs(sc["energy"]), 1e-6)
 
 
+@pytest.mark.parametrize("dtype,cneps,E", [(1, 1e-8, 5e4), (1, 1e-7, 2e6), (0, 1e-5, 5e4)], ids=["fp64", "fp64_stiff", "fp32_tight"])
+def test_line_search_decisions_pinned_against_oracle(hotlib, oracle, dtype, cneps, E):
+    """The accept / reject decisions `Ek <= Ek0` of lineSearch (ImplicitSolver.h:312-333), end to end.  Since round 5 the device evaluates the trial
+    energies from the invariants of F^T F (hot_constitutive.h corotated_psi_invariants) where the reference sums mu |F - R|^2 + lambda / 2 (J - 1)^2
+    through the SVD; a search that accepted one trial later would still converge in a similar number of iterations, so the iteration-count bound of
+    the converged-solve tests does not see it.  Here: the same solve cut off after 1, 2, 3, 5, 8, 13, 21, ... iterations and at convergence, on the
+    device with the trials as full state passes (ls_energy_only = 1), as energy-only passes (2) and adaptive (0), on the oracle in the reference's
+    form, and on the oracle with EVERY energy in the product's form (tests/oracle_lib.py psi_invariants): wherever two runs made the same number of
+    iterations they must have evaluated the same number of trials — at every cut, i.e. search by search up to the point where round-off first
+    moves a decision, which must not happen before convergence in fp64."""
+    from tests.oracle_lib import psi_invariants
+    kw = dict(lsolver=3, levelCnt=2, cneps=cneps)
+    cuts = [1, 2, 3, 5, 8, 13, 21, 34, 55, 10000]
+
+    def history(lib, **over):
+        out = []
+        for k in cuts:
+            ctx, c = pc.make_ctx(lib, n=8, dtype=dtype, E=E, max_iterations=k, **dict(kw, **over))
+            pc.prepare(ctx)
+            st = ctx.solve()
+            out.append((st["iterations"], st["linesearch_trials"], st["converged"]))
+            if st["converged"] == 1 and st["iterations"] < k:
+                break
+        return out
+
+    runs = {"oracle": history(oracle)}
+    with psi_invariants():
+        runs["oracle, product form"] = history(oracle)
+    for mode in (1, 2, 0):
+        runs["device ls_energy_only=%d" % mode] = history(hotlib, ls_energy_only=mode)
+    ref = runs["oracle"]
+    assert ref[-1][2] == 1, ref
+    halvings = ref[-1][1] - ref[-1][0]  # trials beyond the first of every search
+    print("line-search pin (%s): iterations / trials at the cuts: %s" % ("fp64" if dtype else "fp32", {k: [(a, b) for a, b, _ in v] for k, v in runs.items()}))
+    assert halvings >= 3, ("the case must exercise rejections", ref)
+    for name, h in runs.items():
+        assert h[-1][2] == 1, (name, h)
+        for (i0, t0, _), (i1, t1, _) in zip(ref, h):
+            if i0 == i1:
+                assert t0 == t1, (name, ref, h)
+        if dtype == 1:  # fp64: not a single decision moves before convergence; the converged counts agree to within the last search
+            assert all(a[0] == b[0] for a, b in zip(ref[:-1], h[:-1])), (name, ref, h)
+            assert abs(h[-1][0] - ref[-1][0]) <= 1, (name, ref, h)
+
+
 def test_three_time_steps_against_oracle(hotlib, oracle):
     """Whole steps (sort -> P2G -> solve -> G2P) chained three times, fp64.  Each step ends at the solver's termination
     tolerance, so velocities agree to that level (relative to the initial velocity scale), positions much tighter."""
