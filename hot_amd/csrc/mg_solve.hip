@@ -2127,7 +2127,9 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             const T* rhs = fwd ? r : dAu;
             T* xx = fwd ? hdu : du;
             T* hD = fwd ? dAu : u;
+#ifndef HOT_AB_KERNELS
             const char* nm = fwd ? "gs_forward_fused" : "gs_backward_fused";
+#endif
             T* hsub = !fwd ? hdu : (T*)nullptr; // h - du for the residual, row by row
             const int nstream = std::max(8, ab_int("HOT_GS_OFF_WAVES", 4096) / 4 / 8 * 8);
             for (int q = 0; q < 8; ++q) {
@@ -2136,6 +2138,10 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 const int s0 = (cn >= 0 && cn < 8) ? L.gs_slot_rng2[fwd ? 0 : 2][0][cn] : 0, s1 = (cn >= 0 && cn < 8) ? L.gs_slot_rng2[fwd ? 0 : 2][1][cn] : 0;
                 const int grid = nb_pad + (s1 > s0 ? nstream : 0);
                 if (grid == 0) continue;
+#ifdef HOT_AB_KERNELS
+                const std::string nmq = ab_flag("HOT_GS_PROF_COLOURS") ? std::string(fwd ? "gs_forward_fused_q" : "gs_backward_fused_q") + char('0' + q) : std::string(fwd ? "gs_forward_fused" : "gs_backward_fused"); // A/B build: one profile record per pass of the half sweep
+                const char* nm = nmq.c_str();
+#endif
 #define HOT_COLOUR_D(DD)                                                                                                                                                       \
     do {                                                                                                                                                                       \
         if (fwd)                                                                                                                                                               \
