@@ -53,8 +53,8 @@ struct Level {
     // after build_mg every row's slots are regrouped as [nl entries preceding the row in the GS order | diagonal |
     // nu entries following it | structural zeros], so each half sweep streams only the half it needs
     double lMin = 1e-8, lMax = 1e2; // spectrum bounds for the Chebyshev smoother (SquareMatrix.h:37, estimate2norm :375-475)
-    DBuf<T> apv; // n*64*9: A*P of this level (4^3 coarse window per row), kept for the coarse-correction residual update
-    DBuf<int32_t> apc; // n*64: coarse column of every window slot (0 where the coarse node does not exist; its block is 0)
+    DBuf<T> apv; // n*64*9: A*P of this level (coarse window per row, packed: the na nb nc = 27 .. 64 slots that can be non-zero come first, k_ap), kept for the coarse-correction residual update
+    DBuf<int32_t> apc; // n*64: coarse column by geometric window position 16 a + 4 b + c (0 where the coarse node does not exist: its block is 0; -1 at the structurally zero positions, which apv does not store)
     DBuf<int32_t> gs_nbr; // nblocks*26: the adjacent colour blocks (global block id | colour << 28, or -1): whose unknowns a block's rows read
     DBuf<int> gs_flag; // 4*nblocks: sweep number in which the (block, sub-block) was last finished (k_gs_sweep's point-to-point hand-off)
     DBuf<int32_t> gs_pad; // nblocks*64*8 (+ one sentinel record): per (colour block, position) {node or -1, the row's four class counts, first forward slot, first backward slot, pad}: the GS kernels' header in one load

@@ -112,8 +112,13 @@ __global__ void k_coarse_cols(HashMap cmap, const int32_t* __restrict__ ccoord, 
     col[e] = j >= 0 ? j : (n > 0 ? 0 : 1);
 }
 
-// AP[i][(a,b,c) in 4^3][9]: coarse window origin cb = (coord - 2) >> 1 ;  J = cb + (a,b,c)
+// AP[i][(a,b,c) in the coarse window][9]: coarse window origin cb = (coord - 2) >> 1 ;  J = cb + (a,b,c)
 // AP[i,J] = sum_{d in {-1,0,1}^3} w(d) A[i][slot(i - (2J + d))]
+// Round 6: the window is PACKED.  Along an axis on which the fine node's coordinate is even the window holds 3 coarse nodes, not 4 (x = 2 m: the fine
+// neighbours x - 2 .. x + 2 interpolate from m - 1, m, m + 1; position a = 3 is structurally zero), so a row has na nb nc = 27 .. 64 (42.9 on average)
+// non-zero slots, stored first: slot p = (a nb + b) nc + c.  k_apmv_sub, which runs once per V-cycle and level, reads those only — a third fewer bytes;
+// the rest of the 64-slot row is never written nor read.
+__device__ __forceinline__ void ap_window(int x, int y, int z, int& na, int& nb, int& nc) { na = 3 + (x & 1), nb = 3 + (y & 1), nc = 3 + (z & 1); }
 template <class T>
 __global__ __launch_bounds__(256) void k_ap(const int32_t* __restrict__ coord, const T* __restrict__ val, T* ap, int n, const uint8_t* __restrict__ own)
 {
@@ -129,9 +134,12 @@ __global__ __launch_bounds__(256) void k_ap(const int32_t* __restrict__ coord, c
     if (i >= n) return;
     int x = coord[3 * i], y = coord[3 * i + 1], z = coord[3 * i + 2];
     int cbx = (x - 2) >> 1, cby = (y - 2) >> 1, cbz = (z - 2) >> 1;
-    for (int o = lane; o < 576; o += 64) {
+    int na, nb, nc;
+    ap_window(x, y, z, na, nb, nc);
+    const int cnt9 = na * nb * nc * 9;
+    for (int o = lane; o < cnt9; o += 64) {
         int js = o / 9, comp = o - js * 9;
-        int a = js >> 4, b = (js >> 2) & 3, c = js & 3;
+        int a = js / (nb * nc), b = (js / nc) % nb, c = js % nc;
         int Jx = cbx + a, Jy = cby + b, Jz = cbz + c;
         T sum = (T)0;
 #pragma unroll
@@ -154,12 +162,20 @@ __global__ __launch_bounds__(256) void k_ap(const int32_t* __restrict__ coord, c
         ap[(int64_t)i * 576 + o] = sum;
     }
 }
-// coarse column ids of the AP window slots
+// coarse column ids of the AP window, by GEOMETRIC window position js = 16 a + 4 b + c: -1 at the positions that are structurally zero (not stored: the
+// packed slot of a stored position is its rank among the row's stored positions, in this order), 0 where a coarse node of the window does not exist (its
+// block is 0)
 __global__ void k_ap_cols(HashMap cmap, const int32_t* __restrict__ coord, int32_t* apc, int n)
 {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)n * 64) return;
     int i = (int)(e >> 6), js = (int)(e & 63);
+    int na, nb, nc;
+    ap_window(coord[3 * i], coord[3 * i + 1], coord[3 * i + 2], na, nb, nc);
+    if ((js >> 4) >= na || ((js >> 2) & 3) >= nb || (js & 3) >= nc) {
+        apc[e] = -1;
+        return;
+    }
     int Jx = ((coord[3 * i] - 2) >> 1) + (js >> 4), Jy = ((coord[3 * i + 1] - 2) >> 1) + ((js >> 2) & 3), Jz = ((coord[3 * i + 2] - 2) >> 1) + (js & 3);
     int j = (Jx | Jy | Jz) < 0 ? -1 : hash_find_id(cmap, coord_key(Jx, Jy, Jz));
     apc[e] = j >= 0 ? j : 0;
@@ -191,8 +207,9 @@ __global__ __launch_bounds__(256) void k_rap(const int32_t* __restrict__ ccoord,
 #pragma unroll
     for (int batch = 0; batch < 3; ++batch) {
         for (int e = tid; e < 9 * 576; e += 256) {
-            const int ci = sci[9 * batch + e / 576];
-            sap[e] = ci >= 0 ? ap[(int64_t)ci * 576 + e % 576] : (T)0;
+            const int q = 9 * batch + e / 576, ci = sci[q];
+            const int cnt9 = (3 + (q / 9 != 1)) * (3 + ((q / 3) % 3 != 1)) * (3 + (q % 3 != 1)) * 9; // the child's packed window (child = 2 I + d: odd along the axes with d != 0)
+            if (e % 576 < cnt9) sap[e] = ci >= 0 ? ap[(int64_t)ci * 576 + e % 576] : (T)0;
         }
         __syncthreads();
 #pragma unroll
@@ -200,11 +217,12 @@ __global__ __launch_bounds__(256) void k_rap(const int32_t* __restrict__ ccoord,
             const int q = 9 * batch + qq, da = q / 9 - 1, db = (q / 3) % 3 - 1, dc = q % 3 - 1;
             if (sci[q] < 0) continue; // workgroup-uniform
             const T wgt = (da ? (T)0.5 : (T)1) * (db ? (T)0.5 : (T)1) * (dc ? (T)0.5 : (T)1);
+            const int na = 3 + (da != 0), nb = 3 + (db != 0), nc = 3 + (dc != 0); // the child's packed window (k_ap)
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
                 const int a = 3 - kx[t] + (da < 0), bb = 3 - ky[t] + (db < 0), c = 3 - kz[t] + (dc < 0);
-                if ((unsigned)a > 3u || (unsigned)bb > 3u || (unsigned)c > 3u) continue;
-                sum[t] += wgt * sap[qq * 576 + ((a << 4) | (bb << 2) | c) * 9 + comp[t]];
+                if ((unsigned)a >= (unsigned)na || (unsigned)bb >= (unsigned)nb || (unsigned)c >= (unsigned)nc) continue; // (position 3 of an even axis: structurally zero, not stored)
+                sum[t] += wgt * sap[qq * 576 + ((a * nb + bb) * nc + c) * 9 + comp[t]];
             }
         }
         __syncthreads();

@@ -187,12 +187,19 @@ __global__ __launch_bounds__(256) void k_apmv_sub(const int32_t* __restrict__ ap
     if (row >= n) return;
     if (unset && lane < 3) gs_store_unset(unset + 3 * (int64_t)row + lane);
     if (own && !own[row]) return;
+    // lane = geometric window position; -1 where the window is structurally zero (an even coordinate's fourth coarse node): nothing is stored nor loaded
+    // there, and the stored positions are packed in this order (k_ap): a lane's slot is its rank among the row's stored positions.  The wavefront sum
+    // pairs the same positions as before the packing (the skipped ones used to add exact zeros): bit-identical results.
     const int j = apc[(int64_t)row * 64 + lane];
-    const T* b = apv + ((int64_t)row * 64 + lane) * 9;
-    const T x0 = e[3 * (int64_t)j], x1 = e[3 * (int64_t)j + 1], x2 = e[3 * (int64_t)j + 2];
-    T s0 = b[0] * x0 + b[3] * x1 + b[6] * x2;
-    T s1 = b[1] * x0 + b[4] * x1 + b[7] * x2;
-    T s2 = b[2] * x0 + b[5] * x1 + b[8] * x2;
+    const int slot = __popcll(__ballot(j >= 0) & ((1ull << lane) - 1ull));
+    T s0 = (T)0, s1 = (T)0, s2 = (T)0;
+    if (j >= 0) {
+        const T* b = apv + ((int64_t)row * 64 + slot) * 9;
+        const T x0 = e[3 * (int64_t)j], x1 = e[3 * (int64_t)j + 1], x2 = e[3 * (int64_t)j + 2];
+        s0 = b[0] * x0 + b[3] * x1 + b[6] * x2;
+        s1 = b[1] * x0 + b[4] * x1 + b[7] * x2;
+        s2 = b[2] * x0 + b[5] * x1 + b[8] * x2;
+    }
     s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
     if (lane == 0) r[3 * (int64_t)row] -= s0, r[3 * (int64_t)row + 1] -= s1, r[3 * (int64_t)row + 2] -= s2;
 }

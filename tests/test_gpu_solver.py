@@ -280,6 +280,12 @@ def test_three_time_steps_fp32_against_fp32_oracle(hotlib, oracle):
     c = synth.cube_cloud(8, ppc=8, dtype=T)
     state = dict(X=c["X"], V=c["V"], C_=None, F=None)
     o, nrm = synth.sticky_floor(5.0, c["dx"])
+    # Round 6: the start states of the second and third round are FIXTURES (tests/golden/fp32_states.npz, made by tests/golden/make_fp32_states.py with
+    # the HIP library: this cube after one and after four converged fp32 steps), no longer whatever the build under test arrives at: the trajectory is
+    # chaotic, and on some of the states it passes through — a node of mass 5e-13 — the oracle's float PCG on the top level breaks down (the reference's
+    # cg_smooth divides by du'A du unguarded), which used to cost a whole round of comparisons whenever a last-bit change of the device code moved the
+    # trajectory onto such a state.  From every start state the build under test must still take a converged step that stays finite.
+    fixtures = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp32_states.npz"))
 
     def ctx_for(lib, **kw):
         ctx = lib.context(dtype=0, dx=c["dx"], gravity=(0, -9.8, 0), levelCnt=2, **kw)
@@ -326,7 +332,8 @@ def test_three_time_steps_fp32_against_fp32_oracle(hotlib, oracle):
         assert stf["converged"] == 1 and np.isfinite(stf["energy"]) and e4 is not None, (stf, e4)
         p = full.get_particles()
         assert np.isfinite(p["X"]).all() and np.isfinite(p["F"]).all()
-        state = dict(X=p["X"], V=p["V"], C_=p["C"], F=p["F"])
+        if step < 2:
+            state = dict(X=fixtures["X%d" % (step + 1)], V=fixtures["V%d" % (step + 1)], C_=fixtures["C%d" % (step + 1)], F=fixtures["F%d" % (step + 1)])
     assert compared >= 9, compared
 
 
