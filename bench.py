@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measu
 SYMBOL = {  # profile-record prefix -> device symbol as rocprofv3 names it
     "gs_forward": "hot::k_gs_subst<T,true,8>", "gs_backward": "hot::k_gs_subst<T,false,8>", "spmv": "hot::k_spmv<T>",
     "gs_forward_off": "hot::k_gs_offblock<T>", "gs_backward_off": "hot::k_gs_offblock<T>",
-    "gs_forward_fused": "hot::k_gs_colour<T,", "gs_backward_fused": "hot::k_gs_colour<T,",  # <T, true, 8> and <T, false, 8>: one kernel, two sweep directions
+    "gs_forward_fused": "hot::k_gs_colour<T,", "gs_backward_fused": "hot::k_gs_colour<T,",  # <T, true, D>, <T, false, D> and <T, true, D, true> (the turn): one kernel, two sweep directions
     "gs_forward_chained": "hot::k_gs_sweep<T,true,SB>", "gs_backward_chained": "hot::k_gs_sweep<T,false,SB>",
     "gs_residual": "hot::k_gs_residual<T>", "hessian_assemble": "hot::k_hessian_rows<T>", "state_update": "hot::k_state<T>",
     "force_scatter": "hot::k_force_cells2<T>", "p2g": "hot::k_p2g_cells2<T,true>", "g2p": "hot::k_g2p<T,0,true>",

@@ -1185,11 +1185,18 @@ __global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, cons
 // The 729 substitution wavefronts of a C2 colour (< 1 per SIMD, a 64-step dependent chain each) no longer own the chip alone, and a half
 // sweep is 8 launches instead of 15.  Row sums: previous-colour slots first, then the older ones, each in slot order (the pair path cuts the
 // concatenated run into slots instead: equal to rounding).
-template <class T, bool FWD, int D>
+// TURN (forward only, the LAST colour of the forward sweep): the backward sweep starts with the same colour, whose rows have no following off-block
+// column — a block's backward substitution needs nothing but its own forward result (right-hand side D h of its own rows).  The wavefront runs it right
+// behind the forward one (backward index table fetched with the forward one, backward image columns requested into the ring slots the forward walk frees),
+// and the backward sweep's first launch — 729 wavefronts walking a dependent chain with the chip otherwise empty — does not happen.  Same arithmetic as the
+// two launches: bit-identical results.
+template <class T, bool FWD, int D, bool TURN = false>
 __global__ __launch_bounds__(256) void k_gs_colour(const T* __restrict__ img, const uint16_t* __restrict__ imgi, const int32_t* __restrict__ gs_pad, const int4* __restrict__ srec, T* x, T* hD, int block0,
     int nb, int nb_pad /*nb rounded up to a multiple of 8: the streaming workgroups keep their XCD (workgroup id % 8)*/, const T* __restrict__ rhs, T* hsub, const int2* __restrict__ slot,
-    const int32_t* __restrict__ gcol, const T* __restrict__ val, T* part, int s_begin, int s_end /*streaming role: the next colour's older slots*/)
+    const int32_t* __restrict__ gcol, const T* __restrict__ val, T* part, int s_begin, int s_end /*streaming role: the next colour's older slots*/,
+    T* xb /*TURN: the backward sweep's target*/, T* ub /*TURN: the iterate, which takes the correction (or null)*/)
 {
+    static_assert(!TURN || FWD, "the turn is the end of the forward sweep");
     if ((int)blockIdx.x >= nb_pad) {
         gs_off_stream<T>(slot, gcol, val, x, part, s_begin, s_end, (int)blockIdx.x - nb_pad, (int)gridDim.x - nb_pad);
         return;
@@ -1197,56 +1204,27 @@ __global__ __launch_bounds__(256) void k_gs_colour(const T* __restrict__ img, co
     if ((int)blockIdx.x >= nb) return;
     using I = GsImg<T>;
     __shared__ T lprev[3 * 512]; // sums of the block's previous-colour slots (a row has at most 124 off-block columns: eight slots)
-    __shared__ T la[3 * 64]; // a = D^-1 (rhs - the row's off-block products), by position
-    __shared__ uint32_t lidx[64 * 33]; // wavefront 0: its lanes' rows of the index table (33 words a row: lane l reads bank (33 l + s / 2) % 64)
+    __shared__ T ldv[9 * 64]; // D^-1 by position, [entry][position]
+    __shared__ uint32_t lidx[(TURN ? 2 : 1) * 64 * 33]; // wavefront 0: its lanes' rows of the index table (33 words a row: lane l reads bank (33 l + s / 2) % 64)
     const int b = block0 + blockIdx.x;
     const int p0 = FWD ? srec[(int64_t)b * 64].y : srec[(int64_t)b * 64].w, p1 = FWD ? srec[(int64_t)b * 64 + 64].y : srec[(int64_t)b * 64 + 64].w; // the block's previous-colour slots
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const T* hdr = img + (size_t)b * I::per_block;
-    if (wave != 0) {
-        const int64_t pos = (int64_t)b * 64 + lane;
-        int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, sr = r0;
-        if (wave == 1) r0 = *(const int4*)(gs_pad + 8 * pos), r1 = *(const int4*)(gs_pad + 8 * pos + 4), sr = srec[pos]; // (in flight under the steps below)
+    if (wave != 0) { // the previous colour's share of the block's row sums, to LDS
         gs_off_steps<T>(slot, gcol, val, x, p0, p1, wave - 1, 3, (p1 - p0 + 3) >> 2, [&](int sl, T s0, T s1, T s2) __attribute__((always_inline)) {
             T* o = lprev + 3 * (sl - p0);
             o[0] = s0, o[1] = s1, o[2] = s2;
         });
-        if (wave == 1) { // lane = row: a = D^-1 (rhs - previous-colour slots - older slots (the launch before)), each run in slot order
-            const int node = r0.x, nall = FWD ? r0.y : r1.x, nprev_e = FWD ? (r1.w & 0xffff) : ((r1.w >> 16) & 0xffff);
-            const int nold = (nall - nprev_e + 15) >> 4, nprev = (nprev_e + 15) >> 4, so = FWD ? sr.x : sr.z, sp = (FWD ? sr.y : sr.w) - p0;
-            const T* src = rhs + 3 * (int64_t)max(node, 0);
-            T q0 = src[0], q1 = src[1], q2 = src[2];
-            T ps[8][3]; // branch-free: past the row's last slot its first one — or the padding — is read and dropped
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const T* pp = part + 3 * (int64_t)(so + (q < nold ? q : 0));
-                ps[q][0] = pp[0], ps[q][1] = pp[1], ps[q][2] = pp[2];
-            }
-            const T* di = hdr + 576 + 9 * lane;
-            T dv[9];
-#pragma unroll
-            for (int e = 0; e < 9; ++e) dv[e] = di[e];
-            __syncthreads(); // (1) the previous colour's share is in LDS
-            T s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const T* pp = lprev + 3 * (q < nprev ? sp + q : 0);
-                const T v0 = pp[0], v1 = pp[1], v2 = pp[2];
-                s0 += q < nprev ? v0 : (T)0, s1 += q < nprev ? v1 : (T)0, s2 += q < nprev ? v2 : (T)0;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) s0 += q < nold ? ps[q][0] : (T)0, s1 += q < nold ? ps[q][1] : (T)0, s2 += q < nold ? ps[q][2] : (T)0;
-            q0 -= s0, q1 -= s1, q2 -= s2;
-            la[3 * lane] = dv[0] * q0 + dv[3] * q1 + dv[6] * q2, la[3 * lane + 1] = dv[1] * q0 + dv[4] * q1 + dv[7] * q2, la[3 * lane + 2] = dv[2] * q0 + dv[5] * q1 + dv[8] * q2; // gs_store_rhs's product
-        }
-        else
-            __syncthreads(); // (1)
-        __syncthreads(); // (2) a is in LDS
+        __syncthreads();
         return;
     }
-    // wavefront 0: the substitution.  A lane's row of the index table goes through LDS (its own 132 bytes: no barrier), not through 32 registers
+    // wavefront 0: the substitution.  A lane's row of the index table goes through LDS (its own 132 bytes: no barrier), not through 32 registers.
+    // While the other wavefronts sum the previous colour's slots it walks its own two dependent round trips: (1) index table, position record, slot
+    // starts; (2) right-hand side, the older slots' sums (the launch before), D^-1 -> rhs - older sums in six registers, D^-1 parked in LDS; then
+    // the first D image columns are requested and land under the wait for the barrier.
     const T* ent = hdr + I::hdr_elems + (FWD ? 0 : I::per_dir);
-    const int node = gs_pad[8 * ((int64_t)b * 64 + lane)];
+    const int64_t pos = (int64_t)b * 64 + lane;
+    const int4 r0 = *(const int4*)(gs_pad + 8 * pos), r1 = *(const int4*)(gs_pad + 8 * pos + 4), sr = srec[pos];
     {
         const uint4* ip = (const uint4*)(imgi + ((size_t)b * 2 + (FWD ? 0 : 1)) * I::idx_per_dir + lane * 64);
         uint4 v[8];
@@ -1254,22 +1232,69 @@ __global__ __launch_bounds__(256) void k_gs_colour(const T* __restrict__ img, co
         for (int q = 0; q < 8; ++q) v[q] = ip[q];
 #pragma unroll
         for (int q = 0; q < 8; ++q) lidx[33 * lane + 4 * q] = v[q].x, lidx[33 * lane + 4 * q + 1] = v[q].y, lidx[33 * lane + 4 * q + 2] = v[q].z, lidx[33 * lane + 4 * q + 3] = v[q].w;
+        if (TURN) {
+            const uint4* ipb = (const uint4*)(imgi + ((size_t)b * 2 + 1) * I::idx_per_dir + lane * 64);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = ipb[q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                lidx[64 * 33 + 33 * lane + 4 * q] = v[q].x, lidx[64 * 33 + 33 * lane + 4 * q + 1] = v[q].y, lidx[64 * 33 + 33 * lane + 4 * q + 2] = v[q].z, lidx[64 * 33 + 33 * lane + 4 * q + 3] = v[q].w;
+        }
+    }
+    const int node = r0.x, nall = FWD ? r0.y : r1.x, nprev_e = FWD ? (r1.w & 0xffff) : ((r1.w >> 16) & 0xffff);
+    const int nold = (nall - nprev_e + 15) >> 4, nprev = (nprev_e + 15) >> 4, so = FWD ? sr.x : sr.z, sp = (FWD ? sr.y : sr.w) - p0;
+    T q0, q1, q2;
+    {
+        const T* src = rhs + 3 * (int64_t)max(node, 0);
+        q0 = src[0], q1 = src[1], q2 = src[2];
+        T ps[8][3]; // branch-free: past the row's last slot its first one — or the padding — is read and dropped
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const T* pp = part + 3 * (int64_t)(so + (q < nold ? q : 0));
+            ps[q][0] = pp[0], ps[q][1] = pp[1], ps[q][2] = pp[2];
+        }
+        const T* di = hdr + 576 + 9 * lane;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) ldv[64 * e + lane] = di[e];
+        T s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s0 += q < nold ? ps[q][0] : (T)0, s1 += q < nold ? ps[q][1] : (T)0, s2 += q < nold ? ps[q][2] : (T)0;
+        q0 -= s0, q1 -= s1, q2 -= s2;
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2)::"memory"); // the image columns are requested BEHIND these sums (the asm consumes them): 72 registers of row data and 144 of columns never live together
     }
     const uint16_t* lrow = (const uint16_t*)(lidx + 33 * lane);
     T ring[D][9];
-#define HOT_GS_ISSUE(s, L)                                                                   \
+#define HOT_GS_ISSUE(E, LR, s, L)                                                            \
     do {                                                                                      \
-        const uint32_t idx_ = lrow[s];                                                        \
-        const T* p_ = ent + (size_t)idx_ * 9;                                                 \
+        const uint32_t idx_ = (LR)[s];                                                        \
+        const T* p_ = (E) + (size_t)idx_ * 9;                                                 \
         _Pragma("unroll") for (int e_ = 0; e_ < 9; ++e_) L[e_] = p_[e_];                      \
         asm volatile("" ::: "memory"); /* the loads stay HERE, D steps ahead of their use */ \
     } while (0)
 #pragma unroll
-    for (int k = 0; k < D; ++k) HOT_GS_ISSUE(k, ring[k]);
-    __syncthreads(); // (1)
-    __syncthreads(); // (2)
-    T a0 = la[3 * lane], a1 = la[3 * lane + 1], a2 = la[3 * lane + 2];
+    for (int k = 0; k < D; ++k) HOT_GS_ISSUE(ent, lrow, k, ring[k]);
+    __syncthreads(); // the previous colour's share of the row sums is in LDS
+    T a0, a1, a2;
+    {
+        T s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const T* pp = lprev + 3 * (q < nprev ? sp + q : 0);
+            const T v0 = pp[0], v1 = pp[1], v2 = pp[2];
+            s0 += q < nprev ? v0 : (T)0, s1 += q < nprev ? v1 : (T)0, s2 += q < nprev ? v2 : (T)0;
+            if (q & 1) asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2)); // two slots' reads in flight, not eight: their 48 registers would come on top of the 144 of the image columns
+        }
+        q0 -= s0, q1 -= s1, q2 -= s2; // rhs - older slots - previous-colour slots, each run in slot order
+        // gs_store_rhs's product D^-1 q, one row of D^-1 at a time (six registers of it beside the image columns, not eighteen)
+        a0 = ldv[lane] * q0 + ldv[64 * 3 + lane] * q1 + ldv[64 * 6 + lane] * q2;
+        asm volatile("" : "+v"(a0));
+        a1 = ldv[64 + lane] * q0 + ldv[64 * 4 + lane] * q1 + ldv[64 * 7 + lane] * q2;
+        asm volatile("" : "+v"(a1));
+        a2 = ldv[64 * 2 + lane] * q0 + ldv[64 * 5 + lane] * q1 + ldv[64 * 8 + lane] * q2;
+    }
     T dd[9];
+    const T* entb = hdr + I::hdr_elems + I::per_dir;
+    const uint16_t* lrowb = (const uint16_t*)(lidx + 64 * 33 + 33 * lane);
 #pragma unroll
     for (int s = 0; s < 64; ++s) {
         const int c = FWD ? s : 63 - s;
@@ -1278,25 +1303,57 @@ __global__ __launch_bounds__(256) void k_gs_colour(const T* __restrict__ img, co
         a0 = fma(L[0], b0, a0), a1 = fma(L[1], b0, a1), a2 = fma(L[2], b0, a2);
         a0 = fma(L[3], b1, a0), a1 = fma(L[4], b1, a1), a2 = fma(L[5], b1, a2);
         a0 = fma(L[6], b2, a0), a1 = fma(L[7], b2, a1), a2 = fma(L[8], b2, a2);
-        if (s + D < 64) HOT_GS_ISSUE(s + D, L);
-        if (FWD && s + D == 64) { // D by position (for hD = D h), into the registers the ring no longer needs
+        if (s + D < 64) HOT_GS_ISSUE(ent, lrow, s + D, L);
+        else if (TURN) HOT_GS_ISSUE(entb, lrowb, s + D - 64, L); // the backward walk's first columns, into the slots the forward walk no longer needs
+        if (FWD && s + D == 64) { // D by position (for hD = D h)
 #pragma unroll
             for (int e = 0; e < 9; ++e) dd[e] = hdr[9 * lane + e];
             asm volatile("" ::: "memory");
         }
     }
-#undef HOT_GS_ISSUE
-    if (node < 0) return;
-    x[3 * (int64_t)node] = a0, x[3 * (int64_t)node + 1] = a1, x[3 * (int64_t)node + 2] = a2;
+    if (!TURN && node < 0) return;
+    T h0 = 0, h1 = 0, h2 = 0;
     if (FWD) {
-        hD[3 * (int64_t)node] = dd[0] * a0 + dd[3] * a1 + dd[6] * a2;
-        hD[3 * (int64_t)node + 1] = dd[1] * a0 + dd[4] * a1 + dd[7] * a2;
-        hD[3 * (int64_t)node + 2] = dd[2] * a0 + dd[5] * a1 + dd[8] * a2;
+        h0 = dd[0] * a0 + dd[3] * a1 + dd[6] * a2, h1 = dd[1] * a0 + dd[4] * a1 + dd[7] * a2, h2 = dd[2] * a0 + dd[5] * a1 + dd[8] * a2;
+        if (node >= 0) {
+            if (!TURN) x[3 * (int64_t)node] = a0, x[3 * (int64_t)node + 1] = a1, x[3 * (int64_t)node + 2] = a2; // (TURN: written below as h - du, or as h)
+            hD[3 * (int64_t)node] = h0, hD[3 * (int64_t)node + 1] = h1, hD[3 * (int64_t)node + 2] = h2;
+        }
     }
     else {
+        x[3 * (int64_t)node] = a0, x[3 * (int64_t)node + 1] = a1, x[3 * (int64_t)node + 2] = a2;
         if (hD) hD[3 * (int64_t)node] += a0, hD[3 * (int64_t)node + 1] += a1, hD[3 * (int64_t)node + 2] += a2; // backward: hD is the iterate u, which takes the correction here (u += du of gs_smooth)
         if (hsub) hsub[3 * (int64_t)node] -= a0, hsub[3 * (int64_t)node + 1] -= a1, hsub[3 * (int64_t)node + 2] -= a2; // (nothing in the backward sweep reads h)
     }
+    if constexpr (TURN) {
+        // the block's backward substitution: right-hand side D h of its own rows (no following off-block column exists), du = D^-1 (D h) + the strictly upper
+        // in-block triangle, exactly what the backward sweep's first launch would compute from the stored D h
+        const T f0 = a0, f1 = a1, f2 = a2; // h
+        a0 = ldv[lane] * h0 + ldv[64 * 3 + lane] * h1 + ldv[64 * 6 + lane] * h2;
+        asm volatile("" : "+v"(a0));
+        a1 = ldv[64 + lane] * h0 + ldv[64 * 4 + lane] * h1 + ldv[64 * 7 + lane] * h2;
+        asm volatile("" : "+v"(a1));
+        a2 = ldv[64 * 2 + lane] * h0 + ldv[64 * 5 + lane] * h1 + ldv[64 * 8 + lane] * h2;
+#pragma unroll
+        for (int s = 0; s < 64; ++s) {
+            const int c = 63 - s;
+            const T b0 = lane_bcast(a0, c), b1 = lane_bcast(a1, c), b2 = lane_bcast(a2, c);
+            T(&L)[9] = ring[(64 + s) % D]; // the ring keeps turning: the forward walk's step 64 - D + k requested the backward walk's column k into slot (64 - D + k) % D
+            a0 = fma(L[0], b0, a0), a1 = fma(L[1], b0, a1), a2 = fma(L[2], b0, a2);
+            a0 = fma(L[3], b1, a0), a1 = fma(L[4], b1, a1), a2 = fma(L[5], b1, a2);
+            a0 = fma(L[6], b2, a0), a1 = fma(L[7], b2, a1), a2 = fma(L[8], b2, a2);
+            if (s + D < 64) HOT_GS_ISSUE(entb, lrowb, s + D, L);
+        }
+        if (node < 0) return;
+        xb[3 * (int64_t)node] = a0, xb[3 * (int64_t)node + 1] = a1, xb[3 * (int64_t)node + 2] = a2;
+        if (ub) ub[3 * (int64_t)node] += a0, ub[3 * (int64_t)node + 1] += a1, ub[3 * (int64_t)node + 2] += a2;
+        // the forward target: h - du where the residual wants it (hsub), h otherwise
+        if (hsub)
+            x[3 * (int64_t)node] = f0 - a0, x[3 * (int64_t)node + 1] = f1 - a1, x[3 * (int64_t)node + 2] = f2 - a2;
+        else
+            x[3 * (int64_t)node] = f0, x[3 * (int64_t)node + 1] = f1, x[3 * (int64_t)node + 2] = f2;
+    }
+#undef HOT_GS_ISSUE
 }
 
 // A whole half sweep (all colours, all sub-blocks) in ONE launch.  Workgroups are ordered by pass = (colour, sub-block)
@@ -2130,6 +2187,8 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         };
         // ---- one rank: the colour pass as ONE launch, the next colour's older off-block sums beside this colour's substitutions (k_gs_colour)
         const bool fused_path = pair_path && L.gs_fused_ready && !L.part;
+        // the forward sweep's last colour also runs its blocks' backward substitutions (k_gs_colour<.., TURN>); A/B build: HOT_GS_NO_TURN = two launches
+        const bool turn = !ab_flag("HOT_GS_NO_TURN");
         auto colour_sweep = [&](bool fwd) {
             const T* rhs = fwd ? r : dAu;
             T* xx = fwd ? hdu : du;
@@ -2139,27 +2198,35 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
 #endif
             T* hsub = !fwd ? hdu : (T*)nullptr; // h - du for the residual, row by row
             const int nstream = std::max(8, ab_int("HOT_GS_OFF_WAVES", 4096) / 4 / 8 * 8);
+            int last = -1; // the last colour of the forward sweep that has blocks = the first of the backward sweep
+            for (int c = 7; c >= 0 && last < 0; --c)
+                if (L.color_block_begin[c + 1] > L.color_block_begin[c]) last = c;
             for (int q = 0; q < 8; ++q) {
                 const int c = fwd ? q : 7 - q, cn = fwd ? c + 1 : c - 1;
                 const int b0 = L.color_block_begin[c], nb = L.color_block_begin[c + 1] - b0, nb_pad = (nb + 7) & ~7;
                 const int s0 = (cn >= 0 && cn < 8) ? L.gs_slot_rng2[fwd ? 0 : 2][0][cn] : 0, s1 = (cn >= 0 && cn < 8) ? L.gs_slot_rng2[fwd ? 0 : 2][1][cn] : 0;
-                const int grid = nb_pad + (s1 > s0 ? nstream : 0);
+                const bool do_turn = turn && c == last && nb > 0; // (forward: substitute both ways; backward: the forward launch has done this colour)
+                const int grid = (!fwd && do_turn ? 0 : nb_pad) + (s1 > s0 ? nstream : 0);
                 if (grid == 0) continue;
+                const int nbk = (!fwd && do_turn) ? 0 : nb, nbk_pad = (!fwd && do_turn) ? 0 : nb_pad;
 #ifdef HOT_AB_KERNELS
                 const std::string nmq = ab_flag("HOT_GS_PROF_COLOURS") ? std::string(fwd ? "gs_forward_fused_q" : "gs_backward_fused_q") + char('0' + q) : std::string(fwd ? "gs_forward_fused" : "gs_backward_fused"); // A/B build: one profile record per pass of the half sweep
                 const char* nm = nmq.c_str();
 #endif
 #define HOT_COLOUR_D(DD)                                                                                                                                                       \
     do {                                                                                                                                                                       \
-        if (fwd)                                                                                                                                                               \
-            HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_colour<T, true, DD>), grid, 256, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_srec.p, xx, hD, b0, nb, nb_pad, rhs, hsub, \
-                L.gs_slot.p, L.gs_col.p, L.val.p, L.gs_p1.p, s0, s1);                                                                                                          \
+        if (fwd && do_turn)                                                                                                                                                    \
+            HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_colour<T, true, DD, true>), grid, 256, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_srec.p, xx, hD, b0, nbk, nbk_pad, rhs, \
+                (!L.part ? hdu : (T*)nullptr), L.gs_slot.p, L.gs_col.p, L.val.p, L.gs_p1.p, s0, s1, du, u);                                                                       \
+        else if (fwd)                                                                                                                                                          \
+            HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_colour<T, true, DD>), grid, 256, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_srec.p, xx, hD, b0, nbk, nbk_pad, rhs, hsub, \
+                L.gs_slot.p, L.gs_col.p, L.val.p, L.gs_p1.p, s0, s1, (T*)nullptr, (T*)nullptr);                                                                                \
         else                                                                                                                                                                   \
-            HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_colour<T, false, DD>), grid, 256, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_srec.p, xx, hD, b0, nb, nb_pad, rhs, hsub, \
-                L.gs_slot.p, L.gs_col.p, L.val.p, L.gs_p1.p, s0, s1);                                                                                                          \
+            HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_colour<T, false, DD>), grid, 256, 0, L.gs_img.p, L.gs_imgi.p, L.gs_pad.p, L.gs_srec.p, xx, hD, b0, nbk, nbk_pad, rhs, hsub, \
+                L.gs_slot.p, L.gs_col.p, L.val.p, L.gs_p1.p, s0, s1, (T*)nullptr, (T*)nullptr);                                                                                \
     } while (0)
 #ifdef HOT_AB_KERNELS
-                const int depth = ab_int("HOT_GS_SUBST_D", 8); // A/B build: image columns in flight per block
+                const int depth = ab_int("HOT_GS_SUBST_D", 0); // A/B build: image columns in flight per block (0: the production choice)
                 if (depth == 4) {
                     HOT_COLOUR_D(4);
                     continue;
@@ -2168,8 +2235,21 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                     HOT_COLOUR_D(6);
                     continue;
                 }
+                if (depth == 7) {
+                    HOT_COLOUR_D(7);
+                    continue;
+                }
+                if (depth == 8) {
+                    HOT_COLOUR_D(8);
+                    continue;
+                }
 #endif
-                HOT_COLOUR_D(8);
+                // image columns in flight per substitution wavefront: fp64 seven (126 registers of them: the kernel stays below 168, three wavefronts per SIMD for
+                // the streaming role; with eight it needs 176 — two per SIMD —: 42.6 against 41.4 us per launch at C2), fp32 eight
+                if constexpr (sizeof(T) == 8)
+                    HOT_COLOUR_D(7);
+                else
+                    HOT_COLOUR_D(8);
 #undef HOT_COLOUR_D
             }
         };

@@ -30,6 +30,8 @@ CASES = [
     ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_PAIR": "1", "HOT_GS_OFF_WAVES": "64"}, SOLVER, "smoothers or vcycle"),
     ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_SUBST_D": "4"}, SOLVER, "smoothers or vcycle"),  # image columns in flight per substitution wavefront
     ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_SUBST_D": "6"}, SOLVER, "smoothers or vcycle"),
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_SUBST_D": "8"}, SOLVER, "smoothers or vcycle or iterates"),
+    ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_NO_TURN": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # the backward sweep's first colour as a launch of its own instead of riding on the forward sweep's last (k_gs_colour<.., TURN>)
     ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_OFF_WAVES": "4100"}, SOLVER, "smoothers or vcycle"),  # a grid that is no multiple of 8: off-block steps dealt round robin instead of in per-XCD runs
     ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_OFF_WAVES": "64"}, SOLVER, "smoothers or vcycle"),  # few wavefronts: many steps per wavefront, odd and even step counts
     ({"HOT_TEST_CFG": "gs_chain=1,gs_sub_block=32", "HOT_GS_V1": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # first-generation k_gs_block instead of the off-block / substitution pair
