@@ -42,8 +42,8 @@ template <class T>
 __global__ __launch_bounds__(256) void k_dpdf_rec(const T* __restrict__ X, const T* __restrict__ Fn, const T* __restrict__ Ft, const T* __restrict__ Vol, const T* __restrict__ Mu,
     const T* __restrict__ Lam, T* __restrict__ rec, int64_t Np, T dt, T one_over_dx, int project)
 {
-    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= Np) return;
+    // (a lane past the last particle computes the last particle's record again and stores nothing: the stores below are a wavefront's joint work)
+    const int64_t p = min((int64_t)blockIdx.x * 256 + threadIdx.x, Np - 1);
     Mat3<T> Fc;
 #pragma unroll
     for (int c = 0; c < 9; ++c) Fc.a[c] = Ft[(int64_t)c * Np + p];
@@ -104,16 +104,6 @@ __global__ __launch_bounds__(256) void k_dpdf_rec(const T* __restrict__ X, const
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int n = 0; n < 9; ++n) Th[(a + 3 * r) * 9 + n] = F9[r] * D[a * 9 + n] + F9[r + 3] * D[(a + 3) * 9 + n] + F9[r + 6] * D[(a + 6) * 9 + n];
-    T* o = rec + p * REC;
-#pragma unroll
-    for (int m = 0; m < 9; ++m)
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int n = b + 3 * s;
-                if (n >= m) o[sym45i(m, n)] = F9[s] * Th[m * 9 + b] + F9[s + 3] * Th[m * 9 + b + 3] + F9[s + 6] * Th[m * 9 + b + 6];
-            }
     T w[3][3], dw[3][3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -122,12 +112,40 @@ __global__ __launch_bounds__(256) void k_dpdf_rec(const T* __restrict__ X, const
 #pragma unroll
         for (int k = 0; k < 3; ++k) dw[d][k] *= one_over_dx;
     }
+    // The record leaves through LDS, a quarter (32 scalars) at a time: a lane holds ONE particle's values, and stored from there its 128 scalars would be
+    // 128 instructions of 64 eight-byte pieces 1 KB apart (rounds 4 - 5: 0.96 ms per C2 assembly, most of it these stores); transposed in the wavefront's
+    // own LDS stage (32 x 64 scalars, rows padded to 65: conflict-free both ways, no barrier — nothing but this wavefront touches it) a store instruction
+    // writes 32 consecutive scalars of two particles: whole 128-byte lines.
+    __shared__ T stage[4][32 * 65];
+    T* st = stage[threadIdx.x >> 6];
+    const int ln = threadIdx.x & 63;
+    const int64_t pw0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); // the wavefront's first particle
 #pragma unroll
-    for (int j = 0; j < 27; ++j) {
-        const int j0 = j / 9, j1 = (j / 3) % 3, j2 = j % 3;
-        o[45 + 3 * j] = dw[0][j0] * (w[1][j1] * w[2][j2]), o[46 + 3 * j] = (w[0][j0] * w[2][j2]) * dw[1][j1], o[47 + 3 * j] = (w[0][j0] * w[1][j1]) * dw[2][j2];
+    for (int q = 0; q < 4; ++q) {
+        auto emit = [&](int idx, T v) __attribute__((always_inline)) {
+            if ((idx >> 5) == q) st[(idx & 31) * 65 + ln] = v; // (idx is a constant after unrolling: a quarter computes its own 32 values only)
+        };
+#pragma unroll
+        for (int m = 0; m < 9; ++m)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int n = b + 3 * s;
+                    if (n >= m) emit(sym45i(m, n), F9[s] * Th[m * 9 + b] + F9[s + 3] * Th[m * 9 + b + 3] + F9[s + 6] * Th[m * 9 + b + 6]);
+                }
+#pragma unroll
+        for (int j = 0; j < 27; ++j) {
+            const int j0 = j / 9, j1 = (j / 3) % 3, j2 = j % 3;
+            emit(45 + 3 * j, dw[0][j0] * (w[1][j1] * w[2][j2])), emit(46 + 3 * j, (w[0][j0] * w[2][j2]) * dw[1][j1]), emit(47 + 3 * j, (w[0][j0] * w[1][j1]) * dw[2][j2]);
+        }
+        emit(126, (T)0), emit(127, (T)0);
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const int pp = 2 * k + (ln >> 5), il = ln & 31;
+            if (pw0 + pp < Np) rec[(pw0 + pp) * REC + 32 * q + il] = st[il * 65 + pp];
+        }
     }
-    o[126] = o[127] = (T)0;
 }
 
 // ---- the 15 broadcast FMAs of a (particle, row): acc[ab] += K(lane 3 ab + s of this lane's 16-lane row) * g[s].  The s_nop covers

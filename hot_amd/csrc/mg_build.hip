@@ -711,63 +711,85 @@ __global__ __launch_bounds__(512) void k_gs_images(const int32_t* __restrict__ g
     if (tid < 128) mlo[tid >> 6][tid & 63] = 0u, mhi[tid >> 6][tid & 63] = 0u;
     if (tid < 18) hdr[I::hdr_elems + (tid / 9) * I::per_dir + tid % 9] = (T)0;
     __syncthreads();
-    // this thread's entries: rows r = w + 8 t, both directions; kept for the third pass
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int dir = 0; dir < 2; ++dir) {
-            T* dbase = hdr + I::hdr_elems + dir * I::per_dir;
-            for (int t = 0; t < 8; ++t) {
-                const int r = w + 8 * t;
-                const int i = nodes[r];
-                if (i < 0) continue; // wave-uniform
-                const int po = rcl[4 * r], pi = rcl[4 * r + 1], fi = rcl[4 * r + 2];
-                const int kbeg = dir == 0 ? po : po + pi + 1, kend = dir == 0 ? po + pi : po + pi + 1 + fi; // at most 63 in-block entries
-                const int k = kbeg + lane;
-                if (k >= kend) continue;
-                const int cpos = -1 - gcol[(int64_t)i * 125 + k];
-                if (pass == 0) {
-                    if (r < 32)
-                        atomicOr(&mlo[dir][cpos], 1u << r);
-                    else
-                        atomicOr(&mhi[dir][cpos], 1u << (r - 32));
-                    continue;
-                }
-                T A[9], di[9];
+    // this thread's entries: rows r = w + 8 t, both directions.  A wavefront has sixteen (direction, row) steps; their column positions are fetched in ONE
+    // round trip and kept for the second pass, whose values come four steps at a time (rounds 4 - 5 walked the sixteen steps one dependent load chain
+    // after the other, twice: 1.28 ms per C2 build, bound by those chains)
+    int cpos[2][8], ek[2][8];
+    bool act[2][8];
 #pragma unroll
-                for (int e = 0; e < 9; ++e) A[e] = val[((int64_t)i * 125 + k) * 9 + e], di[e] = diagBlockInv[9 * (int64_t)i + e];
-                const unsigned long long m = ((unsigned long long)mhi[dir][cpos] << 32) | mlo[dir][cpos];
+    for (int dir = 0; dir < 2; ++dir)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int r = w + 8 * t, i = nodes[r];
+            const int po = rcl[4 * r], pi = rcl[4 * r + 1], fi = rcl[4 * r + 2];
+            const int kbeg = dir == 0 ? po : po + pi + 1, kend = dir == 0 ? po + pi : po + pi + 1 + fi; // at most 63 in-block entries
+            act[dir][t] = i >= 0 && kbeg + lane < kend;
+            ek[dir][t] = act[dir][t] ? i * 125 + kbeg + lane : 0; // entry index (< 2^31: k_gs_slot_fill)
+            cpos[dir][t] = -1 - gcol[ek[dir][t]]; // (an idle lane: entry 0 of the matrix, not used)
+        }
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int r = w + 8 * t;
+            if (!act[dir][t]) continue;
+            if (r < 32)
+                atomicOr(&mlo[dir][cpos[dir][t]], 1u << r);
+            else
+                atomicOr(&mhi[dir][cpos[dir][t]], 1u << (r - 32));
+        }
+    __syncthreads();
+    {
+    if (tid < 2) { // offsets in the order the substitution walks the columns: forward ascending, backward descending
+        int off = 1; // entry 0 of either direction is all zeros: what a lane without an entry in a column reads
+        for (int s = 0; s < 64; ++s) {
+            const int c = tid == 0 ? s : 63 - s;
+            coff[tid][c] = off;
+            off += __popc(mlo[tid][c]) + __popc(mhi[tid][c]);
+        }
+    }
+    __syncthreads();
+    { // the row's entry index at every step of the direction's walk (0: none, the all-zero entry): 64 x 16 bits = the 128 bytes a lane of k_gs_subst loads; a thread writes a quarter of a row's
+        const int dir = tid >> 8, r = (tid >> 2) & 63, q4 = tid & 3;
+        uint32_t* o = (uint32_t*)(imgi + ((size_t)b * 2 + dir) * I::idx_per_dir + r * 64) + 8 * q4;
+        const unsigned long long below = (1ULL << r) - 1ULL;
+        for (int s2 = 0; s2 < 8; ++s2) {
+            uint32_t pair = 0;
+            for (int h = 0; h < 2; ++h) {
+                const int st = 16 * q4 + 2 * s2 + h, c = dir == 0 ? st : 63 - st;
+                const unsigned long long m = ((unsigned long long)mhi[dir][c] << 32) | mlo[dir][c];
+                const uint32_t idx = ((m >> r) & 1ULL) ? (uint32_t)(coff[dir][c] + __popcll(m & below)) : 0u;
+                pair |= idx << (16 * h);
+            }
+            o[s2] = pair;
+        }
+    }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+        T* dbase = hdr + I::hdr_elems + dir * I::per_dir;
+#pragma unroll
+        for (int tg = 0; tg < 8; tg += 4) {
+            T A[4][9], di[4][9];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = max(nodes[w + 8 * (tg + u)], 0);
+#pragma unroll
+                for (int e = 0; e < 9; ++e) A[u][e] = val[(int64_t)ek[dir][tg + u] * 9 + e], di[u][e] = diagBlockInv[9 * i + e];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = tg + u, r = w + 8 * t;
+                if (!act[dir][t]) continue;
+                const int cp = cpos[dir][t];
+                const unsigned long long m = ((unsigned long long)mhi[dir][cp] << 32) | mlo[dir][cp];
                 const int rank = __popcll(m & ((1ULL << r) - 1ULL));
-                T* dst = dbase + (size_t)(coff[dir][cpos] + rank) * 9;
+                T* dst = dbase + (size_t)(coff[dir][cp] + rank) * 9;
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
-                    for (int rr = 0; rr < 3; ++rr) dst[rr + 3 * c] = -(di[rr] * A[3 * c] + di[rr + 3] * A[3 * c + 1] + di[rr + 6] * A[3 * c + 2]); // gs_store_tri's product
-            }
-        }
-        __syncthreads();
-        if (pass == 0) {
-            if (tid < 2) { // offsets in the order the substitution walks the columns: forward ascending, backward descending
-                int off = 1; // entry 0 of either direction is all zeros: what a lane without an entry in a column reads
-                for (int s = 0; s < 64; ++s) {
-                    const int c = tid == 0 ? s : 63 - s;
-                    coff[tid][c] = off;
-                    off += __popc(mlo[tid][c]) + __popc(mhi[tid][c]);
-                }
-            }
-            __syncthreads();
-            { // the row's entry index at every step of the direction's walk (0: none, the all-zero entry): 64 x 16 bits = the 128 bytes a lane of k_gs_subst loads; a thread writes a quarter of a row's
-                const int dir = tid >> 8, r = (tid >> 2) & 63, q4 = tid & 3;
-                uint32_t* o = (uint32_t*)(imgi + ((size_t)b * 2 + dir) * I::idx_per_dir + r * 64) + 8 * q4;
-                const unsigned long long below = (1ULL << r) - 1ULL;
-                for (int s2 = 0; s2 < 8; ++s2) {
-                    uint32_t pair = 0;
-                    for (int h = 0; h < 2; ++h) {
-                        const int st = 16 * q4 + 2 * s2 + h, c = dir == 0 ? st : 63 - st;
-                        const unsigned long long m = ((unsigned long long)mhi[dir][c] << 32) | mlo[dir][c];
-                        const uint32_t idx = ((m >> r) & 1ULL) ? (uint32_t)(coff[dir][c] + __popcll(m & below)) : 0u;
-                        pair |= idx << (16 * h);
-                    }
-                    o[s2] = pair;
-                }
+                    for (int rr = 0; rr < 3; ++rr) dst[rr + 3 * c] = -(di[u][rr] * A[u][3 * c] + di[u][rr + 3] * A[u][3 * c + 1] + di[u][rr + 6] * A[u][3 * c + 2]); // gs_store_tri's product
             }
         }
     }
