@@ -335,9 +335,11 @@ struct Ctx : CtxBase {
     DBuf<uint64_t> col_hk; // mark_colors scratch (block hash map, colour block heads)
     DBuf<unsigned long long> col_hr;
     DBuf<int32_t> col_hi, col_cb;
-    DBuf<unsigned> cg_bar; // k_cg_persist: barrier arrival counter + exit counter (zero between launches)
-    bool cg_bar_dirty = false; // a spinning kernel timed out since the counters were last cleared (Ctx::sync): they may hold a partial count
-    DBuf<double> cg_dep; // its dot-product deposits, two alternating sets of two per workgroup
+    bool cg_bar_dirty = false; // a spinning kernel timed out since the deposit slots were last reset (Ctx::sync): they may hold a partial phase
+    DBuf<double> cg_dep; // k_cg_persist: its dot-product deposits = barrier flags, four rotating sets of two per workgroup
+    unsigned cg_phase = 0; // barriers passed by the persistent solves since the slots were reset, mod 4 (which set the next launch starts with)
+    int cg_G = 0; // the grid the slots are laid out for
+    bool attr_cg_set = false;
     int cg_group = 2; // iterations the last fused top-level PCG took: size of the first group of launches of the next one
     int gs_epoch = 0; // sweep number, never reused inside a context
     bool attr_tiles_set = false, attr_rows_set = false, attr_gs_set = false, attr_winv_set = false; // dynamic-LDS limits raised on this context's device (hipFuncSetAttribute is per device)

@@ -307,57 +307,74 @@ __global__ void k_cg_direction(size_t n3, const T* __restrict__ z, T* __restrict
 // deposits its partial sum before the barrier and adds ALL deposits in index order after it, so every workgroup holds the same bits and
 // takes the same exit decision.  Same recurrences as k_cg_spmv_dot / k_cg_update / k_cg_direction; only the association of the dot
 // products differs.  count / exitc are zero between launches (the last workgroup to leave resets them).
-template <class T>
+// RPW > 0 (round 6): a wavefront has at most RPW rows, and everything of them LIVES IN REGISTERS for the whole solve — the matrix row (lane k holds entries
+// k and k + 64: 18 scalars + 2 column ids a row), and in lane 0 D^-1, u, r, z, du, dAu.  An iteration then goes to memory for the gathers of du in the product
+// and the publication of the new du, nothing else (the streaming version walks six dependent round trips an iteration besides its three barriers: 176 us a
+// solve at C2's level 2, 5.4 k rows, of which the barriers are the smaller part).  Same arithmetic, bit-identical results.
+template <class T, int RPW = 0>
 __global__ __launch_bounds__(1024) void k_cg_persist(const int32_t* __restrict__ col, const T* __restrict__ val, const T* __restrict__ Dinv, const T* __restrict__ init, T* __restrict__ u,
-    T* __restrict__ r, T* __restrict__ z, T* du, T* __restrict__ dAu, int n, int max_iters, unsigned* count, double* dep /*[2][2][gridDim.x]*/, double* hm, double* ticket, double ticket_val,
+    T* __restrict__ r, T* __restrict__ z, T* du, T* __restrict__ dAu, int n, int max_iters, unsigned phase0 /*barriers this context's persistent solves have passed so far, mod 4*/, double* dep /*[4][gridDim.x][SS]*/, int SS /*doubles between two workgroups' slots*/, double* hm, double* ticket, double ticket_val,
     int* err /*pinned host word (k_gs_sweep's): a barrier that does not complete — the workgroups are not all resident because something else holds the chip — sets it; the host redoes the solve with launches*/)
 {
-    __shared__ double red[32], sdep[2][256], sres[2];
+    __shared__ double red[32], sres[2];
     __shared__ int s_bail;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int G = gridDim.x, wg = blockIdx.x;
-    unsigned phase = 0;
+    unsigned phase = phase0;
+    if (tid == 0) s_bail = 0;
     auto ldu = [&](int64_t j, int c) { return __hip_atomic_load(du + 3 * j + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto sdu = [&](int64_t j, int c, T v) { __hip_atomic_store(du + 3 * j + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    // workgroup-wide fixed-order sum of the wavefronts' lane-0 values, deposit, barrier, ordered sum of all deposits -> (o0, o1) everywhere
+    // Grid barrier + two dot products in one: workgroup-wide fixed-order sum of the wavefronts' lane-0 values, deposit, wait until every workgroup's
+    // deposit of this phase is there, ordered sum of all deposits -> (o0, o1) everywhere.  The deposits are their own arrival flags (round 6; rounds 4 - 5:
+    // deposit, wait for it to be performed, two-level arrival counters, poll, then fetch the deposits: five dependent trips to the memory side, ~5 us a
+    // barrier, three barriers an iteration): four rotating sets of slots, a slot holds a signalling-NaN pattern no sum can produce until its owner writes
+    // the phase's sums (write-through stores, agent-scope loads: k_gs_sweep's hand-off); with the deposit of phase p a workgroup resets its slots of phase
+    // p + 2 — everybody has left phase p - 2, the previous tenant of that set, before anybody deposits for p - 1.  Wavefront 0 polls and sums the first
+    // value, wavefront 1 the second: a lane adds slots lane, lane + 64, .. in ascending order, then the fixed DPP tree: the same bits everywhere.
     auto all_sum = [&](double v0, double v1, double& o0, double& o1) -> bool {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every thread's write-through stores of du have been performed before its workgroup is counted
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every thread's write-through stores of du have been performed before its workgroup deposits
         if (lane == 0) red[w] = v0, red[16 + w] = v1;
         __syncthreads();
-        double* d = dep + (size_t)(phase & 1u) * 2 * G;
+        // (a workgroup's two sums share a line; the workgroups' lines are SS doubles apart, so that the 256 pollers' uncached loads spread over the memory
+        // channels instead of queueing on the one or two that hold a packed 4 KB array)
+        double* d = dep + (size_t)(phase & 3u) * G * SS;
         if (tid == 0) {
             double t0 = 0, t1 = 0;
             for (int k = 0; k < 16; ++k) t0 += red[k], t1 += red[16 + k];
-            __hip_atomic_store(d + wg, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(d + G + wg, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // ... and so have the deposits
-            // two-level arrival: 256 read-modify-writes of ONE word serialise at the memory side (~12 us a barrier, measured); eight group
-            // counters in separate lines take 32 each, the last arrival of a group bumps the top word everybody polls
-            const unsigned grp = (unsigned)wg & 7u, ngrp = (unsigned)min(G, 8), gsz = ((unsigned)G - grp + 7u) / 8u;
-            const unsigned prev = __hip_atomic_fetch_add(count + 32 * (1 + grp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (prev + 1u == (phase + 1u) * gsz) __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = (phase + 1u) * ngrp;
+            double* dn = dep + (size_t)((phase + 2u) & 3u) * G * SS + (size_t)wg * SS;
+            __hip_atomic_store((unsigned long long*)dn, GsUnset<double>::bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((unsigned long long*)(dn + 1), GsUnset<double>::bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d + (size_t)wg * SS, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d + (size_t)wg * SS + 1, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (w < 2) {
+            const double* dv = d + w;
+            double a = 0;
             int spins = 0, bail = 0;
-            while (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            for (;;) {
+                bool all = true;
+                a = 0;
+                for (int k = lane; k < G; k += 64) {
+                    const double x = __hip_atomic_load(dv + (size_t)k * SS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    all = all && !GsUnset<double>::is(x);
+                    a += x;
+                }
+                if (__all(all)) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22) || ((spins & 255) == 0 && *(volatile int*)err)) {
+                if (++spins > (1 << 21) || ((spins & 255) == 0 && *(volatile int*)err)) { // (wave-uniform)
                     *(volatile int*)err = 1;
                     bail = 1;
                     break;
                 }
             }
-            s_bail = bail;
+            a = wave_sum(a);
+            if (lane == 0) {
+                sres[w] = a;
+                if (bail) s_bail = 1;
+            }
         }
         __syncthreads();
         if (s_bail) return false; // workgroup-uniform
-        if (tid < G) sdep[0][tid] = __hip_atomic_load(d + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sdep[1][tid] = __hip_atomic_load(d + G + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (tid < 2) {
-            double a = 0;
-            for (int k = 0; k < G; ++k) a += sdep[tid][k];
-            sres[tid] = a;
-        }
-        __syncthreads();
         o0 = sres[0], o1 = sres[1];
         ++phase;
         return true;
@@ -367,6 +384,152 @@ __global__ __launch_bounds__(1024) void k_cg_persist(const int32_t* __restrict__
         o[0] = d[0] * v[0] + d[3] * v[1] + d[6] * v[2], o[1] = d[1] * v[0] + d[4] * v[1] + d[7] * v[2], o[2] = d[2] * v[0] + d[5] * v[1] + d[8] * v[2];
     };
     const int stride = 16 * G;
+    if constexpr (RPW > 0) {
+        // ---- the register-resident version
+        int rowq[RPW];
+        int32_t mc[RPW][2];
+        T mv[RPW][2][9], di[RPW][9], uu[RPW][3], rr[RPW][3], zz[RPW][3], dd[RPW][3], ad[RPW][3];
+        double p0 = 0, p1 = 0;
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int row = wg * 16 + w + q * stride;
+            rowq[q] = row < n ? row : -1;
+            const int64_t rc = row < n ? row : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = min(lane + 64 * h, 124);
+                mc[q][h] = col[rc * 125 + k];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) mv[q][h][e] = (lane + 64 * h < 125) ? val[rc * 1125 + k * 9 + e] : (T)0;
+            }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) di[q][e] = Dinv[9 * rc + e];
+            T a[3], za[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[c] = init[3 * rc + c], rr[q][c] = r[3 * rc + c], uu[q][c] = u[3 * rc + c], ad[q][c] = (T)0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) za[c] = di[q][c] * a[0] + di[q][3 + c] * a[1] + di[q][6 + c] * a[2], zz[q][c] = di[q][c] * rr[q][0] + di[q][3 + c] * rr[q][1] + di[q][6 + c] * rr[q][2];
+            if (lane == 0 && rowq[q] >= 0) {
+                p0 += (double)(za[0] * a[0]) + (double)(za[1] * a[1]) + (double)(za[2] * a[2]);
+                p1 += (double)(zz[q][0] * rr[q][0]) + (double)(zz[q][1] * rr[q][1]) + (double)(zz[q][2] * rr[q][2]);
+                for (int c = 0; c < 3; ++c) sdu(row, c, zz[q][c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dd[q][c] = zz[q][c];
+        }
+        double zTr0, zTr;
+        if (!all_sum(p0, p1, zTr0, zTr)) return;
+        const double tol = (double)(T)(zTr0 * 0.25); // cgratio 0.5, squared (MultigridPreconditioner.h:203-209)
+        // The product gathers du from LDS: behind the barrier that publishes it every workgroup copies the WHOLE vector (3 n scalars: 140 KB at C2's level 2)
+        // with 16-byte uncached loads, coalesced — 33 MB an iteration over the chip.  The streaming version gathers du entry by entry with agent-scope loads,
+        // which pass the L2 one 8-byte request at a time: 2 M of them an iteration (5.4 k rows x 125 entries x 3), ~50 us — that, not the barriers, was an
+        // iteration's cost (measured: neither a cheaper barrier nor one barrier fewer moved it; cached gathers behind an agent-scope acquire fence, which
+        // invalidates the XCD's L2 from every wavefront, cost 2.6 x more).
+        extern __shared__ double cg_lds[]; // [3 n] du
+        T* ldsdu = (T*)cg_lds;
+        const int n3 = 3 * n;
+        auto pull_du = [&]() {
+            const int n16 = n3 >> 1; // 16-byte pieces
+            for (int e0 = 0; e0 < n16; e0 += 4 * 1024) {
+                double2 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = min(e0 + k * 1024 + tid, n16 - 1);
+                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[k]) : "v"((const double2*)du + e) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = e0 + k * 1024 + tid;
+                    if (e < n16) ((double2*)ldsdu)[e] = v[k];
+                }
+            }
+            if ((n3 & 1) && tid == 0) ldsdu[n3 - 1] = ldu(n - 1, 2);
+            __syncthreads();
+        };
+        int cnt = 0;
+#ifdef HOT_AB_KERNELS
+        unsigned long long tk[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t0_ = wall_clock64(); // A/B build, HOT_CG_DBG: 100 MHz clock of workgroup 0 between the phases, summed over the iterations
+#define CG_TK(i) \
+    do { \
+        const unsigned long long t_ = wall_clock64(); \
+        tk[i] += t_ - t0_, t0_ = t_; \
+    } while (0)
+#else
+#define CG_TK(i)
+#endif
+        for (; cnt < max_iters && cg_active(zTr, tol); ++cnt) {
+            pull_du();
+            CG_TK(0);
+            double pd = 0;
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) {
+                T s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (lane + 64 * h < 125) {
+                        const int j = mc[q][h];
+                        const T* b = mv[q][h];
+                        const T x0 = ldsdu[3 * j], x1 = ldsdu[3 * j + 1], x2 = ldsdu[3 * j + 2];
+                        s0 += b[0] * x0 + b[3] * x1 + b[6] * x2;
+                        s1 += b[1] * x0 + b[4] * x1 + b[7] * x2;
+                        s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
+                    }
+                }
+                s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
+                ad[q][0] = s0, ad[q][1] = s1, ad[q][2] = s2;
+                if (lane == 0 && rowq[q] >= 0) pd += (double)(s0 * dd[q][0]) + (double)(s1 * dd[q][1]) + (double)(s2 * dd[q][2]);
+            }
+            CG_TK(1);
+            double dAd, unused;
+            if (!all_sum(pd, 0.0, dAd, unused)) return;
+            CG_TK(2);
+            const double omega = zTr / dAd;
+            const T wp = (T)omega, wm = (T)(-omega);
+            double pz = 0;
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) uu[q][c] += wp * dd[q][c], rr[q][c] = rr[q][c] + wm * ad[q][c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) zz[q][c] = di[q][c] * rr[q][0] + di[q][3 + c] * rr[q][1] + di[q][6 + c] * rr[q][2];
+                if (lane == 0 && rowq[q] >= 0) pz += (double)(zz[q][0] * rr[q][0]) + (double)(zz[q][1] * rr[q][1]) + (double)(zz[q][2] * rr[q][2]);
+            }
+            CG_TK(3);
+            double zTrNew;
+            if (!all_sum(pz, 0.0, zTrNew, unused)) return;
+            CG_TK(4);
+            const T beta = (T)(zTrNew / zTr);
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dd[q][c] = zz[q][c] + beta * dd[q][c];
+                if (lane == 0 && rowq[q] >= 0)
+                    for (int c = 0; c < 3; ++c) sdu(rowq[q], c, dd[q][c]);
+            }
+            zTr = zTrNew;
+            CG_TK(5);
+            if (!all_sum(0.0, 0.0, unused, unused)) return;
+            CG_TK(6);
+        }
+#ifdef HOT_AB_KERNELS
+        if (tid == 0 && wg == 0)
+            for (int i = 0; i < 7; ++i) hm[8 + i] = (double)tk[i];
+#endif
+        // what the streaming version leaves in memory: u, r, z, dAu of the last iteration (du has been published)
+#pragma unroll
+        for (int q = 0; q < RPW; ++q)
+            if (lane == 0 && rowq[q] >= 0)
+                for (int c = 0; c < 3; ++c) {
+                    const int64_t e = 3 * (int64_t)rowq[q] + c;
+                    u[e] = uu[q][c], r[e] = rr[q][c], z[e] = zz[q][c], dAu[e] = ad[q][c];
+                }
+        if (tid == 0 && wg == 0) {
+            hm[0] = zTr, hm[1] = (double)cnt, hm[2] = tol;
+            if (ticket) host_ticket_store(ticket, ticket_val);
+        }
+        return;
+    }
     // ---- set-up: z'r of the reference residual (the tolerance) and of r; du = z = Dinv r
     double p0 = 0, p1 = 0;
     for (int row = wg * 16 + w; row < n; row += stride) {
@@ -442,12 +605,6 @@ __global__ __launch_bounds__(1024) void k_cg_persist(const int32_t* __restrict__
         if (wg == 0) {
             hm[0] = zTr, hm[1] = (double)cnt, hm[2] = tol;
             if (ticket) host_ticket_store(ticket, ticket_val);
-        }
-        // the last workgroup to leave re-arms the counters (everybody is past every barrier by then)
-        const unsigned prev = __hip_atomic_fetch_add(count + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == (unsigned)G - 1u) {
-            for (int k = 0; k < 9; ++k) __hip_atomic_store(count + 32 * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -1903,17 +2060,32 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
         // parity test was validated against the launch-per-operation sums)
         if (fused && sizeof(T) == 8 && L.n <= 65536 && !gs_no_chain && !sharded() && !ab_flag("HOT_CG_LAUNCHES")) { // A/B build: HOT_CG_LAUNCHES = three launches per iteration on small levels too
             // the whole solve in one persistent launch (k_cg_persist), one host round trip for the iteration count
-            const int G = std::min(std::min(256, device_cus()), div_up(L.n, 16)); // 1024-thread workgroups that must all be resident: one per compute unit at most
-            if (!cg_bar.p || cg_bar_dirty) { // cleared once: the last workgroup to leave a launch re-arms the counters.  A launch that gave up (a barrier timed out) leaves them
-                // dirty and switches this path off until rearm_chain() switches it on again 32 clean steps later: cleared again then
-                cg_bar.reserve(32 * 9 + 8), cg_dep.reserve(4 * 256);
-                HOT_HIP(hipMemsetAsync(cg_bar.p, 0, (32 * 9 + 8) * sizeof(unsigned), stream));
-                cg_bar_dirty = false;
+            const int G = std::min(std::min(ab_int("HOT_CG_WGS", 256), device_cus()), div_up(L.n, 16)); // 1024-thread workgroups that must all be resident: one per compute unit at most
+            const int cg_ss = ab_int("HOT_CG_SLOT_STRIDE", 32); // doubles between the workgroups' deposit slots
+            if (!cg_dep.p || cg_bar_dirty || cg_G != G) { // the deposit slots start "not written" (k_cg_persist's barrier); again after a launch that gave up — a barrier timed
+                // out, which switches this path off until rearm_chain() switches it on 32 clean steps later — and when the grid changes (the slots are laid out by it)
+                cg_dep.reserve((size_t)4 * 256 * cg_ss);
+                HOT_LAUNCH(this, "gs_fill_unset", k_gs_fill_unset<double>, div_up((size_t)4 * 256 * cg_ss, 256), 256, 0, (size_t)4 * 256 * cg_ss, cg_dep.p);
+                cg_bar_dirty = false, cg_G = G, cg_phase = 0;
             }
-            HOT_LAUNCH(this, lname("cg_persistent", L.id).c_str(), k_cg_persist<T>, G, 1024, 0, L.col.p, L.val.p, L.diagInv.p, L.initialResidual.p, u, r, z, du, dAu, L.n, iterations, cg_bar.p, cg_dep.p,
-                hscal + 40, hscal + 251, new_ticket(), (int*)(hscal + 250));
+            // (levels of up to two rows per wavefront: everything of a row stays in registers between the barriers; A/B build: HOT_CG_STREAM = the streaming version)
+            const bool cg_resident = L.n <= 2 * 16 * G && 3 * (size_t)L.n * sizeof(double) <= 150 * 1024 && !ab_flag("HOT_CG_STREAM"); // (du of the whole level in LDS)
+            if (cg_resident && !attr_cg_set) {
+                HOT_HIP(hipFuncSetAttribute((const void*)k_cg_persist<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                attr_cg_set = true;
+            }
+            if (cg_resident)
+                HOT_LAUNCH(this, lname("cg_persistent", L.id).c_str(), (k_cg_persist<T, 2>), G, 1024, 3 * (size_t)L.n * sizeof(double), L.col.p, L.val.p, L.diagInv.p, L.initialResidual.p, u, r, z, du, dAu, L.n, iterations, cg_phase, cg_dep.p, cg_ss,
+                    hscal + 40, hscal + 251, new_ticket(), (int*)(hscal + 250));
+            else
+                HOT_LAUNCH(this, lname("cg_persistent", L.id).c_str(), k_cg_persist<T>, G, 1024, 0, L.col.p, L.val.p, L.diagInv.p, L.initialResidual.p, u, r, z, du, dAu, L.n, iterations, cg_phase, cg_dep.p, cg_ss,
+                    hscal + 40, hscal + 251, new_ticket(), (int*)(hscal + 250));
             wait_ticket(); // a timed-out barrier shows in hscal[250]: sync() inside throws ERR_RETRY and the caller redoes the operation with launches
             cnt = (int)hscal[41];
+            if (ab_flag("HOT_CG_DBG")) // A/B build: 10 ns ticks of workgroup 0 by phase
+                fprintf(stderr, "cg_persistent level %d: %d rows, %d workgroups, %d iterations; ticks pull %.0f product %.0f barrier1 %.0f update %.0f barrier2 %.0f direction %.0f barrier3 %.0f\n", L.id, L.n, G, cnt,
+                    hscal[48], hscal[49], hscal[50], hscal[51], hscal[52], hscal[53], hscal[54]);
+            cg_phase = (cg_phase + 1u + 3u * (unsigned)cnt) & 3u; // one barrier at the set-up, three an iteration
             iterations = 0;
         }
         else if (fused) {

@@ -42,6 +42,8 @@ CASES = [
     ({"HOT_LBFGS_UNFUSED": "1"}, SOLVER, "iterates"),
     ({"HOT_LS_NO_BATCH": "1"}, SOLVER, "iterates or objective_concept or knobs"),  # line-search trials one pass each (their own gradient gather) instead of batches of 2 / 4 / 8 on F(alpha) = A0 + alpha A1 (trial_batch, force.hip)
     ({"HOT_CG_UNFUSED": "1"}, SOLVER, "smoothers or vcycle or iterates"),
+    ({"HOT_CG_STREAM": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # the persistent top-level PCG reading its rows from memory every iteration instead of holding them in registers (k_cg_persist<T, 2>)
+    ({"HOT_CG_WGS": "40"}, SOLVER, "smoothers or vcycle or iterates"),  # fewer workgroups than rows / 32: the streaming version on a small level
     ({"HOT_CG_LAUNCHES": "1"}, SOLVER, "smoothers or vcycle or iterates"),  # three launches per PCG iteration instead of the persistent launch on small top levels
     ({"HOT_GS_FAKE_TIMEOUT": "2"}, SOLVER, "smoothers or vcycle or iterates"),  # a chained sweep "times out" at the second synchronisation of every context: the operation is redone with one launch per pass
     ({"HOT_HESSIAN_V1": "1"}, SOLVER, "hessian_and_hierarchy"),
