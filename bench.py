@@ -367,7 +367,7 @@ def main():
                 "traffic_source": traffic_src,
                 "timer": "HIP events around every launch on the library's stream, averaged over the launches of the profiled steps (includes the launch boundary, 3 - 4 us per launch)",
                 # the attainable figure, measured on this box in this run: a device-to-device copy of 1 GiB (read + write bytes counted)
-                "peak_measured": copy_gbs, "peak_measured_how": "hot_copy_bandwidth: the library's own copy kernel (16 bytes per lane, four loads in flight per thread) over 1 GiB, 20 launches between two HIP events on the library's stream, bytes read + bytes written",
+                "peak_measured": copy_gbs, "peak_measured_how": "hot_copy_bandwidth: the library's own copy kernel (one non-temporal 16-byte piece per thread) over 1 GiB, 20 launches between two HIP events on the library's stream, bytes read + bytes written",
                 "peak_measured_torch": copy_torch_gbs,  # torch Tensor.copy_ of 1 GiB: the figure of rounds 4 - 5
                 "frac_of_measured": achieved / copy_gbs if copy_gbs else None,
                 # the kernel-only duration of the committed rocprofv3 --kernel-trace --stats summary of this command (no launch boundary), for comparison

@@ -255,30 +255,27 @@ int hot_get_level_inblock_nnzb(hot_ctx* ctx, int32_t level, int64_t* nnzb)
     HOT_API_END
 }
 // ---- what this box streams: a device-to-device copy KERNEL on the context's stream (bench.py roofline.peak_measured)
-__global__ __launch_bounds__(256) void k_copy16(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16)
+typedef float hot_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy16(const hot_f4* __restrict__ src, hot_f4* __restrict__ dst, size_t n16)
 {
-    // four independent 16-byte loads per thread in flight, grid-stride; consecutive lanes on consecutive 16 bytes
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
-    }
-    for (; i < n16; i += stride) dst[i] = src[i];
+    // ONE 16-byte piece per thread, non-temporal both ways, consecutive lanes on consecutive pieces: the shape that streams fastest here
+    // (tools/micro/copy_bw.hip, 1 GiB: 6.5 TB/s; 6.2 without the non-temporal hint; grid-stride loops of 4096 workgroups 4.3 - 4.7; hipMemcpyAsync 5.0)
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 int hot_copy_bandwidth(hot_ctx* ctx, int64_t bytes, int32_t reps, double* gbytes_per_s)
 {
     HOT_API_BEGIN
     HOT_CHECK(bytes >= (1 << 20) && reps > 0 && gbytes_per_s, HOT_ERR_INVALID, "hot_copy_bandwidth: at least 1 MiB, one repetition");
     hipStream_t st = ctx->impl->stream;
-    hot::DBuf<float4> a, b;
+    hot::DBuf<hot_f4> a, b;
     const size_t n16 = (size_t)bytes / 16;
     a.reserve(n16), b.reserve(n16);
     HOT_HIP(hipMemsetAsync(a.p, 0x11, n16 * 16, st));
     hipEvent_t e0, e1;
     HOT_HIP(hipEventCreate(&e0));
     HOT_HIP(hipEventCreate(&e1));
-    const int grid = 256 * 16; // 16 workgroups per compute unit's worth of threads; the loop covers the rest
+    const unsigned grid = (unsigned)((n16 + 255) / 256);
     for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, st, a.p, b.p, n16);
     HOT_HIP(hipEventRecord(e0, st));
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, st, a.p, b.p, n16);

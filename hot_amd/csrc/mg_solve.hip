@@ -154,6 +154,14 @@ __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ col, c
     s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
     if (lane == 0) y[3 * (int64_t)row] = s0, y[3 * (int64_t)row + 1] = s1, y[3 * (int64_t)row + 2] = s2;
 }
+// A load of data a kernel reads ONCE (matrix values, column ids, images).  An ORDINARY load: the non-temporal hint, which helps a 16-byte-per-lane copy
+// (tools/micro/copy_bw.hip: 6.2 -> 6.5 TB/s), makes these 8-byte pieces — several lanes and instructions per cache line — miss on every piece: measured
+// with __builtin_nontemporal_load here, C2: the colour pass 46 -> 77 us per launch, k_gs_residual 260 -> 327 us, k_apmv_sub 183 -> 329 us.
+template <class U>
+__device__ __forceinline__ U nt_load(const U* p)
+{
+    return *p;
+}
 // "not written yet" marks of the chained GS sweeps (k_gs_sweep): signalling-NaN payloads that no arithmetic result carries
 template <class T>
 struct GsUnset;
@@ -190,11 +198,14 @@ __global__ __launch_bounds__(256) void k_apmv_sub(const int32_t* __restrict__ ap
     // lane = geometric window position; -1 where the window is structurally zero (an even coordinate's fourth coarse node): nothing is stored nor loaded
     // there, and the stored positions are packed in this order (k_ap): a lane's slot is its rank among the row's stored positions.  The wavefront sum
     // pairs the same positions as before the packing (the skipped ones used to add exact zeros): bit-identical results.
-    const int j = apc[(int64_t)row * 64 + lane];
+    const int j = nt_load(apc + (int64_t)row * 64 + lane);
     const int slot = __popcll(__ballot(j >= 0) & ((1ull << lane) - 1ull));
     T s0 = (T)0, s1 = (T)0, s2 = (T)0;
     if (j >= 0) {
-        const T* b = apv + ((int64_t)row * 64 + slot) * 9;
+        const T* bp = apv + ((int64_t)row * 64 + slot) * 9;
+        T b[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) b[t] = nt_load(bp + t);
         const T x0 = e[3 * (int64_t)j], x1 = e[3 * (int64_t)j + 1], x2 = e[3 * (int64_t)j + 2];
         s0 = b[0] * x0 + b[3] * x1 + b[6] * x2;
         s1 = b[1] * x0 + b[4] * x1 + b[7] * x2;
@@ -1180,10 +1191,10 @@ __device__ __forceinline__ void gs_off_steps(const int2* __restrict__ slot, cons
     auto values = [&](int n, const int2 d, GsOffItem<T>& R) __attribute__((always_inline)) {
         R.valid = n < nstep && s_begin + 4 * n + g < s_end && l16 < d.y;
         const int64_t e = (int64_t)d.x + (R.valid ? l16 : 0);
-        R.j = gcol[e];
+        R.j = nt_load(gcol + e);
         const T* bb = val + e * 9;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) R.bv[t] = bb[t];
+        for (int t = 0; t < 9; ++t) R.bv[t] = nt_load(bb + t);
     };
     auto finish = [&](int n, const GsOffItem<T>& R, int nn, const int2 dn, GsOffItem<T>& N, int nd, int2& dd) __attribute__((always_inline)) {
         const int64_t jj = R.j; // (a dropped lane: the column of the slot's first entry)
@@ -1425,7 +1436,7 @@ __global__ __launch_bounds__(256) void k_gs_colour(const T* __restrict__ img, co
     do {                                                                                      \
         const uint32_t idx_ = (LR)[s];                                                        \
         const T* p_ = (E) + (size_t)idx_ * 9;                                                 \
-        _Pragma("unroll") for (int e_ = 0; e_ < 9; ++e_) L[e_] = p_[e_];                      \
+        _Pragma("unroll") for (int e_ = 0; e_ < 9; ++e_) L[e_] = nt_load(p_ + e_);            \
         asm volatile("" ::: "memory"); /* the loads stay HERE, D steps ahead of their use */ \
     } while (0)
 #pragma unroll
@@ -1971,9 +1982,9 @@ __global__ __launch_bounds__(256) void k_gs_residual(const int32_t* __restrict__
             const int k = base + k0 + q;
             const bool ok = lane < 63 && k < nl;
             const int kk = ok ? k : 0; // (branch-free: a lane without an entry reads the row's first one and multiplies by zero)
-            const int64_t j = c[kk];
+            const int64_t j = nt_load(c + kk);
             const T* b = v + kk * 9 + 3 * cc;
-            const T b0 = b[0], b1 = b[1], b2 = b[2];
+            const T b0 = nt_load(b), b1 = nt_load(b + 1), b2 = nt_load(b + 2);
             T x = h[3 * j + cc];
             if (!DIFF) x -= du[3 * j + cc];
             x = ok ? x : (T)0;

@@ -232,8 +232,7 @@ int hot_get_level_nnzb(hot_ctx*, int32_t level, int64_t* nnzb);
  * of the two kernels.  Valid after hot_build_mg on levels that were coloured; HIP product only. */
 int hot_get_level_inblock_nnzb(hot_ctx*, int32_t level, int64_t* nnzb);
 int hot_get_prolongation(hot_ctx*, int32_t level, int32_t* entryCol /*8*nrows(level)*/, void* weight /*8*nrows(level)*/);
-/* measurement aid, HIP product only: the rate (GB/s, bytes read + bytes written) of a device-to-device copy KERNEL (16 bytes per lane, four loads in
- * flight per thread) over `bytes` bytes, `reps` launches between two events on the context's stream — the attainable streaming rate of the box the
+/* measurement aid, HIP product only: the rate (GB/s, bytes read + bytes written) of a device-to-device copy KERNEL (one non-temporal 16-byte piece per thread) over `bytes` bytes, `reps` launches between two events on the context's stream — the attainable streaming rate of the box the
  * roofline fractions are quoted beside ("a device-to-device copy kernel"); allocates and frees two buffers of `bytes` bytes */
 int hot_copy_bandwidth(hot_ctx*, int64_t bytes, int32_t reps, double* gbytes_per_s);
 

@@ -21,7 +21,7 @@ find "$OUT" -name "*counter_collection.csv" -delete
 python - <<PY
 import json
 d = json.load(open("$OUT/sq_${CFG}_summary.json"))
-keep = ("k_hessian_rows", "k_dpdf_rec", "k_state", "k_gs_block", "k_gs_offblock", "k_gs_subst", "k_gs_sweep", "k_gs_residual", "k_force_cells", "k_p2g_cells2", "k_g2p", "k_dpdf45", "k_spmv", "k_apmv_sub")
+keep = ("k_hessian_rows", "k_dpdf_rec", "k_state", "k_gs_block", "k_gs_offblock", "k_gs_subst", "k_gs_colour", "k_gs_sweep", "k_gs_residual", "k_force_cells", "k_p2g_cells2", "k_p2g_stream", "k_g2p", "k_dpdf45", "k_spmv", "k_apmv_sub", "k_cg_persist")
 for k, v in sorted(d.items()):
     if any(s in k for s in keep):
         print(k[:70], {c: round(r["avg"], 1) for c, r in v.items() if isinstance(r, dict)})
