@@ -39,7 +39,7 @@ SYMBOL = {  # profile-record prefix -> device symbol as rocprofv3 names it
     "gs_forward_fused": "hot::k_gs_colour<T,", "gs_backward_fused": "hot::k_gs_colour<T,",  # <T, true, D>, <T, false, D> and <T, true, D, true> (the turn): one kernel, two sweep directions
     "gs_forward_chained": "hot::k_gs_sweep<T,true,SB>", "gs_backward_chained": "hot::k_gs_sweep<T,false,SB>",
     "gs_residual": "hot::k_gs_residual<T>", "hessian_assemble": "hot::k_hessian_rows<T>", "state_update": "hot::k_state<T>",
-    "force_scatter": "hot::k_force_cells2<T>", "p2g": "hot::k_p2g_cells2<T,true>", "g2p": "hot::k_g2p<T,0,true>",
+    "force_scatter": "hot::k_force_cells2<T>", "p2g": "hot::k_p2g_stream<T,true>", "g2p": "hot::k_g2p<T,0,true>",
 }
 
 
@@ -388,8 +388,12 @@ def main():
             tp, src = pmc_traffic(SYMBOL["p2g"], "double" if s == 8 else "float")
             tg, _ = pmc_traffic(SYMBOL["g2p"], "double" if s == 8 else "float")
             if tp and tg:
+                tr, _ = pmc_traffic("hot::k_tile_reduce<T", "double" if s == 8 else "float")  # (the launches of both scatters' reductions, averaged)
                 transfers.update({"pmc_bytes_p2g_kernel": tp, "pmc_bytes_g2p_kernel": tg, "pmc_source": src,
-                                  "g2p_traffic_GBps": tg / (t_g2p * 1e-3) / 1e9, "g2p_traffic_frac_of_hbm_peak": tg / (t_g2p * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                                  "g2p_traffic_GBps": tg / (t_g2p * 1e-3) / 1e9, "g2p_traffic_frac_of_hbm_peak": tg / (t_g2p * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  # what P2G (+ its tile reduction) and G2P MOVE over the time they take, against the 8 TB/s: the fused design's own figure
+                                  # (SURVEY 8(d)'s bytes leave out the partial tiles and the strain update G2P carries)
+                                  "frac_of_hbm_peak_traffic": (tp + (tr or 0.0) + tg) / ((t_p2g + t_g2p) * 1e-3) / 1e9 / HBM_PEAK_GBS})
         prof_top = sorted(((k, round(v["ms"] / nprof, 3), v["calls"] // nprof) for k, v in groups.items()), key=lambda x: -x[1])[:14]
         del pctx
 
