@@ -217,9 +217,10 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo with --share-gpu on a one-GPU box)")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N > 1: native stream-ordered RCCL communicator of the library (falls back to torch if RCCL "
                     "cannot be attached) or hot_amd.dist.TorchComm (torch.distributed collectives, host-synchronous)")
-    ap.add_argument("--shard-gs", type=int, default=0, choices=[0, 1], help="N > 1, coloured GS across ranks: 0 = colour-synchronous (default since round 6: the reference's update order, the single-rank "
+    ap.add_argument("--shard-gs", type=int, default=0, choices=[0, 1, 2], help="N > 1, coloured GS across ranks: 0 = colour-synchronous (default since round 6: the reference's update order, the single-rank "
                     "iterates and iteration counts, sixteen halo exchanges per symmetric sweep), 1 = processor-block / rank-local (one exchange per symmetric sweep; another smoother: "
-                    "iteration counts drift by +-15 - 25 % and small sub-domains — 24^3 cells per rank — do not converge, profiles/r05_shard_ownership.txt)")
+                    "iteration counts drift by +-15 - 25 % and small sub-domains — 24^3 cells per rank — do not converge, profiles/r05_shard_ownership.txt), "
+                    "2 = rank-local with the l1 norms of a row's off-rank couplings added to its diagonal block: convergent whatever the sub-domain size")
     ap.add_argument("--shard-owner", type=int, default=0, choices=[0, 1, 2], help="N > 1, hot_config.shard_owner: 0 = by the smoother (default: page-range ownership under --shard-gs 0, first touch under --shard-gs 1), "
                     "1 = the first-touching rank owns a block (rounds 2 - 4), 2 = the rank whose page range holds the block (balanced along the cuts)")
     ap.add_argument("--watchdog-s", type=float, default=1500.0, help="N > 1: abort the rank (exit code 3) if the run has not finished after this many seconds (a peer that died or a wedged collective would otherwise hang the job); 0 = off")
@@ -467,7 +468,7 @@ def main():
                                    + ({1: f", von Mises return mapping (yield {cfg.get('yield_stress', 0):g})", 2: ", snow plasticity return mapping"}.get(cfg.get("plasticity", 0), "")),
                        "particles_per_gpu": int(total_particles / world), "particles_total": int(total_particles), "nodes_total": stats[-1]["num_nodes"], "levels": stats[-1]["num_levels"],
                        "parallelism": "1 GPU" if world == 1 else f"one connected body sharded over {world} ranks: particle ranges of the sort order, node tiles summed between the ranks sharing a block, "
-                                                                 f"row-partitioned operators with halo gathers, partitioned vector algebra, coloured Gauss-Seidel {'rank-local (processor-block), one exchange per symmetric sweep' if args.shard_gs else 'colour-synchronous across ranks'} ({args.backend})"},
+                                                                 f"row-partitioned operators with halo gathers, partitioned vector algebra, coloured Gauss-Seidel {('rank-local (processor-block), one exchange per symmetric sweep' + (', l1-scaled diagonal' if args.shard_gs == 2 else '')) if args.shard_gs else 'colour-synchronous across ranks'} ({args.backend})"},
             "iterations_per_step": iters / max(args.steps, 1),
             "hessian_mg_build_ms_per_step": build_ms / max(args.steps, 1),
             "ms_per_iter_build_amortised": solve_ms / max(iters, 1),

@@ -65,8 +65,8 @@ int hot_create(const hot_config* cfg, hot_ctx** out)
         return HOT_ERR_DEVICE;
     }
     if (cfg->device < 0 || cfg->device >= ndev || (cfg->dtype != 0 && cfg->dtype != 1) || !(cfg->dx > 0)) return HOT_ERR_INVALID;
-    if (cfg->shard_owner < 0 || cfg->shard_owner > 2 || cfg->shard_gs < 0 || cfg->shard_gs > 1) {
-        fprintf(stderr, "libhotmi355x: hot_create: hot_config.shard_owner must be 0 (by the sweep), 1 (first touch) or 2 (page range), shard_gs 0 or 1\n");
+    if (cfg->shard_owner < 0 || cfg->shard_owner > 2 || cfg->shard_gs < 0 || cfg->shard_gs > 2) {
+        fprintf(stderr, "libhotmi355x: hot_create: hot_config.shard_owner must be 0 (by the sweep), 1 (first touch) or 2 (page range), shard_gs 0 (colour-synchronous), 1 (rank-local) or 2 (rank-local, l1-scaled)\n");
         return HOT_ERR_INVALID;
     }
     hot_ctx* c = new hot_ctx;

@@ -107,6 +107,12 @@ struct Level {
     DBuf<int32_t> dxtab; // the same two tables on the device (xbeg | xcnt)
     int xmax_full = 0, xmax_col[8] = { 0 }; // largest per-rank counts (padded all-gather slots)
     const uint8_t* mask() const { return part ? own.p : nullptr; }
+    // hot_config.shard_gs = 2 (l1-scaled rank-local GS): the smoother's own diagonal blocks D' = D + diag(l1 norms of the row's off-rank couplings),
+    // their inverses, and E = D' - D (3 per row) for the residual identity (k_l1_diag, mg_build.hip)
+    DBuf<T> gsD, gsDinv, gsE;
+    bool l1 = false;
+    const T* gs_d() const { return l1 ? gsD.p : diagVal.p; }
+    const T* gs_dinv() const { return l1 ? gsDinv.p : diagBlockInv.p; }
     // ---- halo mode (hot_config.shard_replicated == 0): the entries of a DOF vector of this level this rank reads but does not own, and
     // who owns them; both lists are ordered by (owner | reader, colour, position in gs_order), so one colour of a GS sweep is a sub-range
     struct Halo {

@@ -795,9 +795,57 @@ __global__ __launch_bounds__(512) void k_gs_images(const int32_t* __restrict__ g
     }
 }
 
+// hot_config.shard_gs = 2: the l1-scaled processor-block smoother (Baker, Falgout, Kolev, Yang, SIAM J. Sci. Comput. 33 (2011), section 6.2).  A rank that
+// sweeps its own rows against its own rows only is the symmetric GS of its diagonal block of A, which need not converge; with the absolute row sums of a
+// row's OFF-RANK couplings added to its diagonal, D' = D + diag(sum_j |A_ij| 1), it does for every symmetric positive definite A.  One wavefront per owned row.
+template <class T>
+__global__ __launch_bounds__(256) void k_l1_diag(const int32_t* __restrict__ col, const T* __restrict__ val, const uint8_t* __restrict__ owner, int me, const T* __restrict__ diagVal,
+    const T* __restrict__ diagBlockInv, T* __restrict__ gsD, T* __restrict__ gsDinv, T* __restrict__ gsE, int n)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    T e0 = 0, e1 = 0, e2 = 0;
+    if (owner[row] == me) {
+        for (int k = lane; k < 125; k += 64) {
+            const int j = col[(int64_t)row * 125 + k];
+            if (owner[j] == me) continue;
+            const T* b = val + ((int64_t)row * 125 + k) * 9; // column-major 3 x 3: entry (r, c) at r + 3 c
+            e0 += habs(b[0]) + habs(b[3]) + habs(b[6]), e1 += habs(b[1]) + habs(b[4]) + habs(b[7]), e2 += habs(b[2]) + habs(b[5]) + habs(b[8]);
+        }
+    }
+    e0 = wave_sum(e0), e1 = wave_sum(e1), e2 = wave_sum(e2);
+    if (lane != 0) return;
+    Mat3<T> D;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) D.a[c] = diagVal[9 * (int64_t)row + c];
+    gsE[3 * (int64_t)row] = e0, gsE[3 * (int64_t)row + 1] = e1, gsE[3 * (int64_t)row + 2] = e2;
+    if (e0 == (T)0 && e1 == (T)0 && e2 == (T)0) { // an interior row: the smoother's blocks are the matrix's
+#pragma unroll
+        for (int c = 0; c < 9; ++c) gsD[9 * (int64_t)row + c] = D.a[c], gsDinv[9 * (int64_t)row + c] = diagBlockInv[9 * (int64_t)row + c];
+        return;
+    }
+    D.a[0] += e0, D.a[4] += e1, D.a[8] += e2;
+    T amax = (T)0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) amax = fmax(amax, habs(D.a[c]));
+    const int ex = (amax > (T)0 && amax < (T)INFINITY) ? ilogb(amax) : 0; // (k_diag's scaling: the determinant of a very light node does not underflow in fp32)
+    Mat3<T> Ds;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Ds.a[c] = scalbn(D.a[c], -ex);
+    Mat3<T> Bi = m3_inverse(Ds);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) gsD[9 * (int64_t)row + c] = D.a[c], gsDinv[9 * (int64_t)row + c] = scalbn(Bi.a[c], -ex);
+}
+
 template <class T>
 static void split_rows(Ctx<T>* ctx, Level<T>& L)
 {
+    L.l1 = false;
+    if (L.part && ctx->cfg.shard_gs == 2) {
+        L.gsD.reserve(9 * (size_t)L.n), L.gsDinv.reserve(9 * (size_t)L.n), L.gsE.reserve(3 * (size_t)L.n);
+        HOT_LAUNCH(ctx, "gs_l1_diag", k_l1_diag<T>, div_up(L.n, 4), 256, 0, L.col.p, L.val.p, L.owner.p, ctx->comm.rank, L.diagVal.p, L.diagBlockInv.p, L.gsD.p, L.gsDinv.p, L.gsE.p, L.n);
+        L.l1 = true;
+    }
     L.rowcnt.reserve(4 * (size_t)L.n);
     if (L.part) HOT_HIP(hipMemsetAsync(L.rowcnt.p, 0, 4 * (size_t)L.n * sizeof(int32_t), ctx->stream)); // rows of other ranks: no matrix, zero counts
     L.gs_col.reserve(125 * (size_t)L.n);
@@ -889,12 +937,12 @@ static void split_rows(Ctx<T>* ctx, Level<T>& L)
                     for (int c = 0; c < 8; ++c) L.gs_slot_rng[dir][fe][c] = h[16 * dir + 8 * fe + c];
         }
         if (!L.part) // every block, one launch (all shifts are 0)
-            HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, L.nblocks, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p, L.gs_imgi.p, 0);
+            HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, L.nblocks, 512, 0, L.gs_col.p, L.val.p, L.gs_dinv(), L.gs_d(), L.gs_pad.p, L.gs_img.p, L.gs_imgi.p, 0);
         for (int c = 0; c < 8 && L.part; ++c) {
             const int R1 = ctx->comm.size + 1, me = ctx->comm.rank;
             const int b0 = L.color_block_begin[c] + L.csplit[c * R1 + me], b1 = L.color_block_begin[c] + L.csplit[c * R1 + me + 1];
             if (b1 > b0)
-                HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, b1 - b0, 512, 0, L.gs_col.p, L.val.p, L.diagBlockInv.p, L.diagVal.p, L.gs_pad.p, L.gs_img.p + L.gs_img_shift[c] * (long long)GsImg<T>::per_block,
+                HOT_LAUNCH(ctx, "gs_images", k_gs_images<T>, b1 - b0, 512, 0, L.gs_col.p, L.val.p, L.gs_dinv(), L.gs_d(), L.gs_pad.p, L.gs_img.p + L.gs_img_shift[c] * (long long)GsImg<T>::per_block,
                     L.gs_imgi.p + L.gs_img_shift[c] * 2 * (long long)GsImg<T>::idx_per_dir, b0);
         }
         L.gs_img_ready = true;

@@ -1954,7 +1954,7 @@ __global__ void k_gs_hdiff(size_t n3, T* __restrict__ h, const T* __restrict__ d
 template <class T, bool DIFF = false>
 __global__ __launch_bounds__(256) void k_gs_residual(const int32_t* __restrict__ col, const T* __restrict__ val, const int32_t* __restrict__ rowcnt, const T* __restrict__ h,
     const T* __restrict__ du, T* __restrict__ r, int n, const uint8_t* __restrict__ own, const uint8_t* __restrict__ owner /*rank-local GS (hot_config.shard_gs): owning rank of every row, else null*/,
-    int me)
+    int me, const T* __restrict__ l1e /*shard_gs = 2: E = D' - D of the l1-scaled sweep, 3 per row (else null): r - A du = L (h - du) + E du*/)
 {
     const int lane = threadIdx.x & 63;
     const int row = xcd_block() * 4 + (threadIdx.x >> 6);
@@ -2002,7 +2002,10 @@ __global__ __launch_bounds__(256) void k_gs_residual(const int32_t* __restrict__
         }
     }
     s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
-    if (lane == 0) r[3 * (int64_t)row] = s0, r[3 * (int64_t)row + 1] = s1, r[3 * (int64_t)row + 2] = s2;
+    if (lane == 0) {
+        if (l1e) s0 += l1e[3 * (int64_t)row] * du[3 * (int64_t)row], s1 += l1e[3 * (int64_t)row + 1] * du[3 * (int64_t)row + 1], s2 += l1e[3 * (int64_t)row + 2] * du[3 * (int64_t)row + 2];
+        r[3 * (int64_t)row] = s0, r[3 * (int64_t)row + 1] = s1, r[3 * (int64_t)row + 2] = s2;
+    }
 }
 
 template <class T>
@@ -2283,15 +2286,15 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             if (simple_gs) {
                 if (h != 0) return;
                 if (fwd)
-                    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_color<T, true>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, b0, nb);
+                    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_color<T, true>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.gs_d(), L.gs_dinv(), rhs, xx, hD, b0, nb);
                 else
-                    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_color<T, false>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, b0, nb);
+                    HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_color<T, false>), nb, 64, 0, L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, L.gs_d(), L.gs_dinv(), rhs, xx, hD, b0, nb);
                 return;
             }
 #endif
 #define HOT_GS_CASE(F, S)                                                                                                                                      \
     HOT_LAUNCH(this, lname(nm, L.id).c_str(), (k_gs_block<T, F, S>), nb, gs_threads, (GsLds<T, S>::bytes), L.col.p, L.val.p, L.ckey.p, L.gs_order.p, L.gs_block_start.p, \
-        L.diagVal.p, L.diagBlockInv.p, rhs, xx, hD, b0, h | (nmerge << 16), rc, L.gs_pad.p)
+        L.gs_d(), L.gs_dinv(), rhs, xx, hD, b0, h | (nmerge << 16), rc, L.gs_pad.p)
             if (fwd) {
                 if (sb == 64) HOT_GS_CASE(true, 64);
                 else if (sb == 32) HOT_GS_CASE(true, 32);
@@ -2556,11 +2559,11 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 if (!dataflow) { // (the chained sweeps keep marks in hdu)
                     if (!(pair_path && !L.part)) HOT_LAUNCH(this, "gs_hdiff", k_gs_hdiff<T>, div_up(n3, 256), 256, 0, n3, hdu, du); // (the pair path's backward substitutions have subtracted already)
                     HOT_LAUNCH(this, lname("gs_residual", L.id).c_str(), (k_gs_residual<T, true>), xcd_grid(div_up(L.n, 4)), 256, 0, L.col.p, L.val.p, L.rowcnt.p, hdu, du, r, L.n, L.mask(),
-                        rank_local ? L.owner.p : (const uint8_t*)nullptr, comm.rank);
+                        rank_local ? L.owner.p : (const uint8_t*)nullptr, comm.rank, (rank_local && L.l1) ? L.gsE.p : (const T*)nullptr);
                 }
                 else
                     HOT_LAUNCH(this, lname("gs_residual", L.id).c_str(), k_gs_residual<T>, xcd_grid(div_up(L.n, 4)), 256, 0, L.col.p, L.val.p, L.rowcnt.p, hdu, du, r, L.n, L.mask(),
-                        rank_local ? L.owner.p : (const uint8_t*)nullptr, comm.rank);
+                        rank_local ? L.owner.p : (const uint8_t*)nullptr, comm.rank, (rank_local && L.l1) ? L.gsE.p : (const T*)nullptr);
                 if (!hm) exchange(L, r, -1); // first-generation sharding: the restriction / the next smoother read all of r (halo mode: r is needed on owned rows only; restrict_dev fetches what it reads)
             }
             else {

@@ -80,7 +80,9 @@ typedef struct hot_config {
     int32_t shard_gs; /* sharded runs (hot_set_comm), coloured GS on a row-partitioned level: 0 = colour-synchronous (default): after every colour the
                          owners' new values are handed to all ranks, i.e. the reference's update order and single-rank iterates; 1 = processor-block:
                          a rank sweeps its own rows against its own rows only (couplings to other ranks' rows enter through the residual), one
-                         exchange per symmetric sweep instead of sixteen; a different (still symmetric positive definite) smoother — see DESIGN.md §7 */
+                         exchange per symmetric sweep instead of sixteen; a different (still symmetric positive definite) smoother that needs large
+                         sub-domains to converge; 2 = the same with the l1 norms of a row's off-rank couplings added to its diagonal block (D' = D +
+                         diag(sum_j |A_ij| 1), Baker / Falgout / Kolev / Yang 2011): convergent for every SPD matrix whatever the sub-domain size — see DESIGN.md §7 */
     int32_t shard_replicated; /* sharded runs: 0 (default) = halo mode: DOF vectors live on the rows a rank owns plus the halo it reads, node tiles are summed
                                  between the ranks that share a block, inner products are summed with one small all-reduce per batch; 1 = the first-generation
                                  decomposition: every DOF vector replicated, whole-array all-reduce per scatter and all-gather per operator (kept for A/B) */

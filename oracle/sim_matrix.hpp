@@ -708,6 +708,36 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
         const bool part = partitioned(level);
         const bool rank_local = part && cfg.shard_gs != 0;
         auto mine = [&](const std::vector<int>& blockNodes) { return !part || owner_of_block(level, blockNodes) == comm.rank; };
+        // hot_config.shard_gs = 2: the l1-scaled processor-block sweep (the product's rule, hot_amd/csrc/mg_build.hip k_l1_diag; Baker, Falgout, Kolev, Yang,
+        // "Multigrid smoothers for ultraparallel computing", SIAM J. Sci. Comput. 33 (2011), section 6.2): the diagonal block of a row that couples to other
+        // ranks' rows is D' = D + diag(sum over the off-rank columns j of the absolute row sums of A_ij) — the symmetric GS of the rank's own diagonal block
+        // with that diagonal is a convergent smoother for every symmetric positive definite A, which the unscaled one is not.
+        std::vector<TM> Dl1, Dl1inv;
+        if (rank_local && cfg.shard_gs == 2) {
+            std::vector<int> own_of(n, -1);
+            for (int c = 0; c < 8; ++c)
+                for (const auto& blockNodes : A.coloredBlockDofs[c]) {
+                    const int o = owner_of_block(level, blockNodes);
+                    for (int i : blockNodes) own_of[i] = o;
+                }
+            Dl1.assign(A.diagonalVal.begin(), A.diagonalVal.end());
+            Dl1inv.assign(A.diagonalBlock.begin(), A.diagonalBlock.end());
+            for (int i = 0; i < n; ++i) {
+                if (own_of[i] != comm.rank) continue;
+                T e[3] = { 0, 0, 0 };
+                for (size_t st = (size_t)i * A.colsize; st < (size_t)(i + 1) * A.colsize; ++st) {
+                    const int col = A.entryCol[st];
+                    if (own_of[col] == comm.rank) continue;
+                    for (int r = 0; r < 3; ++r)
+                        for (int cc = 0; cc < 3; ++cc) e[r] += std::abs(A.entryVal[st](r, cc));
+                }
+                if (e[0] == 0 && e[1] == 0 && e[2] == 0) continue;
+                for (int r = 0; r < 3; ++r) Dl1[i](r, r) += e[r];
+                Dl1inv[i] = inverse(Dl1[i]);
+            }
+        }
+        const std::vector<TM>& gsD = Dl1.empty() ? A.diagonalVal : Dl1;
+        const std::vector<TM>& gsDinv = Dl1inv.empty() ? A.diagonalBlock : Dl1inv;
         auto exchange_colour = [&](std::vector<TV>& x, int c) {
             if (!part) return;
             std::vector<T> buf((size_t)n * 3, (T)0);
@@ -733,13 +763,13 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
                             int col = A.entryCol[st];
                             if (color_comp<T>(A.colorOrder[col], A.colorOrder[i]) < 0) sigma += A.entryVal[st] * hdu[col];
                         }
-                        hdu[i] = A.diagonalBlock[i] * (r[i] - sigma);
+                        hdu[i] = gsDinv[i] * (r[i] - sigma);
                     }
                 }
                 if (!rank_local) exchange_colour(hdu, c);
             }
             HOT_FAIR_FOR
-            for (int i = 0; i < n; ++i) hdu[i] = A.diagonalVal[i] * hdu[i];
+            for (int i = 0; i < n; ++i) hdu[i] = gsD[i] * hdu[i];
             du.assign(n, TV::zero());
             for (int c = 7; c >= 0; --c) {
 #pragma omp parallel for schedule(dynamic, 4)
@@ -753,7 +783,7 @@ void Sim<T>::smooth(int kind, int level, std::vector<TV>& u, std::vector<TV>& r,
                             int col = A.entryCol[st];
                             if (color_comp<T>(A.colorOrder[col], A.colorOrder[i]) > 0) sigma += A.entryVal[st] * du[col];
                         }
-                        du[i] = A.diagonalBlock[i] * (hdu[i] - sigma);
+                        du[i] = gsDinv[i] * (hdu[i] - sigma);
                     }
                 }
                 if (!rank_local) exchange_colour(du, c);
