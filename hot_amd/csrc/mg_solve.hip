@@ -1358,6 +1358,51 @@ __global__ __launch_bounds__(64) void k_gs_subst(const T* __restrict__ img, cons
 // behind the forward one (backward index table fetched with the forward one, backward image columns requested into the ring slots the forward walk frees),
 // and the backward sweep's first launch — 729 wavefronts walking a dependent chain with the chip otherwise empty — does not happen.  Same arithmetic as the
 // two launches: bit-identical results.
+// Development aid (-DHOT_GSC_CLOCKS, tools/gs_colour_phases.sh): the 100 MHz clock of every colour block's substitution wavefront at its phase boundaries
+// (prologue round trips 1 + 2, image requests, wait for the previous colour's sums, the 64 steps, the stores), of its first summing wavefront at the barrier,
+// and the start / end of every block and streaming workgroup — plain stores per workgroup (atomics on shared words cost more than the kernel), summed per
+// pass of the symmetric sweep by k_gsc_pass behind each launch; smooth_dev prints the table every ten sweeps (profiles/r06_gs_colour_clocks.txt).
+#ifdef HOT_GSC_CLOCKS
+__device__ unsigned long long gsc_clk[16][12]; // [pass of the symmetric sweep: forward q | 8 + backward q][0 blocks, 1 - 5 phases, 6 block workgroups' span, 7 summing wavefront, 8 streaming workgroups' span, 9 launches]
+__device__ unsigned long long gsc_blk[4096][8]; // of the launch in flight, per block workgroup: five phases, summing wavefront done, start, end (plain stores: atomics on one word per block cost more than the kernel)
+__device__ unsigned long long gsc_str[4096][2]; // per streaming workgroup: start, end
+__global__ void k_gsc_pass(int p, int nb, int ns) // behind a launch: its workgroups' clocks to the sums of its pass
+{
+    __shared__ unsigned long long red[8][256], lo[2][256], hi[2][256];
+    const int t = threadIdx.x;
+    unsigned long long a[8] = {}, l0 = ~0ull, h0 = 0, l1 = ~0ull, h1 = 0;
+    for (int i = t; i < nb && i < 4096; i += 256) {
+        for (int k = 0; k < 6; ++k) a[k] += gsc_blk[i][k];
+        l0 = min(l0, gsc_blk[i][6]), h0 = max(h0, gsc_blk[i][7]);
+    }
+    for (int i = t; i < ns && i < 4096; i += 256) l1 = min(l1, gsc_str[i][0]), h1 = max(h1, gsc_str[i][1]);
+    for (int k = 0; k < 6; ++k) red[k][t] = a[k];
+    lo[0][t] = l0, hi[0][t] = h0, lo[1][t] = l1, hi[1][t] = h1;
+    __syncthreads();
+    if (t == 0) {
+        for (int i = 1; i < 256; ++i) {
+            for (int k = 0; k < 6; ++k) red[k][0] += red[k][i];
+            lo[0][0] = min(lo[0][0], lo[0][i]), hi[0][0] = max(hi[0][0], hi[0][i]), lo[1][0] = min(lo[1][0], lo[1][i]), hi[1][0] = max(hi[1][0], hi[1][i]);
+        }
+        unsigned long long* c = gsc_clk[p];
+        c[0] += (unsigned long long)nb;
+        for (int k = 0; k < 5; ++k) c[1 + k] += red[k][0];
+        c[7] += red[5][0];
+        if (nb > 0 && hi[0][0] > lo[0][0]) c[6] += hi[0][0] - lo[0][0];
+        if (ns > 0 && hi[1][0] > lo[1][0]) c[8] += hi[1][0] - lo[1][0];
+        c[9] += 1;
+    }
+}
+#define HOT_GS_CLK(i)                                  \
+    do {                                               \
+        asm volatile("" ::: "memory");                 \
+        const unsigned long long t_ = wall_clock64();  \
+        clk_[i] = t_ - tl_, tl_ = t_;                  \
+        asm volatile("" ::: "memory");                 \
+    } while (0)
+#else
+#define HOT_GS_CLK(i)
+#endif
 template <class T, bool FWD, int D, bool TURN = false>
 __global__ __launch_bounds__(256) void k_gs_colour(const T* __restrict__ img, const uint16_t* __restrict__ imgi, const int32_t* __restrict__ gs_pad, const int4* __restrict__ srec, T* x, T* hD, int block0,
     int nb, int nb_pad /*nb rounded up to a multiple of 8: the streaming workgroups keep their XCD (workgroup id % 8)*/, const T* __restrict__ rhs, T* hsub, const int2* __restrict__ slot,
@@ -1365,8 +1410,16 @@ __global__ __launch_bounds__(256) void k_gs_colour(const T* __restrict__ img, co
     T* xb /*TURN: the backward sweep's target*/, T* ub /*TURN: the iterate, which takes the correction (or null)*/)
 {
     static_assert(!TURN || FWD, "the turn is the end of the forward sweep");
+#ifdef HOT_GSC_CLOCKS
+    const unsigned long long t00_ = wall_clock64();
+    unsigned long long tl_ = t00_, clk_[6] = {};
+#endif
     if ((int)blockIdx.x >= nb_pad) {
         gs_off_stream<T>(slot, gcol, val, x, part, s_begin, s_end, (int)blockIdx.x - nb_pad, (int)gridDim.x - nb_pad);
+#ifdef HOT_GSC_CLOCKS
+        const int sid_ = (int)blockIdx.x - nb_pad;
+        if (threadIdx.x == 0 && sid_ < 4096) gsc_str[sid_][0] = t00_, gsc_str[sid_][1] = wall_clock64();
+#endif
         return;
     }
     if ((int)blockIdx.x >= nb) return;
@@ -1383,6 +1436,9 @@ __global__ __launch_bounds__(256) void k_gs_colour(const T* __restrict__ img, co
             T* o = lprev + 3 * (sl - p0);
             o[0] = s0, o[1] = s1, o[2] = s2;
         });
+#ifdef HOT_GSC_CLOCKS
+        if (threadIdx.x == 64 && blockIdx.x < 4096) gsc_blk[blockIdx.x][5] = wall_clock64() - t00_;
+#endif
         __syncthreads();
         return;
     }
@@ -1430,6 +1486,7 @@ __global__ __launch_bounds__(256) void k_gs_colour(const T* __restrict__ img, co
         q0 -= s0, q1 -= s1, q2 -= s2;
         asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2)::"memory"); // the image columns are requested BEHIND these sums (the asm consumes them): 72 registers of row data and 144 of columns never live together
     }
+    HOT_GS_CLK(0);
     const uint16_t* lrow = (const uint16_t*)(lidx + 33 * lane);
     T ring[D][9];
 #define HOT_GS_ISSUE(E, LR, s, L)                                                            \
@@ -1441,7 +1498,9 @@ __global__ __launch_bounds__(256) void k_gs_colour(const T* __restrict__ img, co
     } while (0)
 #pragma unroll
     for (int k = 0; k < D; ++k) HOT_GS_ISSUE(ent, lrow, k, ring[k]);
+    HOT_GS_CLK(1);
     __syncthreads(); // the previous colour's share of the row sums is in LDS
+    HOT_GS_CLK(2);
     T a0, a1, a2;
     {
         T s0 = 0, s1 = 0, s2 = 0;
@@ -1479,6 +1538,19 @@ __global__ __launch_bounds__(256) void k_gs_colour(const T* __restrict__ img, co
             asm volatile("" ::: "memory");
         }
     }
+#ifdef HOT_GSC_CLOCKS
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2)::"memory");
+    HOT_GS_CLK(3);
+    auto clk_out = [&]() __attribute__((always_inline)) {
+        HOT_GS_CLK(4);
+        if (lane == 0) {
+            if (blockIdx.x < 4096) {
+                for (int i = 0; i < 5; ++i) gsc_blk[blockIdx.x][i] = clk_[i];
+                gsc_blk[blockIdx.x][6] = t00_, gsc_blk[blockIdx.x][7] = tl_;
+            }
+        }
+    };
+#endif
     if (!TURN && node < 0) return;
     T h0 = 0, h1 = 0, h2 = 0;
     if (FWD) {
@@ -1521,6 +1593,9 @@ __global__ __launch_bounds__(256) void k_gs_colour(const T* __restrict__ img, co
         else
             x[3 * (int64_t)node] = f0, x[3 * (int64_t)node + 1] = f1, x[3 * (int64_t)node + 2] = f2;
     }
+#ifdef HOT_GSC_CLOCKS
+    if (!TURN) clk_out(); // (the turn's second walk is not clocked: its lanes without a row have left)
+#endif
 #undef HOT_GS_ISSUE
 }
 
@@ -2437,6 +2512,9 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
                 else
                     HOT_COLOUR_D(8);
 #undef HOT_COLOUR_D
+#ifdef HOT_GSC_CLOCKS
+                if (L.id == 0) hipLaunchKernelGGL(k_gsc_pass, dim3(1), dim3(256), 0, stream, (fwd ? 0 : 8) + q, nbk, grid - nbk_pad);
+#endif
             }
         };
         HOT_CHECK(sb == 16 || sb == 32 || sb == 64, HOT_ERR_INVALID, "hot_config.gs_sub_block must be 0 (auto), 16, 32 or 64");
@@ -2543,8 +2621,29 @@ void Ctx<T>::smooth_dev(int level, int kind, int iterations, T tolerance, T* u, 
             // dAu now holds D h ; du = backward solve
             if (dataflow)
                 sweep(false);
-            else if (fused_path)
+            else if (fused_path) {
                 colour_sweep(false);
+#ifdef HOT_GSC_CLOCKS
+                if (L.id == 0) { // every 10 symmetric sweeps: the per-role clocks of the 15 passes, averaged
+                    static int sweeps = 0;
+                    if (++sweeps % 10 == 0) {
+                        unsigned long long h[16][12];
+                        HOT_HIP(hipStreamSynchronize(stream));
+                        HOT_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(gsc_clk), sizeof(h)));
+                        fprintf(stderr, "k_gs_colour, per-role clocks (100 MHz), us: per block of the substitution wavefront | per launch\n"
+                                        "pass        blocks  trips1+2  requests  wait-prev  64-steps  stores | summing-done | block-wgs-span  stream-wgs-span\n");
+                        for (int p = 0; p < 16; ++p) {
+                            if (!h[p][9] || !h[p][0]) continue;
+                            const double nb = (double)h[p][0], nl = (double)h[p][9];
+                            fprintf(stderr, "%s q%d  %7.0f  %8.2f  %8.2f  %9.2f  %8.2f  %6.2f | %12.2f | %14.2f  %15.2f\n", p < 8 ? "forward " : "backward", p & 7, nb / nl, h[p][1] / (100 * nb), h[p][2] / (100 * nb),
+                                h[p][3] / (100 * nb), h[p][4] / (100 * nb), h[p][5] / (100 * nb), h[p][7] / (100 * nb), h[p][6] / (100 * nl), h[p][8] / (100 * nl));
+                        }
+                        memset(h, 0, sizeof(h));
+                        HOT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gsc_clk), h, sizeof(h)));
+                    }
+                }
+#endif
+            }
             else if (pair_path)
                 pair_sweep(false);
             else
