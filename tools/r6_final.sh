@@ -11,4 +11,6 @@ bash profiles/run_sq_counters.sh r06 C2 > $O/sq.log 2>&1; tail -3 $O/sq.log
 R=$(pwd); (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1; python $R/tools/gpu_idle.py /tmp/kt > $R/$O/gpu_idle_C2.txt 2>&1); tail -4 $O/gpu_idle_C2.txt
 timeout 900 python bench.py --share-gpu --gpus 8 --steps 2 --warmup 1 --no-cpu --cells 32 --backend gloo 2> $O/bench_8r.err | tail -1 > $O/bench_eight_ranks_one_gpu_functional.json; echo "8 ranks rc=$?"
 timeout 900 python bench.py --share-gpu --gpus 2 --steps 2 --warmup 1 --no-cpu --cells 40 --backend gloo 2> $O/bench_2r.err | tail -1 > $O/bench_two_ranks_one_gpu_functional.json; echo "2 ranks rc=$?"
+timeout 600 python tools/soak.py C2 40 > $O/soak_C2.txt 2>&1; echo "soak rc=$?"; tail -1 $O/soak_C2.txt | cut -c1-300
+timeout 900 python tools/fuzz_parity.py 24 6 > $O/fuzz_parity.txt 2>&1; echo "fuzz rc=$?"; tail -2 $O/fuzz_parity.txt
 du -sh $O
