@@ -109,3 +109,18 @@ def test_frame_output_containers(hotlib, oracle, dtype, tmp_path):
     g = io_checks.check_io(hotlib, dtype, tmp_path / "g")
     c = io_checks.check_io(oracle, dtype, tmp_path / "c")
     assert g[0] == c[0] and g[1] == c[1]
+
+
+def test_copy_bandwidth_measurement_aid(hotlib):
+    """hot_copy_bandwidth (include/hot_mi355x.h: SURVEY.md 8(d)'s "device-to-device copy kernel", the measured peak bench.py quotes beside roofline.frac):
+    a plausible streaming rate on an MI355X, stable between two calls, and the stated argument checks."""
+    import hot_amd
+    ctx, _ = pc.make_ctx(hotlib, n=4, dtype=1)
+    a = ctx.copy_bandwidth(256 << 20, 10)
+    b = ctx.copy_bandwidth(256 << 20, 10)
+    assert 1000.0 < a < 8000.0 and 1000.0 < b < 8000.0, (a, b)  # GB/s, read + written: between a PCIe-class rate and the HBM3E peak
+    assert abs(a - b) < 0.25 * max(a, b), (a, b)
+    with pytest.raises(hot_amd.HotError):
+        ctx.copy_bandwidth(1000, 10)  # below 1 MiB
+    with pytest.raises(hot_amd.HotError):
+        ctx.copy_bandwidth(1 << 20, 0)
